@@ -1,0 +1,226 @@
+/*
+ * rdyhip.h -- C ABI of the MI355X-native shallow-water RHS operator.
+ *
+ * This library replaces ONE path of RDycore: the operator that PETSc's
+ * explicit TS calls for every right-hand-side evaluation (first-order Roe
+ * fluxes over edges + bed-slope / Manning friction / external sources over
+ * cells).  Every entry point below names the RDycore interface it stands in
+ * for (file:line relative to the RDycore source tree); INTEGRATION.md shows
+ * the adapter a maintainer would add on the RDycore side.
+ *
+ * Conventions
+ *  - plain C, no PETSc / torch types: pointers, sizes, an opaque handle;
+ *  - every function returns 0 on success (PETSC_SUCCESS) or one of the
+ *    RDYHIP_ERR_* codes, whose values are PETSc's (petscerror.h) so an adapter
+ *    can pass them straight to PetscCall(); rdyhip_last_error() gives the text;
+ *  - "device" pointers are HIP device memory on the device that was current at
+ *    rdyhip_create(); "host" pointers are ordinary memory;
+ *  - `stream` is a hipStream_t passed as void* (NULL = the default stream);
+ *    the apply calls enqueue work and return without synchronising;
+ *  - indices are 32-bit (a PetscInt=int32 build; a 64-bit-PetscInt adapter
+ *    narrows local indices, which always fit), global ids are 64-bit;
+ *  - one operator per rank, one rank per GPU, no threads (as in the reference).
+ */
+#ifndef RDYHIP_H
+#define RDYHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RDYHIP_VERSION 100
+
+/* error codes = PETSc's values */
+#define RDYHIP_SUCCESS 0
+#define RDYHIP_ERR_MEM 55      /* PETSC_ERR_MEM */
+#define RDYHIP_ERR_ARG_SIZ 60  /* PETSC_ERR_ARG_SIZ */
+#define RDYHIP_ERR_ARG_OUTOFRANGE 63
+#define RDYHIP_ERR_LIB 76      /* PETSC_ERR_LIB: a HIP runtime call failed */
+#define RDYHIP_ERR_USER 83     /* PETSC_ERR_USER */
+
+/* RDyConditionType (include/rdycore.h:133-139) */
+#define RDYHIP_CONDITION_DIRICHLET 0
+#define RDYHIP_CONDITION_REFLECTING 2
+#define RDYHIP_CONDITION_CRITICAL_OUTFLOW 3
+
+/* RDyFlowSourceMethod (include/private/rdyconfigimpl.h:52-56) */
+#define RDYHIP_SOURCE_SEMI_IMPLICIT 0
+#define RDYHIP_SOURCE_IMPLICIT_XQ2018 1
+
+/* RDyNumericsRiemann (include/private/rdyconfigimpl.h:118-122); only Roe exists
+ * in the reference (src/swe/swe_petsc.c:264-270) */
+#define RDYHIP_RIEMANN_ROE 0
+
+/* The six scalars of RDyConfig that reach the kernels
+ * (config.physics.flow.{tiny_h,h_anuga_regular,source.method,source.xq2018_threshold},
+ *  config.numerics.riemann; include/private/rdyconfigimpl.h:73-85,125-132). */
+typedef struct {
+  double  tiny_h;
+  double  h_anuga_regular;
+  double  xq2018_threshold;
+  int32_t source_method; /* RDYHIP_SOURCE_* */
+  int32_t riemann;       /* RDYHIP_RIEMANN_ROE */
+} RDyHipConfig;
+
+/* The RDyMesh arrays the SWE operators read (include/private/rdymeshimpl.h:26-202).
+ * All host pointers, borrowed for the duration of rdyhip_create() only. */
+typedef struct {
+  int32_t num_cells;          /* mesh->num_cells (owned + ghost) */
+  int32_t num_owned_cells;    /* mesh->num_owned_cells */
+  int32_t num_edges;          /* mesh->num_edges */
+  int32_t num_internal_edges; /* mesh->num_internal_edges */
+  const int32_t *cell_is_owned;       /* cells.is_owned       [num_cells] */
+  const int32_t *cell_local_to_owned; /* cells.local_to_owned [num_cells] */
+  const int64_t *cell_global_ids;     /* cells.global_ids     [num_cells] */
+  const double  *cell_areas;          /* cells.areas          [num_cells] */
+  const double  *cell_dz_dx;          /* cells.dz_dx          [num_cells] */
+  const double  *cell_dz_dy;          /* cells.dz_dy          [num_cells] */
+  const int32_t *edge_cell_ids;       /* edges.cell_ids       [2*num_edges], right = -1 on the boundary */
+  const int32_t *edge_internal_ids;   /* edges.internal_edge_ids [num_internal_edges] */
+  const int64_t *edge_global_ids;     /* edges.global_ids     [num_edges] */
+  const double  *edge_lengths;        /* edges.lengths        [num_edges] */
+  const double  *edge_cn;             /* edges.cn             [num_edges] */
+  const double  *edge_sn;             /* edges.sn             [num_edges] */
+} RDyHipMesh;
+
+/* RDyBoundary (include/private/rdyboundaryimpl.h:7-14) + the flow condition
+ * type of the RDyCondition attached to it (include/private/rdyconditionimpl.h:12-24). */
+typedef struct {
+  int32_t        num_edges;
+  const int32_t *edge_ids; /* local edge ids, host, borrowed during create */
+  int32_t        condition_type; /* RDYHIP_CONDITION_* */
+} RDyHipBoundary;
+
+/* CourantNumberDiagnostics (include/private/rdyoperatorimpl.h:21-25) */
+typedef struct {
+  double  max_courant_num;
+  int64_t global_edge_id;
+  int64_t global_cell_id;
+} RDyHipCourant;
+
+/* opaque Operator (include/private/rdyoperatorimpl.h:103-201) */
+typedef struct RDyHipOperator_s *RDyHipOperator;
+
+/* device-resident operator fields that may be read (or, for inputs, written)
+ * in place; see rdyhip_field_ptr() */
+typedef enum {
+  RDYHIP_FIELD_PRIMITIVE_VARIABLES = 0, /* Operator.primitive_variables [owned][3] (h,u,v); out */
+  RDYHIP_FIELD_EXTERNAL_SOURCES    = 1, /* Operator.petsc.external_sources [owned][3]; in; also src_inst */
+  RDYHIP_FIELD_MANNINGS            = 2, /* Operator.petsc.material_properties [owned][1]; in */
+  RDYHIP_FIELD_FLUX_DIVERGENCE     = 3, /* Operator.flux_divergence [owned][3]; out, only if enabled */
+} RDyHipField;
+
+/* which cells a partial apply covers (multi-GPU overlap, see rdyhip_apply_phase) */
+#define RDYHIP_PHASE_ALL 0
+#define RDYHIP_PHASE_INTERIOR 1 /* owned cells with no ghost neighbour */
+#define RDYHIP_PHASE_HALO 2     /* owned cells with at least one ghost neighbour */
+
+const char *rdyhip_last_error(void);
+int32_t     rdyhip_version(void);
+
+/* ---- lifecycle -------------------------------------------------------------
+ * CreateOperator(RDyConfig*, DM, RDyMesh*, num_comp, num_regions, RDyRegion*,
+ *                num_boundaries, RDyBoundary*, RDyCondition*, Operator**)
+ *   include/private/rdyoperatorimpl.h:208, src/operator.c:348-417;
+ * together with CreatePetscSWEInteriorFluxOperator / ...BoundaryFluxOperator /
+ * ...SourceOperator (include/private/rdysweimpl.h:37-42, src/swe/swe_petsc.c:341,653,948).
+ * num_comp is fixed at 3 (SWE); regions only matter to the setters below.
+ * Repacks the mesh into the device layout and allocates the operator-owned
+ * vectors (boundary values/fluxes/accum, external sources, Manning n,
+ * primitive variables), all zero-initialised as in src/operator.c:91-129. */
+int rdyhip_create(const RDyHipConfig *config, const RDyHipMesh *mesh, int32_t num_boundaries, const RDyHipBoundary *boundaries,
+                  RDyHipOperator *op);
+
+/* DestroyOperator(Operator**)  include/private/rdyoperatorimpl.h:210, src/operator.c:421-493 */
+int rdyhip_destroy(RDyHipOperator *op);
+
+/* ---- the hot path -----------------------------------------------------------
+ * ApplyOperator(Operator*, PetscReal dt, Vec u_local, Vec f_global)
+ *   include/private/rdyoperatorimpl.h:213, src/operator.c:680-690 (-> ApplyPetscOperator 656-672).
+ * u_local: device, [num_cells][3] (h,hu,hv), ghosts filled by the caller.
+ * f_global: device, [num_owned_cells][3]; the operator ADDS into it exactly as
+ * the reference does, and the friction term sees the incoming content through
+ * the flux-divergence sum (src/operator.c:663). */
+int rdyhip_apply(RDyHipOperator op, double dt, const double *u_local, double *f_global, void *stream);
+
+/* OperatorRHSFunction's "VecZeroEntries(F); ResetOperatorDiagnostics; ApplyOperator"
+ *   src/rdysetup.c:1130,1136,1139 -- fused: f_global is overwritten (never read),
+ * diagnostics are reset on the stream first.  The halo update of u_local
+ * (rdysetup.c:1133-1134) stays with the caller. */
+int rdyhip_rhs_function(RDyHipOperator op, double dt, const double *u_local, double *f_global, void *stream);
+
+/* The same as rdyhip_rhs_function restricted to a subset of the owned cells, so
+ * that a caller can overlap the halo exchange with the interior cells:
+ *   reset_diagnostics; apply_phase(INTERIOR) || exchange; apply_phase(HALO).
+ * `overwrite` != 0 gives rdyhip_rhs_function semantics, 0 gives rdyhip_apply's.
+ * Does not reset diagnostics. */
+int rdyhip_apply_phase(RDyHipOperator op, int32_t phase, int32_t overwrite, double dt, const double *u_local, double *f_global,
+                       void *stream);
+
+/* ---- operator data (host-side setters, as in the reference) -----------------
+ * SetOperatorBoundaryValues(Operator*, RDyBoundary, comp_offset, num_comp, num_edges, values[num_comp*e+c])
+ *   include/private/rdyoperatorimpl.h:254, src/operator.c:1045-1061.  `values` is a host pointer. */
+int rdyhip_set_boundary_values(RDyHipOperator op, int32_t boundary, int32_t comp_offset, int32_t num_comp, int32_t num_edges,
+                               const double *values);
+
+/* ExtractOperatorBoundaryFluxes (include/private/rdyoperatorimpl.h:256): copies
+ * boundary_fluxes[b] or boundary_fluxes_accum[b] ([num_edges][3], src/operator.c:124-129) to the host. */
+int rdyhip_get_boundary_fluxes(RDyHipOperator op, int32_t boundary, int32_t accumulated, int32_t num_edges, double *fluxes);
+int rdyhip_reset_boundary_fluxes_accum(RDyHipOperator op);
+
+/* Get/RestoreOperator{Regional,Domain}ExternalSource (include/private/rdyoperatorimpl.h:258-261,
+ *   src/operator.c:1203-1241,1394-1429) as used by RDySet{Regional,Domain}{Water,XMomentum,YMomentum}Source
+ *   (src/rdydata.c:225-366): sets component `comp` of the external source of
+ *   `n` owned cells; owned_cell_ids == NULL means owned cells 0..n-1 (domain). Host pointers. */
+int rdyhip_set_external_source(RDyHipOperator op, int32_t comp, int32_t n, const int32_t *owned_cell_ids, const double *values);
+
+/* Get/RestoreOperator{Regional,Domain}MaterialProperties (rdyoperatorimpl.h:263-266)
+ *   as used by RDySet{Regional,Domain}ManningsN (src/rdydata.c:506-539). */
+int rdyhip_set_mannings(RDyHipOperator op, int32_t n, const int32_t *owned_cell_ids, const double *values);
+
+/* In-place access to the device-resident fields (no copy): e.g. a forcing
+ * kernel can write the external source on the GPU, an output routine can read
+ * primitive_variables (read by src/rdyadvance.c's averaging monitors). */
+int rdyhip_field_ptr(RDyHipOperator op, RDyHipField field, double **device_ptr, int64_t *num_values);
+/* keep Operator.flux_divergence (one extra [owned][3] store per apply); off by default */
+int rdyhip_enable_flux_divergence(RDyHipOperator op, int32_t enable);
+
+/* ---- diagnostics ------------------------------------------------------------
+ * ResetOperatorDiagnostics / UpdateOperatorDiagnostics / GetOperatorDiagnostics
+ *   include/private/rdyoperatorimpl.h:269-271, src/operator.c:772-784,867-893.
+ * reset is enqueued on `stream`; update synchronises `stream`, copies the
+ * 16-byte result to the host and resolves the edge/cell ids.  The cross-rank
+ * MPI_Allreduce of src/operator.c:879 stays with the caller (one struct). */
+int rdyhip_reset_diagnostics(RDyHipOperator op, void *stream);
+int rdyhip_update_diagnostics(RDyHipOperator op, void *stream);
+int rdyhip_get_diagnostics(RDyHipOperator op, RDyHipCourant *courant);
+
+/* ---- halo helpers (DMGlobalToLocalBegin/End, src/rdysetup.c:1133-1134) -------
+ * pack:   buf[i][0..2] = u_local[cell_ids[i]][0..2]   (cells a neighbour rank needs)
+ * unpack: u_local[cell_ids[i]][0..2] = buf[i][0..2]   (this rank's ghost cells)
+ * all device pointers; the transport between ranks (RCCL) is the caller's. */
+int rdyhip_pack_cells(const double *u_local, const int32_t *cell_ids, int32_t n, double *buf, void *stream);
+int rdyhip_unpack_cells(double *u_local, const int32_t *cell_ids, int32_t n, const double *buf, void *stream);
+
+/* ---- explicit update kept on the device (what TSEULER does between RHS calls)
+ * u_local[owned cell o] += dt * f_global[o]   (PETSc TSStep_Euler VecAXPY; the
+ * scatter from the global to the local vector is folded in). */
+int rdyhip_axpy_owned(RDyHipOperator op, double dt, const double *f_global, double *u_local, void *stream);
+
+/* ---- introspection ----------------------------------------------------------
+ * numbers describing the device layout, for DESIGN.md / bench.py */
+typedef struct {
+  int32_t num_owned_cells, num_cells, slots_per_cell, num_boundary_edges;
+  int32_t num_halo_cells;     /* owned cells with a ghost neighbour */
+  int32_t owned_is_prefix;    /* 1 if owned cell o is local cell o */
+  int64_t device_bytes;       /* bytes of device memory held by the operator */
+  int64_t bytes_per_apply;    /* bytes one full apply must move (layout-exact, not the 176 B/cell model) */
+} RDyHipLayoutInfo;
+int rdyhip_layout_info(RDyHipOperator op, RDyHipLayoutInfo *info);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RDYHIP_H */

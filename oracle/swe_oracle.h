@@ -1,0 +1,89 @@
+/*
+ * TEST INFRASTRUCTURE -- NOT PRODUCT CODE.
+ *
+ * CPU restatement, in plain C, of the arithmetic RDycore's PETSc backend runs
+ * for one shallow-water right-hand-side evaluation.  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this.
+ *
+ * Pinning: the reference's own build (PETSc + libCEED) is absent from this
+ * image, so the reference sources cannot be compiled here; this restatement is
+ * pinned by (1) the Roe-flux known-answer vectors recorded from the reference
+ * arithmetic in SURVEY.md section 8.a and (2) the reference's only accuracy
+ * gate for this path, the MMS convergence-rate thresholds of
+ * driver/tests/swe_roe/mms_conv_study.yaml:48-64 (tests/test_oracle_pins.py).
+ *
+ * Each function cites the reference file:line it follows (paths relative to
+ * the RDycore source tree).
+ */
+#ifndef SWE_ORACLE_H
+#define SWE_ORACLE_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* RDyConditionType, include/rdycore.h:133-139 */
+enum { ORACLE_BC_DIRICHLET = 0, ORACLE_BC_REFLECTING = 2, ORACLE_BC_CRITICAL_OUTFLOW = 3 };
+/* RDyFlowSourceMethod, include/private/rdyconfigimpl.h:52-56 */
+enum { ORACLE_SOURCE_SEMI_IMPLICIT = 0, ORACLE_SOURCE_IMPLICIT_XQ2018 = 1 };
+
+/* the RDyMesh fields the operators read (include/private/rdymeshimpl.h) */
+typedef struct {
+  int num_cells, num_owned_cells, num_edges, num_internal_edges;
+  const int       *is_owned;          /* cells.is_owned        [num_cells] */
+  const int       *local_to_owned;    /* cells.local_to_owned  [num_cells] */
+  const long long *cell_global_ids;   /* cells.global_ids      [num_cells] */
+  const double    *areas;             /* cells.areas           [num_cells] */
+  const double    *dz_dx, *dz_dy;     /* cells.dz_dx/dz_dy     [num_cells] */
+  const int       *cell_ids;          /* edges.cell_ids        [2*num_edges] */
+  const int       *internal_edge_ids; /* edges.internal_edge_ids [num_internal_edges] */
+  const long long *edge_global_ids;   /* edges.global_ids      [num_edges] */
+  const double    *lengths, *cn, *sn; /* edges.lengths/cn/sn   [num_edges] */
+} OracleMesh;
+
+typedef struct {
+  int        num_edges;
+  const int *edge_ids; /* RDyBoundary.edge_ids */
+  int        bc_type;  /* RDyCondition.flow->type */
+} OracleBoundary;
+
+typedef struct {
+  double tiny_h, h_anuga_regular, xq2018_threshold; /* RDyPhysicsFlow, rdyconfigimpl.h:74-85 */
+  int    source_method;
+} OracleConfig;
+
+/* CourantNumberDiagnostics, include/private/rdyoperatorimpl.h:21-25 */
+typedef struct {
+  double    max_courant_num;
+  long long global_edge_id, global_cell_id;
+} OracleCourant;
+
+typedef struct OracleOperator OracleOperator;
+
+/* CreateOperator (src/operator.c:348-417): allocates the per-sub-operator
+ * scratch and the operator-owned vectors.  The mesh arrays are borrowed. */
+OracleOperator *oracle_create(const OracleMesh *mesh, const OracleConfig *config, int num_boundaries, const OracleBoundary *boundaries);
+void            oracle_destroy(OracleOperator *op);
+
+/* ApplyPetscOperator (src/operator.c:656-672): f_global += flux divergence + sources. */
+int oracle_apply(OracleOperator *op, double dt, const double *u_local, double *f_global);
+
+/* operator-owned vectors (src/operator.c:91-129, 224-335) */
+double *oracle_boundary_values(OracleOperator *op, int b);       /* [num_edges][3] */
+double *oracle_boundary_fluxes(OracleOperator *op, int b);       /* [num_edges][3] */
+double *oracle_boundary_fluxes_accum(OracleOperator *op, int b); /* [num_edges][3] */
+double *oracle_external_sources(OracleOperator *op);             /* [owned][3] */
+double *oracle_material_properties(OracleOperator *op);          /* [owned][1] Manning n */
+double *oracle_flux_divergence(OracleOperator *op);              /* [owned][3] */
+double *oracle_primitive_variables(OracleOperator *op);          /* [owned][3] */
+
+void oracle_reset_diagnostics(OracleOperator *op); /* ResetOperatorDiagnostics, src/operator.c:772-784 */
+void oracle_get_diagnostics(OracleOperator *op, OracleCourant *out);
+
+/* ComputeSWERoeFlux for one edge (src/swe/swe_roe_flux_petsc.h:91-132) */
+void oracle_roe_flux(double hl, double ul, double vl, double hr, double ur, double vr, double sn, double cn, double fij[3], double *amax);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

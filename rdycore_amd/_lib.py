@@ -1,0 +1,111 @@
+"""ctypes binding of the C ABI in include/rdyhip.h.
+
+There is deliberately no fallback: if librdyhip.so is missing or fails to
+load, importing the operator fails loudly (the product path is the HIP
+extension or nothing).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from . import build as _build
+
+c_double_p = C.POINTER(C.c_double)
+c_int32_p = C.POINTER(C.c_int32)
+c_int64_p = C.POINTER(C.c_int64)
+
+
+class RDyHipConfig(C.Structure):
+    _fields_ = [("tiny_h", C.c_double), ("h_anuga_regular", C.c_double), ("xq2018_threshold", C.c_double),
+                ("source_method", C.c_int32), ("riemann", C.c_int32)]
+
+
+class RDyHipMesh(C.Structure):
+    _fields_ = [
+        ("num_cells", C.c_int32), ("num_owned_cells", C.c_int32), ("num_edges", C.c_int32), ("num_internal_edges", C.c_int32),
+        ("cell_is_owned", c_int32_p), ("cell_local_to_owned", c_int32_p), ("cell_global_ids", c_int64_p),
+        ("cell_areas", c_double_p), ("cell_dz_dx", c_double_p), ("cell_dz_dy", c_double_p),
+        ("edge_cell_ids", c_int32_p), ("edge_internal_ids", c_int32_p), ("edge_global_ids", c_int64_p),
+        ("edge_lengths", c_double_p), ("edge_cn", c_double_p), ("edge_sn", c_double_p),
+    ]
+
+
+class RDyHipBoundary(C.Structure):
+    _fields_ = [("num_edges", C.c_int32), ("edge_ids", c_int32_p), ("condition_type", C.c_int32)]
+
+
+class RDyHipCourant(C.Structure):
+    _fields_ = [("max_courant_num", C.c_double), ("global_edge_id", C.c_int64), ("global_cell_id", C.c_int64)]
+
+
+class RDyHipLayoutInfo(C.Structure):
+    _fields_ = [("num_owned_cells", C.c_int32), ("num_cells", C.c_int32), ("slots_per_cell", C.c_int32),
+                ("num_boundary_edges", C.c_int32), ("num_halo_cells", C.c_int32), ("owned_is_prefix", C.c_int32),
+                ("device_bytes", C.c_int64), ("bytes_per_apply", C.c_int64)]
+
+
+# every symbol include/rdyhip.h declares: name -> (restype, argtypes)
+_H = C.c_void_p  # RDyHipOperator
+SYMBOLS = {
+    "rdyhip_last_error": (C.c_char_p, []),
+    "rdyhip_version": (C.c_int32, []),
+    "rdyhip_create": (C.c_int, [C.POINTER(RDyHipConfig), C.POINTER(RDyHipMesh), C.c_int32, C.POINTER(RDyHipBoundary), C.POINTER(_H)]),
+    "rdyhip_destroy": (C.c_int, [C.POINTER(_H)]),
+    "rdyhip_apply": (C.c_int, [_H, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rdyhip_rhs_function": (C.c_int, [_H, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rdyhip_apply_phase": (C.c_int, [_H, C.c_int32, C.c_int32, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rdyhip_set_boundary_values": (C.c_int, [_H, C.c_int32, C.c_int32, C.c_int32, C.c_int32, c_double_p]),
+    "rdyhip_get_boundary_fluxes": (C.c_int, [_H, C.c_int32, C.c_int32, C.c_int32, c_double_p]),
+    "rdyhip_reset_boundary_fluxes_accum": (C.c_int, [_H]),
+    "rdyhip_set_external_source": (C.c_int, [_H, C.c_int32, C.c_int32, c_int32_p, c_double_p]),
+    "rdyhip_set_mannings": (C.c_int, [_H, C.c_int32, c_int32_p, c_double_p]),
+    "rdyhip_field_ptr": (C.c_int, [_H, C.c_int, C.POINTER(C.c_void_p), c_int64_p]),
+    "rdyhip_enable_flux_divergence": (C.c_int, [_H, C.c_int32]),
+    "rdyhip_reset_diagnostics": (C.c_int, [_H, C.c_void_p]),
+    "rdyhip_update_diagnostics": (C.c_int, [_H, C.c_void_p]),
+    "rdyhip_get_diagnostics": (C.c_int, [_H, C.POINTER(RDyHipCourant)]),
+    "rdyhip_pack_cells": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "rdyhip_unpack_cells": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "rdyhip_axpy_owned": (C.c_int, [_H, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rdyhip_layout_info": (C.c_int, [_H, C.POINTER(RDyHipLayoutInfo)]),
+}
+
+_LIB = None
+
+
+class RDyHipError(RuntimeError):
+    """A non-zero return code from the C ABI (PETSc-valued error codes)."""
+
+    def __init__(self, code: int, message: str):
+        super().__init__(f"rdyhip error {code}: {message}")
+        self.code = code
+        self.message = message
+
+
+def load(build_if_missing: bool = False):
+    """dlopen rdycore_amd/csrc/librdyhip.so and bind every declared symbol."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = _build.lib_path()
+    if not os.path.exists(path):
+        if build_if_missing:
+            _build.build_native()
+        else:
+            raise ImportError(
+                f"{path} not found: the HIP extension is required (run `python -m rdycore_amd.build` or "
+                "__graft_entry__.build()); there is no CPU fallback for the operator")
+    lib = C.CDLL(path)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export it
+        fn.restype = res
+        fn.argtypes = args
+    _LIB = lib
+    return lib
+
+
+def check(rc: int):
+    if rc != 0:
+        msg = load().rdyhip_last_error()
+        raise RDyHipError(rc, msg.decode() if msg else "")

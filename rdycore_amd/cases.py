@@ -1,0 +1,107 @@
+"""Synthetic workloads for the SWE right-hand side:
+states, bathymetry, Manning fields and boundary data on the meshes of mesh.py.
+Shared by bench.py and the tests; numpy only.
+"""
+from __future__ import annotations
+
+import dataclasses
+from typing import Dict, List, Optional
+
+import numpy as np
+
+from .mesh import (CONDITION_CRITICAL_OUTFLOW, CONDITION_DIRICHLET, CONDITION_REFLECTING, RDyMesh)
+from .operator import RDyFlowConfig, SOURCE_IMPLICIT_XQ2018, SOURCE_SEMI_IMPLICIT
+
+
+@dataclasses.dataclass
+class Case:
+    name: str
+    mesh: RDyMesh
+    config: RDyFlowConfig
+    condition_types: List[int]
+    u_local: np.ndarray                 # [num_cells,3]
+    mannings: np.ndarray                # [num_owned]
+    ext_src: np.ndarray                 # [num_owned,3]
+    boundary_values: Dict[int, np.ndarray]   # boundary index -> [num_edges,3]
+    dt: float
+
+
+def mms_fields(x, y, H=1.0, U=0.5, V=0.5, N=0.02, K=2 * np.pi / 200.0):
+    """t=0 fields of driver/tests/swe_roe/mms_conv_study.yaml:11-46, rescaled."""
+    s, c = np.sin, np.cos
+    h = H * (1 + s(K * x) * s(K * y))
+    u = U * c(K * x) * s(K * y)
+    v = V * s(K * x) * c(K * y)
+    n = N * (1 + s(K * x) * s(K * y))
+    return h, u, v, n
+
+
+def mms_bathymetry(Z=0.25, K=2 * np.pi / 200.0):
+    return lambda x, y: Z * np.sin(K * x) * np.sin(K * y)
+
+
+def dam_break_case(mesh: RDyMesh, lx: float, dt: float = 1e-3, perturb: float = 0.01, seed: int = 12345,
+                   source_method: int = SOURCE_SEMI_IMPLICIT) -> Case:
+    """C2: flat-bed dam break, h = 10 (x < lx/2) / 5, Manning 0.015 (ex2b.yaml:58,84-93),
+    all-reflecting boundaries.  hu, hv get a small seeded perturbation so the
+    fluxes are not trivially symmetric."""
+    xc = mesh.cell_centroids[:, 0]
+    yc = mesh.cell_centroids[:, 1]
+    u = np.zeros((mesh.num_cells, 3))
+    u[:, 0] = np.where(xc < 0.5 * lx, 10.0, 5.0)
+    if perturb:
+        # a smooth, partition-independent perturbation (depends on position only)
+        u[:, 1] = perturb * u[:, 0] * np.sin(0.37 * xc + 0.11 * yc + seed % 7)
+        u[:, 2] = perturb * u[:, 0] * np.cos(0.23 * xc - 0.19 * yc + seed % 5)
+    no = mesh.num_owned_cells
+    return Case("dam_break", mesh, RDyFlowConfig(source_method=source_method), [CONDITION_REFLECTING] * len(mesh.boundaries), u,
+                np.full(no, 0.015), np.zeros((no, 3)), {}, dt)
+
+
+def friction_slope_case(mesh: RDyMesh, lx: float, ly: float, dt: float = 1e-3,
+                        source_method: int = SOURCE_SEMI_IMPLICIT, dry_disc: bool = True,
+                        K: Optional[float] = None) -> Case:
+    """C3: MMS-style analytic state over sinusoidal bathymetry (the mesh must
+    have been built with zfunc=mms_bathymetry(K=K)), Manning field, rain-like
+    water source 1e-5, a dry disc, and one boundary of each type:
+    left = Dirichlet (analytic state), right = critical outflow, rest reflecting."""
+    K = 2 * np.pi / 200.0 if K is None else K
+    xc = mesh.cell_centroids[:, 0]
+    yc = mesh.cell_centroids[:, 1]
+    h, uu, vv, _ = mms_fields(xc, yc, K=K)
+    if dry_disc:
+        r2 = (xc - 0.5 * lx) ** 2 + (yc - 0.5 * ly) ** 2
+        h = np.where(r2 < (0.1 * ly) ** 2, 0.0, h)
+    u = np.stack([h, h * uu, h * vv], axis=1)
+    oc = mesh.owned_centroids()
+    _, _, _, n = mms_fields(oc[:, 0], oc[:, 1], K=K)
+    no = mesh.num_owned_cells
+    src = np.zeros((no, 3))
+    src[:, 0] = 1e-5
+    ctypes: List[int] = []
+    bvals: Dict[int, np.ndarray] = {}
+    for i, b in enumerate(mesh.boundaries):
+        if b.name == "left":
+            ctypes.append(CONDITION_DIRICHLET)
+            ec = mesh.edge_centroids[b.edge_ids]
+            hb, ub, vb, _ = mms_fields(ec[:, 0], ec[:, 1], K=K)
+            bvals[i] = np.stack([hb, hb * ub, hb * vb], axis=1)
+        elif b.name == "right":
+            ctypes.append(CONDITION_CRITICAL_OUTFLOW)
+        else:
+            ctypes.append(CONDITION_REFLECTING)
+    return Case("friction_slope", mesh, RDyFlowConfig(source_method=source_method), ctypes, u, n, src, bvals, dt)
+
+
+def create_operator(case: Case):
+    """CreateOperator + the data setters the reference's setup calls
+    (InitMaterialProperties / InitSourceConditions / InitDirichletBoundaryConditions,
+    src/rdysetup.c:1546-1555), for a Case."""
+    from .operator import Operator
+    op = Operator.create(case.config, case.mesh, case.condition_types)
+    op.set_domain_mannings_n(case.mannings)
+    for comp in range(3):
+        op.set_domain_external_source(comp, case.ext_src[:, comp])
+    for b, vals in case.boundary_values.items():
+        op.set_boundary_values(b, vals)
+    return op

@@ -1,0 +1,626 @@
+"""Finite-volume view of a 2-D unstructured mesh, laid out like RDycore's RDyMesh.
+
+This is the host-side stand-in for what the reference builds from a PETSc DMPlex
+(`RDyMeshCreateFromDM`, src/rdymesh.c:1401).  DMPlex itself is out of scope
+(SURVEY.md section 2, rows 8/9); what the SWE operator consumes is only the
+struct-of-arrays below, whose names and conventions follow
+include/private/rdymeshimpl.h:26-202:
+
+* `cell_ids[2e]` is the "left" cell of edge e (always >= 0), `cell_ids[2e+1]`
+  the "right" cell or -1 on the domain boundary (rdymeshimpl.h:119-122).
+* the edge's vertices are ordered so that the clockwise perpendicular of
+  v1->v2 points from left to right; `sn = -dx/ds`, `cn = dy/ds`
+  (src/rdymesh.c:607-688) -- `(cn, sn)` is the unit normal left->right.
+* `dz_dx`, `dz_dy`: plane through a triangle's vertices (src/rdymesh.c:747-784);
+  quads use the area-weighted mean over the 4 (edge, centroid) sub-triangles
+  (src/rdymesh.c:822-858).
+* `local_to_owned` numbers owned cells 0..num_owned-1 in local order and the
+  ghosts after them (src/rdymesh.c:159-177).
+
+Everything here is numpy; the arrays are handed to the C-ABI (include/rdyhip.h)
+and, in tests only, to the CPU oracle.
+"""
+from __future__ import annotations
+
+import dataclasses
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+# RDyConditionType, include/rdycore.h:133-139
+CONDITION_DIRICHLET = 0
+CONDITION_NEUMANN = 1
+CONDITION_REFLECTING = 2
+CONDITION_CRITICAL_OUTFLOW = 3
+
+
+@dataclasses.dataclass
+class RDyBoundary:
+    """include/private/rdyboundaryimpl.h:7-14 (id, name, edge_ids)."""
+    id: int
+    name: str
+    edge_ids: np.ndarray  # int32 local edge ids
+
+    @property
+    def num_edges(self) -> int:
+        return int(self.edge_ids.shape[0])
+
+
+@dataclasses.dataclass
+class RDyMesh:
+    # counts (rdymeshimpl.h:152-170)
+    num_cells: int
+    num_owned_cells: int
+    num_cells_global: int
+    num_edges: int
+    num_internal_edges: int
+    num_boundary_edges: int
+    num_vertices: int
+    # vertices
+    xyz: np.ndarray            # [Nv,3]
+    # cells (local index)
+    cell_conn: np.ndarray      # [Nc,4] int32 vertex ids, -1 pad for triangles
+    cell_nverts: np.ndarray    # [Nc] int32
+    cell_is_owned: np.ndarray  # [Nc] int32 (PetscBool)
+    cell_local_to_owned: np.ndarray  # [Nc] int32
+    cell_owned_to_local: np.ndarray  # [Nowned] int32
+    cell_global_ids: np.ndarray      # [Nc] int64
+    cell_centroids: np.ndarray       # [Nc,3]
+    cell_areas: np.ndarray           # [Nc]
+    cell_dz_dx: np.ndarray           # [Nc]
+    cell_dz_dy: np.ndarray           # [Nc]
+    # edges (local index)
+    edge_cell_ids: np.ndarray        # [2*Ne] int32
+    edge_vertex_ids: np.ndarray      # [Ne,2] int32 (oriented)
+    edge_internal_ids: np.ndarray    # [Ni] int32   (edges.internal_edge_ids)
+    edge_boundary_ids: np.ndarray    # [Nb] int32   (edges.boundary_edge_ids)
+    edge_global_ids: np.ndarray      # [Ne] int64
+    edge_lengths: np.ndarray         # [Ne]
+    edge_cn: np.ndarray              # [Ne]
+    edge_sn: np.ndarray              # [Ne]
+    edge_centroids: np.ndarray       # [Ne,3]
+    boundaries: List[RDyBoundary] = dataclasses.field(default_factory=list)
+
+    # ---- convenience -----------------------------------------------------
+    def owned_centroids(self) -> np.ndarray:
+        return self.cell_centroids[self.cell_owned_to_local]
+
+    def boundary_by_name(self, name: str) -> int:
+        for i, b in enumerate(self.boundaries):
+            if b.name == name:
+                return i
+        raise KeyError(name)
+
+
+# ---------------------------------------------------------------------------
+# geometry helpers
+# ---------------------------------------------------------------------------
+
+def _tri_slopes(p0, p1, p2):
+    """ComputeXYSlopesForTriangle, src/rdymesh.c:747-784 (vectorised)."""
+    x0, y0, z0 = p0[:, 0], p0[:, 1], p0[:, 2]
+    # AreVerticesOrientedCounterClockwise, src/rdymesh.c:720-737
+    ccw = (p1[:, 1] - y0) * (p2[:, 0] - p1[:, 0]) - (p2[:, 1] - p1[:, 1]) * (p1[:, 0] - x0) < 0
+    a = np.where(ccw[:, None], p1, p2)
+    b = np.where(ccw[:, None], p2, p1)
+    x1, y1, z1 = a[:, 0], a[:, 1], a[:, 2]
+    x2, y2, z2 = b[:, 0], b[:, 1], b[:, 2]
+    num = (y2 - y0) * (z1 - z0) - (y1 - y0) * (z2 - z0)
+    den = (y2 - y0) * (x1 - x0) - (y1 - y0) * (x2 - x0)
+    dzdx = num / den
+    num = (x2 - x0) * (z1 - z0) - (x1 - x0) * (z2 - z0)
+    den = (x2 - x0) * (y1 - y0) - (x1 - x0) * (y2 - y0)
+    dzdy = num / den
+    return dzdx, dzdy
+
+
+def _tri_area3(a, b, c):
+    return 0.5 * np.linalg.norm(np.cross(b - a, c - a), axis=1)
+
+
+def _tri_area2(a, b, c):
+    """TriangleProjected2DArea, src/rdymesh.c:786-797."""
+    e1 = b - a
+    e2 = c - a
+    return 0.5 * np.abs(e1[:, 0] * e2[:, 1] - e1[:, 1] * e2[:, 0])
+
+
+def _cell_geometry(xyz, conn, nverts):
+    """Cell centroids, areas and bed slopes.
+
+    Areas/centroids stand in for DMPlexComputeCellGeometryFVM (src/rdymesh.c:119):
+    a triangle's centroid is the vertex mean and its area the 3-D triangle area;
+    a quad is split into the fan (v0,v1,v2),(v0,v2,v3), area = sum, centroid =
+    area-weighted mean of the two triangle centroids.  Exact for planar cells.
+    """
+    nc = conn.shape[0]
+    cent = np.zeros((nc, 3))
+    area = np.zeros(nc)
+    dzdx = np.zeros(nc)
+    dzdy = np.zeros(nc)
+    tri = np.nonzero(nverts == 3)[0]
+    quad = np.nonzero(nverts == 4)[0]
+    if tri.size:
+        p0, p1, p2 = (xyz[conn[tri, k]] for k in range(3))
+        cent[tri] = (p0 + p1 + p2) / 3.0
+        area[tri] = _tri_area3(p0, p1, p2)
+        dzdx[tri], dzdy[tri] = _tri_slopes(p0, p1, p2)
+    if quad.size:
+        p = [xyz[conn[quad, k]] for k in range(4)]
+        a1 = _tri_area3(p[0], p[1], p[2])
+        a2 = _tri_area3(p[0], p[2], p[3])
+        c1 = (p[0] + p[1] + p[2]) / 3.0
+        c2 = (p[0] + p[2] + p[3]) / 3.0
+        area[quad] = a1 + a2
+        cq = (c1 * a1[:, None] + c2 * a2[:, None]) / (a1 + a2)[:, None]
+        cent[quad] = cq
+        # src/rdymesh.c:822-858
+        sx = np.zeros(quad.size)
+        sy = np.zeros(quad.size)
+        tot = np.zeros(quad.size)
+        for k in range(4):
+            a, b = p[k], p[(k + 1) % 4]
+            ak = _tri_area2(a, b, cq)
+            gx, gy = _tri_slopes(a, b, cq)
+            sx += ak * gx
+            sy += ak * gy
+            tot += ak
+        dzdx[quad] = sx / tot
+        dzdy[quad] = sy / tot
+    return cent, area, dzdx, dzdy
+
+
+# ---------------------------------------------------------------------------
+# generic builder
+# ---------------------------------------------------------------------------
+
+def build_mesh(xyz: np.ndarray, conn: np.ndarray,
+               is_owned: Optional[np.ndarray] = None,
+               cell_global_ids: Optional[np.ndarray] = None,
+               num_cells_global: Optional[int] = None,
+               boundary_classifier: Optional[Callable[["RDyMesh"], List[RDyBoundary]]] = None,
+               ) -> RDyMesh:
+    """Build the RDyMesh arrays from vertices + cell->vertex connectivity.
+
+    `conn` is [Nc,3] or [Nc,4] (pad triangles with -1 in a mixed mesh).
+    Edge e's left cell is the lower-numbered of its two cells; edges are
+    numbered in order of first appearance while walking the cells.
+    """
+    xyz = np.ascontiguousarray(xyz, dtype=np.float64)
+    conn = np.asarray(conn)
+    if conn.shape[1] == 3:
+        conn = np.concatenate([conn, -np.ones((conn.shape[0], 1), conn.dtype)], axis=1)
+    conn = np.ascontiguousarray(conn, dtype=np.int32)
+    nc = conn.shape[0]
+    nv = xyz.shape[0]
+    nverts = (conn >= 0).sum(axis=1).astype(np.int32)
+
+    cent, area, dzdx, dzdy = _cell_geometry(xyz, conn, nverts)
+
+    # ---- sides -> edges --------------------------------------------------
+    j = np.arange(4)
+    va = conn                                        # [Nc,4]
+    nxt = (j[None, :] + 1) % nverts[:, None]         # wrap per cell
+    vb = np.take_along_axis(conn, nxt.astype(np.int64), axis=1)
+    valid = conn >= 0
+    side_cell = np.broadcast_to(np.arange(nc, dtype=np.int32)[:, None], (nc, 4))[valid]
+    sa = va[valid].astype(np.int64)
+    sb = vb[valid].astype(np.int64)
+    key = np.minimum(sa, sb) * nv + np.maximum(sa, sb)
+    order = np.argsort(key, kind="stable")
+    ks = key[order]
+    newgrp = np.ones(ks.shape[0], dtype=bool)
+    newgrp[1:] = ks[1:] != ks[:-1]
+    gid_sorted = np.cumsum(newgrp) - 1
+    ngroups = int(gid_sorted[-1]) + 1 if ks.size else 0
+    first_side = order[newgrp]                       # lowest side index of each group
+    perm = np.argsort(first_side, kind="stable")
+    rank = np.empty(ngroups, dtype=np.int64)
+    rank[perm] = np.arange(ngroups)
+    ne = ngroups
+    # second member of each group (if any)
+    grp_start = np.nonzero(newgrp)[0]
+    grp_size = np.diff(np.append(grp_start, ks.shape[0]))
+    if np.any(grp_size > 2):
+        raise ValueError("non-manifold mesh: an edge is shared by more than two cells")
+    second_side = np.full(ngroups, -1, dtype=np.int64)
+    has2 = grp_size == 2
+    second_side[has2] = order[grp_start[has2] + 1]
+
+    edge_first = np.empty(ne, dtype=np.int64)
+    edge_second = np.empty(ne, dtype=np.int64)
+    edge_first[rank] = first_side
+    edge_second[rank] = second_side
+
+    left = side_cell[edge_first].astype(np.int32)
+    right = np.where(edge_second >= 0, side_cell[np.maximum(edge_second, 0)], -1).astype(np.int32)
+    v1 = sa[edge_first].astype(np.int32)
+    v2 = sb[edge_first].astype(np.int32)
+
+    # ---- orientation, cn/sn (src/rdymesh.c:607-688) ------------------------
+    par = xyz[v2, :2] - xyz[v1, :2]
+    mid = 0.5 * (xyz[v1] + xyz[v2])
+    internal = right >= 0
+    tgt = np.where(internal[:, None], cent[np.maximum(right, 0), :2], mid[:, :2])
+    vec = tgt - cent[left, :2]
+    perp = np.stack([par[:, 1], -par[:, 0]], axis=1)
+    flip = (vec * perp).sum(axis=1) < 0.0
+    v1f = np.where(flip, v2, v1)
+    v2f = np.where(flip, v1, v2)
+    dx = xyz[v2f, 0] - xyz[v1f, 0]
+    dy = xyz[v2f, 1] - xyz[v1f, 1]
+    ds = np.sqrt(dx * dx + dy * dy)
+    sn = -dx / ds
+    cn = dy / ds
+    lengths = np.linalg.norm(xyz[v2f] - xyz[v1f], axis=1)
+
+    cell_ids = np.empty(2 * ne, dtype=np.int32)
+    cell_ids[0::2] = left
+    cell_ids[1::2] = right
+    internal_ids = np.nonzero(internal)[0].astype(np.int32)
+    boundary_ids = np.nonzero(~internal)[0].astype(np.int32)
+
+    # ---- ownership -------------------------------------------------------
+    if is_owned is None:
+        is_owned = np.ones(nc, dtype=np.int32)
+    is_owned = np.ascontiguousarray(is_owned, dtype=np.int32)
+    owned = np.nonzero(is_owned)[0].astype(np.int32)
+    ghost = np.nonzero(is_owned == 0)[0].astype(np.int32)
+    l2o = np.empty(nc, dtype=np.int32)
+    l2o[owned] = np.arange(owned.size, dtype=np.int32)
+    l2o[ghost] = owned.size + np.arange(ghost.size, dtype=np.int32)
+    if cell_global_ids is None:
+        cell_global_ids = np.arange(nc, dtype=np.int64)
+    if num_cells_global is None:
+        num_cells_global = int(nc)
+
+    mesh = RDyMesh(
+        num_cells=nc, num_owned_cells=int(owned.size), num_cells_global=int(num_cells_global),
+        num_edges=ne, num_internal_edges=int(internal_ids.size),
+        num_boundary_edges=int(boundary_ids.size), num_vertices=nv,
+        xyz=xyz, cell_conn=conn, cell_nverts=nverts, cell_is_owned=is_owned,
+        cell_local_to_owned=l2o, cell_owned_to_local=owned,
+        cell_global_ids=np.ascontiguousarray(cell_global_ids, dtype=np.int64),
+        cell_centroids=cent, cell_areas=area, cell_dz_dx=dzdx, cell_dz_dy=dzdy,
+        edge_cell_ids=cell_ids,
+        edge_vertex_ids=np.stack([v1f, v2f], axis=1).astype(np.int32),
+        edge_internal_ids=internal_ids, edge_boundary_ids=boundary_ids,
+        edge_global_ids=np.arange(ne, dtype=np.int64),
+        edge_lengths=lengths, edge_cn=cn, edge_sn=sn, edge_centroids=mid,
+    )
+    if boundary_classifier is not None:
+        mesh.boundaries = boundary_classifier(mesh)
+    return mesh
+
+
+def single_boundary(name: str = "domain_boundary", bid: int = 1):
+    """All domain-boundary edges whose left cell exists, as one boundary."""
+    def f(mesh: RDyMesh) -> List[RDyBoundary]:
+        return [RDyBoundary(bid, name, mesh.edge_boundary_ids.copy())]
+    return f
+
+
+def box_side_boundaries(x0: float, x1: float, y0: float, y1: float, tol: float = 1e-9):
+    """Four boundaries (left, right, bottom, top) of a rectangular domain.
+
+    Only edges lying on the rectangle's sides are classified, so the
+    artificial outer edges of ghost cells in a partitioned mesh belong to no
+    boundary (as edges outside the DMPlex boundary label are in the reference).
+    """
+    def f(mesh: RDyMesh) -> List[RDyBoundary]:
+        be = mesh.edge_boundary_ids
+        a = mesh.xyz[mesh.edge_vertex_ids[be, 0]]
+        b = mesh.xyz[mesh.edge_vertex_ids[be, 1]]
+        out = []
+        sel = [
+            ("left", (np.abs(a[:, 0] - x0) < tol) & (np.abs(b[:, 0] - x0) < tol)),
+            ("right", (np.abs(a[:, 0] - x1) < tol) & (np.abs(b[:, 0] - x1) < tol)),
+            ("bottom", (np.abs(a[:, 1] - y0) < tol) & (np.abs(b[:, 1] - y0) < tol)),
+            ("top", (np.abs(a[:, 1] - y1) < tol) & (np.abs(b[:, 1] - y1) < tol)),
+        ]
+        for i, (name, m) in enumerate(sel):
+            out.append(RDyBoundary(i + 1, name, be[m].astype(np.int32)))
+        return out
+    return f
+
+
+# ---------------------------------------------------------------------------
+# generators
+# ---------------------------------------------------------------------------
+
+def structured_tri_connectivity(nx: int, ny: int, d: float = 1.0, i0: int = 0,
+                                x_origin: float = 0.0, order: str = "rowmajor",
+                                tile: int = 16):
+    """Vertices + triangles for an nx x ny block of squares split in two by
+    alternating diagonals (SURVEY.md section 8.d "Synthetic mesh").
+
+    `i0` is the global column index of the block's first column (the diagonal
+    parity and x coordinates follow the global index so strips of a larger
+    mesh match).  `order` is the cell numbering: "rowmajor" (quads row by row,
+    two triangles each) or "tiled" (tile x tile blocks of quads, row-major
+    inside a block) -- a locality-preserving numbering a mesh generator or
+    a DMPlex reordering would give.
+    Returns xyz [Nv,3], conn [Nc,3], quad_of_cell [Nc], (qi, qj) of each cell.
+    """
+    ii, jj = np.meshgrid(np.arange(nx + 1), np.arange(ny + 1), indexing="xy")  # [ny+1, nx+1]
+    xyz = np.zeros(((nx + 1) * (ny + 1), 3))
+    xyz[:, 0] = x_origin + (ii.ravel() + i0) * d
+    xyz[:, 1] = jj.ravel() * d
+
+    def vid(i, j):
+        return j * (nx + 1) + i
+
+    qi, qj = np.meshgrid(np.arange(nx), np.arange(ny), indexing="xy")
+    qi = qi.ravel()
+    qj = qj.ravel()
+    if order == "tiled":
+        key = ((qj // tile) * ((nx + tile - 1) // tile) + (qi // tile)) * (tile * tile) + (qj % tile) * tile + (qi % tile)
+        perm = np.argsort(key, kind="stable")
+        qi = qi[perm]
+        qj = qj[perm]
+    elif order != "rowmajor":
+        raise ValueError(order)
+    v00 = vid(qi, qj)
+    v10 = vid(qi + 1, qj)
+    v11 = vid(qi + 1, qj + 1)
+    v01 = vid(qi, qj + 1)
+    par = ((qi + i0 + qj) % 2) == 0
+    # parity 0: diagonal v00-v11 ; parity 1: diagonal v10-v01 (both triangles CCW)
+    t0 = np.where(par[:, None], np.stack([v00, v10, v11], 1), np.stack([v00, v10, v01], 1))
+    t1 = np.where(par[:, None], np.stack([v00, v11, v01], 1), np.stack([v10, v11, v01], 1))
+    conn = np.empty((2 * qi.size, 3), dtype=np.int32)
+    conn[0::2] = t0
+    conn[1::2] = t1
+    cqi = np.repeat(qi, 2)
+    cqj = np.repeat(qj, 2)
+    return xyz, conn, cqi, cqj
+
+
+def structured_tri_mesh(nx: int, ny: int, d: float = 1.0,
+                        zfunc: Optional[Callable[[np.ndarray, np.ndarray], np.ndarray]] = None,
+                        order: str = "rowmajor", tile: int = 16,
+                        boundaries: str = "sides") -> RDyMesh:
+    """Single-rank synthetic triangle mesh on [0,nx*d] x [0,ny*d]."""
+    xyz, conn, _, _ = structured_tri_connectivity(nx, ny, d, order=order, tile=tile)
+    if zfunc is not None:
+        xyz[:, 2] = zfunc(xyz[:, 0], xyz[:, 1])
+    cls = box_side_boundaries(0.0, nx * d, 0.0, ny * d) if boundaries == "sides" else single_boundary()
+    return build_mesh(xyz, conn, boundary_classifier=cls)
+
+
+def structured_quad_mesh(nx: int, ny: int, dx: float = 1.0, dy: float = 1.0,
+                         zfunc=None, boundaries: str = "sides") -> RDyMesh:
+    ii, jj = np.meshgrid(np.arange(nx + 1), np.arange(ny + 1), indexing="xy")
+    xyz = np.zeros(((nx + 1) * (ny + 1), 3))
+    xyz[:, 0] = ii.ravel() * dx
+    xyz[:, 1] = jj.ravel() * dy
+    if zfunc is not None:
+        xyz[:, 2] = zfunc(xyz[:, 0], xyz[:, 1])
+    qi, qj = np.meshgrid(np.arange(nx), np.arange(ny), indexing="xy")
+    qi = qi.ravel()
+    qj = qj.ravel()
+    v = lambda i, j: j * (nx + 1) + i
+    conn = np.stack([v(qi, qj), v(qi + 1, qj), v(qi + 1, qj + 1), v(qi, qj + 1)], 1).astype(np.int32)
+    cls = box_side_boundaries(0.0, nx * dx, 0.0, ny * dy) if boundaries == "sides" else single_boundary()
+    return build_mesh(xyz, conn, boundary_classifier=cls)
+
+
+def refine_triangles(xyz: np.ndarray, conn: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+    """Regular refinement: every triangle -> 4 by edge midpoints (what
+    `-dm_refine` does to a simplex DMPlex, used by src/rdymms.c:945-948)."""
+    conn = np.asarray(conn)[:, :3].astype(np.int64)
+    nv = xyz.shape[0]
+    a = np.concatenate([conn[:, 0], conn[:, 1], conn[:, 2]])
+    b = np.concatenate([conn[:, 1], conn[:, 2], conn[:, 0]])
+    key = np.minimum(a, b) * nv + np.maximum(a, b)
+    uk, inv = np.unique(key, return_inverse=True)
+    lo = uk // nv
+    hi = uk % nv
+    mid = 0.5 * (xyz[lo] + xyz[hi])
+    new_xyz = np.concatenate([xyz, mid], axis=0)
+    nc = conn.shape[0]
+    m01 = nv + inv[0:nc]
+    m12 = nv + inv[nc:2 * nc]
+    m20 = nv + inv[2 * nc:3 * nc]
+    v0, v1, v2 = conn[:, 0], conn[:, 1], conn[:, 2]
+    new_conn = np.empty((4 * nc, 3), dtype=np.int32)
+    new_conn[0::4] = np.stack([v0, m01, m20], 1)
+    new_conn[1::4] = np.stack([m01, v1, m12], 1)
+    new_conn[2::4] = np.stack([m20, m12, v2], 1)
+    new_conn[3::4] = np.stack([m01, m12, m20], 1)
+    return new_xyz, new_conn
+
+
+# ---------------------------------------------------------------------------
+# partitioning: owned cells + 1 layer of edge-adjacent ghosts
+# ---------------------------------------------------------------------------
+
+def extract_local_mesh(xyz: np.ndarray, conn: np.ndarray, owned_mask: np.ndarray,
+                       cell_global_ids: Optional[np.ndarray] = None,
+                       num_cells_global: Optional[int] = None,
+                       boundary_classifier=None,
+                       ghosts: str = "tail") -> RDyMesh:
+    """Local mesh of one rank: the cells flagged in `owned_mask` plus every
+    cell sharing an edge with one of them (the 1-cell overlap of
+    DMPlexDistributeOverlap(dm, 1, ...), src/rdydm.c:145-157, under edge
+    adjacency, which is all a first-order flux needs).
+
+    `ghosts="tail"` numbers ghosts after the owned cells; "interleaved" keeps
+    the source order (owned and ghost cells mixed, as a DMPlex local numbering
+    may be).
+    """
+    conn = np.asarray(conn)
+    if conn.shape[1] == 3:
+        conn = np.concatenate([conn, -np.ones((conn.shape[0], 1), conn.dtype)], axis=1)
+    nc = conn.shape[0]
+    nv = xyz.shape[0]
+    owned_mask = np.asarray(owned_mask, dtype=bool)
+    nverts = (conn >= 0).sum(axis=1)
+    j = np.arange(4)
+    nxt = (j[None, :] + 1) % nverts[:, None]
+    vb = np.take_along_axis(conn, nxt.astype(np.int64), axis=1)
+    valid = conn >= 0
+    side_cell = np.broadcast_to(np.arange(nc)[:, None], (nc, 4))[valid]
+    sa = conn[valid].astype(np.int64)
+    sb = vb[valid].astype(np.int64)
+    key = np.minimum(sa, sb) * nv + np.maximum(sa, sb)
+    order = np.argsort(key, kind="stable")
+    ks = key[order]
+    same = ks[1:] == ks[:-1]
+    c1 = side_cell[order[:-1]][same]
+    c2 = side_cell[order[1:]][same]
+    keep = owned_mask.copy()
+    keep[c2[owned_mask[c1]]] = True
+    keep[c1[owned_mask[c2]]] = True
+    if ghosts == "tail":
+        sel = np.concatenate([np.nonzero(owned_mask)[0], np.nonzero(keep & ~owned_mask)[0]])
+    elif ghosts == "interleaved":
+        sel = np.nonzero(keep)[0]
+    else:
+        raise ValueError(ghosts)
+    sub_conn = conn[sel]
+    used = np.unique(sub_conn[sub_conn >= 0])
+    remap = -np.ones(nv, dtype=np.int64)
+    remap[used] = np.arange(used.size)
+    sub_conn = np.where(sub_conn >= 0, remap[np.maximum(sub_conn, 0)], -1).astype(np.int32)
+    gids = np.arange(nc, dtype=np.int64) if cell_global_ids is None else np.asarray(cell_global_ids)
+    return build_mesh(xyz[used], sub_conn, is_owned=owned_mask[sel].astype(np.int32),
+                      cell_global_ids=gids[sel],
+                      num_cells_global=num_cells_global if num_cells_global is not None else nc,
+                      boundary_classifier=boundary_classifier)
+
+
+def strip_partition_tri_mesh(nx_per_rank: int, ny: int, rank: int, nranks: int, d: float = 1.0,
+                             zfunc=None, order: str = "rowmajor", tile: int = 16) -> RDyMesh:
+    """Rank `rank`'s piece of a (nx_per_rank*nranks) x ny structured triangle
+    mesh cut into strips along x: its own columns plus
+    one extra column of squares on each interior side, from which the
+    edge-adjacent ghost triangles are kept.  Built without ever forming the
+    global mesh.  Global cell id = 2*(qj*nx_global + qi) + t.
+    """
+    nxg = nx_per_rank * nranks
+    g0 = 1 if rank > 0 else 0
+    g1 = 1 if rank < nranks - 1 else 0
+    i0 = rank * nx_per_rank - g0
+    nxl = nx_per_rank + g0 + g1
+    xyz, conn, cqi, cqj = structured_tri_connectivity(nxl, ny, d, i0=i0, order=order, tile=tile)
+    if zfunc is not None:
+        xyz[:, 2] = zfunc(xyz[:, 0], xyz[:, 1])
+    gi = cqi + i0
+    owned = (gi >= rank * nx_per_rank) & (gi < (rank + 1) * nx_per_rank)
+    t = np.arange(conn.shape[0]) % 2
+    gids = 2 * (cqj.astype(np.int64) * nxg + gi) + t
+    cls = box_side_boundaries(0.0, nxg * d, 0.0, ny * d)
+    return extract_local_mesh(xyz, conn, owned, cell_global_ids=gids,
+                              num_cells_global=2 * nxg * ny, boundary_classifier=cls)
+
+
+# ---------------------------------------------------------------------------
+# file readers for the reference's small test meshes (data fixtures)
+# ---------------------------------------------------------------------------
+
+def read_gmsh41(path: str) -> Tuple[np.ndarray, np.ndarray, np.ndarray, Dict[Tuple[int, int], int], Dict[int, str]]:
+    """Minimal Gmsh 4.1 ASCII reader (share/meshes/planar_dam_10x5.msh).
+
+    Returns xyz, conn [Nc,4] (quads/triangles, -1 padded), region id per cell
+    (physical tag of the surface), {sorted vertex pair: physical curve tag},
+    {(dim,tag) names}.
+    """
+    with open(path) as f:
+        toks = f.read().split("\n")
+    it = iter(toks)
+    sections: Dict[str, List[str]] = {}
+    cur = None
+    for line in it:
+        line = line.strip()
+        if line.startswith("$End"):
+            cur = None
+        elif line.startswith("$"):
+            cur = line[1:]
+            sections[cur] = []
+        elif cur is not None and line:
+            sections[cur].append(line)
+    names = {}
+    for ln in sections.get("PhysicalNames", [])[1:]:
+        p = ln.split(None, 2)
+        names[(int(p[0]), int(p[1]))] = p[2].strip('"')
+    ent = sections["Entities"]
+    npnt, ncur, nsur, nvol = map(int, ent[0].split())
+    curve_phys: Dict[int, int] = {}
+    surf_phys: Dict[int, int] = {}
+    k = 1 + npnt
+    for ln in ent[k:k + ncur]:
+        p = ln.split()
+        tag = int(p[0])
+        nphys = int(p[7])
+        if nphys:
+            curve_phys[tag] = int(p[8])
+    k += ncur
+    for ln in ent[k:k + nsur]:
+        p = ln.split()
+        tag = int(p[0])
+        nphys = int(p[7])
+        if nphys:
+            surf_phys[tag] = int(p[8])
+    nodes = sections["Nodes"]
+    nblocks, nnodes, _, _ = map(int, nodes[0].split())
+    coords: Dict[int, Tuple[float, float, float]] = {}
+    k = 1
+    for _ in range(nblocks):
+        _, _, _, n = map(int, nodes[k].split())
+        tags = [int(nodes[k + 1 + i]) for i in range(n)]
+        for i, t in enumerate(tags):
+            coords[t] = tuple(map(float, nodes[k + 1 + n + i].split()))
+        k += 1 + 2 * n
+    tag_sorted = sorted(coords)
+    tmap = {t: i for i, t in enumerate(tag_sorted)}
+    xyz = np.array([coords[t] for t in tag_sorted], dtype=np.float64)
+    els = sections["Elements"]
+    nblocks = int(els[0].split()[0])
+    k = 1
+    cells = []
+    regions = []
+    edge_tag: Dict[Tuple[int, int], int] = {}
+    for _ in range(nblocks):
+        edim, etag, etype, n = map(int, els[k].split())
+        for i in range(n):
+            p = list(map(int, els[k + 1 + i].split()))[1:]
+            vs = [tmap[t] for t in p]
+            if edim == 1 and etype == 1:
+                if etag in curve_phys:
+                    edge_tag[(min(vs), max(vs))] = curve_phys[etag]
+            elif edim == 2 and etype == 2:
+                cells.append(vs + [-1])
+                regions.append(surf_phys.get(etag, 0))
+            elif edim == 2 and etype == 3:
+                cells.append(vs)
+                regions.append(surf_phys.get(etag, 0))
+        k += 1 + n
+    return xyz, np.array(cells, dtype=np.int32), np.array(regions, dtype=np.int32), edge_tag, names
+
+
+def boundaries_from_edge_tags(edge_tag: Dict[Tuple[int, int], int], names: Dict[Tuple[int, int], str]):
+    def f(mesh: RDyMesh) -> List[RDyBoundary]:
+        be = mesh.edge_boundary_ids
+        v = mesh.edge_vertex_ids[be]
+        tags = np.array([edge_tag.get((int(min(a, b)), int(max(a, b))), 0) for a, b in v])
+        out = []
+        for t in sorted(set(tags.tolist())):
+            if t == 0:
+                continue
+            out.append(RDyBoundary(t, names.get((1, t), f"boundary_{t}"), be[tags == t].astype(np.int32)))
+        return out
+    return f
+
+
+def read_exodus_tri(path: str) -> Tuple[np.ndarray, np.ndarray]:
+    """Read a single-block Exodus II (NetCDF-3) triangle/quad mesh such as
+    share/meshes/mms_triangles_dx1.exo; returns xyz and 0-based conn."""
+    from scipy.io import netcdf_file
+    f = netcdf_file(path, "r", mmap=False)
+    x = np.array(f.variables["coordx"][:], dtype=np.float64)
+    y = np.array(f.variables["coordy"][:], dtype=np.float64)
+    z = np.array(f.variables["coordz"][:], dtype=np.float64) if "coordz" in f.variables else np.zeros_like(x)
+    conn = np.array(f.variables["connect1"][:], dtype=np.int32) - 1
+    f.close()
+    return np.stack([x, y, z], axis=1), conn
