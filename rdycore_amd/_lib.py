@@ -88,6 +88,11 @@ def load(build_if_missing: bool = False):
     global _LIB
     if _LIB is not None:
         return _LIB
+    # torch bundles its own HIP runtime (torch/lib/libamdhip64.so, soname
+    # libamdhip64.so.7).  It must be in the process before librdyhip.so is
+    # opened, so that our DT_NEEDED libamdhip64.so.7 binds to that same copy;
+    # two HIP runtimes in one process cannot both own the device.
+    import torch  # noqa: F401
     path = _build.lib_path()
     if not os.path.exists(path):
         if build_if_missing:
