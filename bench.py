@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""Benchmark of the SWE right-hand-side evaluation (BASELINE.json metric:
+M cell-updates/s + achieved HBM GB/s).
+
+  python bench.py --gpus N --steps K --warmup W
+
+A "step" is one OperatorRHSFunction (src/rdysetup.c:1120-1172): for N > 1 the
+ghost update of u_local, then the fused Roe-flux + source kernel over every
+owned cell, including the Courant-number reduction.  Workload (N = 1):
+BASELINE.json configs[2] -- the 10 M-cell friction + bed-slope mesh the
+north-star's >= 40 % HBM target is quoted on (SURVEY.md section 8.d "C3");
+for N > 1 each rank owns one such block (strips along x, configs[3], weak
+scaling).  State is resident in HBM before the timed region.
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ALG_BYTES_PER_CELL = 176.0     # algorithmic bytes per cell-update
+HBM_PEAK_GBPS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=200)
+    p.add_argument("--warmup", type=int, default=20)
+    p.add_argument("--nx", type=int, default=2500, help="squares per rank along x")
+    p.add_argument("--ny", type=int, default=2000, help="squares along y")
+    p.add_argument("--order", default="tiled", choices=["rowmajor", "tiled"], help="cell numbering of the synthetic mesh")
+    p.add_argument("--source", default="semi_implicit", choices=["semi_implicit", "implicit_xq2018"])
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-sample", default="1000x500", help="nx x ny of the CPU-baseline sample mesh")
+    return p.parse_args()
+
+
+def build_case(nx, ny, rank, world, order, source):
+    from rdycore_amd import cases as CS
+    from rdycore_amd import mesh as M
+    from rdycore_amd.operator import SOURCE_IMPLICIT_XQ2018, SOURCE_SEMI_IMPLICIT
+    K = 2 * np.pi / 200.0
+    src = SOURCE_SEMI_IMPLICIT if source == "semi_implicit" else SOURCE_IMPLICIT_XQ2018
+    if world == 1:
+        mesh = M.structured_tri_mesh(nx, ny, 1.0, zfunc=CS.mms_bathymetry(K=K), order=order)
+    else:
+        mesh = M.strip_partition_tri_mesh(nx, ny, rank, world, 1.0, zfunc=CS.mms_bathymetry(K=K), order=order)
+    return CS.friction_slope_case(mesh, nx * world * 1.0, ny * 1.0, dt=1e-3, source_method=src, K=K)
+
+
+def cpu_baseline(sample: str, source: str):
+    """The CPU oracle (a plain-C restatement of the reference's PETSc path, one
+    core) timed on a bounded sample of the same workload."""
+    from oracle import oracle as O  # test infrastructure; used here only as the timed CPU baseline
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import oracle_from_case
+    nx, ny = map(int, sample.split("x"))
+    case = build_case(nx, ny, 0, 1, "rowmajor", source)
+    orc = oracle_from_case(case)
+    f = np.zeros((case.mesh.num_owned_cells, 3))
+    orc.apply(case.dt, case.u_local, f)  # warm
+    times = []
+    t_end = time.time() + 12.0
+    while len(times) < 3 or (time.time() < t_end and len(times) < 10):
+        f[:] = 0.0
+        t0 = time.perf_counter()
+        orc.apply(case.dt, case.u_local, f)
+        times.append(time.perf_counter() - t0)
+    med = float(np.median(times))
+    nc = case.mesh.num_owned_cells
+    return {"value": round(nc / med / 1e6, 3), "unit": "M cell-updates/s", "cores": 1, "kind": "port",
+            "sample": f"{len(times)} RHS evaluations of the same workload on a {nx}x{ny}x2 = {nc}-cell mesh, "
+                      f"oracle/swe_oracle.c (gcc -O2, 1 thread), median {med * 1e3:.1f} ms/RHS"}
+
+
+def load_traffic(workload_key: str):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes, if present."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(path) as fh:
+            t = json.load(fh)
+        return t.get(workload_key, {}).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from rdycore_amd import cases as CS
+    from rdycore_amd.halo import HaloExchange
+
+    t0 = time.time()
+    case = build_case(args.nx, args.ny, rank, world, args.order, args.source)
+    mesh = case.mesh
+    op = CS.create_operator(case)
+    halo = HaloExchange(mesh, dev) if world > 1 else None
+    u = torch.tensor(case.u_local, dtype=torch.float64, device=dev)
+    f = torch.empty((mesh.num_owned_cells, 3), dtype=torch.float64, device=dev)
+    setup_s = time.time() - t0
+    n_owned = mesh.num_owned_cells
+
+    def step():
+        if halo is not None:
+            halo.rhs_overlapped(op, case.dt, u, f)
+        else:
+            op.rhs_function(case.dt, u, f)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t_start = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t_start
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        tot = torch.tensor([n_owned], dtype=torch.int64, device=dev)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        total_cells = int(tot.item())
+    else:
+        total_cells = n_owned
+
+    # ---- dominant kernel: average duration with HIP events on the launch stream
+    # (one rhs call = reset (1 thread) + swe_rhs_kernel + Courant finalize (1 block))
+    k_iters = max(10, min(args.steps, 50))
+    starts = [torch.cuda.Event(enable_timing=True) for _ in range(k_iters)]
+    ends = [torch.cuda.Event(enable_timing=True) for _ in range(k_iters)]
+    for i in range(k_iters):
+        starts[i].record()
+        op.rhs_function(case.dt, u, f)
+        ends[i].record()
+    torch.cuda.synchronize()
+    kern_ms = float(np.mean([s.elapsed_time(e) for s, e in zip(starts, ends)]))
+
+    # sanity: the result is finite and the Courant diagnostic is alive
+    op.update_diagnostics()
+    courant = op.get_diagnostics().max_courant_num
+    finite = bool(torch.isfinite(f).all().item())
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = total_cells / (elapsed / args.steps) / 1e6
+        achieved = n_owned * ALG_BYTES_PER_CELL / (kern_ms * 1e-3) / 1e9
+        info = op.layout_info()
+        workload = (f"C3: synthetic {args.nx * world}x{args.ny}x2 = {total_cells}-cell triangle mesh "
+                    f"({n_owned} cells/GPU), MMS-style state over sinusoidal bathymetry, Manning field, rain source, "
+                    f"dry disc, Dirichlet + critical-outflow + reflecting boundaries, {args.source} friction, dt=1e-3")
+        out = {
+            "metric": "M cell-updates/s (SWE RHS eval)",
+            "value": round(value, 1),
+            "unit": "M cell-updates/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 5),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": workload, "cells_per_gpu": n_owned, "cell_order": args.order,
+                       "partition": "single" if world == 1 else f"strips_x{world}",
+                       "halo_bytes_per_rank": halo.bytes_sent_per_exchange if halo else 0,
+                       "setup_seconds": round(setup_s, 1), "max_courant": courant, "finite": finite},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                         "traffic": load_traffic(f"{args.nx}x{args.ny}_{args.order}_{args.source}"),
+                         "kernel": "swe_rhs_kernel<3,%d>" % (0 if args.source == "semi_implicit" else 1),
+                         "kernel_avg_ms": round(kern_ms, 5),
+                         "algorithmic_bytes_per_launch": int(n_owned * ALG_BYTES_PER_CELL),
+                         "layout_bytes_per_launch": int(info["bytes_per_apply"])},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.source)
+        print(json.dumps(out), flush=True)
+    op.destroy()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -105,3 +105,20 @@ def create_operator(case: Case):
     for b, vals in case.boundary_values.items():
         op.set_boundary_values(b, vals)
     return op
+
+
+def ex2b_case(msh_path: str) -> Case:
+    """C1: driver/tests/swe_roe/ex2b.yaml on share/meshes/planar_dam_10x5.msh --
+    44 quads, h = 10 upstream / 5 downstream (ex2b.yaml:84-93), Manning 0.015
+    (:58), implicit_xq2018 friction (:7), "bottom_wall" critical outflow, the
+    other two boundaries reflecting (:71-82), dt = 0.005 h / 1000 steps = 0.018 s
+    (:17-20)."""
+    from . import mesh as M
+    xyz, conn, region, edge_tag, names = M.read_gmsh41(msh_path)
+    mesh = M.build_mesh(xyz, conn, boundary_classifier=M.boundaries_from_edge_tags(edge_tag, names))
+    u = np.zeros((mesh.num_cells, 3))
+    u[:, 0] = np.where(region == 1, 10.0, 5.0)
+    ctypes = [CONDITION_CRITICAL_OUTFLOW if b.name == "bottom_wall" else CONDITION_REFLECTING for b in mesh.boundaries]
+    no = mesh.num_owned_cells
+    return Case("ex2b", mesh, RDyFlowConfig(source_method=SOURCE_IMPLICIT_XQ2018), ctypes, u,
+                np.full(no, 0.015), np.zeros((no, 3)), {}, 0.005 * 3600.0 / 1000.0)

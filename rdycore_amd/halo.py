@@ -1,0 +1,138 @@
+"""Ghost-cell update of the local solution vector between ranks.
+
+Stands in for DMGlobalToLocalBegin/End in OperatorRHSFunction
+(src/rdysetup.c:1133-1134): before an RHS evaluation every ghost cell of
+`u_local` receives the state of the rank that owns it (3 doubles per cell,
+1-cell overlap, src/rdydm.c:145-157).  First-order fluxes need no reverse
+exchange (src/swe/swe_petsc.c:272-274).
+
+One process per GPU; the transport is torch.distributed point-to-point
+(backend "nccl" = RCCL over xGMI on the GPUs, "gloo" in the CPU tests).  The
+pack / unpack kernels are the HIP ones behind the C ABI (rdyhip_pack_cells /
+rdyhip_unpack_cells); on CPU tensors (gloo tests of the host logic) plain
+indexing is used.  The pattern is neighbour point-to-point, not a collective:
+per RHS each rank sends ~perimeter x 24 B to each neighbour, which is
+latency-bound, so it is issued on a side stream and overlapped with the
+interior cells (see `rhs_overlapped`).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .mesh import RDyMesh
+
+
+class HaloExchange:
+    def __init__(self, mesh: RDyMesh, device: torch.device, group=None):
+        self.mesh = mesh
+        self.device = torch.device(device)
+        self.group = group
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.send_ids: Dict[int, torch.Tensor] = {}   # peer -> local ids of owned cells to send
+        self.recv_ids: Dict[int, torch.Tensor] = {}   # peer -> local ids of ghost cells to fill
+        self.send_buf: Dict[int, torch.Tensor] = {}
+        self.recv_buf: Dict[int, torch.Tensor] = {}
+        self._setup()
+        self.comm_stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
+
+    # -- pattern discovery (setup only) -----------------------------------
+    def _setup(self):
+        m = self.mesh
+        ghost_local = np.nonzero(m.cell_is_owned == 0)[0].astype(np.int32)
+        ghost_gid = m.cell_global_ids[ghost_local]
+        if self.world == 1:
+            if ghost_local.size:
+                raise ValueError("mesh has ghost cells but there is only one rank")
+            return
+        owned_local = m.cell_owned_to_local
+        owned_gid = m.cell_global_ids[owned_local]
+        order = np.argsort(owned_gid)
+        sorted_gid = owned_gid[order]
+        # every rank publishes the global ids of the ghosts it needs
+        wanted: List[Optional[np.ndarray]] = [None] * self.world
+        dist.all_gather_object(wanted, ghost_gid, group=self.group)
+        # which of a peer's ghosts do I own?  (answer in the peer's request order)
+        mine_for_peer: List[Optional[np.ndarray]] = []
+        for peer in range(self.world):
+            if peer == self.rank or wanted[peer] is None or len(wanted[peer]) == 0:
+                mine_for_peer.append(np.zeros(0, dtype=np.int64))
+                continue
+            req = np.asarray(wanted[peer])
+            idx = np.searchsorted(sorted_gid, req)
+            idx = np.minimum(idx, max(sorted_gid.size - 1, 0))
+            hit = (sorted_gid[idx] == req) if sorted_gid.size else np.zeros(req.size, dtype=bool)
+            self_local = owned_local[order[idx[hit]]].astype(np.int32)
+            if self_local.size:
+                self.send_ids[peer] = torch.as_tensor(self_local, device=self.device)
+            mine_for_peer.append(req[hit])
+        # tell every peer which of its requests I will serve, so it knows what arrives from me
+        served: List[Optional[List[np.ndarray]]] = [None] * self.world
+        dist.all_gather_object(served, mine_for_peer, group=self.group)
+        gid_to_local = {int(g): int(l) for g, l in zip(ghost_gid, ghost_local)}
+        covered = 0
+        for peer in range(self.world):
+            if peer == self.rank:
+                continue
+            got = np.asarray(served[peer][self.rank])
+            if got.size:
+                loc = np.array([gid_to_local[int(g)] for g in got], dtype=np.int32)
+                self.recv_ids[peer] = torch.as_tensor(loc, device=self.device)
+                covered += got.size
+        if covered != ghost_local.size:
+            raise RuntimeError(f"rank {self.rank}: {ghost_local.size - covered} ghost cells have no owner")
+        for peer, ids in self.send_ids.items():
+            self.send_buf[peer] = torch.empty((ids.numel(), 3), dtype=torch.float64, device=self.device)
+        for peer, ids in self.recv_ids.items():
+            self.recv_buf[peer] = torch.empty((ids.numel(), 3), dtype=torch.float64, device=self.device)
+
+    @property
+    def bytes_sent_per_exchange(self) -> int:
+        return sum(int(b.numel()) * 8 for b in self.send_buf.values())
+
+    # -- one ghost update on the current stream ----------------------------
+    def exchange(self, u_local: torch.Tensor):
+        if self.world == 1 or (not self.send_ids and not self.recv_ids):
+            return
+        cuda = u_local.is_cuda
+        if cuda:
+            from .operator import pack_cells, unpack_cells
+        ops = []
+        for peer, ids in self.send_ids.items():
+            if cuda:
+                pack_cells(u_local, ids, self.send_buf[peer])
+            else:
+                self.send_buf[peer].copy_(u_local.view(-1, 3)[ids.long()])
+        for peer in sorted(set(self.send_ids) | set(self.recv_ids)):
+            if peer in self.send_ids:
+                ops.append(dist.P2POp(dist.isend, self.send_buf[peer], peer, group=self.group))
+            if peer in self.recv_ids:
+                ops.append(dist.P2POp(dist.irecv, self.recv_buf[peer], peer, group=self.group))
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+        for peer, ids in self.recv_ids.items():
+            if cuda:
+                unpack_cells(u_local, ids, self.recv_buf[peer])
+            else:
+                u_local.view(-1, 3)[ids.long()] = self.recv_buf[peer]
+
+    # -- RHS with the exchange hidden behind the interior cells -----------
+    def rhs_overlapped(self, op, dt: float, u_local: torch.Tensor, f_global: torch.Tensor):
+        """OperatorRHSFunction (src/rdysetup.c:1120-1172) on one rank: ghost
+        update on a side stream while the cells without ghost neighbours are
+        evaluated, then the remaining (halo-adjacent) cells."""
+        if self.world == 1:
+            op.rhs_function(dt, u_local, f_global)
+            return
+        main = torch.cuda.current_stream(self.device)
+        self.comm_stream.wait_stream(main)           # u_local's owned part is final
+        with torch.cuda.stream(self.comm_stream):
+            self.exchange(u_local)
+        op.reset_diagnostics()
+        op.apply_phase(1, True, dt, u_local, f_global)      # RDYHIP_PHASE_INTERIOR
+        main.wait_stream(self.comm_stream)
+        op.apply_phase(2, True, dt, u_local, f_global)      # RDYHIP_PHASE_HALO

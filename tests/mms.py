@@ -1,0 +1,149 @@
+"""Method-of-manufactured-solutions convergence study for the SWE RHS.
+
+Restates the reference's only accuracy gate for this path:
+driver/tests/swe_roe/mms_conv_study.yaml (analytic fields, constants, expected
+rates) driven the way src/rdymms.c does it -- initial condition and error norms
+at cell centroids (352-420, 850-902), Dirichlet values at edge centroids and
+source terms at cell centroids, both at t + dt/2 before every step (138-153,
+489-706, 708-770), Manning n at centroids (804-848), vertex z snapped to z(x,y)
+(108-133), forward Euler, rates by linear regression of log10(err) on
+log10(num_cells) times -dim (920-1008).
+
+`make_apply(mesh, bc_types) -> (apply(dt,u,src,bvals)->F, set_mannings)` is
+supplied by the caller, so the same study runs on the CPU oracle and on the
+HIP operator.
+"""
+import os
+
+import numpy as np
+
+from rdycore_amd import mesh as M
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+G = 9.806
+
+# mms_conv_study.yaml:11-19
+H, T, U, V, N, Z = 0.005, 20.0, 0.025, 0.025, 0.01, 0.0025
+K = 0.6283185307179586
+
+# mms_conv_study.yaml:51-63
+EXPECTED = {"h": (0.94, 0.95, 0.94), "hu": (0.91, 0.93, 0.77), "hv": (0.91, 0.93, 0.77)}
+
+s, c, e = np.sin, np.cos, np.exp
+
+
+def fields(x, y, t):
+    """mms_conv_study.yaml:20-46"""
+    et = e(t / T)
+    d = {}
+    d["h"] = H * (1 + s(K * x) * s(K * y)) * et
+    d["dhdx"] = H * K * s(K * y) * c(K * x) * et
+    d["dhdy"] = H * K * s(K * x) * c(K * y) * et
+    d["dhdt"] = H / T * (1 + s(K * x) * s(K * y)) * et
+    d["u"] = U * c(K * x) * s(K * y) * et
+    d["dudx"] = -U * K * s(K * x) * s(K * y) * et
+    d["dudy"] = U * K * c(K * x) * c(K * y) * et
+    d["dudt"] = U / T * c(K * x) * s(K * y) * et
+    d["v"] = V * s(K * x) * c(K * y) * et
+    d["dvdx"] = K * V * c(K * x) * c(K * y) * et
+    d["dvdy"] = -K * V * s(K * x) * s(K * y) * et
+    d["dvdt"] = V / T * s(K * x) * c(K * y) * et
+    d["dzdx"] = Z * K * c(K * x) * s(K * y)
+    d["dzdy"] = Z * K * s(K * x) * c(K * y)
+    d["n"] = N * (1 + s(K * x) * s(K * y))
+    return d
+
+
+def bathymetry(x, y):
+    return Z * s(K * x) * s(K * y)
+
+
+def source_terms(x, y, t):
+    """src/rdymms.c:561-583"""
+    d = fields(x, y, t)
+    h, u, v, n = d["h"], d["u"], d["v"], d["n"]
+    Cd = G * n ** 2 * h ** (-1.0 / 3.0)
+    sh = d["dhdt"] + u * d["dhdx"] + h * d["dudx"] + v * d["dhdy"] + h * d["dvdy"]
+    shu = u * d["dhdt"] + h * d["dudt"]
+    shu += 2.0 * u * h * d["dudx"] + u * u * d["dhdx"] + G * h * d["dhdx"]
+    shu += u * h * d["dvdy"] + v * h * d["dudy"] + u * v * d["dhdy"]
+    shu += d["dzdx"] * G * h
+    shu += Cd * u * np.sqrt(u * u + v * v)
+    shv = v * d["dhdt"] + h * d["dvdt"]
+    shv += u * h * d["dvdx"] + v * h * d["dudx"] + u * v * d["dhdx"]
+    shv += v * v * d["dhdy"] + 2.0 * v * h * d["dvdy"] + G * h * d["dhdy"]
+    shv += d["dzdy"] * G * h
+    shv += Cd * v * np.sqrt(u * u + v * v)
+    return np.stack([sh, shu, shv], axis=1)
+
+
+def solution(x, y, t):
+    d = fields(x, y, t)
+    return np.stack([d["h"], d["h"] * d["u"], d["h"] * d["v"]], axis=1)
+
+
+def level_mesh(refinements: int):
+    xyz, conn = M.read_exodus_tri(os.path.join(HERE, "golden", "mms_triangles_dx1.exo"))
+    for _ in range(refinements):
+        xyz, conn = M.refine_triangles(xyz, conn)
+    xyz[:, 2] = bathymetry(xyz[:, 0], xyz[:, 1])   # SnapVerticesToBathymetry
+    return M.build_mesh(xyz, conn, boundary_classifier=M.single_boundary())
+
+
+def run_level(refinements, make_apply, dt=0.01, t_stop=5.0):
+    mesh = level_mesh(refinements)
+    apply, set_mannings = make_apply(mesh, [M.CONDITION_DIRICHLET])
+    cx, cy = mesh.cell_centroids[:, 0], mesh.cell_centroids[:, 1]
+    be = mesh.boundaries[0].edge_ids
+    ex, ey = mesh.edge_centroids[be, 0], mesh.edge_centroids[be, 1]
+    set_mannings(fields(cx, cy, 0.0)["n"])
+    u = solution(cx, cy, 0.0)
+    nsteps = int(round(t_stop / dt))
+    t = 0.0
+    for _ in range(nsteps):
+        th = t + 0.5 * dt                       # MMSPreStep, src/rdymms.c:138-153
+        f = apply(dt, u, source_terms(cx, cy, th), solution(ex, ey, th))
+        u = u + dt * f                          # TSEULER
+        t += dt
+    err = u - solution(cx, cy, t)
+    a = mesh.cell_areas[:, None]
+    l1 = (np.abs(err) * a).sum(axis=0)
+    l2 = np.sqrt((err * err * a).sum(axis=0))
+    li = np.abs(err).max(axis=0)
+    return mesh.num_cells, l1, l2, li
+
+
+def convergence_rates(make_apply, base_refinement=1, num_refinements=3, dt=0.01, t_stop=5.0):
+    """RDyMMSEstimateConvergenceRates, src/rdymms.c:920-1008"""
+    xs, L1, L2, LI = [], [], [], []
+    for r in range(num_refinements + 1):
+        n, l1, l2, li = run_level(base_refinement + r, make_apply, dt, t_stop)
+        xs.append(np.log10(n))
+        L1.append(np.log10(l1))
+        L2.append(np.log10(l2))
+        LI.append(np.log10(li))
+    xs = np.array(xs)
+    rates = {}
+    for ci, name in enumerate(("h", "hu", "hv")):
+        out = []
+        for Y in (L1, L2, LI):
+            y = np.array([row[ci] for row in Y])
+            slope = np.polyfit(xs, y, 1)[0]
+            out.append(-slope * 2)
+        rates[name] = tuple(out)
+    return rates
+
+
+def oracle_make_apply(mesh, bc_types):
+    from oracle import oracle as O
+    orc = O.OracleOperator(mesh, bc_types, source_method=0)   # semi_implicit: the default, src/yaml_input.c:859
+
+    def apply(dt, u, src, bvals):
+        orc.external_sources[:] = src
+        orc.boundary_values[0][:] = bvals
+        return orc.apply(dt, u)
+
+    def set_mannings(n):
+        orc.mannings[:] = n
+
+    return apply, set_mannings

@@ -1,0 +1,80 @@
+"""The N > 1 path on CPU: two gloo ranks, strip partition, ghost update through
+rdycore_amd.halo.HaloExchange, RHS (oracle) equal to the single-rank RHS."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, ghosts_mode, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from rdycore_amd import cases as CS
+        from rdycore_amd import mesh as M
+        from rdycore_amd.halo import HaloExchange
+        from helpers import oracle_from_case, rel_linf
+        nxg, ny = 8 * world, 9
+        K = 2 * np.pi / 13
+        z = CS.mms_bathymetry(K=K)
+        if ghosts_mode == "tail":
+            mesh = M.strip_partition_tri_mesh(nxg // world, ny, rank, world, 1.0, zfunc=z)
+        else:
+            xyz, conn, cqi, cqj = M.structured_tri_connectivity(nxg, ny)
+            xyz[:, 2] = z(xyz[:, 0], xyz[:, 1])
+            own = (cqi >= rank * (nxg // world)) & (cqi < (rank + 1) * (nxg // world))
+            mesh = M.extract_local_mesh(xyz, conn, own, boundary_classifier=M.box_side_boundaries(0, nxg, 0, ny),
+                                        ghosts="interleaved")
+        case = CS.friction_slope_case(mesh, nxg, ny, dt=1e-2, K=K)
+        truth = case.u_local.copy()
+        u = torch.tensor(case.u_local)
+        ghost = torch.tensor(mesh.cell_is_owned == 0)
+        u[ghost] = float("nan")                       # ghosts unknown before the exchange
+        halo = HaloExchange(mesh, torch.device("cpu"))
+        halo.exchange(u)
+        assert torch.equal(u, torch.tensor(truth)), "ghost cells differ from their owners' values"
+        f = oracle_from_case(case).apply(case.dt, u.numpy())
+        # single-rank answer
+        g = M.structured_tri_mesh(nxg, ny, 1.0, zfunc=z)
+        gc = CS.friction_slope_case(g, nxg, ny, dt=1e-2, K=K)
+        fg = oracle_from_case(gc).apply(gc.dt, gc.u_local)
+        gid = mesh.cell_global_ids[mesh.cell_owned_to_local]
+        err = rel_linf(f, fg[gid])
+        q.put((rank, err, halo.bytes_sent_per_exchange, int(ghost.sum())))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("ghosts_mode", ["tail", "interleaved"])
+@pytest.mark.timeout(180)
+def test_two_rank_halo_exchange_and_partitioned_rhs(ghosts_mode):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, ghosts_mode, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(150)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    res = sorted(q.get(timeout=5) for _ in range(world))
+    for rank, err, nbytes, nghost in res:
+        assert err < 1e-13
+        assert nghost == 9 and nbytes == 9 * 24         # ny ghost triangles per side, 3 doubles each
