@@ -140,8 +140,7 @@ __global__ __launch_bounds__(BLOCK) void swe_rhs_kernel(const KernelArgs a, cons
     const double h  = u[3 * (int64_t)c + 0];
     const double hu = u[3 * (int64_t)c + 1];
     const double hv = u[3 * (int64_t)c + 2];
-    double       uc, vc;
-    riemann_velocity(h, hu, hv, a.tiny_h, a.h_anuga_sq, uc, vc);
+    const RiemannSide self = riemann_side(h, hu, hv, a.tiny_h, a.h_anuga_sq);
 
     double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
     if (!a.overwrite) {
@@ -161,17 +160,20 @@ __global__ __launch_bounds__(BLOCK) void swe_rhs_kernel(const KernelArgs a, cons
       bool         wet;
       double       cfac = fabs(coef);  // len / area_self
       if (nid >= 0) {
-        const int    n   = nid & NBR_MASK;
-        const double hn  = u[3 * (int64_t)n + 0];
-        const double hun = u[3 * (int64_t)n + 1];
-        const double hvn = u[3 * (int64_t)n + 2];
-        double       un, vn;
-        riemann_velocity(hn, hun, hvn, a.tiny_h, a.h_anuga_sq, un, vn);
-        const bool   self_left = coef < 0.0;
-        const double hl = self_left ? h : hn, ul = self_left ? uc : un, vl = self_left ? vc : vn;
-        const double hr = self_left ? hn : h, ur = self_left ? un : uc, vr = self_left ? vn : vc;
-        fl  = roe_flux(hl, ul, vl, hr, ur, vr, sn, cn);
-        wet = !(hr < a.tiny_h && hl < a.tiny_h);
+        const int         n     = nid & NBR_MASK;
+        const double      hn    = u[3 * (int64_t)n + 0];
+        const double      hun   = u[3 * (int64_t)n + 1];
+        const double      hvn   = u[3 * (int64_t)n + 2];
+        const RiemannSide other = riemann_side(hn, hun, hvn, a.tiny_h, a.h_anuga_sq);
+        const bool        self_left = coef < 0.0;
+        RiemannSide       L, R;
+        L.h = self_left ? self.h : other.h;  R.h = self_left ? other.h : self.h;
+        L.u = self_left ? self.u : other.u;  R.u = self_left ? other.u : self.u;
+        L.v = self_left ? self.v : other.v;  R.v = self_left ? other.v : self.v;
+        L.sqh = self_left ? self.sqh : other.sqh;  R.sqh = self_left ? other.sqh : self.sqh;
+        L.c = self_left ? self.c : other.c;  R.c = self_left ? other.c : self.c;
+        fl  = roe_flux(L, R, sn, cn);
+        wet = !(R.h < a.tiny_h && L.h < a.tiny_h);
         if (nid & NBR_GHOST) {
           // the ghost side is not visited on this rank: use len / min(area_l, area_r)
           const double as = a.area_local[c], an = a.area_local[n];
@@ -179,7 +181,7 @@ __global__ __launch_bounds__(BLOCK) void swe_rhs_kernel(const KernelArgs a, cons
         }
       } else {
         const int    k  = -1 - nid;
-        BoundaryFlux bf = boundary_flux(a.btype[k], true, h, uc, vc, a.bvalues + 3 * (int64_t)k, sn, cn, a.tiny_h, a.h_anuga_sq);
+        BoundaryFlux bf = boundary_flux(a.btype[k], true, self, a.bvalues + 3 * (int64_t)k, sn, cn, a.tiny_h, a.h_anuga_sq);
         fl              = bf.flux;
         wet             = bf.wet;
         // boundary_fluxes[b] and VecAXPY(boundary_fluxes_accum, dt, boundary_fluxes), swe_petsc.c:574, 623
@@ -223,12 +225,11 @@ __global__ __launch_bounds__(BLOCK) void swe_rhs_kernel(const KernelArgs a, cons
     f[3 * (int64_t)o + 1] = acc1 + (-bedx - tbx + s1);
     f[3 * (int64_t)o + 2] = acc2 + (-bedy - tby + s2);
 
-    // primitive variables (swe_petsc.c:788-791)
-    const double denom         = h * h + a.h_anuga_sq;
-    const bool   wetc          = h >= a.tiny_h;
+    // primitive variables (swe_petsc.c:788-791): the same regularised velocities
+    // the Riemann states use, zero below tiny_h
     a.pv[3 * (int64_t)o + 0] = h;
-    a.pv[3 * (int64_t)o + 1] = wetc ? (hu * h / denom) : 0.0;
-    a.pv[3 * (int64_t)o + 2] = wetc ? (hv * h / denom) : 0.0;
+    a.pv[3 * (int64_t)o + 1] = self.u;
+    a.pv[3 * (int64_t)o + 2] = self.v;
   }
 
   // ---- block reduction of the Courant number: max value, then the smallest
@@ -257,17 +258,28 @@ __global__ __launch_bounds__(BLOCK) void swe_rhs_kernel(const KernelArgs a, cons
   }
 }
 
-// merges the per-block partials into the persistent diagnostic
+// merges the per-block partials into the persistent diagnostic (reset != 0:
+// the diagnostic is first reset, ResetOperatorDiagnostics src/operator.c:772-784)
 __global__ __launch_bounds__(1024) void courant_finalize_kernel(int nblk, const double *__restrict__ blk_max, const int32_t *__restrict__ blk_pos,
-                                                               DeviceCourant *diag) {
+                                                               DeviceCourant *diag, int reset) {
   double m = 0.0;
   int    p = INT32_MAX;
-  for (int i = threadIdx.x; i < nblk; i += 1024) {
-    const double v = blk_max[i];
-    const int    q = blk_pos[i];
-    if (v > m || (v == m && v > 0.0 && q < p)) {
-      m = v;
-      p = q;
+  constexpr int U = 8;  // independent loads in flight per thread
+  for (int base = threadIdx.x; base < nblk; base += 1024 * U) {
+    double v[U];
+    int    q[U];
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+      const int i = base + j * 1024;
+      v[j]        = i < nblk ? blk_max[i] : 0.0;
+      q[j]        = i < nblk ? blk_pos[i] : INT32_MAX;
+    }
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+      if (v[j] > m || (v[j] == m && v[j] > 0.0 && q[j] < p)) {
+        m = v[j];
+        p = q[j];
+      }
     }
   }
   __shared__ double s_max[16];
@@ -290,10 +302,14 @@ __global__ __launch_bounds__(1024) void courant_finalize_kernel(int nblk, const 
         bp = s_pos[w];
       }
     }
-    if (bm > diag->max_courant || (bm == diag->max_courant && bm > 0.0 && bp < diag->pos)) {
-      diag->max_courant = bm;
-      diag->pos         = bp;
+    double cur_max = reset ? 0.0 : diag->max_courant;
+    int    cur_pos = reset ? -1 : diag->pos;
+    if (bm > cur_max || (bm == cur_max && bm > 0.0 && bp < cur_pos)) {
+      cur_max = bm;
+      cur_pos = bp;
     }
+    diag->max_courant = cur_max;
+    diag->pos         = cur_pos;
   }
 }
 
@@ -314,9 +330,8 @@ __global__ void boundary_ghost_kernel(int n, const int32_t *__restrict__ klist, 
   const int    k = klist[i];
   const int    c = bleft[k];
   const double h = u[3 * (int64_t)c + 0], hu = u[3 * (int64_t)c + 1], hv = u[3 * (int64_t)c + 2];
-  double       uc, vc;
-  riemann_velocity(h, hu, hv, tiny_h, h_anuga_sq, uc, vc);
-  BoundaryFlux bf = boundary_flux(btype[k], false, h, uc, vc, bvalues + 3 * (int64_t)k, bsn[k], bcn[k], tiny_h, h_anuga_sq);
+  const RiemannSide L  = riemann_side(h, hu, hv, tiny_h, h_anuga_sq);
+  BoundaryFlux      bf = boundary_flux(btype[k], false, L, bvalues + 3 * (int64_t)k, bsn[k], bcn[k], tiny_h, h_anuga_sq);
   bflux[3 * (int64_t)k + 0] = bf.flux.f0;
   bflux[3 * (int64_t)k + 1] = bf.flux.f1;
   bflux[3 * (int64_t)k + 2] = bf.flux.f2;
@@ -426,10 +441,10 @@ struct RDyHipOperator_s {
 
 namespace {
 
-int launch_rhs(RDyHipOperator op, int32_t phase, int32_t overwrite, double dt, const double *u, double *f, hipStream_t st) {
+int launch_rhs(RDyHipOperator op, int32_t phase, int32_t overwrite, int reset_diag, double dt, const double *u, double *f, hipStream_t st) {
   if (!op) return fail(RDYHIP_ERR_USER, "null operator");
   if (!u || !f) return fail(RDYHIP_ERR_USER, "null u_local / f_global");
-  if (op->n_owned == 0) return 0;
+  if (op->n_owned == 0) return reset_diag ? rdyhip_reset_diagnostics(op, (void *)st) : 0;
   KernelArgs a{};
   a.n_owned    = op->n_owned;
   a.stride     = op->stride;
@@ -460,7 +475,7 @@ int launch_rhs(RDyHipOperator op, int32_t phase, int32_t overwrite, double dt, c
 
   int grid;
   if (phase == RDYHIP_PHASE_HALO) {
-    if (op->n_halo == 0) return 0;
+    if (op->n_halo == 0) return 0;  // (never combined with reset_diag)
     a.list       = op->d_halo_list.p;
     a.n_work     = op->n_halo;
     a.xcd_chunks = 0;
@@ -481,7 +496,7 @@ int launch_rhs(RDyHipOperator op, int32_t phase, int32_t overwrite, double dt, c
     else hipLaunchKernelGGL((swe_rhs_kernel<4, 0>), dim3(grid), dim3(BLOCK), 0, st, a, dt, u, f);
   }
   HIP_TRY(hipGetLastError());
-  hipLaunchKernelGGL(courant_finalize_kernel, dim3(1), dim3(1024), 0, st, grid, op->d_blk_max.p, op->d_blk_pos.p, op->d_courant.p);
+  hipLaunchKernelGGL(courant_finalize_kernel, dim3(1), dim3(1024), 0, st, grid, op->d_blk_max.p, op->d_blk_pos.p, op->d_courant.p, reset_diag);
   HIP_TRY(hipGetLastError());
   // boundary edges hanging off ghost cells (diagnostic vectors only); once per full apply
   if (op->n_bghost > 0 && phase != RDYHIP_PHASE_INTERIOR) {
@@ -716,18 +731,19 @@ int rdyhip_destroy(RDyHipOperator *op) {
 }
 
 int rdyhip_apply(RDyHipOperator op, double dt, const double *u_local, double *f_global, void *stream) {
-  return launch_rhs(op, RDYHIP_PHASE_ALL, 0, dt, u_local, f_global, (hipStream_t)stream);
+  return launch_rhs(op, RDYHIP_PHASE_ALL, 0, 0, dt, u_local, f_global, (hipStream_t)stream);
 }
 
 int rdyhip_rhs_function(RDyHipOperator op, double dt, const double *u_local, double *f_global, void *stream) {
-  int rc = rdyhip_reset_diagnostics(op, stream);
-  if (rc) return rc;
-  return launch_rhs(op, RDYHIP_PHASE_ALL, 1, dt, u_local, f_global, (hipStream_t)stream);
+  if (!op) return fail(RDYHIP_ERR_USER, "null operator");
+  op->courant = RDyHipCourant{0.0, -1, -1};
+  // the diagnostic reset rides on the Courant finalize kernel (no extra launch)
+  return launch_rhs(op, RDYHIP_PHASE_ALL, 1, 1, dt, u_local, f_global, (hipStream_t)stream);
 }
 
 int rdyhip_apply_phase(RDyHipOperator op, int32_t phase, int32_t overwrite, double dt, const double *u_local, double *f_global, void *stream) {
   if (phase != RDYHIP_PHASE_ALL && phase != RDYHIP_PHASE_INTERIOR && phase != RDYHIP_PHASE_HALO) return fail(RDYHIP_ERR_USER, "bad phase %d", phase);
-  return launch_rhs(op, phase, overwrite, dt, u_local, f_global, (hipStream_t)stream);
+  return launch_rhs(op, phase, overwrite, 0, dt, u_local, f_global, (hipStream_t)stream);
 }
 
 int rdyhip_set_boundary_values(RDyHipOperator op, int32_t boundary, int32_t comp_offset, int32_t num_comp, int32_t num_edges, const double *values) {

@@ -22,30 +22,57 @@ struct RoeFlux {
   double f0, f1, f2, amax;
 };
 
-// ComputeRiemannVelocities, src/swe/swe_petsc.c:57-73 (one state)
+// One side of a Riemann problem with everything that depends on that side
+// alone: velocities (ComputeRiemannVelocities, src/swe/swe_petsc.c:57-73) and
+// the two square roots of swe_roe_flux_petsc.h:21-24.  A cell's own state is
+// prepared once and reused by all of its edges.
+struct RiemannSide {
+  double h, u, v;
+  double sqh;  // sqrt(h)      "duml/dumr"
+  double c;    // sqrt(g h)    "cl/cr"
+};
+
+__device__ __forceinline__ RiemannSide riemann_side(double h, double hu, double hv, double tiny_h, double h_anuga_sq) {
+  RiemannSide s;
+  s.h = h;
+  if (h < tiny_h) {
+    s.u = 0.0;
+    s.v = 0.0;
+  } else {
+    // hu*h/denom and hv*h/denom share one division: r = h/denom
+    const double r = h / (h * h + h_anuga_sq);
+    s.u            = hu * r;
+    s.v            = hv * r;
+  }
+  s.sqh = sqrt(h);
+  s.c   = sqrt(GRAVITY * h);
+  return s;
+}
+
+// ComputeRiemannVelocities for a state given as (h, hu, hv) only
 __device__ __forceinline__ void riemann_velocity(double h, double hu, double hv, double tiny_h, double h_anuga_sq, double &u, double &v) {
   if (h < tiny_h) {
     u = 0.0;
     v = 0.0;
   } else {
-    const double denom = h * h + h_anuga_sq;
-    u                  = hu * h / denom;
-    v                  = hv * h / denom;
+    const double r = h / (h * h + h_anuga_sq);
+    u              = hu * r;
+    v              = hv * r;
   }
 }
 
 // ComputeSWERoeEigenspectrum + ComputeSWERoeFlux for one edge,
-// src/swe/swe_roe_flux_petsc.h:15-81, 103-128
-__device__ __forceinline__ RoeFlux roe_flux(double hl, double ul, double vl, double hr, double ur, double vr, double sn, double cn) {
-  const double duml  = sqrt(hl);
-  const double dumr  = sqrt(hr);
-  const double cl    = sqrt(GRAVITY * hl);
-  const double cr    = sqrt(GRAVITY * hr);
-  const double hhat  = duml * dumr;
-  const double uhat  = (duml * ul + dumr * ur) / (duml + dumr);
-  const double vhat  = (duml * vl + dumr * vr) / (duml + dumr);
-  const double chat  = sqrt(0.5 * GRAVITY * (hl + hr));
-  const double uperp = uhat * cn + vhat * sn;
+// src/swe/swe_roe_flux_petsc.h:15-81, 103-128.  Same formulas; the divisions
+// by (duml+dumr) and by chat are each done once as a reciprocal.
+__device__ __forceinline__ RoeFlux roe_flux(const RiemannSide &L, const RiemannSide &R, double sn, double cn) {
+  const double hl = L.h, ul = L.u, vl = L.v, hr = R.h, ur = R.u, vr = R.v;
+  const double duml = L.sqh, dumr = R.sqh, cl = L.c, cr = R.c;
+  const double hhat    = duml * dumr;
+  const double inv_sum = 1.0 / (duml + dumr);
+  const double uhat    = (duml * ul + dumr * ur) * inv_sum;
+  const double vhat    = (duml * vl + dumr * vr) * inv_sum;
+  const double chat    = sqrt(0.5 * GRAVITY * (hl + hr));
+  const double uperp   = uhat * cn + vhat * sn;
 
   const double dh     = hr - hl;
   const double du     = ur - ul;
@@ -62,35 +89,34 @@ __device__ __forceinline__ RoeFlux roe_flux(double hl, double ul, double vl, dou
   const double a2     = fabs(uperp);
   double       a3     = fabs(uperp + chat);
 
-  // critical flow fix
-  const double al1 = uperpl - cl;
-  const double ar1 = uperpr - cr;
-  const double da1 = fmax(0.0, 2.0 * (ar1 - al1));
+  // critical flow fix (rarely taken: keep the divisions behind real branches)
+  const double da1 = fmax(0.0, 2.0 * ((uperpr - cr) - (uperpl - cl)));
   if (a1 < da1) a1 = 0.5 * (a1 * a1 / da1 + da1);
-  const double al3 = uperpl + cl;
-  const double ar3 = uperpr + cr;
-  const double da3 = fmax(0.0, 2.0 * (ar3 - al3));
+  const double da3 = fmax(0.0, 2.0 * ((uperpr + cr) - (uperpl + cl)));
   if (a3 < da3) a3 = 0.5 * (a3 * a3 / da3 + da3);
 
-  const double dw0 = 0.5 * (dh - hhat * duperp / chat);
+  const double t   = hhat * duperp / chat;
+  const double dw0 = 0.5 * (dh - t);
   const double dw1 = hhat * dupar;
-  const double dw2 = 0.5 * (dh + hhat * duperp / chat);
+  const double dw2 = 0.5 * (dh + t);
 
   RoeFlux out;
   out.amax = chat + fabs(uperp);
 
-  const double fl0 = uperpl * hl;
-  const double fl1 = ul * uperpl * hl + 0.5 * GRAVITY * hl * hl * cn;
-  const double fl2 = vl * uperpl * hl + 0.5 * GRAVITY * hl * hl * sn;
-  const double fr0 = uperpr * hr;
-  const double fr1 = ur * uperpr * hr + 0.5 * GRAVITY * hr * hr * cn;
-  const double fr2 = vr * uperpr * hr + 0.5 * GRAVITY * hr * hr * sn;
+  const double gh2l = 0.5 * GRAVITY * hl * hl, gh2r = 0.5 * GRAVITY * hr * hr;
+  const double ql = uperpl * hl, qr = uperpr * hr;
+  const double fl0 = ql;
+  const double fl1 = ul * ql + gh2l * cn;
+  const double fl2 = vl * ql + gh2l * sn;
+  const double fr0 = qr;
+  const double fr1 = ur * qr + gh2r * cn;
+  const double fr2 = vr * qr + gh2r * sn;
 
-  // R[0][] = {1, 0, 1}: the reference multiplies by these constants; 0*x is
-  // kept so a non-finite a2*dw1 poisons the result exactly as it does there.
-  out.f0 = 0.5 * (fl0 + fr0 - a1 * dw0 - 0.0 * a2 * dw1 - a3 * dw2);
-  out.f1 = 0.5 * (fl1 + fr1 - r10 * a1 * dw0 - r11 * a2 * dw1 - r12 * a3 * dw2);
-  out.f2 = 0.5 * (fl2 + fr2 - r20 * a1 * dw0 - r21 * a2 * dw1 - r22 * a3 * dw2);
+  const double w0 = a1 * dw0, w1 = a2 * dw1, w2 = a3 * dw2;
+  // R[0][] = {1, 0, 1}; 0*w1 is kept so a non-finite w1 poisons f0 as in the reference
+  out.f0 = 0.5 * (fl0 + fr0 - w0 - 0.0 * w1 - w2);
+  out.f1 = 0.5 * (fl1 + fr1 - r10 * w0 - r11 * w1 - r12 * w2);
+  out.f2 = 0.5 * (fl2 + fr2 - r20 * w0 - r21 * w1 - r22 * w2);
   return out;
 }
 
@@ -105,48 +131,52 @@ struct BoundaryFlux {
 // cell's state with Riemann velocities.  For reflecting / outflow edges whose
 // left cell is not owned the reference leaves its zero-initialised scratch
 // untouched (449, 480), i.e. the right state is (0,0,0).
-__device__ __forceinline__ BoundaryFlux boundary_flux(int type, bool left_owned, double hl, double ul, double vl, const double *__restrict__ bval,
-                                                      double sn, double cn, double tiny_h, double h_anuga_sq) {
-  double hr = 0.0, ur = 0.0, vr = 0.0;
+__device__ __forceinline__ BoundaryFlux boundary_flux(int type, bool left_owned, RiemannSide L, const double *__restrict__ bval, double sn, double cn,
+                                                      double tiny_h, double h_anuga_sq) {
+  RiemannSide R;
+  R.h = R.u = R.v = R.sqh = R.c = 0.0;
   if (type == 0 /* CONDITION_DIRICHLET */) {
-    hr = bval[0];
-    riemann_velocity(hr, bval[1], bval[2], tiny_h, h_anuga_sq, ur, vr);
+    R = riemann_side(bval[0], bval[1], bval[2], tiny_h, h_anuga_sq);
   } else if (type == 2 /* CONDITION_REFLECTING */) {
     if (left_owned) {
-      hr                = hl;
       const double dum1 = sn * sn - cn * cn;
       const double dum2 = 2.0 * sn * cn;
-      ur                = ul * dum1 - vl * dum2;
-      vr                = -ul * dum2 - vl * dum1;
+      R.h               = L.h;
+      R.u               = L.u * dum1 - L.v * dum2;
+      R.v               = -L.u * dum2 - L.v * dum1;
+      R.sqh             = L.sqh;
+      R.c               = L.c;
     }
   } else /* CONDITION_CRITICAL_OUTFLOW */ {
     if (left_owned) {
-      const double uperp = ul * cn + vl * sn;
+      const double uperp = L.u * cn + L.v * sn;
       if (uperp < 0.0) {
-        hl = ul = vl = 0.0;
+        L.h = L.u = L.v = L.sqh = L.c = 0.0;
       } else {
-        const double q   = hl * fabs(uperp);
-        hr               = cbrt(q * q / GRAVITY);
-        const double vel = sqrt(GRAVITY * hr);
-        ur               = vel * cn;
-        vr               = vel * sn;
+        const double q = L.h * fabs(uperp);
+        R.h            = cbrt(q * q / GRAVITY);
+        R.sqh          = sqrt(R.h);
+        R.c            = sqrt(GRAVITY * R.h);
+        R.u            = R.c * cn;
+        R.v            = R.c * sn;
       }
     }
   }
   BoundaryFlux out;
-  out.flux = roe_flux(hl, ul, vl, hr, ur, vr, sn, cn);
-  out.wet  = !(hl < tiny_h && hr < tiny_h);
+  out.flux = roe_flux(L, R, sn, cn);
+  out.wet  = !(L.h < tiny_h && R.h < tiny_h);
   return out;
 }
 
 // Friction term of ApplySourceSemiImplicit, src/swe/swe_petsc.c:764-780
 __device__ __forceinline__ void friction_semi_implicit(double h, double hu, double hv, double n, double dt, double fsum_x, double fsum_y, double bedx,
                                                        double bedy, double &tbx, double &tby) {
-  const double u      = hu / h;
-  const double v      = hv / h;
-  const double Cd     = GRAVITY * (n * n) * (1.0 / cbrt(h));  // g n^2 h^(-1/3)
+  const double inv_h  = 1.0 / h;
+  const double u      = hu * inv_h;
+  const double v      = hv * inv_h;
+  const double Cd     = GRAVITY * (n * n) * rcbrt(h);  // g n^2 h^(-1/3)
   const double vel    = sqrt(u * u + v * v);
-  const double tb     = Cd * vel / h;
+  const double tb     = Cd * vel * inv_h;
   const double factor = tb / (1.0 + dt * tb);
   tbx                 = (hu + dt * fsum_x - dt * bedx) * factor;
   tby                 = (hv + dt * fsum_y - dt * bedy) * factor;
@@ -159,22 +189,24 @@ __device__ __forceinline__ void friction_xq2018(double h, double hu, double hv, 
   const double Ay     = fsum_y - bedy;
   const double mx     = hu + Ax * dt;
   const double my     = hv + Ay * dt;
-  const double cb     = cbrt(h);
+  const double rcb    = rcbrt(h);                // h^(-1/3)
+  const double inv_h  = 1.0 / h;
   const double gn2    = GRAVITY * (n * n);
-  const double mxh    = mx / h;
-  const double myh    = my / h;
-  const double lambda = gn2 * (1.0 / (h * cb)) * sqrt(mxh * mxh + myh * myh);  // h^(-4/3)
+  const double mxh    = mx * inv_h;
+  const double myh    = my * inv_h;
+  const double lambda = gn2 * (inv_h * rcb) * sqrt(mxh * mxh + myh * myh);  // h^(-4/3)
   double       qx, qy;
   if (dt * lambda < thresh) {
     qx = mx;
     qy = my;
   } else {
     const double root = sqrt(1.0 + 4.0 * dt * lambda);
-    qx                = (mx - mx * root) / (-2.0 * dt * lambda);
-    qy                = (my - my * root) / (-2.0 * dt * lambda);
+    const double inv  = 1.0 / (-2.0 * dt * lambda);
+    qx                = (mx - mx * root) * inv;
+    qy                = (my - my * root) * inv;
   }
   const double qmag = sqrt(qx * qx + qy * qy);
-  const double hm73 = 1.0 / (h * h * cb);  // h^(-7/3)
+  const double hm73 = inv_h * inv_h * rcb;  // h^(-7/3)
   tbx               = gn2 * hm73 * qx * qmag;
   tby               = gn2 * hm73 * qy * qmag;
 }
