@@ -44,6 +44,7 @@ def parse():
     p.add_argument("--order", default="tiled", choices=["rowmajor", "tiled"], help="cell numbering of the synthetic mesh")
     p.add_argument("--source", default="semi_implicit", choices=["semi_implicit", "implicit_xq2018"])
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--kernel", default=None, choices=["tiled", "cell"], help="kernel variant (default: library default = tiled)")
     p.add_argument("--cpu-sample", default="1000x500", help="nx x ny of the CPU-baseline sample mesh")
     return p.parse_args()
 
@@ -99,6 +100,8 @@ def load_traffic(workload_key: str):
 
 def main():
     args = parse()
+    if args.kernel:
+        os.environ["RDYHIP_KERNEL"] = args.kernel
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -201,7 +204,9 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4),
                          "traffic": load_traffic(f"{args.nx}x{args.ny}_{args.order}_{args.source}"),
-                         "kernel": "swe_rhs_kernel<3,%d>" % (0 if args.source == "semi_implicit" else 1),
+                         "kernel": "%s<3,%d>" % ("swe_rhs_tiled_kernel" if info["tiled_kernel"] else "swe_rhs_kernel",
+                                                 0 if args.source == "semi_implicit" else 1),
+                         "tile_edge_records_per_cell": round(info["num_edge_records"] / max(n_owned, 1), 4),
                          "kernel_avg_ms": round(kern_ms, 5),
                          "algorithmic_bytes_per_launch": int(n_owned * ALG_BYTES_PER_CELL),
                          "layout_bytes_per_launch": int(info["bytes_per_apply"])},

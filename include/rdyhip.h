@@ -214,6 +214,11 @@ int rdyhip_axpy_owned(RDyHipOperator op, double dt, const double *f_global, doub
 typedef struct {
   int32_t num_owned_cells, num_cells, slots_per_cell, num_boundary_edges;
   int32_t num_halo_cells;     /* owned cells with a ghost neighbour */
+  int32_t tiled_kernel;       /* 1: tiled LDS kernel (default), 0: cell-centric kernel (RDYHIP_KERNEL=cell) */
+  int32_t num_tiles;          /* tiles of 256 owned cells */
+  int32_t num_halo_tiles;     /* tiles with a ghost-adjacent cell */
+  int32_t max_tile_edges;     /* largest edge list of a tile */
+  int64_t num_edge_records;   /* sum of the tiles' edge lists (cut edges appear in two tiles) */
   int32_t owned_is_prefix;    /* 1 if owned cell o is local cell o */
   int64_t device_bytes;       /* bytes of device memory held by the operator */
   int64_t bytes_per_apply;    /* bytes one full apply must move (layout-exact, not the 176 B/cell model) */

@@ -32,6 +32,7 @@
 
 #include "rdyhip.h"
 #include "swe_device.h"
+#include "swe_kernels.h"
 
 using namespace rdyhip;
 
@@ -54,321 +55,6 @@ int fail(int code, const char *fmt, ...) {
     hipError_t e_ = (expr);                                                                                 \
     if (e_ != hipSuccess) return fail(RDYHIP_ERR_LIB, "%s failed: %s", #expr, hipGetErrorString(e_));       \
   } while (0)
-
-constexpr int BLOCK = 256;
-
-// persistent Courant diagnostic on the device
-struct DeviceCourant {
-  double  max_courant;
-  int32_t pos;  // position of the edge in the reference's loop order, -1 = none
-  int32_t pad;
-};
-
-// everything a kernel needs, passed by value
-struct KernelArgs {
-  int32_t        n_owned;    // owned cells
-  int32_t        n_work;     // threads with work: n_owned, or the length of `list`
-  int64_t        stride;     // distance between slot planes
-  const int32_t *list;       // owned-cell ids to process, or nullptr for 0..n_owned-1
-  const int32_t *o2l;        // owned -> local cell id, or nullptr if the identity
-  const int32_t *nbr;        // [S][stride]
-  const double  *cn, *sn, *coef;
-  const int32_t *pos;        // [S][stride] loop position of each slot's edge (Courant tie-break only)
-  const double  *dzdx, *dzdy;  // [n_owned]
-  const double  *mannings;   // [n_owned]
-  const double  *extsrc;     // [n_owned][3]
-  const double  *area_local; // [num_cells]
-  const int32_t *btype;      // [K] condition type of boundary edge k
-  const double  *bvalues;    // [K][3]
-  double        *bflux;      // [K][3]
-  double        *baccum;     // [K][3]
-  double        *pv;         // [n_owned][3]
-  double        *fdiv;       // [n_owned][3] or nullptr
-  double        *blk_max;    // [grid]
-  int32_t       *blk_pos;    // [grid]
-  double         tiny_h, h_anuga_sq, xq_thresh;
-  int32_t        phase;      // RDYHIP_PHASE_*
-  int32_t        overwrite;  // 1: f = rhs, 0: f += rhs
-  int32_t        xcd_chunks; // >0: blocks are dealt to XCDs in contiguous chunks of this many tiles
-};
-
-__device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
-  return v;
-}
-__device__ __forceinline__ int wave_min(int v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v = min(v, __shfl_xor(v, off, 64));
-  return v;
-}
-
-// One thread = one owned cell: all edge fluxes of the cell (ApplyInteriorFlux +
-// ApplyBoundaryFlux, src/swe/swe_petsc.c:215-316, 506-630), then the source
-// term on the in-register flux sum (ApplySource*, 704-932), then the block's
-// share of the Courant-number max (289-296, 595-600).
-template <int S, int SRC>
-__global__ __launch_bounds__(BLOCK) void swe_rhs_kernel(const KernelArgs a, const double dt, const double *__restrict__ u,
-                                                        double *__restrict__ f) {
-  // XCD-aware tile mapping: consecutive block ids are dealt round-robin to the
-  // 8 XCDs, so give each XCD a contiguous range of tiles (neighbour gathers
-  // then hit that XCD's own L2).
-  int tile = blockIdx.x;
-  if (a.xcd_chunks > 0) tile = (blockIdx.x & 7) * a.xcd_chunks + (blockIdx.x >> 3);
-  const int i = tile * BLOCK + threadIdx.x;
-
-  double best      = 0.0;  // largest Courant number seen by this thread (> 0 only)
-  int    best_slot = -1;
-  int    o         = 0;
-
-  bool active = i < a.n_work;
-  int32_t id[S];
-  if (active) {
-    o = a.list ? a.list[i] : i;
-    bool has_ghost = false;
-#pragma unroll
-    for (int s = 0; s < S; ++s) {
-      id[s] = a.nbr[s * a.stride + o];
-      has_ghost |= (id[s] >= 0) && (id[s] & NBR_GHOST);
-    }
-    if (a.phase == RDYHIP_PHASE_INTERIOR && has_ghost) active = false;
-    if (a.phase == RDYHIP_PHASE_HALO && !has_ghost) active = false;
-  }
-
-  if (active) {
-    const int    c  = a.o2l ? a.o2l[o] : o;
-    const double h  = u[3 * (int64_t)c + 0];
-    const double hu = u[3 * (int64_t)c + 1];
-    const double hv = u[3 * (int64_t)c + 2];
-    const RiemannSide self = riemann_side(h, hu, hv, a.tiny_h, a.h_anuga_sq);
-
-    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
-    if (!a.overwrite) {
-      acc0 = f[3 * (int64_t)o + 0];
-      acc1 = f[3 * (int64_t)o + 1];
-      acc2 = f[3 * (int64_t)o + 2];
-    }
-
-#pragma unroll
-    for (int s = 0; s < S; ++s) {
-      const int32_t nid = id[s];
-      if (S > 3 && nid == NBR_EMPTY) continue;
-      const double cn   = a.cn[s * a.stride + o];
-      const double sn   = a.sn[s * a.stride + o];
-      const double coef = a.coef[s * a.stride + o];
-      RoeFlux      fl;
-      bool         wet;
-      double       cfac = fabs(coef);  // len / area_self
-      if (nid >= 0) {
-        const int         n     = nid & NBR_MASK;
-        const double      hn    = u[3 * (int64_t)n + 0];
-        const double      hun   = u[3 * (int64_t)n + 1];
-        const double      hvn   = u[3 * (int64_t)n + 2];
-        const RiemannSide other = riemann_side(hn, hun, hvn, a.tiny_h, a.h_anuga_sq);
-        const bool        self_left = coef < 0.0;
-        RiemannSide       L, R;
-        L.h = self_left ? self.h : other.h;  R.h = self_left ? other.h : self.h;
-        L.u = self_left ? self.u : other.u;  R.u = self_left ? other.u : self.u;
-        L.v = self_left ? self.v : other.v;  R.v = self_left ? other.v : self.v;
-        L.sqh = self_left ? self.sqh : other.sqh;  R.sqh = self_left ? other.sqh : self.sqh;
-        L.c = self_left ? self.c : other.c;  R.c = self_left ? other.c : self.c;
-        fl  = roe_flux(L, R, sn, cn);
-        wet = !(R.h < a.tiny_h && L.h < a.tiny_h);
-        if (nid & NBR_GHOST) {
-          // the ghost side is not visited on this rank: use len / min(area_l, area_r)
-          const double as = a.area_local[c], an = a.area_local[n];
-          if (an < as) cfac = cfac * (as / an);
-        }
-      } else {
-        const int    k  = -1 - nid;
-        BoundaryFlux bf = boundary_flux(a.btype[k], true, self, a.bvalues + 3 * (int64_t)k, sn, cn, a.tiny_h, a.h_anuga_sq);
-        fl              = bf.flux;
-        wet             = bf.wet;
-        // boundary_fluxes[b] and VecAXPY(boundary_fluxes_accum, dt, boundary_fluxes), swe_petsc.c:574, 623
-        a.bflux[3 * (int64_t)k + 0] = fl.f0;
-        a.bflux[3 * (int64_t)k + 1] = fl.f1;
-        a.bflux[3 * (int64_t)k + 2] = fl.f2;
-        a.baccum[3 * (int64_t)k + 0] += dt * fl.f0;
-        a.baccum[3 * (int64_t)k + 1] += dt * fl.f1;
-        a.baccum[3 * (int64_t)k + 2] += dt * fl.f2;
-      }
-      if (wet) {
-        acc0 += fl.f0 * coef;
-        acc1 += fl.f1 * coef;
-        acc2 += fl.f2 * coef;
-        const double cnum = fl.amax * cfac * dt;
-        if (cnum > best) {
-          best      = cnum;
-          best_slot = s;
-        }
-      }
-    }
-
-    // ---- source term on the in-register flux sum (operator.c:663: the source reads the pre-source F)
-    const double bedx = a.dzdx[o] * GRAVITY * h;
-    const double bedy = a.dzdy[o] * GRAVITY * h;
-    double       tbx = 0.0, tby = 0.0;
-    if (h >= a.tiny_h) {
-      const double n = a.mannings[o];
-      if (SRC == RDYHIP_SOURCE_SEMI_IMPLICIT) friction_semi_implicit(h, hu, hv, n, dt, acc1, acc2, bedx, bedy, tbx, tby);
-      else friction_xq2018(h, hu, hv, n, dt, a.xq_thresh, acc1, acc2, bedx, bedy, tbx, tby);
-    }
-    if (a.fdiv) {
-      a.fdiv[3 * (int64_t)o + 0] = acc0;
-      a.fdiv[3 * (int64_t)o + 1] = acc1;
-      a.fdiv[3 * (int64_t)o + 2] = acc2;
-    }
-    const double s0 = a.extsrc[3 * (int64_t)o + 0];
-    const double s1 = a.extsrc[3 * (int64_t)o + 1];
-    const double s2 = a.extsrc[3 * (int64_t)o + 2];
-    f[3 * (int64_t)o + 0] = acc0 + s0;
-    f[3 * (int64_t)o + 1] = acc1 + (-bedx - tbx + s1);
-    f[3 * (int64_t)o + 2] = acc2 + (-bedy - tby + s2);
-
-    // primitive variables (swe_petsc.c:788-791): the same regularised velocities
-    // the Riemann states use, zero below tiny_h
-    a.pv[3 * (int64_t)o + 0] = h;
-    a.pv[3 * (int64_t)o + 1] = self.u;
-    a.pv[3 * (int64_t)o + 2] = self.v;
-  }
-
-  // ---- block reduction of the Courant number: max value, then the smallest
-  // loop position among the lanes that hold it (the reference keeps the first
-  // edge that reaches the max, swe_petsc.c:291).
-  __shared__ double s_max[BLOCK / 64];
-  __shared__ int    s_pos[BLOCK / 64];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  double    wmax = wave_max(best);
-  if (lane == 0) s_max[wave] = wmax;
-  __syncthreads();
-  double bmax = s_max[0];
-#pragma unroll
-  for (int w = 1; w < BLOCK / 64; ++w) bmax = fmax(bmax, s_max[w]);
-  int p = INT32_MAX;
-  if (best_slot >= 0 && best == bmax) p = a.pos[best_slot * a.stride + o];
-  p = wave_min(p);
-  if (lane == 0) s_pos[wave] = p;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    int bp = s_pos[0];
-#pragma unroll
-    for (int w = 1; w < BLOCK / 64; ++w) bp = min(bp, s_pos[w]);
-    a.blk_max[blockIdx.x] = bmax;
-    a.blk_pos[blockIdx.x] = (bmax > 0.0) ? bp : -1;
-  }
-}
-
-// merges the per-block partials into the persistent diagnostic (reset != 0:
-// the diagnostic is first reset, ResetOperatorDiagnostics src/operator.c:772-784)
-__global__ __launch_bounds__(1024) void courant_finalize_kernel(int nblk, const double *__restrict__ blk_max, const int32_t *__restrict__ blk_pos,
-                                                               DeviceCourant *diag, int reset) {
-  double m = 0.0;
-  int    p = INT32_MAX;
-  constexpr int U = 8;  // independent loads in flight per thread
-  for (int base = threadIdx.x; base < nblk; base += 1024 * U) {
-    double v[U];
-    int    q[U];
-#pragma unroll
-    for (int j = 0; j < U; ++j) {
-      const int i = base + j * 1024;
-      v[j]        = i < nblk ? blk_max[i] : 0.0;
-      q[j]        = i < nblk ? blk_pos[i] : INT32_MAX;
-    }
-#pragma unroll
-    for (int j = 0; j < U; ++j) {
-      if (v[j] > m || (v[j] == m && v[j] > 0.0 && q[j] < p)) {
-        m = v[j];
-        p = q[j];
-      }
-    }
-  }
-  __shared__ double s_max[16];
-  __shared__ int    s_pos[16];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const double wm = wave_max(m);
-  int          wp = (m == wm && m > 0.0) ? p : INT32_MAX;
-  wp              = wave_min(wp);
-  if (lane == 0) {
-    s_max[wave] = wm;
-    s_pos[wave] = wp;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double bm = 0.0;
-    int    bp = INT32_MAX;
-    for (int w = 0; w < 16; ++w) {
-      if (s_max[w] > bm || (s_max[w] == bm && bm > 0.0 && s_pos[w] < bp)) {
-        bm = s_max[w];
-        bp = s_pos[w];
-      }
-    }
-    double cur_max = reset ? 0.0 : diag->max_courant;
-    int    cur_pos = reset ? -1 : diag->pos;
-    if (bm > cur_max || (bm == cur_max && bm > 0.0 && bp < cur_pos)) {
-      cur_max = bm;
-      cur_pos = bp;
-    }
-    diag->max_courant = cur_max;
-    diag->pos         = cur_pos;
-  }
-}
-
-__global__ void courant_reset_kernel(DeviceCourant *diag) {
-  diag->max_courant = 0.0;
-  diag->pos         = -1;
-}
-
-// boundary edges whose left cell is a ghost: the reference still evaluates
-// their Riemann problem into boundary_fluxes[b] (swe_petsc.c:574) although
-// nothing is accumulated into F (588).  Diagnostic output only.
-__global__ void boundary_ghost_kernel(int n, const int32_t *__restrict__ klist, const int32_t *__restrict__ bleft, const int32_t *__restrict__ btype,
-                                      const double *__restrict__ bcn, const double *__restrict__ bsn, const double *__restrict__ bvalues,
-                                      double *__restrict__ bflux, double *__restrict__ baccum, const double *__restrict__ u, double dt, double tiny_h,
-                                      double h_anuga_sq) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const int    k = klist[i];
-  const int    c = bleft[k];
-  const double h = u[3 * (int64_t)c + 0], hu = u[3 * (int64_t)c + 1], hv = u[3 * (int64_t)c + 2];
-  const RiemannSide L  = riemann_side(h, hu, hv, tiny_h, h_anuga_sq);
-  BoundaryFlux      bf = boundary_flux(btype[k], false, L, bvalues + 3 * (int64_t)k, bsn[k], bcn[k], tiny_h, h_anuga_sq);
-  bflux[3 * (int64_t)k + 0] = bf.flux.f0;
-  bflux[3 * (int64_t)k + 1] = bf.flux.f1;
-  bflux[3 * (int64_t)k + 2] = bf.flux.f2;
-  baccum[3 * (int64_t)k + 0] += dt * bf.flux.f0;
-  baccum[3 * (int64_t)k + 1] += dt * bf.flux.f1;
-  baccum[3 * (int64_t)k + 2] += dt * bf.flux.f2;
-}
-
-__global__ void pack_cells_kernel(int n, const double *__restrict__ u, const int32_t *__restrict__ ids, double *__restrict__ buf) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= 3 * n) return;
-  const int cell = i / 3, comp = i - 3 * cell;
-  buf[i] = u[3 * (int64_t)ids[cell] + comp];
-}
-__global__ void unpack_cells_kernel(int n, double *__restrict__ u, const int32_t *__restrict__ ids, const double *__restrict__ buf) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= 3 * n) return;
-  const int cell = i / 3, comp = i - 3 * cell;
-  u[3 * (int64_t)ids[cell] + comp] = buf[i];
-}
-__global__ void axpy_owned_kernel(int n_owned, const int32_t *__restrict__ o2l, double dt, const double *__restrict__ f, double *__restrict__ u) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= 3 * n_owned) return;
-  if (o2l) {
-    const int o = i / 3, comp = i - 3 * o;
-    u[3 * (int64_t)o2l[o] + comp] += dt * f[i];
-  } else {
-    u[i] += dt * f[i];
-  }
-}
-__global__ void scatter_component_kernel(int n, const int32_t *__restrict__ ids, const double *__restrict__ vals, double *__restrict__ dst, int ncomp,
-                                         int comp) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const int o = ids ? ids[i] : i;
-  dst[(int64_t)o * ncomp + comp] = vals[i];
-}
 
 template <typename T>
 struct DevBuf {
@@ -418,6 +104,14 @@ struct RDyHipOperator_s {
   DevBuf<int32_t> d_blk_pos;
   DevBuf<DeviceCourant> d_courant;
   int32_t n_halo = 0, n_bghost = 0;
+  // tiled kernel (swe_kernels.h)
+  bool             use_tiled = true;
+  int32_t          ntiles = 0, n_halo_tiles = 0, emax = 0;
+  int64_t          nrec = 0;
+  DevBuf<int32_t>  d_tile_off, d_e_left, d_e_right, d_halo_tiles;
+  DevBuf<uint8_t>  d_tile_halo;
+  DevBuf<double>   d_e_cn, d_e_sn;
+  DevBuf<uint16_t> d_slot_ref;
 
   // host copies needed to resolve the Courant position into ids
   std::vector<int32_t> h_internal_edge, h_edge_cells, h_bedge, h_boff;
@@ -436,6 +130,8 @@ struct RDyHipOperator_s {
     d_mannings.release(); d_extsrc.release(); d_area_local.release(); d_bvalues.release(); d_bflux.release();
     d_baccum.release(); d_bcn.release(); d_bsn.release(); d_pv.release(); d_fdiv.release(); d_blk_max.release();
     d_blk_pos.release(); d_courant.release(); d_stage_vals.release(); d_stage_ids.release();
+    d_tile_off.release(); d_e_left.release(); d_e_right.release(); d_halo_tiles.release(); d_tile_halo.release();
+    d_e_cn.release(); d_e_sn.release(); d_slot_ref.release();
   }
 };
 
@@ -473,27 +169,60 @@ int launch_rhs(RDyHipOperator op, int32_t phase, int32_t overwrite, int reset_di
   a.overwrite  = overwrite ? 1 : 0;
   a.phase      = phase;
 
-  int grid;
-  if (phase == RDYHIP_PHASE_HALO) {
-    if (op->n_halo == 0) return 0;  // (never combined with reset_diag)
-    a.list       = op->d_halo_list.p;
-    a.n_work     = op->n_halo;
-    a.xcd_chunks = 0;
-    a.phase      = RDYHIP_PHASE_ALL;  // the list already holds exactly the halo cells
-    grid         = (op->n_halo + BLOCK - 1) / BLOCK;
-  } else {
-    a.list       = nullptr;
-    a.n_work     = op->n_owned;
-    a.xcd_chunks = op->xcd_chunks;
-    grid         = op->grid;
-  }
+  a.tile_off  = op->d_tile_off.p;
+  a.tile_halo = op->d_tile_halo.p;
+  a.e_left    = op->d_e_left.p;
+  a.e_right   = op->d_e_right.p;
+  a.e_cn      = op->d_e_cn.p;
+  a.e_sn      = op->d_e_sn.p;
+  a.slot_ref  = op->d_slot_ref.p;
+  a.emax      = op->emax;
+
+  int        grid;
   const bool xq = op->config.source_method == RDYHIP_SOURCE_IMPLICIT_XQ2018;
-  if (op->S == 3) {
-    if (xq) hipLaunchKernelGGL((swe_rhs_kernel<3, 1>), dim3(grid), dim3(BLOCK), 0, st, a, dt, u, f);
-    else hipLaunchKernelGGL((swe_rhs_kernel<3, 0>), dim3(grid), dim3(BLOCK), 0, st, a, dt, u, f);
+  if (op->use_tiled) {
+    if (phase == RDYHIP_PHASE_HALO) {
+      if (op->n_halo_tiles == 0) return 0;
+      a.list       = op->d_halo_tiles.p;
+      a.n_work     = op->n_halo_tiles;
+      a.xcd_chunks = 0;
+      a.phase      = RDYHIP_PHASE_ALL;  // the list already holds exactly the halo tiles
+      grid         = op->n_halo_tiles;
+    } else {
+      a.list       = nullptr;
+      a.n_work     = op->ntiles;
+      a.xcd_chunks = op->xcd_chunks;
+      grid         = op->grid;
+    }
+    const size_t lds = sizeof(double) * (5 * (size_t)BLOCK + 4 * (size_t)op->emax);
+    if (op->S == 3) {
+      if (xq) hipLaunchKernelGGL((swe_rhs_tiled_kernel<3, 1>), dim3(grid), dim3(BLOCK), lds, st, a, dt, u, f);
+      else hipLaunchKernelGGL((swe_rhs_tiled_kernel<3, 0>), dim3(grid), dim3(BLOCK), lds, st, a, dt, u, f);
+    } else {
+      if (xq) hipLaunchKernelGGL((swe_rhs_tiled_kernel<4, 1>), dim3(grid), dim3(BLOCK), lds, st, a, dt, u, f);
+      else hipLaunchKernelGGL((swe_rhs_tiled_kernel<4, 0>), dim3(grid), dim3(BLOCK), lds, st, a, dt, u, f);
+    }
   } else {
-    if (xq) hipLaunchKernelGGL((swe_rhs_kernel<4, 1>), dim3(grid), dim3(BLOCK), 0, st, a, dt, u, f);
-    else hipLaunchKernelGGL((swe_rhs_kernel<4, 0>), dim3(grid), dim3(BLOCK), 0, st, a, dt, u, f);
+    if (phase == RDYHIP_PHASE_HALO) {
+      if (op->n_halo == 0) return 0;
+      a.list       = op->d_halo_list.p;
+      a.n_work     = op->n_halo;
+      a.xcd_chunks = 0;
+      a.phase      = RDYHIP_PHASE_ALL;  // the list already holds exactly the halo cells
+      grid         = (op->n_halo + BLOCK - 1) / BLOCK;
+    } else {
+      a.list       = nullptr;
+      a.n_work     = op->n_owned;
+      a.xcd_chunks = op->xcd_chunks;
+      grid         = op->grid;
+    }
+    if (op->S == 3) {
+      if (xq) hipLaunchKernelGGL((swe_rhs_kernel<3, 1>), dim3(grid), dim3(BLOCK), 0, st, a, dt, u, f);
+      else hipLaunchKernelGGL((swe_rhs_kernel<3, 0>), dim3(grid), dim3(BLOCK), 0, st, a, dt, u, f);
+    } else {
+      if (xq) hipLaunchKernelGGL((swe_rhs_kernel<4, 1>), dim3(grid), dim3(BLOCK), 0, st, a, dt, u, f);
+      else hipLaunchKernelGGL((swe_rhs_kernel<4, 0>), dim3(grid), dim3(BLOCK), 0, st, a, dt, u, f);
+    }
   }
   HIP_TRY(hipGetLastError());
   hipLaunchKernelGGL(courant_finalize_kernel, dim3(1), dim3(1024), 0, st, grid, op->d_blk_max.p, op->d_blk_pos.p, op->d_courant.p, reset_diag);
@@ -524,7 +253,7 @@ int rdyhip_create(const RDyHipConfig *config, const RDyHipMesh *mesh, int32_t nu
     return fail(RDYHIP_ERR_USER, "Only semi_implicit and implicit_xq2018 are supported");  // swe_petsc.c:973
   const int32_t nc = mesh->num_cells, no = mesh->num_owned_cells, ne = mesh->num_edges, ni = mesh->num_internal_edges;
   if (nc < 0 || no < 0 || no > nc || ne < 0 || ni < 0 || ni > ne) return fail(RDYHIP_ERR_ARG_SIZ, "inconsistent mesh sizes");
-  if (nc >= NBR_GHOST) return fail(RDYHIP_ERR_ARG_SIZ, "too many local cells (%d) for the 30-bit neighbour encoding", nc);
+  if (nc >= END_INTILE) return fail(RDYHIP_ERR_ARG_SIZ, "too many local cells (%d) for the 29-bit neighbour encoding", nc);
   if (nc > 0 && (!mesh->cell_is_owned || !mesh->cell_local_to_owned || !mesh->cell_areas || !mesh->cell_dz_dx || !mesh->cell_dz_dy))
     return fail(RDYHIP_ERR_USER, "null cell array");
   if (ne > 0 && (!mesh->edge_cell_ids || !mesh->edge_lengths || !mesh->edge_cn || !mesh->edge_sn)) return fail(RDYHIP_ERR_USER, "null edge array");
@@ -629,6 +358,75 @@ int rdyhip_create(const RDyHipConfig *config, const RDyHipMesh *mesh, int32_t nu
     if (g) halo.push_back(o);
   }
 
+  // ---- tiles of 256 consecutive owned cells and their edge lists (tiled kernel) ----
+  const int32_t         ntiles = (no + BLOCK - 1) / BLOCK;
+  std::vector<int32_t>  tile_off((size_t)ntiles + 1, 0), e_left, e_right, halo_tiles;
+  std::vector<uint8_t>  tile_halo((size_t)ntiles, 0);
+  std::vector<double>   e_cn, e_sn;
+  std::vector<uint16_t> slot_ref((size_t)no * 4, SLOT_EMPTY);
+  int32_t               emax = 0;
+  {
+    e_left.reserve((size_t)no * 2);
+    e_right.reserve((size_t)no * 2);
+    e_cn.reserve((size_t)no * 2);
+    e_sn.reserve((size_t)no * 2);
+    std::vector<std::pair<int32_t, int32_t>> items;  // (loop position of the edge, owned cell * 4 + slot)
+    items.reserve(4 * BLOCK);
+    auto encode = [&](int32_t cell, int32_t base, int32_t cntc) -> int32_t {
+      if (mesh->cell_is_owned[cell]) {
+        const int32_t oo = mesh->cell_local_to_owned[cell];
+        if (oo >= base && oo < base + cntc) return END_INTILE | (oo - base);
+        return cell;
+      }
+      return cell | NBR_GHOST;
+    };
+    for (int32_t t = 0; t < ntiles; ++t) {
+      const int32_t base = t * BLOCK, cntc = std::min<int32_t>(BLOCK, no - base);
+      items.clear();
+      bool halo_tile = false;
+      for (int32_t j = 0; j < cntc; ++j) {
+        for (int32_t sl = 0; sl < S; ++sl) {
+          const int64_t idx = (int64_t)sl * stride + base + j;
+          if (nbr[idx] == NBR_EMPTY) continue;
+          items.emplace_back(pos[idx], (base + j) * 4 + sl);
+          if (nbr[idx] >= 0 && (nbr[idx] & NBR_GHOST)) halo_tile = true;
+        }
+      }
+      std::sort(items.begin(), items.end());
+      tile_off[t] = (int32_t)e_left.size();
+      int32_t last = -1, local = -1;
+      for (const auto &it : items) {
+        if (it.first != last) {
+          last = it.first;
+          ++local;
+          int32_t e, l, rgt;
+          if (last < ni) {
+            e   = mesh->edge_internal_ids[last];
+            l   = encode(mesh->edge_cell_ids[2 * e], base, cntc);
+            rgt = encode(mesh->edge_cell_ids[2 * e + 1], base, cntc);
+          } else {
+            const int32_t k = last - ni;
+            e               = bedge[k];
+            l               = encode(bleft[k], base, cntc);
+            rgt             = -1 - k;
+          }
+          e_left.push_back(l);
+          e_right.push_back(rgt);
+          e_cn.push_back(mesh->edge_cn[e]);
+          e_sn.push_back(mesh->edge_sn[e]);
+        }
+        slot_ref[(size_t)(it.second >> 2) * 4 + (it.second & 3)] = (uint16_t)local;
+      }
+      emax = std::max(emax, local + 1);
+      if (halo_tile) {
+        tile_halo[t] = 1;
+        halo_tiles.push_back(t);
+      }
+      if ((int64_t)e_left.size() > (int64_t)INT32_MAX - 4 * BLOCK) return fail(RDYHIP_ERR_ARG_SIZ, "too many tile edge records");
+    }
+    tile_off[ntiles] = (int32_t)e_left.size();
+  }
+
   // ---- per-owned-cell geometry --------------------------------------------
   std::vector<double> dzdx((size_t)no), dzdy((size_t)no);
   for (int32_t o = 0; o < no; ++o) {
@@ -649,6 +447,14 @@ int rdyhip_create(const RDyHipConfig *config, const RDyHipMesh *mesh, int32_t nu
   op->prefix     = prefix;
   op->n_halo     = (int32_t)halo.size();
   op->n_bghost   = (int32_t)bghost.size();
+  op->ntiles       = ntiles;
+  op->n_halo_tiles = (int32_t)halo_tiles.size();
+  op->emax         = emax;
+  op->nrec         = (int64_t)e_left.size();
+  {
+    const char *kenv = getenv("RDYHIP_KERNEL");
+    op->use_tiled    = !(kenv && strcmp(kenv, "cell") == 0);
+  }
   int rc         = 0;
   if (hipGetDevice(&op->device) != hipSuccess) {
     delete op;
@@ -689,6 +495,14 @@ int rdyhip_create(const RDyHipConfig *config, const RDyHipMesh *mesh, int32_t nu
     TRY_RC(op->d_area_local.upload(area));
     op->h_area.swap(area);
   }
+  TRY_RC(op->d_tile_off.upload(tile_off));
+  TRY_RC(op->d_tile_halo.upload(tile_halo));
+  TRY_RC(op->d_halo_tiles.upload(halo_tiles));
+  TRY_RC(op->d_e_left.upload(e_left));
+  TRY_RC(op->d_e_right.upload(e_right));
+  TRY_RC(op->d_e_cn.upload(e_cn));
+  TRY_RC(op->d_e_sn.upload(e_sn));
+  TRY_RC(op->d_slot_ref.upload(slot_ref));
   TRY_RC(op->d_mannings.zeros((size_t)no));
   TRY_RC(op->d_extsrc.zeros((size_t)3 * no));
   TRY_RC(op->d_bvalues.zeros((size_t)3 * K));
@@ -715,7 +529,8 @@ int rdyhip_create(const RDyHipConfig *config, const RDyHipMesh *mesh, int32_t nu
   op->device_bytes = op->d_o2l.bytes() + op->d_nbr.bytes() + op->d_pos.bytes() + op->d_cn.bytes() + op->d_sn.bytes() + op->d_coef.bytes() +
                      op->d_dzdx.bytes() + op->d_dzdy.bytes() + op->d_mannings.bytes() + op->d_extsrc.bytes() + op->d_area_local.bytes() +
                      op->d_pv.bytes() + op->d_bvalues.bytes() + op->d_bflux.bytes() + op->d_baccum.bytes() + op->d_blk_max.bytes() +
-                     op->d_blk_pos.bytes();
+                     op->d_blk_pos.bytes() + op->d_tile_off.bytes() + op->d_tile_halo.bytes() + op->d_e_left.bytes() + op->d_e_right.bytes() +
+                     op->d_e_cn.bytes() + op->d_e_sn.bytes() + op->d_slot_ref.bytes();
   *op_out = op;
   return 0;
 }
@@ -925,10 +740,20 @@ int rdyhip_layout_info(RDyHipOperator op, RDyHipLayoutInfo *info) {
   info->slots_per_cell     = op->S;
   info->num_boundary_edges = op->K;
   info->num_halo_cells     = op->n_halo;
+  info->tiled_kernel       = op->use_tiled ? 1 : 0;
+  info->num_tiles          = op->ntiles;
+  info->num_halo_tiles     = op->n_halo_tiles;
+  info->max_tile_edges     = op->emax;
+  info->num_edge_records   = op->nrec;
   info->owned_is_prefix    = op->prefix ? 1 : 0;
   info->device_bytes       = op->device_bytes;
   // u (own cell) 24 + slots S*(4+8+8+8) + dz 16 + n 8 + ext src 24 + F 24 + pv 24 (+4 for o2l)
-  info->bytes_per_apply = (int64_t)op->n_owned * (24 + op->S * 28 + 16 + 8 + 24 + 24 + 24 + (op->prefix ? 0 : 4));
+  if (op->use_tiled) {
+    // u 24 + slot refs 8 + coef S*8 + dz 16 + n 8 + ext src 24 + F 24 + pv 24 (+4 for o2l) per cell; 24 B per edge record
+    info->bytes_per_apply = (int64_t)op->n_owned * (24 + 8 + op->S * 8 + 16 + 8 + 24 + 24 + 24 + (op->prefix ? 0 : 4)) + op->nrec * 24;
+  } else {
+    info->bytes_per_apply = (int64_t)op->n_owned * (24 + op->S * 28 + 16 + 8 + 24 + 24 + 24 + (op->prefix ? 0 : 4));
+  }
   return 0;
 }
 

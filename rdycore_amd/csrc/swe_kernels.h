@@ -1,0 +1,518 @@
+// HIP kernels of the SWE right-hand side for gfx950 (wave64, 160 KB LDS per CU).
+//
+// Two implementations of the same operator share the epilogue and the
+// Courant reduction:
+//
+//  * swe_rhs_tiled_kernel (default): one workgroup = one tile of 256
+//    consecutive owned cells.
+//      phase 0  every thread loads its cell's state, derives the Riemann side
+//               data (velocities, sqrt(h), sqrt(g h)) once and stages it in LDS;
+//      phase 1  threads sweep the tile's edge list (every edge that touches a
+//               tile cell, built at setup): left/right states come from LDS
+//               (or from global memory for the few cells outside the tile),
+//               each Roe flux is evaluated ONCE and parked in LDS;
+//      phase 2  every thread sums its cell's <= S edge fluxes from LDS in the
+//               reference's loop order (a segmented reduction with no
+//               atomics), applies the source terms and writes F and the
+//               primitive variables.
+//    Edges cut by a tile boundary are evaluated by both tiles (bitwise
+//    identically), so no inter-workgroup communication is needed.
+//
+//  * swe_rhs_kernel (RDYHIP_KERNEL=cell): one thread = one cell, every edge of
+//    the cell evaluated by that thread (each interior edge twice overall).
+//    Kept as the simple reference point for A/B measurements.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rdyhip.h"
+#include "swe_device.h"
+
+namespace rdyhip {
+
+constexpr int BLOCK = 256;
+
+// encoding of a tile edge's end points
+constexpr int32_t END_INTILE = 1 << 29;  // low bits = index of the cell inside the tile (LDS slot)
+// otherwise: local cell id (| NBR_GHOST), or -1-k for the boundary edge k on the right side
+constexpr uint16_t SLOT_EMPTY = 0xFFFF;
+
+// persistent Courant diagnostic on the device
+struct DeviceCourant {
+  double  max_courant;
+  int32_t pos;  // position of the edge in the reference's loop order, -1 = none
+  int32_t pad;
+};
+
+// everything a kernel needs, passed by value
+struct KernelArgs {
+  int32_t        n_owned;    // owned cells
+  int32_t        n_work;     // cell kernel: threads with work; tiled kernel: number of tiles to run
+  int64_t        stride;     // distance between slot planes
+  const int32_t *list;       // cell kernel: owned-cell ids; tiled kernel: tile ids; or nullptr for 0..n_work-1
+  const int32_t *o2l;        // owned -> local cell id, or nullptr if the identity
+  const int32_t *nbr;        // [S][stride] (cell kernel)
+  const double  *cn, *sn;    // [S][stride] (cell kernel)
+  const double  *coef;       // [S][stride]
+  const int32_t *pos;        // [S][stride] loop position of each slot's edge (Courant tie-break only)
+  const double  *dzdx, *dzdy;  // [n_owned]
+  const double  *mannings;   // [n_owned]
+  const double  *extsrc;     // [n_owned][3]
+  const double  *area_local; // [num_cells]
+  const int32_t *btype;      // [K] condition type of boundary edge k
+  const double  *bvalues;    // [K][3]
+  double        *bflux;      // [K][3]
+  double        *baccum;     // [K][3]
+  double        *pv;         // [n_owned][3]
+  double        *fdiv;       // [n_owned][3] or nullptr
+  double        *blk_max;    // [grid]
+  int32_t       *blk_pos;    // [grid]
+  double         tiny_h, h_anuga_sq, xq_thresh;
+  int32_t        phase;      // RDYHIP_PHASE_*
+  int32_t        overwrite;  // 1: f = rhs, 0: f += rhs
+  int32_t        xcd_chunks; // >0: blocks are dealt to XCDs in contiguous chunks of this many tiles
+  // ---- tiled kernel only
+  const int32_t  *tile_off;  // [ntiles+1] first edge record of each tile
+  const uint8_t  *tile_halo; // [ntiles] 1 if a cell of the tile has a ghost neighbour
+  const int32_t  *e_left, *e_right;  // [nrec] encoded end points
+  const double   *e_cn, *e_sn;       // [nrec]
+  const uint16_t *slot_ref;  // [n_owned][4] index of each slot's edge in the tile's edge list
+  int32_t         emax;      // largest edge count of a tile (LDS sizing)
+};
+
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+  return v;
+}
+__device__ __forceinline__ int wave_min(int v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v = min(v, __shfl_xor(v, off, 64));
+  return v;
+}
+
+// Source terms on the in-register flux sum, then the stores of F and the
+// primitive variables.  ApplySourceSemiImplicit / ApplySourceImplicitXQ2018
+// (src/swe/swe_petsc.c:704-804, 816-932); the source reads the pre-source F
+// (src/operator.c:663).
+template <int SRC>
+__device__ __forceinline__ void cell_epilogue(const KernelArgs &a, int o, double dt, double h, double hu, double hv, double pu, double pv_, double acc0,
+                                              double acc1, double acc2, double dzdx, double dzdy, double n, double s0, double s1, double s2,
+                                              double *__restrict__ f) {
+  const double bedx = dzdx * GRAVITY * h;
+  const double bedy = dzdy * GRAVITY * h;
+  double       tbx = 0.0, tby = 0.0;
+  if (h >= a.tiny_h) {
+    if (SRC == RDYHIP_SOURCE_SEMI_IMPLICIT) friction_semi_implicit(h, hu, hv, n, dt, acc1, acc2, bedx, bedy, tbx, tby);
+    else friction_xq2018(h, hu, hv, n, dt, a.xq_thresh, acc1, acc2, bedx, bedy, tbx, tby);
+  }
+  if (a.fdiv) {
+    a.fdiv[3 * (int64_t)o + 0] = acc0;
+    a.fdiv[3 * (int64_t)o + 1] = acc1;
+    a.fdiv[3 * (int64_t)o + 2] = acc2;
+  }
+  f[3 * (int64_t)o + 0] = acc0 + s0;
+  f[3 * (int64_t)o + 1] = acc1 + (-bedx - tbx + s1);
+  f[3 * (int64_t)o + 2] = acc2 + (-bedy - tby + s2);
+  // primitive variables (swe_petsc.c:788-791): the regularised velocities of the Riemann states, zero below tiny_h
+  a.pv[3 * (int64_t)o + 0] = h;
+  a.pv[3 * (int64_t)o + 1] = pu;
+  a.pv[3 * (int64_t)o + 2] = pv_;
+}
+
+// Block reduction of the Courant number: max value, then the smallest loop
+// position among the lanes that hold it (the reference keeps the first edge
+// that reaches the max, swe_petsc.c:291).  Writes the block's partial.
+__device__ __forceinline__ void block_courant_reduce(const KernelArgs &a, double best, int best_slot, int o) {
+  __shared__ double s_max[BLOCK / 64];
+  __shared__ int    s_pos[BLOCK / 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double    wmax = wave_max(best);
+  if (lane == 0) s_max[wave] = wmax;
+  __syncthreads();
+  double bmax = s_max[0];
+#pragma unroll
+  for (int w = 1; w < BLOCK / 64; ++w) bmax = fmax(bmax, s_max[w]);
+  int p = INT32_MAX;
+  if (best_slot >= 0 && best == bmax) p = a.pos[best_slot * a.stride + o];
+  p = wave_min(p);
+  if (lane == 0) s_pos[wave] = p;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int bp = s_pos[0];
+#pragma unroll
+    for (int w = 1; w < BLOCK / 64; ++w) bp = min(bp, s_pos[w]);
+    a.blk_max[blockIdx.x] = bmax;
+    a.blk_pos[blockIdx.x] = (bmax > 0.0) ? bp : -1;
+  }
+}
+
+__device__ __forceinline__ void store_boundary_flux(const KernelArgs &a, int k, const RoeFlux &fl, double dt) {
+  // boundary_fluxes[b] and VecAXPY(boundary_fluxes_accum, dt, boundary_fluxes), swe_petsc.c:574, 623
+  a.bflux[3 * (int64_t)k + 0] = fl.f0;
+  a.bflux[3 * (int64_t)k + 1] = fl.f1;
+  a.bflux[3 * (int64_t)k + 2] = fl.f2;
+  a.baccum[3 * (int64_t)k + 0] += dt * fl.f0;
+  a.baccum[3 * (int64_t)k + 1] += dt * fl.f1;
+  a.baccum[3 * (int64_t)k + 2] += dt * fl.f2;
+}
+
+// ---------------------------------------------------------------------------
+// tiled kernel
+// ---------------------------------------------------------------------------
+template <int S, int SRC>
+__global__ __launch_bounds__(BLOCK) void swe_rhs_tiled_kernel(const KernelArgs a, const double dt, const double *__restrict__ u,
+                                                              double *__restrict__ f) {
+  extern __shared__ double lds[];
+  double *sd_h = lds, *sd_u = lds + BLOCK, *sd_v = lds + 2 * BLOCK, *sd_sq = lds + 3 * BLOCK, *sd_c = lds + 4 * BLOCK;
+  double *ef0 = lds + 5 * BLOCK, *ef1 = ef0 + a.emax, *ef2 = ef1 + a.emax, *eam = ef2 + a.emax;
+
+  // XCD-aware tile mapping: block ids are dealt round-robin to the 8 XCDs, so
+  // give each XCD a contiguous range of tiles (cut edges and out-of-tile
+  // neighbours then hit that XCD's own L2).
+  int ti = blockIdx.x;
+  if (a.xcd_chunks > 0) ti = (blockIdx.x & 7) * a.xcd_chunks + (blockIdx.x >> 3);
+  bool valid = ti < a.n_work;
+  int  tile  = 0;
+  if (valid) {
+    tile = a.list ? a.list[ti] : ti;
+    if (a.phase == RDYHIP_PHASE_INTERIOR && a.tile_halo[tile]) valid = false;
+  }
+  if (!valid) {  // uniform over the block
+    if (threadIdx.x == 0) {
+      a.blk_max[blockIdx.x] = 0.0;
+      a.blk_pos[blockIdx.x] = -1;
+    }
+    return;
+  }
+  const int  base   = tile * BLOCK;
+  const int  o      = base + threadIdx.x;
+  const bool active = o < a.n_owned;
+  const int  e_off  = a.tile_off[tile];
+  const int  ne     = a.tile_off[tile + 1] - e_off;
+
+  // ---- phase 0: own state -> Riemann side data -> LDS; start the loads phase 2 needs
+  double      h = 0.0, hu = 0.0, hv = 0.0;
+  RiemannSide self;
+  self.h = self.u = self.v = self.sqh = self.c = 0.0;
+  double   coef[S];
+  uint2    refs = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+  double   dzdx = 0.0, dzdy = 0.0, nman = 0.0, s0 = 0.0, s1 = 0.0, s2 = 0.0;
+  double   acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
+  if (active) {
+    const int c = a.o2l ? a.o2l[o] : o;
+    h           = u[3 * (int64_t)c + 0];
+    hu          = u[3 * (int64_t)c + 1];
+    hv          = u[3 * (int64_t)c + 2];
+    refs        = *reinterpret_cast<const uint2 *>(a.slot_ref + 4 * (int64_t)o);
+#pragma unroll
+    for (int s = 0; s < S; ++s) coef[s] = a.coef[s * a.stride + o];
+    dzdx = a.dzdx[o];
+    dzdy = a.dzdy[o];
+    nman = a.mannings[o];
+    s0   = a.extsrc[3 * (int64_t)o + 0];
+    s1   = a.extsrc[3 * (int64_t)o + 1];
+    s2   = a.extsrc[3 * (int64_t)o + 2];
+    if (!a.overwrite) {
+      acc0 = f[3 * (int64_t)o + 0];
+      acc1 = f[3 * (int64_t)o + 1];
+      acc2 = f[3 * (int64_t)o + 2];
+    }
+    self = riemann_side(h, hu, hv, a.tiny_h, a.h_anuga_sq);
+  } else {
+#pragma unroll
+    for (int s = 0; s < S; ++s) coef[s] = 0.0;
+  }
+  sd_h[threadIdx.x]  = self.h;
+  sd_u[threadIdx.x]  = self.u;
+  sd_v[threadIdx.x]  = self.v;
+  sd_sq[threadIdx.x] = self.sqh;
+  sd_c[threadIdx.x]  = self.c;
+  __syncthreads();
+
+  // ---- phase 1: every edge of the tile once (ApplyInteriorFlux / ApplyBoundaryFlux, swe_petsc.c:215-316, 506-630)
+  for (int e = threadIdx.x; e < ne; e += BLOCK) {
+    const int32_t el = a.e_left[e_off + e];
+    const int32_t er = a.e_right[e_off + e];
+    const double  cn = a.e_cn[e_off + e];
+    const double  sn = a.e_sn[e_off + e];
+    RiemannSide   L;
+    int           cl;  // local cell id of the left cell (only needed on rare paths)
+    if (el & END_INTILE) {
+      const int j = el & (BLOCK - 1);
+      L.h = sd_h[j]; L.u = sd_u[j]; L.v = sd_v[j]; L.sqh = sd_sq[j]; L.c = sd_c[j];
+      cl = -1 - j;
+    } else {
+      cl = el & NBR_MASK;
+      L  = riemann_side(u[3 * (int64_t)cl + 0], u[3 * (int64_t)cl + 1], u[3 * (int64_t)cl + 2], a.tiny_h, a.h_anuga_sq);
+    }
+    RoeFlux fl;
+    bool    wet;
+    double  gfac = 1.0;
+    if (er >= 0) {
+      RiemannSide R;
+      int         cr;
+      if (er & END_INTILE) {
+        const int j = er & (BLOCK - 1);
+        R.h = sd_h[j]; R.u = sd_u[j]; R.v = sd_v[j]; R.sqh = sd_sq[j]; R.c = sd_c[j];
+        cr = -1 - j;
+      } else {
+        cr = er & NBR_MASK;
+        R  = riemann_side(u[3 * (int64_t)cr + 0], u[3 * (int64_t)cr + 1], u[3 * (int64_t)cr + 2], a.tiny_h, a.h_anuga_sq);
+      }
+      fl  = roe_flux(L, R, sn, cn);
+      wet = !(R.h < a.tiny_h && L.h < a.tiny_h);
+      if ((el | er) & NBR_GHOST) {
+        // the ghost side is not visited on this rank: make amax*|coef_owned| equal amax*len/min(area_l, area_r)
+        if (cl < 0) cl = a.o2l ? a.o2l[base + (-1 - cl)] : base + (-1 - cl);
+        if (cr < 0) cr = a.o2l ? a.o2l[base + (-1 - cr)] : base + (-1 - cr);
+        const double al = a.area_local[cl], ar = a.area_local[cr];
+        const double a_owned = (el & NBR_GHOST) ? ar : al, a_ghost = (el & NBR_GHOST) ? al : ar;
+        if (a_ghost < a_owned) gfac = a_owned / a_ghost;
+      }
+    } else {
+      const int    k  = -1 - er;
+      BoundaryFlux bf = boundary_flux(a.btype[k], true, L, a.bvalues + 3 * (int64_t)k, sn, cn, a.tiny_h, a.h_anuga_sq);
+      fl              = bf.flux;
+      wet             = bf.wet;
+      store_boundary_flux(a, k, fl, dt);
+    }
+    ef0[e] = fl.f0;
+    ef1[e] = fl.f1;
+    ef2[e] = fl.f2;
+    eam[e] = wet ? fl.amax * gfac : -1.0;  // -1 marks a dry-dry edge (skipped, swe_petsc.c:285)
+  }
+  __syncthreads();
+
+  // ---- phase 2: per-cell sum in the reference's edge order, source terms, stores
+  double best      = 0.0;
+  int    best_slot = -1;
+  if (active) {
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      const uint32_t w   = (s < 2) ? refs.x : refs.y;
+      const uint32_t ref = (s & 1) ? (w >> 16) : (w & 0xFFFFu);
+      if (ref == SLOT_EMPTY) continue;
+      const double am = eam[ref];
+      if (am != -1.0) {
+        const double k = coef[s];
+        acc0 += ef0[ref] * k;
+        acc1 += ef1[ref] * k;
+        acc2 += ef2[ref] * k;
+        const double cnum = am * fabs(k) * dt;
+        if (cnum > best) {
+          best      = cnum;
+          best_slot = s;
+        }
+      }
+    }
+    cell_epilogue<SRC>(a, o, dt, h, hu, hv, self.u, self.v, acc0, acc1, acc2, dzdx, dzdy, nman, s0, s1, s2, f);
+  }
+  block_courant_reduce(a, best, best_slot, o);
+}
+
+// ---------------------------------------------------------------------------
+// cell-centric kernel: one thread = one owned cell, all of its edges
+// ---------------------------------------------------------------------------
+template <int S, int SRC>
+__global__ __launch_bounds__(BLOCK) void swe_rhs_kernel(const KernelArgs a, const double dt, const double *__restrict__ u,
+                                                        double *__restrict__ f) {
+  int tile = blockIdx.x;
+  if (a.xcd_chunks > 0) tile = (blockIdx.x & 7) * a.xcd_chunks + (blockIdx.x >> 3);
+  const int i = tile * BLOCK + threadIdx.x;
+
+  double best      = 0.0;  // largest Courant number seen by this thread (> 0 only)
+  int    best_slot = -1;
+  int    o         = 0;
+
+  bool    active = i < a.n_work;
+  int32_t id[S];
+  if (active) {
+    o              = a.list ? a.list[i] : i;
+    bool has_ghost = false;
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      id[s] = a.nbr[s * a.stride + o];
+      has_ghost |= (id[s] >= 0) && (id[s] & NBR_GHOST);
+    }
+    if (a.phase == RDYHIP_PHASE_INTERIOR && has_ghost) active = false;
+    if (a.phase == RDYHIP_PHASE_HALO && !has_ghost) active = false;
+  }
+
+  if (active) {
+    const int         c    = a.o2l ? a.o2l[o] : o;
+    const double      h    = u[3 * (int64_t)c + 0];
+    const double      hu   = u[3 * (int64_t)c + 1];
+    const double      hv   = u[3 * (int64_t)c + 2];
+    const RiemannSide self = riemann_side(h, hu, hv, a.tiny_h, a.h_anuga_sq);
+
+    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
+    if (!a.overwrite) {
+      acc0 = f[3 * (int64_t)o + 0];
+      acc1 = f[3 * (int64_t)o + 1];
+      acc2 = f[3 * (int64_t)o + 2];
+    }
+
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      const int32_t nid = id[s];
+      if (S > 3 && nid == NBR_EMPTY) continue;
+      const double cn   = a.cn[s * a.stride + o];
+      const double sn   = a.sn[s * a.stride + o];
+      const double coef = a.coef[s * a.stride + o];
+      RoeFlux      fl;
+      bool         wet;
+      double       cfac = fabs(coef);  // len / area_self
+      if (nid >= 0) {
+        const int         n     = nid & NBR_MASK;
+        const RiemannSide other = riemann_side(u[3 * (int64_t)n + 0], u[3 * (int64_t)n + 1], u[3 * (int64_t)n + 2], a.tiny_h, a.h_anuga_sq);
+        const bool        self_left = coef < 0.0;
+        RiemannSide       L, R;
+        L.h = self_left ? self.h : other.h;        R.h = self_left ? other.h : self.h;
+        L.u = self_left ? self.u : other.u;        R.u = self_left ? other.u : self.u;
+        L.v = self_left ? self.v : other.v;        R.v = self_left ? other.v : self.v;
+        L.sqh = self_left ? self.sqh : other.sqh;  R.sqh = self_left ? other.sqh : self.sqh;
+        L.c = self_left ? self.c : other.c;        R.c = self_left ? other.c : self.c;
+        fl  = roe_flux(L, R, sn, cn);
+        wet = !(R.h < a.tiny_h && L.h < a.tiny_h);
+        if (nid & NBR_GHOST) {
+          // the ghost side is not visited on this rank: use len / min(area_l, area_r)
+          const double as = a.area_local[c], an = a.area_local[n];
+          if (an < as) cfac = cfac * (as / an);
+        }
+      } else {
+        const int    k  = -1 - nid;
+        BoundaryFlux bf = boundary_flux(a.btype[k], true, self, a.bvalues + 3 * (int64_t)k, sn, cn, a.tiny_h, a.h_anuga_sq);
+        fl              = bf.flux;
+        wet             = bf.wet;
+        store_boundary_flux(a, k, fl, dt);
+      }
+      if (wet) {
+        acc0 += fl.f0 * coef;
+        acc1 += fl.f1 * coef;
+        acc2 += fl.f2 * coef;
+        const double cnum = fl.amax * cfac * dt;
+        if (cnum > best) {
+          best      = cnum;
+          best_slot = s;
+        }
+      }
+    }
+    cell_epilogue<SRC>(a, o, dt, h, hu, hv, self.u, self.v, acc0, acc1, acc2, a.dzdx[o], a.dzdy[o], a.mannings[o], a.extsrc[3 * (int64_t)o + 0],
+                       a.extsrc[3 * (int64_t)o + 1], a.extsrc[3 * (int64_t)o + 2], f);
+  }
+  block_courant_reduce(a, best, best_slot, o);
+}
+
+// merges the per-block partials into the persistent diagnostic (reset != 0:
+// the diagnostic is first reset, ResetOperatorDiagnostics src/operator.c:772-784)
+__global__ __launch_bounds__(1024) void courant_finalize_kernel(int nblk, const double *__restrict__ blk_max, const int32_t *__restrict__ blk_pos,
+                                                               DeviceCourant *diag, int reset) {
+  double m = 0.0;
+  int    p = INT32_MAX;
+  constexpr int U = 8;  // independent loads in flight per thread
+  for (int base = threadIdx.x; base < nblk; base += 1024 * U) {
+    double v[U];
+    int    q[U];
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+      const int i = base + j * 1024;
+      v[j]        = i < nblk ? blk_max[i] : 0.0;
+      q[j]        = i < nblk ? blk_pos[i] : INT32_MAX;
+    }
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+      if (v[j] > m || (v[j] == m && v[j] > 0.0 && q[j] < p)) {
+        m = v[j];
+        p = q[j];
+      }
+    }
+  }
+  __shared__ double s_max[16];
+  __shared__ int    s_pos[16];
+  const int    lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const double wm = wave_max(m);
+  int          wp = (m == wm && m > 0.0) ? p : INT32_MAX;
+  wp              = wave_min(wp);
+  if (lane == 0) {
+    s_max[wave] = wm;
+    s_pos[wave] = wp;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double bm = 0.0;
+    int    bp = INT32_MAX;
+    for (int w = 0; w < 16; ++w) {
+      if (s_max[w] > bm || (s_max[w] == bm && bm > 0.0 && s_pos[w] < bp)) {
+        bm = s_max[w];
+        bp = s_pos[w];
+      }
+    }
+    double cur_max = reset ? 0.0 : diag->max_courant;
+    int    cur_pos = reset ? -1 : diag->pos;
+    if (bm > cur_max || (bm == cur_max && bm > 0.0 && bp < cur_pos)) {
+      cur_max = bm;
+      cur_pos = bp;
+    }
+    diag->max_courant = cur_max;
+    diag->pos         = cur_pos;
+  }
+}
+
+__global__ void courant_reset_kernel(DeviceCourant *diag) {
+  diag->max_courant = 0.0;
+  diag->pos         = -1;
+}
+
+// boundary edges whose left cell is a ghost: the reference still evaluates
+// their Riemann problem into boundary_fluxes[b] (swe_petsc.c:574) although
+// nothing is accumulated into F (588).  Diagnostic output only.
+__global__ void boundary_ghost_kernel(int n, const int32_t *__restrict__ klist, const int32_t *__restrict__ bleft, const int32_t *__restrict__ btype,
+                                      const double *__restrict__ bcn, const double *__restrict__ bsn, const double *__restrict__ bvalues,
+                                      double *__restrict__ bflux, double *__restrict__ baccum, const double *__restrict__ u, double dt, double tiny_h,
+                                      double h_anuga_sq) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int         k = klist[i];
+  const int         c = bleft[k];
+  const RiemannSide L = riemann_side(u[3 * (int64_t)c + 0], u[3 * (int64_t)c + 1], u[3 * (int64_t)c + 2], tiny_h, h_anuga_sq);
+  BoundaryFlux      bf = boundary_flux(btype[k], false, L, bvalues + 3 * (int64_t)k, bsn[k], bcn[k], tiny_h, h_anuga_sq);
+  bflux[3 * (int64_t)k + 0] = bf.flux.f0;
+  bflux[3 * (int64_t)k + 1] = bf.flux.f1;
+  bflux[3 * (int64_t)k + 2] = bf.flux.f2;
+  baccum[3 * (int64_t)k + 0] += dt * bf.flux.f0;
+  baccum[3 * (int64_t)k + 1] += dt * bf.flux.f1;
+  baccum[3 * (int64_t)k + 2] += dt * bf.flux.f2;
+}
+
+__global__ void pack_cells_kernel(int n, const double *__restrict__ u, const int32_t *__restrict__ ids, double *__restrict__ buf) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 3 * n) return;
+  const int cell = i / 3, comp = i - 3 * cell;
+  buf[i]         = u[3 * (int64_t)ids[cell] + comp];
+}
+__global__ void unpack_cells_kernel(int n, double *__restrict__ u, const int32_t *__restrict__ ids, const double *__restrict__ buf) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 3 * n) return;
+  const int cell = i / 3, comp = i - 3 * cell;
+  u[3 * (int64_t)ids[cell] + comp] = buf[i];
+}
+__global__ void axpy_owned_kernel(int n_owned, const int32_t *__restrict__ o2l, double dt, const double *__restrict__ f, double *__restrict__ u) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 3 * n_owned) return;
+  if (o2l) {
+    const int o = i / 3, comp = i - 3 * o;
+    u[3 * (int64_t)o2l[o] + comp] += dt * f[i];
+  } else {
+    u[i] += dt * f[i];
+  }
+}
+__global__ void scatter_component_kernel(int n, const int32_t *__restrict__ ids, const double *__restrict__ vals, double *__restrict__ dst, int ncomp,
+                                         int comp) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int o                    = ids ? ids[i] : i;
+  dst[(int64_t)o * ncomp + comp] = vals[i];
+}
+
+}  // namespace rdyhip
