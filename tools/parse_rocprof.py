@@ -42,7 +42,16 @@ for ctr in ("SQ_WAVES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_INSTS_VALU", "SQ
     for k, v in acc.items():
         if "swe_rhs" in k:
             sq[ctr] = mean(v)
+for ctr in ("SQ_INSTS_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_SALU", "SQ_WAIT_INST_LDS", "GRBM_GUI_ACTIVE"):
+    acc = pmc_per_kernel("pmc_sq2", ctr)
+    for k, v in acc.items():
+        if "swe_rhs" in k:
+            sq[ctr] = mean(v)
 summary["sq"] = sq
 with open(os.path.join(out, "summary.json"), "w") as fh:
     json.dump(summary, fh, indent=1)
-print(json.dumps(summary, indent=1)[:6000])
+summary.pop("kernel_stats", None) if len(sys.argv) > 3 else None
+print(json.dumps({k: summary[k] for k in ("pmc_raw_KB", "sq")}, indent=1))
+if ks:
+    for r in rows[:4]:
+        print(r["Name"][:70], r["Calls"], r["AverageNs"])
