@@ -37,8 +37,9 @@ def build_native(force: bool = False, verbose: bool = False) -> str:
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: cannot build librdyhip.so (the HIP extension is required; there is no CPU fallback)")
+    extra = os.environ.get("RDYHIP_EXTRA_HIPCC_FLAGS", "").split()   # experiments only
     cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
-           f"-I{INCLUDE}", f"-I{CSRC}", "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+           f"-I{INCLUDE}", f"-I{CSRC}"] + extra + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

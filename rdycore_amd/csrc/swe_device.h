@@ -44,8 +44,12 @@ __device__ __forceinline__ RiemannSide riemann_side(double h, double hu, double 
     s.u            = hu * r;
     s.v            = hv * r;
   }
+#ifdef RDYHIP_STUB_FLUX
+  s.sqh = h; s.c = h;
+#else
   s.sqh = sqrt(h);
   s.c   = sqrt(GRAVITY * h);
+#endif
   return s;
 }
 
@@ -65,6 +69,11 @@ __device__ __forceinline__ void riemann_velocity(double h, double hu, double hv,
 // src/swe/swe_roe_flux_petsc.h:15-81, 103-128.  Same formulas; the divisions
 // by (duml+dumr) and by chat are each done once as a reciprocal.
 __device__ __forceinline__ RoeFlux roe_flux(const RiemannSide &L, const RiemannSide &R, double sn, double cn) {
+#ifdef RDYHIP_STUB_FLUX  // timing experiment only: memory-side floor of the kernel structure
+  RoeFlux o;
+  o.f0 = L.h * cn + R.h * sn; o.f1 = L.u + R.u; o.f2 = L.v + R.v; o.amax = L.c + R.c + L.sqh + R.sqh;
+  return o;
+#endif
   const double hl = L.h, ul = L.u, vl = L.v, hr = R.h, ur = R.u, vr = R.v;
   const double duml = L.sqh, dumr = R.sqh, cl = L.c, cr = R.c;
   const double hhat    = duml * dumr;

@@ -160,8 +160,11 @@ __device__ __forceinline__ void store_boundary_flux(const KernelArgs &a, int k, 
 // ---------------------------------------------------------------------------
 // tiled kernel
 // ---------------------------------------------------------------------------
+#ifndef RDYHIP_TILED_MINWAVES
+#define RDYHIP_TILED_MINWAVES 1
+#endif
 template <int S, int SRC>
-__global__ __launch_bounds__(BLOCK) void swe_rhs_tiled_kernel(const KernelArgs a, const double dt, const double *__restrict__ u,
+__global__ __launch_bounds__(BLOCK, RDYHIP_TILED_MINWAVES) void swe_rhs_tiled_kernel(const KernelArgs a, const double dt, const double *__restrict__ u,
                                                               double *__restrict__ f) {
   extern __shared__ double lds[];
   double *sd_h = lds, *sd_u = lds + BLOCK, *sd_v = lds + 2 * BLOCK, *sd_sq = lds + 3 * BLOCK, *sd_c = lds + 4 * BLOCK;
@@ -223,6 +226,10 @@ __global__ __launch_bounds__(BLOCK) void swe_rhs_tiled_kernel(const KernelArgs a
 #pragma unroll
     for (int s = 0; s < S; ++s) coef[s] = 0.0;
   }
+#ifdef RDYHIP_EXP_PREFETCH
+  int32_t pel = 0, per = 0; double pcn = 0.0, psn = 0.0;
+  if ((int)threadIdx.x < ne) { pel = a.e_left[e_off + threadIdx.x]; per = a.e_right[e_off + threadIdx.x]; pcn = a.e_cn[e_off + threadIdx.x]; psn = a.e_sn[e_off + threadIdx.x]; }
+#endif
   sd_h[threadIdx.x]  = self.h;
   sd_u[threadIdx.x]  = self.u;
   sd_v[threadIdx.x]  = self.v;
@@ -232,44 +239,47 @@ __global__ __launch_bounds__(BLOCK) void swe_rhs_tiled_kernel(const KernelArgs a
 
   // ---- phase 1: every edge of the tile once (ApplyInteriorFlux / ApplyBoundaryFlux, swe_petsc.c:215-316, 506-630)
   for (int e = threadIdx.x; e < ne; e += BLOCK) {
+#ifdef RDYHIP_EXP_PREFETCH
+    const bool    first = e == (int)threadIdx.x;
+    const int32_t el = first ? pel : a.e_left[e_off + e];
+    const int32_t er = first ? per : a.e_right[e_off + e];
+    const double  cn = first ? pcn : a.e_cn[e_off + e];
+    const double  sn = first ? psn : a.e_sn[e_off + e];
+#else
     const int32_t el = a.e_left[e_off + e];
     const int32_t er = a.e_right[e_off + e];
     const double  cn = a.e_cn[e_off + e];
     const double  sn = a.e_sn[e_off + e];
+#endif
     RiemannSide   L;
-    int           cl;  // local cell id of the left cell (only needed on rare paths)
     if (el & END_INTILE) {
       const int j = el & (BLOCK - 1);
       L.h = sd_h[j]; L.u = sd_u[j]; L.v = sd_v[j]; L.sqh = sd_sq[j]; L.c = sd_c[j];
-      cl = -1 - j;
     } else {
-      cl = el & NBR_MASK;
-      L  = riemann_side(u[3 * (int64_t)cl + 0], u[3 * (int64_t)cl + 1], u[3 * (int64_t)cl + 2], a.tiny_h, a.h_anuga_sq);
+#ifdef RDYHIP_EXP_NOGATHER
+      L.h = sd_h[0]; L.u = sd_u[0]; L.v = sd_v[0]; L.sqh = sd_sq[0]; L.c = sd_c[0];
+#else
+      const int cl = el & NBR_MASK;
+      L            = riemann_side(u[3 * (int64_t)cl + 0], u[3 * (int64_t)cl + 1], u[3 * (int64_t)cl + 2], a.tiny_h, a.h_anuga_sq);
+#endif
     }
     RoeFlux fl;
     bool    wet;
-    double  gfac = 1.0;
     if (er >= 0) {
       RiemannSide R;
-      int         cr;
       if (er & END_INTILE) {
         const int j = er & (BLOCK - 1);
         R.h = sd_h[j]; R.u = sd_u[j]; R.v = sd_v[j]; R.sqh = sd_sq[j]; R.c = sd_c[j];
-        cr = -1 - j;
       } else {
-        cr = er & NBR_MASK;
-        R  = riemann_side(u[3 * (int64_t)cr + 0], u[3 * (int64_t)cr + 1], u[3 * (int64_t)cr + 2], a.tiny_h, a.h_anuga_sq);
+#ifdef RDYHIP_EXP_NOGATHER
+        R.h = sd_h[1]; R.u = sd_u[1]; R.v = sd_v[1]; R.sqh = sd_sq[1]; R.c = sd_c[1];
+#else
+        const int cr = er & NBR_MASK;
+        R            = riemann_side(u[3 * (int64_t)cr + 0], u[3 * (int64_t)cr + 1], u[3 * (int64_t)cr + 2], a.tiny_h, a.h_anuga_sq);
+#endif
       }
       fl  = roe_flux(L, R, sn, cn);
       wet = !(R.h < a.tiny_h && L.h < a.tiny_h);
-      if ((el | er) & NBR_GHOST) {
-        // the ghost side is not visited on this rank: make amax*|coef_owned| equal amax*len/min(area_l, area_r)
-        if (cl < 0) cl = a.o2l ? a.o2l[base + (-1 - cl)] : base + (-1 - cl);
-        if (cr < 0) cr = a.o2l ? a.o2l[base + (-1 - cr)] : base + (-1 - cr);
-        const double al = a.area_local[cl], ar = a.area_local[cr];
-        const double a_owned = (el & NBR_GHOST) ? ar : al, a_ghost = (el & NBR_GHOST) ? al : ar;
-        if (a_ghost < a_owned) gfac = a_owned / a_ghost;
-      }
     } else {
       const int    k  = -1 - er;
       BoundaryFlux bf = boundary_flux(a.btype[k], true, L, a.bvalues + 3 * (int64_t)k, sn, cn, a.tiny_h, a.h_anuga_sq);
@@ -280,7 +290,7 @@ __global__ __launch_bounds__(BLOCK) void swe_rhs_tiled_kernel(const KernelArgs a
     ef0[e] = fl.f0;
     ef1[e] = fl.f1;
     ef2[e] = fl.f2;
-    eam[e] = wet ? fl.amax * gfac : -1.0;  // -1 marks a dry-dry edge (skipped, swe_petsc.c:285)
+    eam[e] = wet ? fl.amax : -1.0;  // -1 marks a dry-dry edge (skipped, swe_petsc.c:285)
   }
   __syncthreads();
 
@@ -362,7 +372,7 @@ __global__ __launch_bounds__(BLOCK) void swe_rhs_kernel(const KernelArgs a, cons
       const double coef = a.coef[s * a.stride + o];
       RoeFlux      fl;
       bool         wet;
-      double       cfac = fabs(coef);  // len / area_self
+      const double cfac = fabs(coef);  // len / area_self: the max over an edge's two cells is len / min(area_l, area_r)
       if (nid >= 0) {
         const int         n     = nid & NBR_MASK;
         const RiemannSide other = riemann_side(u[3 * (int64_t)n + 0], u[3 * (int64_t)n + 1], u[3 * (int64_t)n + 2], a.tiny_h, a.h_anuga_sq);
@@ -375,11 +385,6 @@ __global__ __launch_bounds__(BLOCK) void swe_rhs_kernel(const KernelArgs a, cons
         L.c = self_left ? self.c : other.c;        R.c = self_left ? other.c : self.c;
         fl  = roe_flux(L, R, sn, cn);
         wet = !(R.h < a.tiny_h && L.h < a.tiny_h);
-        if (nid & NBR_GHOST) {
-          // the ghost side is not visited on this rank: use len / min(area_l, area_r)
-          const double as = a.area_local[c], an = a.area_local[n];
-          if (an < as) cfac = cfac * (as / an);
-        }
       } else {
         const int    k  = -1 - nid;
         BoundaryFlux bf = boundary_flux(a.btype[k], true, self, a.bvalues + 3 * (int64_t)k, sn, cn, a.tiny_h, a.h_anuga_sq);
