@@ -218,6 +218,8 @@ typedef struct {
   int32_t num_tiles;          /* tiles of 256 owned cells */
   int32_t num_halo_tiles;     /* tiles with a ghost-adjacent cell */
   int32_t max_tile_edges;     /* largest edge list of a tile */
+  int32_t max_tile_halo_cells; /* largest number of out-of-tile neighbour cells of a tile */
+  int64_t num_halo_entries;   /* sum of the tiles' halo-cell lists */
   int64_t num_edge_records;   /* sum of the tiles' edge lists (cut edges appear in two tiles) */
   int32_t owned_is_prefix;    /* 1 if owned cell o is local cell o */
   int64_t device_bytes;       /* bytes of device memory held by the operator */

@@ -43,7 +43,8 @@ class RDyHipLayoutInfo(C.Structure):
     _fields_ = [("num_owned_cells", C.c_int32), ("num_cells", C.c_int32), ("slots_per_cell", C.c_int32),
                 ("num_boundary_edges", C.c_int32), ("num_halo_cells", C.c_int32),
                 ("tiled_kernel", C.c_int32), ("num_tiles", C.c_int32), ("num_halo_tiles", C.c_int32),
-                ("max_tile_edges", C.c_int32), ("num_edge_records", C.c_int64), ("owned_is_prefix", C.c_int32),
+                ("max_tile_edges", C.c_int32), ("max_tile_halo_cells", C.c_int32), ("num_halo_entries", C.c_int64),
+                ("num_edge_records", C.c_int64), ("owned_is_prefix", C.c_int32),
                 ("device_bytes", C.c_int64), ("bytes_per_apply", C.c_int64)]
 
 

@@ -108,8 +108,12 @@ struct RDyHipOperator_s {
   bool             use_tiled = true;
   int32_t          ntiles = 0, n_halo_tiles = 0, emax = 0;
   int64_t          nrec = 0;
-  DevBuf<int32_t>  d_tile_off, d_e_left, d_e_right, d_halo_tiles;
-  DevBuf<uint8_t>  d_tile_halo;
+  int32_t          hmax = 0;
+  int64_t          nhalo_entries = 0;
+  size_t           lds_bytes = 0;
+  DevBuf<TileDesc> d_tiles;
+  DevBuf<uint32_t> d_e_lr;
+  DevBuf<int32_t>  d_hcells, d_tile_bk, d_halo_tiles;
   DevBuf<double>   d_e_cn, d_e_sn;
   DevBuf<uint16_t> d_slot_ref;
 
@@ -130,7 +134,7 @@ struct RDyHipOperator_s {
     d_mannings.release(); d_extsrc.release(); d_area_local.release(); d_bvalues.release(); d_bflux.release();
     d_baccum.release(); d_bcn.release(); d_bsn.release(); d_pv.release(); d_fdiv.release(); d_blk_max.release();
     d_blk_pos.release(); d_courant.release(); d_stage_vals.release(); d_stage_ids.release();
-    d_tile_off.release(); d_e_left.release(); d_e_right.release(); d_halo_tiles.release(); d_tile_halo.release();
+    d_tiles.release(); d_e_lr.release(); d_hcells.release(); d_tile_bk.release(); d_halo_tiles.release();
     d_e_cn.release(); d_e_sn.release(); d_slot_ref.release();
   }
 };
@@ -169,14 +173,15 @@ int launch_rhs(RDyHipOperator op, int32_t phase, int32_t overwrite, int reset_di
   a.overwrite  = overwrite ? 1 : 0;
   a.phase      = phase;
 
-  a.tile_off  = op->d_tile_off.p;
-  a.tile_halo = op->d_tile_halo.p;
-  a.e_left    = op->d_e_left.p;
-  a.e_right   = op->d_e_right.p;
-  a.e_cn      = op->d_e_cn.p;
-  a.e_sn      = op->d_e_sn.p;
-  a.slot_ref  = op->d_slot_ref.p;
-  a.emax      = op->emax;
+  a.tiles    = op->d_tiles.p;
+  a.e_lr     = op->d_e_lr.p;
+  a.e_cn     = op->d_e_cn.p;
+  a.e_sn     = op->d_e_sn.p;
+  a.hcells   = op->d_hcells.p;
+  a.tile_bk  = op->d_tile_bk.p;
+  a.slot_ref = op->d_slot_ref.p;
+  a.emax     = op->emax;
+  a.hmax     = op->hmax;
 
   int        grid;
   const bool xq = op->config.source_method == RDYHIP_SOURCE_IMPLICIT_XQ2018;
@@ -194,7 +199,7 @@ int launch_rhs(RDyHipOperator op, int32_t phase, int32_t overwrite, int reset_di
       a.xcd_chunks = op->xcd_chunks;
       grid         = op->grid;
     }
-    const size_t lds = sizeof(double) * (5 * (size_t)BLOCK + 4 * (size_t)op->emax);
+    const size_t lds = op->lds_bytes;
     if (op->S == 3) {
       if (xq) hipLaunchKernelGGL((swe_rhs_tiled_kernel<3, 1>), dim3(grid), dim3(BLOCK), lds, st, a, dt, u, f);
       else hipLaunchKernelGGL((swe_rhs_tiled_kernel<3, 0>), dim3(grid), dim3(BLOCK), lds, st, a, dt, u, f);
@@ -253,7 +258,7 @@ int rdyhip_create(const RDyHipConfig *config, const RDyHipMesh *mesh, int32_t nu
     return fail(RDYHIP_ERR_USER, "Only semi_implicit and implicit_xq2018 are supported");  // swe_petsc.c:973
   const int32_t nc = mesh->num_cells, no = mesh->num_owned_cells, ne = mesh->num_edges, ni = mesh->num_internal_edges;
   if (nc < 0 || no < 0 || no > nc || ne < 0 || ni < 0 || ni > ne) return fail(RDYHIP_ERR_ARG_SIZ, "inconsistent mesh sizes");
-  if (nc >= END_INTILE) return fail(RDYHIP_ERR_ARG_SIZ, "too many local cells (%d) for the 29-bit neighbour encoding", nc);
+  if (nc >= NBR_GHOST) return fail(RDYHIP_ERR_ARG_SIZ, "too many local cells (%d) for the 30-bit neighbour encoding", nc);
   if (nc > 0 && (!mesh->cell_is_owned || !mesh->cell_local_to_owned || !mesh->cell_areas || !mesh->cell_dz_dx || !mesh->cell_dz_dy))
     return fail(RDYHIP_ERR_USER, "null cell array");
   if (ne > 0 && (!mesh->edge_cell_ids || !mesh->edge_lengths || !mesh->edge_cn || !mesh->edge_sn)) return fail(RDYHIP_ERR_USER, "null edge array");
@@ -358,28 +363,22 @@ int rdyhip_create(const RDyHipConfig *config, const RDyHipMesh *mesh, int32_t nu
     if (g) halo.push_back(o);
   }
 
-  // ---- tiles of 256 consecutive owned cells and their edge lists (tiled kernel) ----
+  // ---- tiles of 256 consecutive owned cells: edge list, halo cells, boundary edges (tiled kernel) ----
   const int32_t         ntiles = (no + BLOCK - 1) / BLOCK;
-  std::vector<int32_t>  tile_off((size_t)ntiles + 1, 0), e_left, e_right, halo_tiles;
-  std::vector<uint8_t>  tile_halo((size_t)ntiles, 0);
+  std::vector<TileDesc> tiles((size_t)ntiles + 1);
+  std::vector<uint32_t> e_lr;
+  std::vector<int32_t>  hcells, tile_bk, halo_tiles;
   std::vector<double>   e_cn, e_sn;
   std::vector<uint16_t> slot_ref((size_t)no * 4, SLOT_EMPTY);
-  int32_t               emax = 0;
+  int32_t               emax = 0, hmax = 0;
   {
-    e_left.reserve((size_t)no * 2);
-    e_right.reserve((size_t)no * 2);
+    e_lr.reserve((size_t)no * 2);
     e_cn.reserve((size_t)no * 2);
     e_sn.reserve((size_t)no * 2);
     std::vector<std::pair<int32_t, int32_t>> items;  // (loop position of the edge, owned cell * 4 + slot)
     items.reserve(4 * BLOCK);
-    auto encode = [&](int32_t cell, int32_t base, int32_t cntc) -> int32_t {
-      if (mesh->cell_is_owned[cell]) {
-        const int32_t oo = mesh->cell_local_to_owned[cell];
-        if (oo >= base && oo < base + cntc) return END_INTILE | (oo - base);
-        return cell;
-      }
-      return cell | NBR_GHOST;
-    };
+    std::vector<int32_t> hslot((size_t)nc, -1);      // local cell -> halo slot in the current tile
+    std::vector<int32_t> touched;
     for (int32_t t = 0; t < ntiles; ++t) {
       const int32_t base = t * BLOCK, cntc = std::min<int32_t>(BLOCK, no - base);
       items.clear();
@@ -393,39 +392,62 @@ int rdyhip_create(const RDyHipConfig *config, const RDyHipMesh *mesh, int32_t nu
         }
       }
       std::sort(items.begin(), items.end());
-      tile_off[t] = (int32_t)e_left.size();
+      tiles[t].e_off = (int32_t)e_lr.size();
+      tiles[t].h_off = (int32_t)hcells.size();
+      tiles[t].b_off = (int32_t)tile_bk.size();
+      tiles[t].halo  = halo_tile ? 1 : 0;
+      if (halo_tile) halo_tiles.push_back(t);
+      touched.clear();
+      int32_t nh = 0, nbk = 0;
+      // LDS slot of a cell: 0..255 inside the tile, 256.. for the tile's halo cells
+      auto slot_of = [&](int32_t cell) -> uint32_t {
+        if (mesh->cell_is_owned[cell]) {
+          const int32_t oo = mesh->cell_local_to_owned[cell];
+          if (oo >= base && oo < base + cntc) return (uint32_t)(oo - base);
+        }
+        if (hslot[cell] < 0) {
+          hslot[cell] = nh++;
+          hcells.push_back(cell);
+          touched.push_back(cell);
+        }
+        return (uint32_t)(BLOCK + hslot[cell]);
+      };
       int32_t last = -1, local = -1;
       for (const auto &it : items) {
         if (it.first != last) {
           last = it.first;
           ++local;
-          int32_t e, l, rgt;
+          int32_t  e;
+          uint32_t lr;
           if (last < ni) {
-            e   = mesh->edge_internal_ids[last];
-            l   = encode(mesh->edge_cell_ids[2 * e], base, cntc);
-            rgt = encode(mesh->edge_cell_ids[2 * e + 1], base, cntc);
+            e  = mesh->edge_internal_ids[last];
+            lr = slot_of(mesh->edge_cell_ids[2 * e]) | (slot_of(mesh->edge_cell_ids[2 * e + 1]) << EDGE_R_SHIFT);
           } else {
             const int32_t k = last - ni;
             e               = bedge[k];
-            l               = encode(bleft[k], base, cntc);
-            rgt             = -1 - k;
+            lr              = slot_of(bleft[k]) | ((uint32_t)nbk << EDGE_R_SHIFT) | EDGE_BOUNDARY;
+            tile_bk.push_back(k);
+            ++nbk;
           }
-          e_left.push_back(l);
-          e_right.push_back(rgt);
+          e_lr.push_back(lr);
           e_cn.push_back(mesh->edge_cn[e]);
           e_sn.push_back(mesh->edge_sn[e]);
         }
         slot_ref[(size_t)(it.second >> 2) * 4 + (it.second & 3)] = (uint16_t)local;
       }
+      for (int32_t cell : touched) hslot[cell] = -1;
       emax = std::max(emax, local + 1);
-      if (halo_tile) {
-        tile_halo[t] = 1;
-        halo_tiles.push_back(t);
-      }
-      if ((int64_t)e_left.size() > (int64_t)INT32_MAX - 4 * BLOCK) return fail(RDYHIP_ERR_ARG_SIZ, "too many tile edge records");
+      hmax = std::max(hmax, nh);
+      if ((int64_t)e_lr.size() > (int64_t)INT32_MAX - 4 * BLOCK) return fail(RDYHIP_ERR_ARG_SIZ, "too many tile edge records");
     }
-    tile_off[ntiles] = (int32_t)e_left.size();
+    tiles[ntiles].e_off = (int32_t)e_lr.size();
+    tiles[ntiles].h_off = (int32_t)hcells.size();
+    tiles[ntiles].b_off = (int32_t)tile_bk.size();
+    tiles[ntiles].halo  = 0;
+    // a tile has at most 4*256 edges, so 256 + hmax <= 1280 slots < 2^11 and <= 1024 boundary edges
   }
+  const size_t lds_bytes = sizeof(double) * (5 * ((size_t)BLOCK + hmax) + 4 * (size_t)emax);
+  if (lds_bytes > 160 * 1024) return fail(RDYHIP_ERR_USER, "tile working set (%zu B of LDS) too large: the cell numbering has no locality", lds_bytes);
 
   // ---- per-owned-cell geometry --------------------------------------------
   std::vector<double> dzdx((size_t)no), dzdy((size_t)no);
@@ -450,7 +472,22 @@ int rdyhip_create(const RDyHipConfig *config, const RDyHipMesh *mesh, int32_t nu
   op->ntiles       = ntiles;
   op->n_halo_tiles = (int32_t)halo_tiles.size();
   op->emax         = emax;
-  op->nrec         = (int64_t)e_left.size();
+  op->hmax         = hmax;
+  op->lds_bytes    = lds_bytes;
+  if (lds_bytes > 64 * 1024) {
+    // more than the default 64 KB of dynamic LDS (only for numberings with poor locality)
+    const int nb = (int)lds_bytes;
+    bool ok = hipFuncSetAttribute((const void *)swe_rhs_tiled_kernel<3, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, nb) == hipSuccess;
+    ok = ok && hipFuncSetAttribute((const void *)swe_rhs_tiled_kernel<3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, nb) == hipSuccess;
+    ok = ok && hipFuncSetAttribute((const void *)swe_rhs_tiled_kernel<4, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, nb) == hipSuccess;
+    ok = ok && hipFuncSetAttribute((const void *)swe_rhs_tiled_kernel<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, nb) == hipSuccess;
+    if (!ok) {
+      delete op;
+      return fail(RDYHIP_ERR_LIB, "cannot reserve %d bytes of LDS per workgroup", nb);
+    }
+  }
+  op->nrec         = (int64_t)e_lr.size();
+  op->nhalo_entries = (int64_t)hcells.size();
   {
     const char *kenv = getenv("RDYHIP_KERNEL");
     op->use_tiled    = !(kenv && strcmp(kenv, "cell") == 0);
@@ -461,11 +498,11 @@ int rdyhip_create(const RDyHipConfig *config, const RDyHipMesh *mesh, int32_t nu
     return fail(RDYHIP_ERR_LIB, "hipGetDevice failed: no usable HIP device");
   }
 
-  const int tiles   = (no + BLOCK - 1) / BLOCK;
+  const int tiles_n = (no + BLOCK - 1) / BLOCK;
   const char *env   = getenv("RDYHIP_XCD_SWIZZLE");
   const bool  swz   = env ? atoi(env) != 0 : true;
-  op->xcd_chunks    = (swz && tiles >= 64) ? (tiles + 7) / 8 : 0;
-  op->grid          = op->xcd_chunks > 0 ? op->xcd_chunks * 8 : tiles;
+  op->xcd_chunks    = (swz && tiles_n >= 64) ? (tiles_n + 7) / 8 : 0;
+  op->grid          = op->xcd_chunks > 0 ? op->xcd_chunks * 8 : tiles_n;
   const int maxgrid = std::max(op->grid, 1);
 
 #define TRY_RC(x)     \
@@ -495,11 +532,11 @@ int rdyhip_create(const RDyHipConfig *config, const RDyHipMesh *mesh, int32_t nu
     TRY_RC(op->d_area_local.upload(area));
     op->h_area.swap(area);
   }
-  TRY_RC(op->d_tile_off.upload(tile_off));
-  TRY_RC(op->d_tile_halo.upload(tile_halo));
+  TRY_RC(op->d_tiles.upload(tiles));
   TRY_RC(op->d_halo_tiles.upload(halo_tiles));
-  TRY_RC(op->d_e_left.upload(e_left));
-  TRY_RC(op->d_e_right.upload(e_right));
+  TRY_RC(op->d_e_lr.upload(e_lr));
+  TRY_RC(op->d_hcells.upload(hcells));
+  TRY_RC(op->d_tile_bk.upload(tile_bk));
   TRY_RC(op->d_e_cn.upload(e_cn));
   TRY_RC(op->d_e_sn.upload(e_sn));
   TRY_RC(op->d_slot_ref.upload(slot_ref));
@@ -529,7 +566,7 @@ int rdyhip_create(const RDyHipConfig *config, const RDyHipMesh *mesh, int32_t nu
   op->device_bytes = op->d_o2l.bytes() + op->d_nbr.bytes() + op->d_pos.bytes() + op->d_cn.bytes() + op->d_sn.bytes() + op->d_coef.bytes() +
                      op->d_dzdx.bytes() + op->d_dzdy.bytes() + op->d_mannings.bytes() + op->d_extsrc.bytes() + op->d_area_local.bytes() +
                      op->d_pv.bytes() + op->d_bvalues.bytes() + op->d_bflux.bytes() + op->d_baccum.bytes() + op->d_blk_max.bytes() +
-                     op->d_blk_pos.bytes() + op->d_tile_off.bytes() + op->d_tile_halo.bytes() + op->d_e_left.bytes() + op->d_e_right.bytes() +
+                     op->d_blk_pos.bytes() + op->d_tiles.bytes() + op->d_e_lr.bytes() + op->d_hcells.bytes() + op->d_tile_bk.bytes() +
                      op->d_e_cn.bytes() + op->d_e_sn.bytes() + op->d_slot_ref.bytes();
   *op_out = op;
   return 0;
@@ -744,13 +781,17 @@ int rdyhip_layout_info(RDyHipOperator op, RDyHipLayoutInfo *info) {
   info->num_tiles          = op->ntiles;
   info->num_halo_tiles     = op->n_halo_tiles;
   info->max_tile_edges     = op->emax;
+  info->max_tile_halo_cells = op->hmax;
+  info->num_halo_entries   = op->nhalo_entries;
   info->num_edge_records   = op->nrec;
   info->owned_is_prefix    = op->prefix ? 1 : 0;
   info->device_bytes       = op->device_bytes;
   // u (own cell) 24 + slots S*(4+8+8+8) + dz 16 + n 8 + ext src 24 + F 24 + pv 24 (+4 for o2l)
   if (op->use_tiled) {
-    // u 24 + slot refs 8 + coef S*8 + dz 16 + n 8 + ext src 24 + F 24 + pv 24 (+4 for o2l) per cell; 24 B per edge record
-    info->bytes_per_apply = (int64_t)op->n_owned * (24 + 8 + op->S * 8 + 16 + 8 + 24 + 24 + 24 + (op->prefix ? 0 : 4)) + op->nrec * 24;
+    // u 24 + slot refs 8 + coef S*8 + dz 16 + n 8 + ext src 24 + F 24 + pv 24 (+4 for o2l) per cell;
+    // 20 B per edge record; 4 B id + 24 B state per halo-cell entry (the states are mostly L2 hits)
+    info->bytes_per_apply = (int64_t)op->n_owned * (24 + 8 + op->S * 8 + 16 + 8 + 24 + 24 + 24 + (op->prefix ? 0 : 4)) + op->nrec * 20 +
+                            op->nhalo_entries * 4 + (int64_t)op->ntiles * 16;
   } else {
     info->bytes_per_apply = (int64_t)op->n_owned * (24 + op->S * 28 + 16 + 8 + 24 + 24 + 24 + (op->prefix ? 0 : 4));
   }

@@ -32,9 +32,6 @@ namespace rdyhip {
 
 constexpr int BLOCK = 256;
 
-// encoding of a tile edge's end points
-constexpr int32_t END_INTILE = 1 << 29;  // low bits = index of the cell inside the tile (LDS slot)
-// otherwise: local cell id (| NBR_GHOST), or -1-k for the boundary edge k on the right side
 constexpr uint16_t SLOT_EMPTY = 0xFFFF;
 
 // persistent Courant diagnostic on the device
@@ -45,6 +42,8 @@ struct DeviceCourant {
 };
 
 // everything a kernel needs, passed by value
+struct TileDesc;
+
 struct KernelArgs {
   int32_t        n_owned;    // owned cells
   int32_t        n_work;     // cell kernel: threads with work; tiled kernel: number of tiles to run
@@ -72,12 +71,14 @@ struct KernelArgs {
   int32_t        overwrite;  // 1: f = rhs, 0: f += rhs
   int32_t        xcd_chunks; // >0: blocks are dealt to XCDs in contiguous chunks of this many tiles
   // ---- tiled kernel only
-  const int32_t  *tile_off;  // [ntiles+1] first edge record of each tile
-  const uint8_t  *tile_halo; // [ntiles] 1 if a cell of the tile has a ghost neighbour
-  const int32_t  *e_left, *e_right;  // [nrec] encoded end points
-  const double   *e_cn, *e_sn;       // [nrec]
+  const struct TileDesc *tiles;  // [ntiles+1]
+  const uint32_t *e_lr;      // [nrec] packed LDS slots of the edge's cells
+  const double   *e_cn, *e_sn;  // [nrec]
+  const int32_t  *hcells;    // halo cells of each tile (local cell ids)
+  const int32_t  *tile_bk;   // boundary-edge ids k of each tile's boundary edges
   const uint16_t *slot_ref;  // [n_owned][4] index of each slot's edge in the tile's edge list
   int32_t         emax;      // largest edge count of a tile (LDS sizing)
+  int32_t         hmax;      // largest halo-cell count of a tile (LDS sizing)
 };
 
 __device__ __forceinline__ double wave_max(double v) {
@@ -160,26 +161,39 @@ __device__ __forceinline__ void store_boundary_flux(const KernelArgs &a, int k, 
 // ---------------------------------------------------------------------------
 // tiled kernel
 // ---------------------------------------------------------------------------
-#ifndef RDYHIP_TILED_MINWAVES
-#define RDYHIP_TILED_MINWAVES 1
-#endif
+// packed end points of a tile edge: LDS slot of the left cell | slot of the
+// right cell << 11 | EDGE_BOUNDARY.  Slots 0..255 are the tile's own cells,
+// 256.. the tile's halo cells (cells outside the tile that share an edge with
+// it).  For a boundary edge the right field is the index into the tile's
+// boundary-edge list.
+constexpr uint32_t EDGE_SLOT_MASK = 0x7FF;
+constexpr int      EDGE_R_SHIFT   = 11;
+constexpr uint32_t EDGE_BOUNDARY  = 1u << 22;
+
+struct TileDesc {  // 16 B, one per tile (+1 sentinel)
+  int32_t e_off;   // first edge record
+  int32_t h_off;   // first halo-cell entry
+  int32_t b_off;   // first boundary-edge entry
+  int32_t halo;    // 1 if a tile cell has a ghost neighbour
+};
+
 template <int S, int SRC>
-__global__ __launch_bounds__(BLOCK, RDYHIP_TILED_MINWAVES) void swe_rhs_tiled_kernel(const KernelArgs a, const double dt, const double *__restrict__ u,
+__global__ __launch_bounds__(BLOCK) void swe_rhs_tiled_kernel(const KernelArgs a, const double dt, const double *__restrict__ u,
                                                               double *__restrict__ f) {
   extern __shared__ double lds[];
-  double *sd_h = lds, *sd_u = lds + BLOCK, *sd_v = lds + 2 * BLOCK, *sd_sq = lds + 3 * BLOCK, *sd_c = lds + 4 * BLOCK;
-  double *ef0 = lds + 5 * BLOCK, *ef1 = ef0 + a.emax, *ef2 = ef1 + a.emax, *eam = ef2 + a.emax;
+  const int nside = BLOCK + a.hmax;
+  double   *sd_h = lds, *sd_u = lds + nside, *sd_v = lds + 2 * nside, *sd_sq = lds + 3 * nside, *sd_c = lds + 4 * nside;
+  double   *ef0 = lds + 5 * nside, *ef1 = ef0 + a.emax, *ef2 = ef1 + a.emax, *eam = ef2 + a.emax;
 
   // XCD-aware tile mapping: block ids are dealt round-robin to the 8 XCDs, so
-  // give each XCD a contiguous range of tiles (cut edges and out-of-tile
-  // neighbours then hit that XCD's own L2).
+  // give each XCD a contiguous range of tiles (halo cells then hit that XCD's own L2).
   int ti = blockIdx.x;
   if (a.xcd_chunks > 0) ti = (blockIdx.x & 7) * a.xcd_chunks + (blockIdx.x >> 3);
   bool valid = ti < a.n_work;
   int  tile  = 0;
   if (valid) {
     tile = a.list ? a.list[ti] : ti;
-    if (a.phase == RDYHIP_PHASE_INTERIOR && a.tile_halo[tile]) valid = false;
+    if (a.phase == RDYHIP_PHASE_INTERIOR && a.tiles[tile].halo) valid = false;
   }
   if (!valid) {  // uniform over the block
     if (threadIdx.x == 0) {
@@ -188,26 +202,40 @@ __global__ __launch_bounds__(BLOCK, RDYHIP_TILED_MINWAVES) void swe_rhs_tiled_ke
     }
     return;
   }
-  const int  base   = tile * BLOCK;
-  const int  o      = base + threadIdx.x;
-  const bool active = o < a.n_owned;
-  const int  e_off  = a.tile_off[tile];
-  const int  ne     = a.tile_off[tile + 1] - e_off;
+  const TileDesc td = a.tiles[tile], tn = a.tiles[tile + 1];
+  const int      ne = tn.e_off - td.e_off, nh = tn.h_off - td.h_off;
+  const int      base   = tile * BLOCK;
+  const int      o      = base + threadIdx.x;
+  const bool     active = o < a.n_owned;
 
-  // ---- phase 0: own state -> Riemann side data -> LDS; start the loads phase 2 needs
-  double      h = 0.0, hu = 0.0, hv = 0.0;
-  RiemannSide self;
-  self.h = self.u = self.v = self.sqh = self.c = 0.0;
-  double   coef[S];
-  uint2    refs = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
-  double   dzdx = 0.0, dzdy = 0.0, nman = 0.0, s0 = 0.0, s1 = 0.0, s2 = 0.0;
-  double   acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
+  // ---- phase 0: issue every independent load of the tile up front --------
+  // halo-cell ids first (their states need a second, dependent load)
+  int hid = -1;
+  if ((int)threadIdx.x < nh) hid = a.hcells[td.h_off + threadIdx.x];
+  double h = 0.0, hu = 0.0, hv = 0.0;
   if (active) {
     const int c = a.o2l ? a.o2l[o] : o;
     h           = u[3 * (int64_t)c + 0];
     hu          = u[3 * (int64_t)c + 1];
     hv          = u[3 * (int64_t)c + 2];
-    refs        = *reinterpret_cast<const uint2 *>(a.slot_ref + 4 * (int64_t)o);
+  }
+  // first round of edge records
+  uint32_t lr0 = 0;
+  double   cn0 = 0.0, sn0 = 0.0;
+  if ((int)threadIdx.x < ne) {
+    lr0 = a.e_lr[td.e_off + threadIdx.x];
+    cn0 = a.e_cn[td.e_off + threadIdx.x];
+    sn0 = a.e_sn[td.e_off + threadIdx.x];
+  }
+  // per-cell streams used in phase 2
+  double coef[S];
+  uint2  refs = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+  double dzdx = 0.0, dzdy = 0.0, nman = 0.0, s0 = 0.0, s1 = 0.0, s2 = 0.0;
+  double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
+#pragma unroll
+  for (int s = 0; s < S; ++s) coef[s] = 0.0;
+  if (active) {
+    refs = *reinterpret_cast<const uint2 *>(a.slot_ref + 4 * (int64_t)o);
 #pragma unroll
     for (int s = 0; s < S; ++s) coef[s] = a.coef[s * a.stride + o];
     dzdx = a.dzdx[o];
@@ -221,15 +249,20 @@ __global__ __launch_bounds__(BLOCK, RDYHIP_TILED_MINWAVES) void swe_rhs_tiled_ke
       acc1 = f[3 * (int64_t)o + 1];
       acc2 = f[3 * (int64_t)o + 2];
     }
-    self = riemann_side(h, hu, hv, a.tiny_h, a.h_anuga_sq);
-  } else {
-#pragma unroll
-    for (int s = 0; s < S; ++s) coef[s] = 0.0;
   }
-#ifdef RDYHIP_EXP_PREFETCH
-  int32_t pel = 0, per = 0; double pcn = 0.0, psn = 0.0;
-  if ((int)threadIdx.x < ne) { pel = a.e_left[e_off + threadIdx.x]; per = a.e_right[e_off + threadIdx.x]; pcn = a.e_cn[e_off + threadIdx.x]; psn = a.e_sn[e_off + threadIdx.x]; }
-#endif
+  // halo-cell states (dependent on hid), then the Riemann side data of both into LDS
+  for (int j = threadIdx.x; j < nh; j += BLOCK) {
+    const int         cell = (j == (int)threadIdx.x) ? hid : a.hcells[td.h_off + j];
+    const RiemannSide hs   = riemann_side(u[3 * (int64_t)cell + 0], u[3 * (int64_t)cell + 1], u[3 * (int64_t)cell + 2], a.tiny_h, a.h_anuga_sq);
+    sd_h[BLOCK + j]  = hs.h;
+    sd_u[BLOCK + j]  = hs.u;
+    sd_v[BLOCK + j]  = hs.v;
+    sd_sq[BLOCK + j] = hs.sqh;
+    sd_c[BLOCK + j]  = hs.c;
+  }
+  RiemannSide self;
+  self.h = self.u = self.v = self.sqh = self.c = 0.0;
+  if (active) self = riemann_side(h, hu, hv, a.tiny_h, a.h_anuga_sq);
   sd_h[threadIdx.x]  = self.h;
   sd_u[threadIdx.x]  = self.u;
   sd_v[threadIdx.x]  = self.v;
@@ -237,51 +270,26 @@ __global__ __launch_bounds__(BLOCK, RDYHIP_TILED_MINWAVES) void swe_rhs_tiled_ke
   sd_c[threadIdx.x]  = self.c;
   __syncthreads();
 
-  // ---- phase 1: every edge of the tile once (ApplyInteriorFlux / ApplyBoundaryFlux, swe_petsc.c:215-316, 506-630)
+  // ---- phase 1: every edge of the tile once, operands from LDS only
+  // (ApplyInteriorFlux / ApplyBoundaryFlux, swe_petsc.c:215-316, 506-630)
   for (int e = threadIdx.x; e < ne; e += BLOCK) {
-#ifdef RDYHIP_EXP_PREFETCH
-    const bool    first = e == (int)threadIdx.x;
-    const int32_t el = first ? pel : a.e_left[e_off + e];
-    const int32_t er = first ? per : a.e_right[e_off + e];
-    const double  cn = first ? pcn : a.e_cn[e_off + e];
-    const double  sn = first ? psn : a.e_sn[e_off + e];
-#else
-    const int32_t el = a.e_left[e_off + e];
-    const int32_t er = a.e_right[e_off + e];
-    const double  cn = a.e_cn[e_off + e];
-    const double  sn = a.e_sn[e_off + e];
-#endif
-    RiemannSide   L;
-    if (el & END_INTILE) {
-      const int j = el & (BLOCK - 1);
-      L.h = sd_h[j]; L.u = sd_u[j]; L.v = sd_v[j]; L.sqh = sd_sq[j]; L.c = sd_c[j];
-    } else {
-#ifdef RDYHIP_EXP_NOGATHER
-      L.h = sd_h[0]; L.u = sd_u[0]; L.v = sd_v[0]; L.sqh = sd_sq[0]; L.c = sd_c[0];
-#else
-      const int cl = el & NBR_MASK;
-      L            = riemann_side(u[3 * (int64_t)cl + 0], u[3 * (int64_t)cl + 1], u[3 * (int64_t)cl + 2], a.tiny_h, a.h_anuga_sq);
-#endif
-    }
+    const bool     first = e == (int)threadIdx.x;
+    const uint32_t lr    = first ? lr0 : a.e_lr[td.e_off + e];
+    const double   cn    = first ? cn0 : a.e_cn[td.e_off + e];
+    const double   sn    = first ? sn0 : a.e_sn[td.e_off + e];
+    const int      jl    = lr & EDGE_SLOT_MASK;
+    RiemannSide    L;
+    L.h = sd_h[jl]; L.u = sd_u[jl]; L.v = sd_v[jl]; L.sqh = sd_sq[jl]; L.c = sd_c[jl];
     RoeFlux fl;
     bool    wet;
-    if (er >= 0) {
+    if (!(lr & EDGE_BOUNDARY)) {
+      const int   jr = (lr >> EDGE_R_SHIFT) & EDGE_SLOT_MASK;
       RiemannSide R;
-      if (er & END_INTILE) {
-        const int j = er & (BLOCK - 1);
-        R.h = sd_h[j]; R.u = sd_u[j]; R.v = sd_v[j]; R.sqh = sd_sq[j]; R.c = sd_c[j];
-      } else {
-#ifdef RDYHIP_EXP_NOGATHER
-        R.h = sd_h[1]; R.u = sd_u[1]; R.v = sd_v[1]; R.sqh = sd_sq[1]; R.c = sd_c[1];
-#else
-        const int cr = er & NBR_MASK;
-        R            = riemann_side(u[3 * (int64_t)cr + 0], u[3 * (int64_t)cr + 1], u[3 * (int64_t)cr + 2], a.tiny_h, a.h_anuga_sq);
-#endif
-      }
+      R.h = sd_h[jr]; R.u = sd_u[jr]; R.v = sd_v[jr]; R.sqh = sd_sq[jr]; R.c = sd_c[jr];
       fl  = roe_flux(L, R, sn, cn);
       wet = !(R.h < a.tiny_h && L.h < a.tiny_h);
     } else {
-      const int    k  = -1 - er;
+      const int    k  = a.tile_bk[td.b_off + ((lr >> EDGE_R_SHIFT) & EDGE_SLOT_MASK)];
       BoundaryFlux bf = boundary_flux(a.btype[k], true, L, a.bvalues + 3 * (int64_t)k, sn, cn, a.tiny_h, a.h_anuga_sq);
       fl              = bf.flux;
       wet             = bf.wet;
@@ -309,6 +317,7 @@ __global__ __launch_bounds__(BLOCK, RDYHIP_TILED_MINWAVES) void swe_rhs_tiled_ke
         acc0 += ef0[ref] * k;
         acc1 += ef1[ref] * k;
         acc2 += ef2[ref] * k;
+        // len/area_self: the max over an edge's two cells is len / min(area_l, area_r) (swe_petsc.c:289)
         const double cnum = am * fabs(k) * dt;
         if (cnum > best) {
           best      = cnum;

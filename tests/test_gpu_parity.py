@@ -228,3 +228,26 @@ def test_error_behaviour():
     with pytest.raises(RDyHipError):
         op.apply(0.1, u, f)
     op.destroy()
+
+
+@pytest.mark.parametrize("kind", ["tri", "quad"])
+def test_random_cell_numbering(kind):
+    # a numbering with no locality: every tile's neighbours are almost all outside the tile
+    # (exercises the halo-cell staging of the tiled kernel and its > 64 KB LDS request)
+    rng = np.random.default_rng(3)
+    K = 2 * np.pi / 31
+    if kind == "tri":
+        xyz, conn, _, _ = M.structured_tri_connectivity(40, 30)
+    else:
+        base = M.structured_quad_mesh(36, 25)
+        xyz, conn = base.xyz.copy(), base.cell_conn.copy()
+    xyz[:, 2] = CS.mms_bathymetry(K=K)(xyz[:, 0], xyz[:, 1])
+    conn = conn[rng.permutation(conn.shape[0])]
+    lx, ly = xyz[:, 0].max(), xyz[:, 1].max()
+    mesh = M.build_mesh(xyz, conn, boundary_classifier=M.box_side_boundaries(0, lx, 0, ly))
+    case = CS.friction_slope_case(mesh, lx, ly, dt=1e-2, K=K)
+    f, fr, op, orc = run_both(case)
+    check_all(case, f, fr, op, orc)
+    info = op.layout_info()
+    if info["tiled_kernel"]:
+        assert info["max_tile_halo_cells"] > 256
