@@ -95,7 +95,8 @@ struct RDyHipOperator_s {
   int32_t      n_cells = 0, n_owned = 0, S = 3, K = 0, n_internal = 0;
   int64_t      stride = 0;
   bool         prefix = true;
-  int          grid = 0, xcd_chunks = 0;
+  int          grid = 0, xcd_chunks = 0;        // cell kernel
+  int          pgrid = 0, tiled_xcd_chunks = 0; // tiled (persistent) kernel
   bool         keep_fdiv = false;
 
   DevBuf<int32_t> d_o2l, d_nbr, d_pos, d_halo_list, d_btype, d_bleft, d_bghost_list;
@@ -186,18 +187,24 @@ int launch_rhs(RDyHipOperator op, int32_t phase, int32_t overwrite, int reset_di
   int        grid;
   const bool xq = op->config.source_method == RDYHIP_SOURCE_IMPLICIT_XQ2018;
   if (op->use_tiled) {
+    // persistent workgroups: at most as many as the device holds at once
     if (phase == RDYHIP_PHASE_HALO) {
       if (op->n_halo_tiles == 0) return 0;
       a.list       = op->d_halo_tiles.p;
       a.n_work     = op->n_halo_tiles;
       a.xcd_chunks = 0;
       a.phase      = RDYHIP_PHASE_ALL;  // the list already holds exactly the halo tiles
-      grid         = op->n_halo_tiles;
+      grid         = std::min(op->pgrid, op->n_halo_tiles);
     } else {
-      a.list       = nullptr;
-      a.n_work     = op->ntiles;
-      a.xcd_chunks = op->xcd_chunks;
-      grid         = op->grid;
+      a.list   = nullptr;
+      a.n_work = op->ntiles;
+      if (op->tiled_xcd_chunks > 0) {
+        a.xcd_chunks = op->tiled_xcd_chunks;
+        grid         = std::min(op->pgrid & ~7, op->tiled_xcd_chunks * 8);
+      } else {
+        a.xcd_chunks = 0;
+        grid         = std::min(op->pgrid, op->ntiles);
+      }
     }
     const size_t lds = op->lds_bytes;
     if (op->S == 3) {
@@ -446,7 +453,7 @@ int rdyhip_create(const RDyHipConfig *config, const RDyHipMesh *mesh, int32_t nu
     tiles[ntiles].halo  = 0;
     // a tile has at most 4*256 edges, so 256 + hmax <= 1280 slots < 2^11 and <= 1024 boundary edges
   }
-  const size_t lds_bytes = sizeof(double) * (5 * ((size_t)BLOCK + hmax) + 4 * (size_t)emax);
+  const size_t lds_bytes = sizeof(double) * (5 * ((size_t)BLOCK + hmax) + 2 * (size_t)BLOCK + 4 * (size_t)emax);
   if (lds_bytes > 160 * 1024) return fail(RDYHIP_ERR_USER, "tile working set (%zu B of LDS) too large: the cell numbering has no locality", lds_bytes);
 
   // ---- per-owned-cell geometry --------------------------------------------
@@ -503,7 +510,22 @@ int rdyhip_create(const RDyHipConfig *config, const RDyHipMesh *mesh, int32_t nu
   const bool  swz   = env ? atoi(env) != 0 : true;
   op->xcd_chunks    = (swz && tiles_n >= 64) ? (tiles_n + 7) / 8 : 0;
   op->grid          = op->xcd_chunks > 0 ? op->xcd_chunks * 8 : tiles_n;
-  const int maxgrid = std::max(op->grid, 1);
+  {
+    // size of the persistent grid: resident workgroups per CU (occupancy query) x CUs
+    int cus = 256, per_cu = 4;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, op->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+    int q = 0;
+    const void *kfn = S == 3 ? (config->source_method == RDYHIP_SOURCE_IMPLICIT_XQ2018 ? (const void *)swe_rhs_tiled_kernel<3, 1> : (const void *)swe_rhs_tiled_kernel<3, 0>)
+                             : (config->source_method == RDYHIP_SOURCE_IMPLICIT_XQ2018 ? (const void *)swe_rhs_tiled_kernel<4, 1> : (const void *)swe_rhs_tiled_kernel<4, 0>);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, kfn, BLOCK, lds_bytes) == hipSuccess && q > 0) per_cu = q;
+    if (const char *e2 = getenv("RDYHIP_BLOCKS_PER_CU")) {
+      if (atoi(e2) > 0) per_cu = atoi(e2);
+    }
+    op->pgrid            = std::max(8, cus * per_cu);
+    op->tiled_xcd_chunks = (swz && tiles_n >= 64) ? (tiles_n + 7) / 8 : 0;
+  }
+  const int maxgrid = std::max(std::max(op->grid, op->pgrid), 1);
 
 #define TRY_RC(x)     \
   do {                \

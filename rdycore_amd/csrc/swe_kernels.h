@@ -177,157 +177,219 @@ struct TileDesc {  // 16 B, one per tile (+1 sentinel)
   int32_t halo;    // 1 if a tile cell has a ghost neighbour
 };
 
+// Persistent, software-pipelined form: a workgroup walks a sequence of tiles.
+// All index and geometry data is static, and u is read-only during the launch,
+// so while tile T is in its flux phase the loads of tile T+1's cell states
+// (own and halo) are already in flight, the halo-cell ids of tile T+2 are being
+// fetched, and T+1's edge records are requested as soon as T's have been
+// consumed: no tile waits for a dependent chain of global loads.
 template <int S, int SRC>
 __global__ __launch_bounds__(BLOCK) void swe_rhs_tiled_kernel(const KernelArgs a, const double dt, const double *__restrict__ u,
                                                               double *__restrict__ f) {
   extern __shared__ double lds[];
   const int nside = BLOCK + a.hmax;
   double   *sd_h = lds, *sd_u = lds + nside, *sd_v = lds + 2 * nside, *sd_sq = lds + 3 * nside, *sd_c = lds + 4 * nside;
-  double   *ef0 = lds + 5 * nside, *ef1 = ef0 + a.emax, *ef2 = ef1 + a.emax, *eam = ef2 + a.emax;
+  double   *sd_hu = lds + 5 * nside, *sd_hv = sd_hu + BLOCK;
+  double   *ef0 = sd_hv + BLOCK, *ef1 = ef0 + a.emax, *ef2 = ef1 + a.emax, *eam = ef2 + a.emax;
+  const int tid = threadIdx.x;
 
-  // XCD-aware tile mapping: block ids are dealt round-robin to the 8 XCDs, so
-  // give each XCD a contiguous range of tiles (halo cells then hit that XCD's own L2).
-  int ti = blockIdx.x;
-  if (a.xcd_chunks > 0) ti = (blockIdx.x & 7) * a.xcd_chunks + (blockIdx.x >> 3);
-  bool valid = ti < a.n_work;
-  int  tile  = 0;
-  if (valid) {
-    tile = a.list ? a.list[ti] : ti;
-    if (a.phase == RDYHIP_PHASE_INTERIOR && a.tiles[tile].halo) valid = false;
+  // ---- this workgroup's tile sequence.  Block ids are dealt round-robin to the
+  // 8 XCDs: give each XCD a contiguous range of tiles and let its workgroups
+  // interleave inside it, so concurrently running tiles are neighbours and
+  // their halo cells hit that XCD's own L2.
+  int idx, step, hi;
+  if (a.xcd_chunks > 0) {
+    const int x = blockIdx.x & 7;
+    step        = gridDim.x >> 3;
+    idx         = x * a.xcd_chunks + (blockIdx.x >> 3);
+    hi          = min((x + 1) * a.xcd_chunks, a.n_work);
+  } else {
+    idx  = blockIdx.x;
+    step = gridDim.x;
+    hi   = a.n_work;
   }
-  if (!valid) {  // uniform over the block
-    if (threadIdx.x == 0) {
-      a.blk_max[blockIdx.x] = 0.0;
-      a.blk_pos[blockIdx.x] = -1;
+  auto tile_at = [&](int i) -> int { return a.list ? a.list[i] : i; };
+  auto next_valid = [&](int i) -> int {  // INTERIOR phase skips tiles with ghost-adjacent cells (wave-uniform)
+    if (a.phase == RDYHIP_PHASE_INTERIOR) {
+      while (i < hi && a.tiles[tile_at(i)].halo) i += step;
     }
-    return;
-  }
-  const TileDesc td = a.tiles[tile], tn = a.tiles[tile + 1];
-  const int      ne = tn.e_off - td.e_off, nh = tn.h_off - td.h_off;
-  const int      base   = tile * BLOCK;
-  const int      o      = base + threadIdx.x;
-  const bool     active = o < a.n_owned;
+    return i;
+  };
 
-  // ---- phase 0: issue every independent load of the tile up front --------
-  // halo-cell ids first (their states need a second, dependent load)
-  int hid = -1;
-  if ((int)threadIdx.x < nh) hid = a.hcells[td.h_off + threadIdx.x];
-  double h = 0.0, hu = 0.0, hv = 0.0;
-  if (active) {
-    const int c = a.o2l ? a.o2l[o] : o;
-    h           = u[3 * (int64_t)c + 0];
-    hu          = u[3 * (int64_t)c + 1];
-    hv          = u[3 * (int64_t)c + 2];
-  }
-  // first round of edge records
-  uint32_t lr0 = 0;
-  double   cn0 = 0.0, sn0 = 0.0;
-  if ((int)threadIdx.x < ne) {
-    lr0 = a.e_lr[td.e_off + threadIdx.x];
-    cn0 = a.e_cn[td.e_off + threadIdx.x];
-    sn0 = a.e_sn[td.e_off + threadIdx.x];
-  }
-  // per-cell streams used in phase 2
-  double coef[S];
-  uint2  refs = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
-  double dzdx = 0.0, dzdy = 0.0, nman = 0.0, s0 = 0.0, s1 = 0.0, s2 = 0.0;
-  double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
-#pragma unroll
-  for (int s = 0; s < S; ++s) coef[s] = 0.0;
-  if (active) {
-    refs = *reinterpret_cast<const uint2 *>(a.slot_ref + 4 * (int64_t)o);
-#pragma unroll
-    for (int s = 0; s < S; ++s) coef[s] = a.coef[s * a.stride + o];
-    dzdx = a.dzdx[o];
-    dzdy = a.dzdy[o];
-    nman = a.mannings[o];
-    s0   = a.extsrc[3 * (int64_t)o + 0];
-    s1   = a.extsrc[3 * (int64_t)o + 1];
-    s2   = a.extsrc[3 * (int64_t)o + 2];
-    if (!a.overwrite) {
-      acc0 = f[3 * (int64_t)o + 0];
-      acc1 = f[3 * (int64_t)o + 1];
-      acc2 = f[3 * (int64_t)o + 2];
+  double best      = 0.0;  // largest Courant number seen by this thread (> 0 only)
+  int    best_slot = -1, best_o = 0;
+
+  idx = next_valid(idx);
+  if (idx < hi) {
+    // ---- prologue: everything tile T0 needs, and the halo ids of T1
+    int      tile = tile_at(idx);
+    TileDesc td = a.tiles[tile], tn = a.tiles[tile + 1];
+    double   pu0 = 0.0, pu1 = 0.0, pu2 = 0.0;  // own cell state of the tile being started
+    double   ph0 = 0.0, ph1 = 0.0, ph2 = 0.0;  // state of this thread's halo cell
+    uint32_t lr0 = 0, lr1 = 0;                 // first two rounds of edge records
+    double   cn0 = 0.0, sn0 = 0.0, cn1 = 0.0, sn1 = 0.0;
+    {
+      const int o = tile * BLOCK + tid;
+      if (o < a.n_owned) {
+        const int c = a.o2l ? a.o2l[o] : o;
+        pu0 = u[3 * (int64_t)c + 0]; pu1 = u[3 * (int64_t)c + 1]; pu2 = u[3 * (int64_t)c + 2];
+      }
+      if (tid < tn.h_off - td.h_off) {
+        const int hc = a.hcells[td.h_off + tid];
+        ph0 = u[3 * (int64_t)hc + 0]; ph1 = u[3 * (int64_t)hc + 1]; ph2 = u[3 * (int64_t)hc + 2];
+      }
+      const int ne = tn.e_off - td.e_off;
+      if (tid < ne) { lr0 = a.e_lr[td.e_off + tid]; cn0 = a.e_cn[td.e_off + tid]; sn0 = a.e_sn[td.e_off + tid]; }
+      if (tid + BLOCK < ne) { lr1 = a.e_lr[td.e_off + BLOCK + tid]; cn1 = a.e_cn[td.e_off + BLOCK + tid]; sn1 = a.e_sn[td.e_off + BLOCK + tid]; }
     }
-  }
-  // halo-cell states (dependent on hid), then the Riemann side data of both into LDS
-  for (int j = threadIdx.x; j < nh; j += BLOCK) {
-    const int         cell = (j == (int)threadIdx.x) ? hid : a.hcells[td.h_off + j];
-    const RiemannSide hs   = riemann_side(u[3 * (int64_t)cell + 0], u[3 * (int64_t)cell + 1], u[3 * (int64_t)cell + 2], a.tiny_h, a.h_anuga_sq);
-    sd_h[BLOCK + j]  = hs.h;
-    sd_u[BLOCK + j]  = hs.u;
-    sd_v[BLOCK + j]  = hs.v;
-    sd_sq[BLOCK + j] = hs.sqh;
-    sd_c[BLOCK + j]  = hs.c;
-  }
-  RiemannSide self;
-  self.h = self.u = self.v = self.sqh = self.c = 0.0;
-  if (active) self = riemann_side(h, hu, hv, a.tiny_h, a.h_anuga_sq);
-  sd_h[threadIdx.x]  = self.h;
-  sd_u[threadIdx.x]  = self.u;
-  sd_v[threadIdx.x]  = self.v;
-  sd_sq[threadIdx.x] = self.sqh;
-  sd_c[threadIdx.x]  = self.c;
-  __syncthreads();
-
-  // ---- phase 1: every edge of the tile once, operands from LDS only
-  // (ApplyInteriorFlux / ApplyBoundaryFlux, swe_petsc.c:215-316, 506-630)
-  for (int e = threadIdx.x; e < ne; e += BLOCK) {
-    const bool     first = e == (int)threadIdx.x;
-    const uint32_t lr    = first ? lr0 : a.e_lr[td.e_off + e];
-    const double   cn    = first ? cn0 : a.e_cn[td.e_off + e];
-    const double   sn    = first ? sn0 : a.e_sn[td.e_off + e];
-    const int      jl    = lr & EDGE_SLOT_MASK;
-    RiemannSide    L;
-    L.h = sd_h[jl]; L.u = sd_u[jl]; L.v = sd_v[jl]; L.sqh = sd_sq[jl]; L.c = sd_c[jl];
-    RoeFlux fl;
-    bool    wet;
-    if (!(lr & EDGE_BOUNDARY)) {
-      const int   jr = (lr >> EDGE_R_SHIFT) & EDGE_SLOT_MASK;
-      RiemannSide R;
-      R.h = sd_h[jr]; R.u = sd_u[jr]; R.v = sd_v[jr]; R.sqh = sd_sq[jr]; R.c = sd_c[jr];
-      fl  = roe_flux(L, R, sn, cn);
-      wet = !(R.h < a.tiny_h && L.h < a.tiny_h);
-    } else {
-      const int    k  = a.tile_bk[td.b_off + ((lr >> EDGE_R_SHIFT) & EDGE_SLOT_MASK)];
-      BoundaryFlux bf = boundary_flux(a.btype[k], true, L, a.bvalues + 3 * (int64_t)k, sn, cn, a.tiny_h, a.h_anuga_sq);
-      fl              = bf.flux;
-      wet             = bf.wet;
-      store_boundary_flux(a, k, fl, dt);
+    int      idx1 = next_valid(idx + step);
+    int      tile1 = 0, hid1 = 0;
+    TileDesc td1 = td, tn1 = tn;
+    if (idx1 < hi) {
+      tile1 = tile_at(idx1);
+      td1   = a.tiles[tile1];
+      tn1   = a.tiles[tile1 + 1];
+      if (tid < tn1.h_off - td1.h_off) hid1 = a.hcells[td1.h_off + tid];
     }
-    ef0[e] = fl.f0;
-    ef1[e] = fl.f1;
-    ef2[e] = fl.f2;
-    eam[e] = wet ? fl.amax : -1.0;  // -1 marks a dry-dry edge (skipped, swe_petsc.c:285)
-  }
-  __syncthreads();
 
-  // ---- phase 2: per-cell sum in the reference's edge order, source terms, stores
-  double best      = 0.0;
-  int    best_slot = -1;
-  if (active) {
+    while (true) {
+      const int  ne = tn.e_off - td.e_off, nh = tn.h_off - td.h_off;
+      const int  o      = tile * BLOCK + tid;
+      const bool active = o < a.n_owned;
+
+      // ---- per-cell streams of this tile (consumed in phase 2)
+      double coef[S];
+      uint2  refs = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+      double dzdx = 0.0, dzdy = 0.0, nman = 0.0;
+      double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
 #pragma unroll
-    for (int s = 0; s < S; ++s) {
-      const uint32_t w   = (s < 2) ? refs.x : refs.y;
-      const uint32_t ref = (s & 1) ? (w >> 16) : (w & 0xFFFFu);
-      if (ref == SLOT_EMPTY) continue;
-      const double am = eam[ref];
-      if (am != -1.0) {
-        const double k = coef[s];
-        acc0 += ef0[ref] * k;
-        acc1 += ef1[ref] * k;
-        acc2 += ef2[ref] * k;
-        // len/area_self: the max over an edge's two cells is len / min(area_l, area_r) (swe_petsc.c:289)
-        const double cnum = am * fabs(k) * dt;
-        if (cnum > best) {
-          best      = cnum;
-          best_slot = s;
+      for (int s = 0; s < S; ++s) coef[s] = 0.0;
+      if (active) {
+        refs = *reinterpret_cast<const uint2 *>(a.slot_ref + 4 * (int64_t)o);
+#pragma unroll
+        for (int s = 0; s < S; ++s) coef[s] = a.coef[s * a.stride + o];
+        dzdx = a.dzdx[o];
+        dzdy = a.dzdy[o];
+        nman = a.mannings[o];
+        if (!a.overwrite) {
+          acc0 = f[3 * (int64_t)o + 0];
+          acc1 = f[3 * (int64_t)o + 1];
+          acc2 = f[3 * (int64_t)o + 2];
         }
       }
+
+      // ---- phase 0: Riemann side data of the tile's own and halo cells -> LDS
+      {
+        RiemannSide self;
+        self.h = self.u = self.v = self.sqh = self.c = 0.0;
+        if (active) self = riemann_side(pu0, pu1, pu2, a.tiny_h, a.h_anuga_sq);
+        sd_h[tid] = self.h; sd_u[tid] = self.u; sd_v[tid] = self.v; sd_sq[tid] = self.sqh; sd_c[tid] = self.c;
+        sd_hu[tid] = pu1;
+        sd_hv[tid] = pu2;
+        if (tid < nh) {
+          const RiemannSide hs = riemann_side(ph0, ph1, ph2, a.tiny_h, a.h_anuga_sq);
+          sd_h[BLOCK + tid] = hs.h; sd_u[BLOCK + tid] = hs.u; sd_v[BLOCK + tid] = hs.v; sd_sq[BLOCK + tid] = hs.sqh; sd_c[BLOCK + tid] = hs.c;
+        }
+        for (int j = tid + BLOCK; j < nh; j += BLOCK) {  // only numberings with poor locality get here
+          const int         hc = a.hcells[td.h_off + j];
+          const RiemannSide hs = riemann_side(u[3 * (int64_t)hc + 0], u[3 * (int64_t)hc + 1], u[3 * (int64_t)hc + 2], a.tiny_h, a.h_anuga_sq);
+          sd_h[BLOCK + j] = hs.h; sd_u[BLOCK + j] = hs.u; sd_v[BLOCK + j] = hs.v; sd_sq[BLOCK + j] = hs.sqh; sd_c[BLOCK + j] = hs.c;
+        }
+      }
+      __syncthreads();
+
+      // ---- software pipeline: cell states of the next tile, halo ids of the one after
+      int      idx2 = hi, tile2 = 0, hid2 = 0;
+      TileDesc td2 = td1, tn2 = tn1;
+      if (idx1 < hi) {
+        const int o1 = tile1 * BLOCK + tid;
+        if (o1 < a.n_owned) {
+          const int c1 = a.o2l ? a.o2l[o1] : o1;
+          pu0 = u[3 * (int64_t)c1 + 0]; pu1 = u[3 * (int64_t)c1 + 1]; pu2 = u[3 * (int64_t)c1 + 2];
+        }
+        if (tid < tn1.h_off - td1.h_off) { ph0 = u[3 * (int64_t)hid1 + 0]; ph1 = u[3 * (int64_t)hid1 + 1]; ph2 = u[3 * (int64_t)hid1 + 2]; }
+        idx2 = next_valid(idx1 + step);
+        if (idx2 < hi) {
+          tile2 = tile_at(idx2);
+          td2   = a.tiles[tile2];
+          tn2   = a.tiles[tile2 + 1];
+          if (tid < tn2.h_off - td2.h_off) hid2 = a.hcells[td2.h_off + tid];
+        }
+      }
+
+      // ---- phase 1: every edge of the tile once, operands from LDS only
+      // (ApplyInteriorFlux / ApplyBoundaryFlux, swe_petsc.c:215-316, 506-630)
+      for (int e = tid; e < ne; e += BLOCK) {
+        const int      round = e / BLOCK;  // wave-uniform
+        const uint32_t lr    = round == 0 ? lr0 : (round == 1 ? lr1 : a.e_lr[td.e_off + e]);
+        const double   cn    = round == 0 ? cn0 : (round == 1 ? cn1 : a.e_cn[td.e_off + e]);
+        const double   sn    = round == 0 ? sn0 : (round == 1 ? sn1 : a.e_sn[td.e_off + e]);
+        const int      jl    = lr & EDGE_SLOT_MASK;
+        RiemannSide    L;
+        L.h = sd_h[jl]; L.u = sd_u[jl]; L.v = sd_v[jl]; L.sqh = sd_sq[jl]; L.c = sd_c[jl];
+        RoeFlux fl;
+        bool    wet;
+        if (!(lr & EDGE_BOUNDARY)) {
+          const int   jr = (lr >> EDGE_R_SHIFT) & EDGE_SLOT_MASK;
+          RiemannSide R;
+          R.h = sd_h[jr]; R.u = sd_u[jr]; R.v = sd_v[jr]; R.sqh = sd_sq[jr]; R.c = sd_c[jr];
+          fl  = roe_flux(L, R, sn, cn);
+          wet = !(R.h < a.tiny_h && L.h < a.tiny_h);
+        } else {
+          const int    k  = a.tile_bk[td.b_off + ((lr >> EDGE_R_SHIFT) & EDGE_SLOT_MASK)];
+          BoundaryFlux bf = boundary_flux(a.btype[k], true, L, a.bvalues + 3 * (int64_t)k, sn, cn, a.tiny_h, a.h_anuga_sq);
+          fl              = bf.flux;
+          wet             = bf.wet;
+          store_boundary_flux(a, k, fl, dt);
+        }
+        ef0[e] = fl.f0;
+        ef1[e] = fl.f1;
+        ef2[e] = fl.f2;
+        eam[e] = wet ? fl.amax : -1.0;  // -1 marks a dry-dry edge (skipped, swe_petsc.c:285)
+      }
+      __syncthreads();
+
+      // ---- software pipeline: the next tile's edge records (this tile's are consumed)
+      if (idx1 < hi) {
+        const int ne1 = tn1.e_off - td1.e_off;
+        if (tid < ne1) { lr0 = a.e_lr[td1.e_off + tid]; cn0 = a.e_cn[td1.e_off + tid]; sn0 = a.e_sn[td1.e_off + tid]; }
+        if (tid + BLOCK < ne1) { lr1 = a.e_lr[td1.e_off + BLOCK + tid]; cn1 = a.e_cn[td1.e_off + BLOCK + tid]; sn1 = a.e_sn[td1.e_off + BLOCK + tid]; }
+      }
+
+      // ---- phase 2: per-cell sum in the reference's edge order, source terms, stores
+      if (active) {
+        const double s0 = a.extsrc[3 * (int64_t)o + 0];
+        const double s1 = a.extsrc[3 * (int64_t)o + 1];
+        const double s2 = a.extsrc[3 * (int64_t)o + 2];
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+          const uint32_t w   = (s < 2) ? refs.x : refs.y;
+          const uint32_t ref = (s & 1) ? (w >> 16) : (w & 0xFFFFu);
+          if (ref == SLOT_EMPTY) continue;
+          const double am = eam[ref];
+          if (am != -1.0) {
+            const double k = coef[s];
+            acc0 += ef0[ref] * k;
+            acc1 += ef1[ref] * k;
+            acc2 += ef2[ref] * k;
+            // len/area_self: the max over an edge's two cells is len / min(area_l, area_r) (swe_petsc.c:289)
+            const double cnum = am * fabs(k) * dt;
+            if (cnum > best) {
+              best      = cnum;
+              best_slot = s;
+              best_o    = o;
+            }
+          }
+        }
+        cell_epilogue<SRC>(a, o, dt, sd_h[tid], sd_hu[tid], sd_hv[tid], sd_u[tid], sd_v[tid], acc0, acc1, acc2, dzdx, dzdy, nman, s0, s1, s2, f);
+      }
+
+      if (idx1 >= hi) break;
+      idx = idx1; tile = tile1; td = td1; tn = tn1;
+      idx1 = idx2; tile1 = tile2; td1 = td2; tn1 = tn2; hid1 = hid2;
     }
-    cell_epilogue<SRC>(a, o, dt, h, hu, hv, self.u, self.v, acc0, acc1, acc2, dzdx, dzdy, nman, s0, s1, s2, f);
   }
-  block_courant_reduce(a, best, best_slot, o);
+  block_courant_reduce(a, best, best_slot, best_o);
 }
 
 // ---------------------------------------------------------------------------
