@@ -262,6 +262,11 @@ __global__ __launch_bounds__(BLOCK) void swe_rhs_tiled_kernel(const KernelArgs a
       uint2  refs = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
       double dzdx = 0.0, dzdy = 0.0, nman = 0.0;
       double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
+      if (active && !a.overwrite) {  // ApplyOperator semantics: add into f (and let the friction term see it)
+        acc0 = f[3 * (int64_t)o + 0];
+        acc1 = f[3 * (int64_t)o + 1];
+        acc2 = f[3 * (int64_t)o + 2];
+      }
 #pragma unroll
       for (int s = 0; s < S; ++s) coef[s] = 0.0;
       if (active) {
@@ -271,11 +276,6 @@ __global__ __launch_bounds__(BLOCK) void swe_rhs_tiled_kernel(const KernelArgs a
         dzdx = a.dzdx[o];
         dzdy = a.dzdy[o];
         nman = a.mannings[o];
-        if (!a.overwrite) {
-          acc0 = f[3 * (int64_t)o + 0];
-          acc1 = f[3 * (int64_t)o + 1];
-          acc2 = f[3 * (int64_t)o + 2];
-        }
       }
 
       // ---- phase 0: Riemann side data of the tile's own and halo cells -> LDS

@@ -99,22 +99,31 @@ class HaloExchange:
         if self.world == 1 or (not self.send_ids and not self.recv_ids):
             return
         cuda = u_local.is_cuda
+        # device buffers go straight to RCCL; under gloo (single-GPU rehearsal of
+        # several ranks, CPU tests) device buffers are staged through the host
+        via_host = cuda and dist.get_backend(self.group) == "gloo"
         if cuda:
             from .operator import pack_cells, unpack_cells
         ops = []
+        wire_send, wire_recv = {}, {}
         for peer, ids in self.send_ids.items():
             if cuda:
                 pack_cells(u_local, ids, self.send_buf[peer])
             else:
                 self.send_buf[peer].copy_(u_local.view(-1, 3)[ids.long()])
+            wire_send[peer] = self.send_buf[peer].cpu() if via_host else self.send_buf[peer]
+        for peer in self.recv_ids:
+            wire_recv[peer] = torch.empty_like(self.recv_buf[peer], device="cpu") if via_host else self.recv_buf[peer]
         for peer in sorted(set(self.send_ids) | set(self.recv_ids)):
             if peer in self.send_ids:
-                ops.append(dist.P2POp(dist.isend, self.send_buf[peer], peer, group=self.group))
+                ops.append(dist.P2POp(dist.isend, wire_send[peer], peer, group=self.group))
             if peer in self.recv_ids:
-                ops.append(dist.P2POp(dist.irecv, self.recv_buf[peer], peer, group=self.group))
+                ops.append(dist.P2POp(dist.irecv, wire_recv[peer], peer, group=self.group))
         for w in dist.batch_isend_irecv(ops):
             w.wait()
         for peer, ids in self.recv_ids.items():
+            if via_host:
+                self.recv_buf[peer].copy_(wire_recv[peer])
             if cuda:
                 unpack_cells(u_local, ids, self.recv_buf[peer])
             else:
