@@ -104,6 +104,7 @@ struct RDyHipOperator_s {
   DevBuf<double>  d_bvalues, d_bflux, d_baccum, d_bcn, d_bsn, d_pv, d_fdiv, d_blk_max;
   DevBuf<int32_t> d_blk_pos;
   DevBuf<DeviceCourant> d_courant;
+  DevBuf<unsigned int>  d_done;
   int32_t n_halo = 0, n_bghost = 0;
   // tiled kernel (swe_kernels.h)
   bool             use_tiled = true;
@@ -115,8 +116,9 @@ struct RDyHipOperator_s {
   DevBuf<TileDesc> d_tiles;
   DevBuf<uint32_t> d_e_lr;
   DevBuf<int32_t>  d_hcells, d_tile_bk, d_halo_tiles;
-  DevBuf<double>   d_e_cn, d_e_sn;
-  DevBuf<uint16_t> d_slot_ref;
+  DevBuf<double>   d_e_cs;
+  DevBuf<uint16_t> d_slot_ref;   // S == 4
+  DevBuf<uint32_t> d_slot_ref3;  // S == 3
 
   // host copies needed to resolve the Courant position into ids
   std::vector<int32_t> h_internal_edge, h_edge_cells, h_bedge, h_boff;
@@ -134,9 +136,9 @@ struct RDyHipOperator_s {
     d_bghost_list.release(); d_cn.release(); d_sn.release(); d_coef.release(); d_dzdx.release(); d_dzdy.release();
     d_mannings.release(); d_extsrc.release(); d_area_local.release(); d_bvalues.release(); d_bflux.release();
     d_baccum.release(); d_bcn.release(); d_bsn.release(); d_pv.release(); d_fdiv.release(); d_blk_max.release();
-    d_blk_pos.release(); d_courant.release(); d_stage_vals.release(); d_stage_ids.release();
+    d_blk_pos.release(); d_courant.release(); d_done.release(); d_stage_vals.release(); d_stage_ids.release();
     d_tiles.release(); d_e_lr.release(); d_hcells.release(); d_tile_bk.release(); d_halo_tiles.release();
-    d_e_cn.release(); d_e_sn.release(); d_slot_ref.release();
+    d_e_cs.release(); d_slot_ref.release(); d_slot_ref3.release();
   }
 };
 
@@ -168,6 +170,10 @@ int launch_rhs(RDyHipOperator op, int32_t phase, int32_t overwrite, int reset_di
   a.fdiv       = op->keep_fdiv ? op->d_fdiv.p : nullptr;
   a.blk_max    = op->d_blk_max.p;
   a.blk_pos    = op->d_blk_pos.p;
+  a.diag       = op->d_courant.p;
+  a.done       = op->d_done.p;
+  a.reset_diag = reset_diag ? 1 : 0;
+  a.merge_in_kernel = op->use_tiled ? 1 : 0;  // the persistent kernel has few workgroups: merge their partials in the launch
   a.tiny_h     = op->config.tiny_h;
   a.h_anuga_sq = op->config.h_anuga_regular * op->config.h_anuga_regular;
   a.xq_thresh  = op->config.xq2018_threshold;
@@ -176,11 +182,10 @@ int launch_rhs(RDyHipOperator op, int32_t phase, int32_t overwrite, int reset_di
 
   a.tiles    = op->d_tiles.p;
   a.e_lr     = op->d_e_lr.p;
-  a.e_cn     = op->d_e_cn.p;
-  a.e_sn     = op->d_e_sn.p;
+  a.e_cs     = op->d_e_cs.p;
   a.hcells   = op->d_hcells.p;
   a.tile_bk  = op->d_tile_bk.p;
-  a.slot_ref = op->d_slot_ref.p;
+  a.slot_ref = op->S == 3 ? (const void *)op->d_slot_ref3.p : (const void *)op->d_slot_ref.p;
   a.emax     = op->emax;
   a.hmax     = op->hmax;
 
@@ -237,8 +242,10 @@ int launch_rhs(RDyHipOperator op, int32_t phase, int32_t overwrite, int reset_di
     }
   }
   HIP_TRY(hipGetLastError());
-  hipLaunchKernelGGL(courant_finalize_kernel, dim3(1), dim3(1024), 0, st, grid, op->d_blk_max.p, op->d_blk_pos.p, op->d_courant.p, reset_diag);
-  HIP_TRY(hipGetLastError());
+  if (!op->use_tiled) {
+    hipLaunchKernelGGL(courant_finalize_kernel, dim3(1), dim3(1024), 0, st, grid, op->d_blk_max.p, op->d_blk_pos.p, op->d_courant.p, reset_diag);
+    HIP_TRY(hipGetLastError());
+  }
   // boundary edges hanging off ghost cells (diagnostic vectors only); once per full apply
   if (op->n_bghost > 0 && phase != RDYHIP_PHASE_INTERIOR) {
     hipLaunchKernelGGL(boundary_ghost_kernel, dim3((op->n_bghost + 63) / 64), dim3(64), 0, st, op->n_bghost, op->d_bghost_list.p, op->d_bleft.p,
@@ -375,13 +382,12 @@ int rdyhip_create(const RDyHipConfig *config, const RDyHipMesh *mesh, int32_t nu
   std::vector<TileDesc> tiles((size_t)ntiles + 1);
   std::vector<uint32_t> e_lr;
   std::vector<int32_t>  hcells, tile_bk, halo_tiles;
-  std::vector<double>   e_cn, e_sn;
+  std::vector<double>   e_cs;
   std::vector<uint16_t> slot_ref((size_t)no * 4, SLOT_EMPTY);
   int32_t               emax = 0, hmax = 0;
   {
     e_lr.reserve((size_t)no * 2);
-    e_cn.reserve((size_t)no * 2);
-    e_sn.reserve((size_t)no * 2);
+    e_cs.reserve((size_t)no * 2);
     std::vector<std::pair<int32_t, int32_t>> items;  // (loop position of the edge, owned cell * 4 + slot)
     items.reserve(4 * BLOCK);
     std::vector<int32_t> hslot((size_t)nc, -1);      // local cell -> halo slot in the current tile
@@ -436,9 +442,16 @@ int rdyhip_create(const RDyHipConfig *config, const RDyHipMesh *mesh, int32_t nu
             tile_bk.push_back(k);
             ++nbk;
           }
+          // unit normal as one double: the smaller-magnitude component, the other is +-sqrt(1 - cs^2)
+          const double ecn = mesh->edge_cn[e], esn = mesh->edge_sn[e];
+          if (std::fabs(ecn) <= std::fabs(esn)) {
+            lr |= EDGE_CS_IS_CN | (std::signbit(esn) ? EDGE_OTHER_NEG : 0u);
+            e_cs.push_back(ecn);
+          } else {
+            lr |= (std::signbit(ecn) ? EDGE_OTHER_NEG : 0u);
+            e_cs.push_back(esn);
+          }
           e_lr.push_back(lr);
-          e_cn.push_back(mesh->edge_cn[e]);
-          e_sn.push_back(mesh->edge_sn[e]);
         }
         slot_ref[(size_t)(it.second >> 2) * 4 + (it.second & 3)] = (uint16_t)local;
       }
@@ -559,9 +572,21 @@ int rdyhip_create(const RDyHipConfig *config, const RDyHipMesh *mesh, int32_t nu
   TRY_RC(op->d_e_lr.upload(e_lr));
   TRY_RC(op->d_hcells.upload(hcells));
   TRY_RC(op->d_tile_bk.upload(tile_bk));
-  TRY_RC(op->d_e_cn.upload(e_cn));
-  TRY_RC(op->d_e_sn.upload(e_sn));
-  TRY_RC(op->d_slot_ref.upload(slot_ref));
+  TRY_RC(op->d_e_cs.upload(e_cs));
+  if (S == 3) {
+    std::vector<uint32_t> ref3((size_t)no);
+    for (int32_t o = 0; o < no; ++o) {
+      uint32_t w = 0;
+      for (int sl = 0; sl < 3; ++sl) {
+        const uint16_t r = slot_ref[(size_t)o * 4 + sl];
+        w |= (r == SLOT_EMPTY ? REF3_EMPTY : (uint32_t)r) << (10 * sl);
+      }
+      ref3[o] = w;
+    }
+    TRY_RC(op->d_slot_ref3.upload(ref3));
+  } else {
+    TRY_RC(op->d_slot_ref.upload(slot_ref));
+  }
   TRY_RC(op->d_mannings.zeros((size_t)no));
   TRY_RC(op->d_extsrc.zeros((size_t)3 * no));
   TRY_RC(op->d_bvalues.zeros((size_t)3 * K));
@@ -571,6 +596,7 @@ int rdyhip_create(const RDyHipConfig *config, const RDyHipMesh *mesh, int32_t nu
   TRY_RC(op->d_blk_max.zeros((size_t)maxgrid));
   TRY_RC(op->d_blk_pos.zeros((size_t)maxgrid));
   TRY_RC(op->d_courant.zeros(1));
+  TRY_RC(op->d_done.zeros(1));
 #undef TRY_RC
   hipLaunchKernelGGL(courant_reset_kernel, dim3(1), dim3(1), 0, 0, op->d_courant.p);
   if (hipDeviceSynchronize() != hipSuccess) {
@@ -589,7 +615,7 @@ int rdyhip_create(const RDyHipConfig *config, const RDyHipMesh *mesh, int32_t nu
                      op->d_dzdx.bytes() + op->d_dzdy.bytes() + op->d_mannings.bytes() + op->d_extsrc.bytes() + op->d_area_local.bytes() +
                      op->d_pv.bytes() + op->d_bvalues.bytes() + op->d_bflux.bytes() + op->d_baccum.bytes() + op->d_blk_max.bytes() +
                      op->d_blk_pos.bytes() + op->d_tiles.bytes() + op->d_e_lr.bytes() + op->d_hcells.bytes() + op->d_tile_bk.bytes() +
-                     op->d_e_cn.bytes() + op->d_e_sn.bytes() + op->d_slot_ref.bytes();
+                     op->d_e_cs.bytes() + op->d_slot_ref.bytes() + op->d_slot_ref3.bytes();
   *op_out = op;
   return 0;
 }
@@ -810,10 +836,10 @@ int rdyhip_layout_info(RDyHipOperator op, RDyHipLayoutInfo *info) {
   info->device_bytes       = op->device_bytes;
   // u (own cell) 24 + slots S*(4+8+8+8) + dz 16 + n 8 + ext src 24 + F 24 + pv 24 (+4 for o2l)
   if (op->use_tiled) {
-    // u 24 + slot refs 8 + coef S*8 + dz 16 + n 8 + ext src 24 + F 24 + pv 24 (+4 for o2l) per cell;
-    // 20 B per edge record; 4 B id + 24 B state per halo-cell entry (the states are mostly L2 hits)
-    info->bytes_per_apply = (int64_t)op->n_owned * (24 + 8 + op->S * 8 + 16 + 8 + 24 + 24 + 24 + (op->prefix ? 0 : 4)) + op->nrec * 20 +
-                            op->nhalo_entries * 4 + (int64_t)op->ntiles * 16;
+    // u 24 + slot refs 4 (8 for quads) + coef S*8 + dz 16 + n 8 + ext src 24 + F 24 + pv 24 (+4 for o2l) per cell;
+    // 12 B per edge record; 4 B id per halo-cell entry (the halo states themselves are mostly L2 hits)
+    info->bytes_per_apply = (int64_t)op->n_owned * (24 + (op->S == 3 ? 4 : 8) + op->S * 8 + 16 + 8 + 24 + 24 + 24 + (op->prefix ? 0 : 4)) +
+                            op->nrec * 12 + op->nhalo_entries * 4 + (int64_t)op->ntiles * 16;
   } else {
     info->bytes_per_apply = (int64_t)op->n_owned * (24 + op->S * 28 + 16 + 8 + 24 + 24 + 24 + (op->prefix ? 0 : 4));
   }

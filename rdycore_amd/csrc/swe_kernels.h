@@ -66,6 +66,10 @@ struct KernelArgs {
   double        *fdiv;       // [n_owned][3] or nullptr
   double        *blk_max;    // [grid]
   int32_t       *blk_pos;    // [grid]
+  struct DeviceCourant *diag; // persistent diagnostic
+  unsigned int  *done;       // workgroups that have published their partial (tiled kernel's in-launch merge)
+  int32_t        merge_in_kernel;  // 1: the last workgroup merges the partials into diag (no finalize launch)
+  int32_t        reset_diag;       // 1: diag is reset before the merge (ResetOperatorDiagnostics)
   double         tiny_h, h_anuga_sq, xq_thresh;
   int32_t        phase;      // RDYHIP_PHASE_*
   int32_t        overwrite;  // 1: f = rhs, 0: f += rhs
@@ -73,10 +77,11 @@ struct KernelArgs {
   // ---- tiled kernel only
   const struct TileDesc *tiles;  // [ntiles+1]
   const uint32_t *e_lr;      // [nrec] packed LDS slots of the edge's cells
-  const double   *e_cn, *e_sn;  // [nrec]
+  const double   *e_cs;      // [nrec] smaller-magnitude component of the edge normal
   const int32_t  *hcells;    // halo cells of each tile (local cell ids)
   const int32_t  *tile_bk;   // boundary-edge ids k of each tile's boundary edges
-  const uint16_t *slot_ref;  // [n_owned][4] index of each slot's edge in the tile's edge list
+  const void     *slot_ref;  // index of each slot's edge in the tile's edge list: S == 3: uint32[n_owned] (3 x 10 bits),
+                             // S == 4: uint16[n_owned][4]
   int32_t         emax;      // largest edge count of a tile (LDS sizing)
   int32_t         hmax;      // largest halo-cell count of a tile (LDS sizing)
 };
@@ -139,12 +144,67 @@ __device__ __forceinline__ void block_courant_reduce(const KernelArgs &a, double
   p = wave_min(p);
   if (lane == 0) s_pos[wave] = p;
   __syncthreads();
+  int bp = INT32_MAX;
   if (threadIdx.x == 0) {
-    int bp = s_pos[0];
+    bp = s_pos[0];
 #pragma unroll
     for (int w = 1; w < BLOCK / 64; ++w) bp = min(bp, s_pos[w]);
     a.blk_max[blockIdx.x] = bmax;
     a.blk_pos[blockIdx.x] = (bmax > 0.0) ? bp : -1;
+  }
+  if (!a.merge_in_kernel) return;
+
+  // ---- in-launch merge: the workgroup that publishes last folds every partial
+  // into the persistent diagnostic.  Placement-independent hand-off: partials
+  // are published with an agent-scope release before the counter add, the
+  // last arriver acquires before reading them with L1-bypassing loads.
+  __shared__ int s_last;
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned prev = __hip_atomic_fetch_add(a.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last              = (prev == gridDim.x - 1) ? 1 : 0;
+    if (s_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
+  __syncthreads();
+  if (!s_last) return;
+  double m = 0.0;
+  int    q = INT32_MAX;
+  for (int i = threadIdx.x; i < (int)gridDim.x; i += BLOCK) {
+    const double v = __hip_atomic_load(a.blk_max + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int    r = __hip_atomic_load(a.blk_pos + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (v > m || (v == m && v > 0.0 && r < q)) {
+      m = v;
+      q = r;
+    }
+  }
+  const double wm = wave_max(m);
+  int          wq = (m == wm && m > 0.0) ? q : INT32_MAX;
+  wq              = wave_min(wq);
+  __syncthreads();  // s_max / s_pos are reused
+  if (lane == 0) {
+    s_max[wave] = wm;
+    s_pos[wave] = wq;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double bm = 0.0;
+    int    bq = INT32_MAX;
+    for (int w = 0; w < BLOCK / 64; ++w) {
+      if (s_max[w] > bm || (s_max[w] == bm && bm > 0.0 && s_pos[w] < bq)) {
+        bm = s_max[w];
+        bq = s_pos[w];
+      }
+    }
+    double cur_max = a.reset_diag ? 0.0 : a.diag->max_courant;
+    int    cur_pos = a.reset_diag ? -1 : a.diag->pos;
+    if (bm > cur_max || (bm == cur_max && bm > 0.0 && bq < cur_pos)) {
+      cur_max = bm;
+      cur_pos = bq;
+    }
+    a.diag->max_courant = cur_max;
+    a.diag->pos         = cur_pos;
+    __hip_atomic_store(a.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch on this stream
   }
 }
 
@@ -169,6 +229,20 @@ __device__ __forceinline__ void store_boundary_flux(const KernelArgs &a, int k, 
 constexpr uint32_t EDGE_SLOT_MASK = 0x7FF;
 constexpr int      EDGE_R_SHIFT   = 11;
 constexpr uint32_t EDGE_BOUNDARY  = 1u << 22;
+// The unit normal (cn, sn) is stored as ONE double: the component of smaller
+// magnitude; the other is +-sqrt(1 - cs^2) (well conditioned: cs^2 <= 1/2).
+constexpr uint32_t EDGE_CS_IS_CN     = 1u << 23;  // the stored component is cn (else sn)
+constexpr uint32_t EDGE_OTHER_NEG    = 1u << 24;  // the reconstructed component is negative
+// slot references of a triangle mesh (S == 3): 3 x 10 bits in one uint32, 0x3FF = unused
+constexpr uint32_t REF3_EMPTY = 0x3FF;
+
+__device__ __forceinline__ void edge_normal(uint32_t lr, double cs, double &cn, double &sn) {
+  double other = sqrt(fma(-cs, cs, 1.0));
+  if (lr & EDGE_OTHER_NEG) other = -other;
+  const bool is_cn = lr & EDGE_CS_IS_CN;
+  cn               = is_cn ? cs : other;
+  sn               = is_cn ? other : cs;
+}
 
 struct TileDesc {  // 16 B, one per tile (+1 sentinel)
   int32_t e_off;   // first edge record
@@ -227,7 +301,7 @@ __global__ __launch_bounds__(BLOCK) void swe_rhs_tiled_kernel(const KernelArgs a
     double   pu0 = 0.0, pu1 = 0.0, pu2 = 0.0;  // own cell state of the tile being started
     double   ph0 = 0.0, ph1 = 0.0, ph2 = 0.0;  // state of this thread's halo cell
     uint32_t lr0 = 0, lr1 = 0;                 // first two rounds of edge records
-    double   cn0 = 0.0, sn0 = 0.0, cn1 = 0.0, sn1 = 0.0;
+    double   cs0 = 0.0, cs1 = 0.0;
     {
       const int o = tile * BLOCK + tid;
       if (o < a.n_owned) {
@@ -239,8 +313,8 @@ __global__ __launch_bounds__(BLOCK) void swe_rhs_tiled_kernel(const KernelArgs a
         ph0 = u[3 * (int64_t)hc + 0]; ph1 = u[3 * (int64_t)hc + 1]; ph2 = u[3 * (int64_t)hc + 2];
       }
       const int ne = tn.e_off - td.e_off;
-      if (tid < ne) { lr0 = a.e_lr[td.e_off + tid]; cn0 = a.e_cn[td.e_off + tid]; sn0 = a.e_sn[td.e_off + tid]; }
-      if (tid + BLOCK < ne) { lr1 = a.e_lr[td.e_off + BLOCK + tid]; cn1 = a.e_cn[td.e_off + BLOCK + tid]; sn1 = a.e_sn[td.e_off + BLOCK + tid]; }
+      if (tid < ne) { lr0 = a.e_lr[td.e_off + tid]; cs0 = a.e_cs[td.e_off + tid]; }
+      if (tid + BLOCK < ne) { lr1 = a.e_lr[td.e_off + BLOCK + tid]; cs1 = a.e_cs[td.e_off + BLOCK + tid]; }
     }
     int      idx1 = next_valid(idx + step);
     int      tile1 = 0, hid1 = 0;
@@ -258,8 +332,10 @@ __global__ __launch_bounds__(BLOCK) void swe_rhs_tiled_kernel(const KernelArgs a
       const bool active = o < a.n_owned;
 
       // ---- per-cell streams of this tile (consumed in phase 2)
-      double coef[S];
-      uint2  refs = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+      double   coef[S];
+      uint32_t refs[S];
+#pragma unroll
+      for (int s = 0; s < S; ++s) refs[s] = S == 3 ? REF3_EMPTY : (uint32_t)SLOT_EMPTY;
       double dzdx = 0.0, dzdy = 0.0, nman = 0.0;
       double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
       if (active && !a.overwrite) {  // ApplyOperator semantics: add into f (and let the friction term see it)
@@ -270,7 +346,14 @@ __global__ __launch_bounds__(BLOCK) void swe_rhs_tiled_kernel(const KernelArgs a
 #pragma unroll
       for (int s = 0; s < S; ++s) coef[s] = 0.0;
       if (active) {
-        refs = *reinterpret_cast<const uint2 *>(a.slot_ref + 4 * (int64_t)o);
+        if (S == 3) {
+          const uint32_t w = reinterpret_cast<const uint32_t *>(a.slot_ref)[o];
+          refs[0] = w & 0x3FF; refs[1] = (w >> 10) & 0x3FF; refs[2] = (w >> 20) & 0x3FF;
+        } else {
+          const uint2 w = reinterpret_cast<const uint2 *>(a.slot_ref)[o];
+          refs[0] = w.x & 0xFFFFu; refs[1] = w.x >> 16; refs[2] = w.y & 0xFFFFu;
+          if (S > 3) refs[S - 1] = w.y >> 16;
+        }
 #pragma unroll
         for (int s = 0; s < S; ++s) coef[s] = a.coef[s * a.stride + o];
         dzdx = a.dzdx[o];
@@ -322,8 +405,9 @@ __global__ __launch_bounds__(BLOCK) void swe_rhs_tiled_kernel(const KernelArgs a
       for (int e = tid; e < ne; e += BLOCK) {
         const int      round = e / BLOCK;  // wave-uniform
         const uint32_t lr    = round == 0 ? lr0 : (round == 1 ? lr1 : a.e_lr[td.e_off + e]);
-        const double   cn    = round == 0 ? cn0 : (round == 1 ? cn1 : a.e_cn[td.e_off + e]);
-        const double   sn    = round == 0 ? sn0 : (round == 1 ? sn1 : a.e_sn[td.e_off + e]);
+        const double   cs    = round == 0 ? cs0 : (round == 1 ? cs1 : a.e_cs[td.e_off + e]);
+        double         cn, sn;
+        edge_normal(lr, cs, cn, sn);
         const int      jl    = lr & EDGE_SLOT_MASK;
         RiemannSide    L;
         L.h = sd_h[jl]; L.u = sd_u[jl]; L.v = sd_v[jl]; L.sqh = sd_sq[jl]; L.c = sd_c[jl];
@@ -352,8 +436,8 @@ __global__ __launch_bounds__(BLOCK) void swe_rhs_tiled_kernel(const KernelArgs a
       // ---- software pipeline: the next tile's edge records (this tile's are consumed)
       if (idx1 < hi) {
         const int ne1 = tn1.e_off - td1.e_off;
-        if (tid < ne1) { lr0 = a.e_lr[td1.e_off + tid]; cn0 = a.e_cn[td1.e_off + tid]; sn0 = a.e_sn[td1.e_off + tid]; }
-        if (tid + BLOCK < ne1) { lr1 = a.e_lr[td1.e_off + BLOCK + tid]; cn1 = a.e_cn[td1.e_off + BLOCK + tid]; sn1 = a.e_sn[td1.e_off + BLOCK + tid]; }
+        if (tid < ne1) { lr0 = a.e_lr[td1.e_off + tid]; cs0 = a.e_cs[td1.e_off + tid]; }
+        if (tid + BLOCK < ne1) { lr1 = a.e_lr[td1.e_off + BLOCK + tid]; cs1 = a.e_cs[td1.e_off + BLOCK + tid]; }
       }
 
       // ---- phase 2: per-cell sum in the reference's edge order, source terms, stores
@@ -363,9 +447,8 @@ __global__ __launch_bounds__(BLOCK) void swe_rhs_tiled_kernel(const KernelArgs a
         const double s2 = a.extsrc[3 * (int64_t)o + 2];
 #pragma unroll
         for (int s = 0; s < S; ++s) {
-          const uint32_t w   = (s < 2) ? refs.x : refs.y;
-          const uint32_t ref = (s & 1) ? (w >> 16) : (w & 0xFFFFu);
-          if (ref == SLOT_EMPTY) continue;
+          const uint32_t ref = refs[s];
+          if (ref == (S == 3 ? REF3_EMPTY : (uint32_t)SLOT_EMPTY)) continue;
           const double am = eam[ref];
           if (am != -1.0) {
             const double k = coef[s];
