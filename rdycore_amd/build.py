@@ -19,7 +19,8 @@ ARCH = "gfx950"
 
 
 def lib_path() -> str:
-    return LIB
+    # RDYHIP_LIB: load another build of the same ABI (A/B timing of two revisions in one process tree)
+    return os.environ.get("RDYHIP_LIB", LIB)
 
 
 def needs_build() -> bool:

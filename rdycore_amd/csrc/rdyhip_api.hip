@@ -144,6 +144,18 @@ struct RDyHipOperator_s {
 
 namespace {
 
+using TiledKernelFn = void (*)(const KernelArgs, const double, const double *, double *);
+
+// the instantiation of the tiled kernel for (slots per cell, source method, overwrite)
+TiledKernelFn tiled_kernel_fn(int S, int src, bool ovw) {
+  if (S == 3) {
+    if (src) return ovw ? swe_rhs_tiled_kernel<3, 1, true> : swe_rhs_tiled_kernel<3, 1, false>;
+    return ovw ? swe_rhs_tiled_kernel<3, 0, true> : swe_rhs_tiled_kernel<3, 0, false>;
+  }
+  if (src) return ovw ? swe_rhs_tiled_kernel<4, 1, true> : swe_rhs_tiled_kernel<4, 1, false>;
+  return ovw ? swe_rhs_tiled_kernel<4, 0, true> : swe_rhs_tiled_kernel<4, 0, false>;
+}
+
 int launch_rhs(RDyHipOperator op, int32_t phase, int32_t overwrite, int reset_diag, double dt, const double *u, double *f, hipStream_t st) {
   if (!op) return fail(RDYHIP_ERR_USER, "null operator");
   if (!u || !f) return fail(RDYHIP_ERR_USER, "null u_local / f_global");
@@ -212,13 +224,7 @@ int launch_rhs(RDyHipOperator op, int32_t phase, int32_t overwrite, int reset_di
       }
     }
     const size_t lds = op->lds_bytes;
-    if (op->S == 3) {
-      if (xq) hipLaunchKernelGGL((swe_rhs_tiled_kernel<3, 1>), dim3(grid), dim3(BLOCK), lds, st, a, dt, u, f);
-      else hipLaunchKernelGGL((swe_rhs_tiled_kernel<3, 0>), dim3(grid), dim3(BLOCK), lds, st, a, dt, u, f);
-    } else {
-      if (xq) hipLaunchKernelGGL((swe_rhs_tiled_kernel<4, 1>), dim3(grid), dim3(BLOCK), lds, st, a, dt, u, f);
-      else hipLaunchKernelGGL((swe_rhs_tiled_kernel<4, 0>), dim3(grid), dim3(BLOCK), lds, st, a, dt, u, f);
-    }
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(tiled_kernel_fn(op->S, xq ? 1 : 0, overwrite != 0)), dim3(grid), dim3(BLOCK), lds, st, a, dt, u, f);
   } else {
     if (phase == RDYHIP_PHASE_HALO) {
       if (op->n_halo == 0) return 0;
@@ -497,10 +503,11 @@ int rdyhip_create(const RDyHipConfig *config, const RDyHipMesh *mesh, int32_t nu
   if (lds_bytes > 64 * 1024) {
     // more than the default 64 KB of dynamic LDS (only for numberings with poor locality)
     const int nb = (int)lds_bytes;
-    bool ok = hipFuncSetAttribute((const void *)swe_rhs_tiled_kernel<3, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, nb) == hipSuccess;
-    ok = ok && hipFuncSetAttribute((const void *)swe_rhs_tiled_kernel<3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, nb) == hipSuccess;
-    ok = ok && hipFuncSetAttribute((const void *)swe_rhs_tiled_kernel<4, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, nb) == hipSuccess;
-    ok = ok && hipFuncSetAttribute((const void *)swe_rhs_tiled_kernel<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, nb) == hipSuccess;
+    bool ok = true;
+    for (int ovw = 0; ovw < 2; ++ovw)
+      for (int src = 0; src < 2; ++src)
+        for (int sl = 3; sl <= 4; ++sl)
+          ok = ok && hipFuncSetAttribute((const void *)tiled_kernel_fn(sl, src, ovw != 0), hipFuncAttributeMaxDynamicSharedMemorySize, nb) == hipSuccess;
     if (!ok) {
       delete op;
       return fail(RDYHIP_ERR_LIB, "cannot reserve %d bytes of LDS per workgroup", nb);
@@ -529,8 +536,7 @@ int rdyhip_create(const RDyHipConfig *config, const RDyHipMesh *mesh, int32_t nu
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, op->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
     int q = 0;
-    const void *kfn = S == 3 ? (config->source_method == RDYHIP_SOURCE_IMPLICIT_XQ2018 ? (const void *)swe_rhs_tiled_kernel<3, 1> : (const void *)swe_rhs_tiled_kernel<3, 0>)
-                             : (config->source_method == RDYHIP_SOURCE_IMPLICIT_XQ2018 ? (const void *)swe_rhs_tiled_kernel<4, 1> : (const void *)swe_rhs_tiled_kernel<4, 0>);
+    const void *kfn = (const void *)tiled_kernel_fn(S, config->source_method == RDYHIP_SOURCE_IMPLICIT_XQ2018 ? 1 : 0, true);
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, kfn, BLOCK, lds_bytes) == hipSuccess && q > 0) per_cu = q;
     if (const char *e2 = getenv("RDYHIP_BLOCKS_PER_CU")) {
       if (atoi(e2) > 0) per_cu = atoi(e2);

@@ -251,13 +251,48 @@ struct TileDesc {  // 16 B, one per tile (+1 sentinel)
   int32_t halo;    // 1 if a tile cell has a ghost neighbour
 };
 
+// per-cell streams consumed in phase 2 (slot references, flux coefficients,
+// bed slopes, Manning n, external source)
+template <int S>
+struct CellStreams {
+  uint32_t r0, r1;
+  double   coef[S];
+  double   dzdx, dzdy, nman, s0, s1, s2;
+};
+
+template <int S>
+__device__ __forceinline__ void load_streams(const KernelArgs &a, int o, bool active, CellStreams<S> &c) {
+  c.r0 = c.r1 = 0xFFFFFFFFu;
+#pragma unroll
+  for (int s = 0; s < S; ++s) c.coef[s] = 0.0;
+  c.dzdx = c.dzdy = c.nman = c.s0 = c.s1 = c.s2 = 0.0;
+  if (active) {
+    if (S == 3) {
+      c.r0 = reinterpret_cast<const uint32_t *>(a.slot_ref)[o];
+    } else {
+      const uint2 w = reinterpret_cast<const uint2 *>(a.slot_ref)[o];
+      c.r0          = w.x;
+      c.r1          = w.y;
+    }
+#pragma unroll
+    for (int s = 0; s < S; ++s) c.coef[s] = a.coef[s * a.stride + o];
+    c.dzdx = a.dzdx[o];
+    c.dzdy = a.dzdy[o];
+    c.nman = a.mannings[o];
+    c.s0   = a.extsrc[3 * (int64_t)o + 0];
+    c.s1   = a.extsrc[3 * (int64_t)o + 1];
+    c.s2   = a.extsrc[3 * (int64_t)o + 2];
+  }
+}
+
 // Persistent, software-pipelined form: a workgroup walks a sequence of tiles.
-// All index and geometry data is static, and u is read-only during the launch,
-// so while tile T is in its flux phase the loads of tile T+1's cell states
-// (own and halo) are already in flight, the halo-cell ids of tile T+2 are being
-// fetched, and T+1's edge records are requested as soon as T's have been
-// consumed: no tile waits for a dependent chain of global loads.
-template <int S, int SRC>
+// All index and geometry data is static and u is read-only during the launch,
+// so every global load of tile T+1 is issued while tile T is being computed
+// (and the halo-cell ids of T+2 as well): its per-cell streams at the top of
+// T, its cell states and edge records after T's first barrier.  A tile never
+// waits for a dependent chain of global loads, and every load has about one
+// tile time to complete, which is what keeps HBM busy at 3 workgroups per CU.
+template <int S, int SRC, bool OVW>
 __global__ __launch_bounds__(BLOCK) void swe_rhs_tiled_kernel(const KernelArgs a, const double dt, const double *__restrict__ u,
                                                               double *__restrict__ f) {
   extern __shared__ double lds[];
@@ -302,6 +337,7 @@ __global__ __launch_bounds__(BLOCK) void swe_rhs_tiled_kernel(const KernelArgs a
     double   ph0 = 0.0, ph1 = 0.0, ph2 = 0.0;  // state of this thread's halo cell
     uint32_t lr0 = 0, lr1 = 0;                 // first two rounds of edge records
     double   cs0 = 0.0, cs1 = 0.0;
+    CellStreams<S> cur;
     {
       const int o = tile * BLOCK + tid;
       if (o < a.n_owned) {
@@ -315,6 +351,7 @@ __global__ __launch_bounds__(BLOCK) void swe_rhs_tiled_kernel(const KernelArgs a
       const int ne = tn.e_off - td.e_off;
       if (tid < ne) { lr0 = a.e_lr[td.e_off + tid]; cs0 = a.e_cs[td.e_off + tid]; }
       if (tid + BLOCK < ne) { lr1 = a.e_lr[td.e_off + BLOCK + tid]; cs1 = a.e_cs[td.e_off + BLOCK + tid]; }
+      load_streams<S>(a, o, o < a.n_owned, cur);
     }
     int      idx1 = next_valid(idx + step);
     int      tile1 = 0, hid1 = 0;
@@ -331,35 +368,9 @@ __global__ __launch_bounds__(BLOCK) void swe_rhs_tiled_kernel(const KernelArgs a
       const int  o      = tile * BLOCK + tid;
       const bool active = o < a.n_owned;
 
-      // ---- per-cell streams of this tile (consumed in phase 2)
-      double   coef[S];
-      uint32_t refs[S];
-#pragma unroll
-      for (int s = 0; s < S; ++s) refs[s] = S == 3 ? REF3_EMPTY : (uint32_t)SLOT_EMPTY;
-      double dzdx = 0.0, dzdy = 0.0, nman = 0.0;
-      double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
-      if (active && !a.overwrite) {  // ApplyOperator semantics: add into f (and let the friction term see it)
-        acc0 = f[3 * (int64_t)o + 0];
-        acc1 = f[3 * (int64_t)o + 1];
-        acc2 = f[3 * (int64_t)o + 2];
-      }
-#pragma unroll
-      for (int s = 0; s < S; ++s) coef[s] = 0.0;
-      if (active) {
-        if (S == 3) {
-          const uint32_t w = reinterpret_cast<const uint32_t *>(a.slot_ref)[o];
-          refs[0] = w & 0x3FF; refs[1] = (w >> 10) & 0x3FF; refs[2] = (w >> 20) & 0x3FF;
-        } else {
-          const uint2 w = reinterpret_cast<const uint2 *>(a.slot_ref)[o];
-          refs[0] = w.x & 0xFFFFu; refs[1] = w.x >> 16; refs[2] = w.y & 0xFFFFu;
-          if (S > 3) refs[S - 1] = w.y >> 16;
-        }
-#pragma unroll
-        for (int s = 0; s < S; ++s) coef[s] = a.coef[s * a.stride + o];
-        dzdx = a.dzdx[o];
-        dzdy = a.dzdy[o];
-        nman = a.mannings[o];
-      }
+      // ---- software pipeline (1): the next tile's per-cell streams, a full tile ahead
+      CellStreams<S> nxt;
+      load_streams<S>(a, tile1 * BLOCK + tid, idx1 < hi && tile1 * BLOCK + tid < a.n_owned, nxt);
 
       // ---- phase 0: Riemann side data of the tile's own and halo cells -> LDS
       {
@@ -381,9 +392,11 @@ __global__ __launch_bounds__(BLOCK) void swe_rhs_tiled_kernel(const KernelArgs a
       }
       __syncthreads();
 
-      // ---- software pipeline: cell states of the next tile, halo ids of the one after
+      // ---- software pipeline (2): cell states and edge records of the next tile, halo ids of the one after
       int      idx2 = hi, tile2 = 0, hid2 = 0;
       TileDesc td2 = td1, tn2 = tn1;
+      uint32_t nlr0 = 0, nlr1 = 0;
+      double   ncs0 = 0.0, ncs1 = 0.0;
       if (idx1 < hi) {
         const int o1 = tile1 * BLOCK + tid;
         if (o1 < a.n_owned) {
@@ -391,6 +404,9 @@ __global__ __launch_bounds__(BLOCK) void swe_rhs_tiled_kernel(const KernelArgs a
           pu0 = u[3 * (int64_t)c1 + 0]; pu1 = u[3 * (int64_t)c1 + 1]; pu2 = u[3 * (int64_t)c1 + 2];
         }
         if (tid < tn1.h_off - td1.h_off) { ph0 = u[3 * (int64_t)hid1 + 0]; ph1 = u[3 * (int64_t)hid1 + 1]; ph2 = u[3 * (int64_t)hid1 + 2]; }
+        const int ne1 = tn1.e_off - td1.e_off;
+        if (tid < ne1) { nlr0 = a.e_lr[td1.e_off + tid]; ncs0 = a.e_cs[td1.e_off + tid]; }
+        if (tid + BLOCK < ne1) { nlr1 = a.e_lr[td1.e_off + BLOCK + tid]; ncs1 = a.e_cs[td1.e_off + BLOCK + tid]; }
         idx2 = next_valid(idx1 + step);
         if (idx2 < hi) {
           tile2 = tile_at(idx2);
@@ -408,8 +424,8 @@ __global__ __launch_bounds__(BLOCK) void swe_rhs_tiled_kernel(const KernelArgs a
         const double   cs    = round == 0 ? cs0 : (round == 1 ? cs1 : a.e_cs[td.e_off + e]);
         double         cn, sn;
         edge_normal(lr, cs, cn, sn);
-        const int      jl    = lr & EDGE_SLOT_MASK;
-        RiemannSide    L;
+        const int   jl = lr & EDGE_SLOT_MASK;
+        RiemannSide L;
         L.h = sd_h[jl]; L.u = sd_u[jl]; L.v = sd_v[jl]; L.sqh = sd_sq[jl]; L.c = sd_c[jl];
         RoeFlux fl;
         bool    wet;
@@ -433,25 +449,28 @@ __global__ __launch_bounds__(BLOCK) void swe_rhs_tiled_kernel(const KernelArgs a
       }
       __syncthreads();
 
-      // ---- software pipeline: the next tile's edge records (this tile's are consumed)
-      if (idx1 < hi) {
-        const int ne1 = tn1.e_off - td1.e_off;
-        if (tid < ne1) { lr0 = a.e_lr[td1.e_off + tid]; cs0 = a.e_cs[td1.e_off + tid]; }
-        if (tid + BLOCK < ne1) { lr1 = a.e_lr[td1.e_off + BLOCK + tid]; cs1 = a.e_cs[td1.e_off + BLOCK + tid]; }
-      }
-
       // ---- phase 2: per-cell sum in the reference's edge order, source terms, stores
       if (active) {
-        const double s0 = a.extsrc[3 * (int64_t)o + 0];
-        const double s1 = a.extsrc[3 * (int64_t)o + 1];
-        const double s2 = a.extsrc[3 * (int64_t)o + 2];
+        double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
+        if (!OVW) {  // ApplyOperator semantics: add into f (and let the friction term see it)
+          acc0 = f[3 * (int64_t)o + 0];
+          acc1 = f[3 * (int64_t)o + 1];
+          acc2 = f[3 * (int64_t)o + 2];
+        }
 #pragma unroll
         for (int s = 0; s < S; ++s) {
-          const uint32_t ref = refs[s];
-          if (ref == (S == 3 ? REF3_EMPTY : (uint32_t)SLOT_EMPTY)) continue;
+          uint32_t ref;
+          if (S == 3) {
+            ref = (cur.r0 >> (10 * s)) & 0x3FF;
+            if (ref == REF3_EMPTY) continue;
+          } else {
+            const uint32_t w = (s < 2) ? cur.r0 : cur.r1;
+            ref              = (s & 1) ? (w >> 16) : (w & 0xFFFFu);
+            if (ref == SLOT_EMPTY) continue;
+          }
           const double am = eam[ref];
           if (am != -1.0) {
-            const double k = coef[s];
+            const double k = cur.coef[s];
             acc0 += ef0[ref] * k;
             acc1 += ef1[ref] * k;
             acc2 += ef2[ref] * k;
@@ -464,12 +483,15 @@ __global__ __launch_bounds__(BLOCK) void swe_rhs_tiled_kernel(const KernelArgs a
             }
           }
         }
-        cell_epilogue<SRC>(a, o, dt, sd_h[tid], sd_hu[tid], sd_hv[tid], sd_u[tid], sd_v[tid], acc0, acc1, acc2, dzdx, dzdy, nman, s0, s1, s2, f);
+        cell_epilogue<SRC>(a, o, dt, sd_h[tid], sd_hu[tid], sd_hv[tid], sd_u[tid], sd_v[tid], acc0, acc1, acc2, cur.dzdx, cur.dzdy, cur.nman, cur.s0,
+                           cur.s1, cur.s2, f);
       }
 
       if (idx1 >= hi) break;
       idx = idx1; tile = tile1; td = td1; tn = tn1;
       idx1 = idx2; tile1 = tile2; td1 = td2; tn1 = tn2; hid1 = hid2;
+      lr0 = nlr0; lr1 = nlr1; cs0 = ncs0; cs1 = ncs1;
+      cur = nxt;
     }
   }
   block_courant_reduce(a, best, best_slot, best_o);
