@@ -108,6 +108,7 @@ struct RDyHipOperator_s {
   int32_t n_halo = 0, n_bghost = 0;
   // tiled kernel (swe_kernels.h)
   bool             use_tiled = true;
+  bool             merge_in_kernel = false;  // Courant partials merged by the last workgroup instead of a finalize launch
   int32_t          ntiles = 0, n_halo_tiles = 0, emax = 0;
   int64_t          nrec = 0;
   int32_t          hmax = 0;
@@ -185,7 +186,7 @@ int launch_rhs(RDyHipOperator op, int32_t phase, int32_t overwrite, int reset_di
   a.diag       = op->d_courant.p;
   a.done       = op->d_done.p;
   a.reset_diag = reset_diag ? 1 : 0;
-  a.merge_in_kernel = op->use_tiled ? 1 : 0;  // the persistent kernel has few workgroups: merge their partials in the launch
+  a.merge_in_kernel = op->merge_in_kernel ? 1 : 0;
   a.tiny_h     = op->config.tiny_h;
   a.h_anuga_sq = op->config.h_anuga_regular * op->config.h_anuga_regular;
   a.xq_thresh  = op->config.xq2018_threshold;
@@ -224,7 +225,7 @@ int launch_rhs(RDyHipOperator op, int32_t phase, int32_t overwrite, int reset_di
       }
     }
     const size_t lds = op->lds_bytes;
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(tiled_kernel_fn(op->S, xq ? 1 : 0, overwrite != 0)), dim3(grid), dim3(BLOCK), lds, st, a, dt, u, f);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(tiled_kernel_fn(op->S, xq ? 1 : 0, overwrite != 0)), dim3(grid), dim3(TILE), lds, st, a, dt, u, f);
   } else {
     if (phase == RDYHIP_PHASE_HALO) {
       if (op->n_halo == 0) return 0;
@@ -248,7 +249,7 @@ int launch_rhs(RDyHipOperator op, int32_t phase, int32_t overwrite, int reset_di
     }
   }
   HIP_TRY(hipGetLastError());
-  if (!op->use_tiled) {
+  if (!op->merge_in_kernel) {
     hipLaunchKernelGGL(courant_finalize_kernel, dim3(1), dim3(1024), 0, st, grid, op->d_blk_max.p, op->d_blk_pos.p, op->d_courant.p, reset_diag);
     HIP_TRY(hipGetLastError());
   }
@@ -384,7 +385,7 @@ int rdyhip_create(const RDyHipConfig *config, const RDyHipMesh *mesh, int32_t nu
   }
 
   // ---- tiles of 256 consecutive owned cells: edge list, halo cells, boundary edges (tiled kernel) ----
-  const int32_t         ntiles = (no + BLOCK - 1) / BLOCK;
+  const int32_t         ntiles = (no + TILE - 1) / TILE;
   std::vector<TileDesc> tiles((size_t)ntiles + 1);
   std::vector<uint32_t> e_lr;
   std::vector<int32_t>  hcells, tile_bk, halo_tiles;
@@ -395,11 +396,11 @@ int rdyhip_create(const RDyHipConfig *config, const RDyHipMesh *mesh, int32_t nu
     e_lr.reserve((size_t)no * 2);
     e_cs.reserve((size_t)no * 2);
     std::vector<std::pair<int32_t, int32_t>> items;  // (loop position of the edge, owned cell * 4 + slot)
-    items.reserve(4 * BLOCK);
+    items.reserve(4 * TILE);
     std::vector<int32_t> hslot((size_t)nc, -1);      // local cell -> halo slot in the current tile
     std::vector<int32_t> touched;
     for (int32_t t = 0; t < ntiles; ++t) {
-      const int32_t base = t * BLOCK, cntc = std::min<int32_t>(BLOCK, no - base);
+      const int32_t base = t * TILE, cntc = std::min<int32_t>(TILE, no - base);
       items.clear();
       bool halo_tile = false;
       for (int32_t j = 0; j < cntc; ++j) {
@@ -429,7 +430,7 @@ int rdyhip_create(const RDyHipConfig *config, const RDyHipMesh *mesh, int32_t nu
           hcells.push_back(cell);
           touched.push_back(cell);
         }
-        return (uint32_t)(BLOCK + hslot[cell]);
+        return (uint32_t)(TILE + hslot[cell]);
       };
       int32_t last = -1, local = -1;
       for (const auto &it : items) {
@@ -464,7 +465,7 @@ int rdyhip_create(const RDyHipConfig *config, const RDyHipMesh *mesh, int32_t nu
       for (int32_t cell : touched) hslot[cell] = -1;
       emax = std::max(emax, local + 1);
       hmax = std::max(hmax, nh);
-      if ((int64_t)e_lr.size() > (int64_t)INT32_MAX - 4 * BLOCK) return fail(RDYHIP_ERR_ARG_SIZ, "too many tile edge records");
+      if ((int64_t)e_lr.size() > (int64_t)INT32_MAX - 4 * TILE) return fail(RDYHIP_ERR_ARG_SIZ, "too many tile edge records");
     }
     tiles[ntiles].e_off = (int32_t)e_lr.size();
     tiles[ntiles].h_off = (int32_t)hcells.size();
@@ -472,7 +473,7 @@ int rdyhip_create(const RDyHipConfig *config, const RDyHipMesh *mesh, int32_t nu
     tiles[ntiles].halo  = 0;
     // a tile has at most 4*256 edges, so 256 + hmax <= 1280 slots < 2^11 and <= 1024 boundary edges
   }
-  const size_t lds_bytes = sizeof(double) * (5 * ((size_t)BLOCK + hmax) + 2 * (size_t)BLOCK + 4 * (size_t)emax);
+  const size_t lds_bytes = sizeof(double) * (5 * ((size_t)TILE + hmax) + 2 * (size_t)TILE + 4 * (size_t)emax);
   if (lds_bytes > 160 * 1024) return fail(RDYHIP_ERR_USER, "tile working set (%zu B of LDS) too large: the cell numbering has no locality", lds_bytes);
 
   // ---- per-owned-cell geometry --------------------------------------------
@@ -518,6 +519,8 @@ int rdyhip_create(const RDyHipConfig *config, const RDyHipMesh *mesh, int32_t nu
   {
     const char *kenv = getenv("RDYHIP_KERNEL");
     op->use_tiled    = !(kenv && strcmp(kenv, "cell") == 0);
+    const char *menv = getenv("RDYHIP_MERGE_IN_KERNEL");
+    op->merge_in_kernel = op->use_tiled && menv && atoi(menv) != 0;
   }
   int rc         = 0;
   if (hipGetDevice(&op->device) != hipSuccess) {
@@ -537,12 +540,12 @@ int rdyhip_create(const RDyHipConfig *config, const RDyHipMesh *mesh, int32_t nu
     if (hipGetDeviceProperties(&prop, op->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
     int q = 0;
     const void *kfn = (const void *)tiled_kernel_fn(S, config->source_method == RDYHIP_SOURCE_IMPLICIT_XQ2018 ? 1 : 0, true);
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, kfn, BLOCK, lds_bytes) == hipSuccess && q > 0) per_cu = q;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, kfn, TILE, lds_bytes) == hipSuccess && q > 0) per_cu = q;
     if (const char *e2 = getenv("RDYHIP_BLOCKS_PER_CU")) {
       if (atoi(e2) > 0) per_cu = atoi(e2);
     }
     op->pgrid            = std::max(8, cus * per_cu);
-    op->tiled_xcd_chunks = (swz && tiles_n >= 64) ? (tiles_n + 7) / 8 : 0;
+    op->tiled_xcd_chunks = (swz && ntiles >= 64) ? (ntiles + 7) / 8 : 0;
   }
   const int maxgrid = std::max(std::max(op->grid, op->pgrid), 1);
 

@@ -30,7 +30,11 @@
 
 namespace rdyhip {
 
-constexpr int BLOCK = 256;
+constexpr int BLOCK = 256;  // threads per workgroup of the cell-centric kernel
+#ifndef RDYHIP_TILE
+#define RDYHIP_TILE 256
+#endif
+constexpr int TILE = RDYHIP_TILE;  // cells per tile = threads per workgroup of the tiled kernel (a multiple of 64)
 
 constexpr uint16_t SLOT_EMPTY = 0xFFFF;
 
@@ -129,16 +133,17 @@ __device__ __forceinline__ void cell_epilogue(const KernelArgs &a, int o, double
 // Block reduction of the Courant number: max value, then the smallest loop
 // position among the lanes that hold it (the reference keeps the first edge
 // that reaches the max, swe_petsc.c:291).  Writes the block's partial.
+template <int NT>
 __device__ __forceinline__ void block_courant_reduce(const KernelArgs &a, double best, int best_slot, int o) {
-  __shared__ double s_max[BLOCK / 64];
-  __shared__ int    s_pos[BLOCK / 64];
+  __shared__ double s_max[NT / 64];
+  __shared__ int    s_pos[NT / 64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   double    wmax = wave_max(best);
   if (lane == 0) s_max[wave] = wmax;
   __syncthreads();
   double bmax = s_max[0];
 #pragma unroll
-  for (int w = 1; w < BLOCK / 64; ++w) bmax = fmax(bmax, s_max[w]);
+  for (int w = 1; w < NT / 64; ++w) bmax = fmax(bmax, s_max[w]);
   int p = INT32_MAX;
   if (best_slot >= 0 && best == bmax) p = a.pos[best_slot * a.stride + o];
   p = wave_min(p);
@@ -148,7 +153,7 @@ __device__ __forceinline__ void block_courant_reduce(const KernelArgs &a, double
   if (threadIdx.x == 0) {
     bp = s_pos[0];
 #pragma unroll
-    for (int w = 1; w < BLOCK / 64; ++w) bp = min(bp, s_pos[w]);
+    for (int w = 1; w < NT / 64; ++w) bp = min(bp, s_pos[w]);
     a.blk_max[blockIdx.x] = bmax;
     a.blk_pos[blockIdx.x] = (bmax > 0.0) ? bp : -1;
   }
@@ -170,7 +175,7 @@ __device__ __forceinline__ void block_courant_reduce(const KernelArgs &a, double
   if (!s_last) return;
   double m = 0.0;
   int    q = INT32_MAX;
-  for (int i = threadIdx.x; i < (int)gridDim.x; i += BLOCK) {
+  for (int i = threadIdx.x; i < (int)gridDim.x; i += NT) {
     const double v = __hip_atomic_load(a.blk_max + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int    r = __hip_atomic_load(a.blk_pos + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (v > m || (v == m && v > 0.0 && r < q)) {
@@ -190,7 +195,7 @@ __device__ __forceinline__ void block_courant_reduce(const KernelArgs &a, double
   if (threadIdx.x == 0) {
     double bm = 0.0;
     int    bq = INT32_MAX;
-    for (int w = 0; w < BLOCK / 64; ++w) {
+    for (int w = 0; w < NT / 64; ++w) {
       if (s_max[w] > bm || (s_max[w] == bm && bm > 0.0 && s_pos[w] < bq)) {
         bm = s_max[w];
         bq = s_pos[w];
@@ -293,13 +298,13 @@ __device__ __forceinline__ void load_streams(const KernelArgs &a, int o, bool ac
 // waits for a dependent chain of global loads, and every load has about one
 // tile time to complete, which is what keeps HBM busy at 3 workgroups per CU.
 template <int S, int SRC, bool OVW>
-__global__ __launch_bounds__(BLOCK) void swe_rhs_tiled_kernel(const KernelArgs a, const double dt, const double *__restrict__ u,
+__global__ __launch_bounds__(TILE) void swe_rhs_tiled_kernel(const KernelArgs a, const double dt, const double *__restrict__ u,
                                                               double *__restrict__ f) {
   extern __shared__ double lds[];
-  const int nside = BLOCK + a.hmax;
+  const int nside = TILE + a.hmax;
   double   *sd_h = lds, *sd_u = lds + nside, *sd_v = lds + 2 * nside, *sd_sq = lds + 3 * nside, *sd_c = lds + 4 * nside;
-  double   *sd_hu = lds + 5 * nside, *sd_hv = sd_hu + BLOCK;
-  double   *ef0 = sd_hv + BLOCK, *ef1 = ef0 + a.emax, *ef2 = ef1 + a.emax, *eam = ef2 + a.emax;
+  double   *sd_hu = lds + 5 * nside, *sd_hv = sd_hu + TILE;
+  double   *ef0 = sd_hv + TILE, *ef1 = ef0 + a.emax, *ef2 = ef1 + a.emax, *eam = ef2 + a.emax;
   const int tid = threadIdx.x;
 
   // ---- this workgroup's tile sequence.  Block ids are dealt round-robin to the
@@ -339,7 +344,7 @@ __global__ __launch_bounds__(BLOCK) void swe_rhs_tiled_kernel(const KernelArgs a
     double   cs0 = 0.0, cs1 = 0.0;
     CellStreams<S> cur;
     {
-      const int o = tile * BLOCK + tid;
+      const int o = tile * TILE + tid;
       if (o < a.n_owned) {
         const int c = a.o2l ? a.o2l[o] : o;
         pu0 = u[3 * (int64_t)c + 0]; pu1 = u[3 * (int64_t)c + 1]; pu2 = u[3 * (int64_t)c + 2];
@@ -350,7 +355,7 @@ __global__ __launch_bounds__(BLOCK) void swe_rhs_tiled_kernel(const KernelArgs a
       }
       const int ne = tn.e_off - td.e_off;
       if (tid < ne) { lr0 = a.e_lr[td.e_off + tid]; cs0 = a.e_cs[td.e_off + tid]; }
-      if (tid + BLOCK < ne) { lr1 = a.e_lr[td.e_off + BLOCK + tid]; cs1 = a.e_cs[td.e_off + BLOCK + tid]; }
+      if (tid + TILE < ne) { lr1 = a.e_lr[td.e_off + TILE + tid]; cs1 = a.e_cs[td.e_off + TILE + tid]; }
       load_streams<S>(a, o, o < a.n_owned, cur);
     }
     int      idx1 = next_valid(idx + step);
@@ -365,12 +370,12 @@ __global__ __launch_bounds__(BLOCK) void swe_rhs_tiled_kernel(const KernelArgs a
 
     while (true) {
       const int  ne = tn.e_off - td.e_off, nh = tn.h_off - td.h_off;
-      const int  o      = tile * BLOCK + tid;
+      const int  o      = tile * TILE + tid;
       const bool active = o < a.n_owned;
 
       // ---- software pipeline (1): the next tile's per-cell streams, a full tile ahead
       CellStreams<S> nxt;
-      load_streams<S>(a, tile1 * BLOCK + tid, idx1 < hi && tile1 * BLOCK + tid < a.n_owned, nxt);
+      load_streams<S>(a, tile1 * TILE + tid, idx1 < hi && tile1 * TILE + tid < a.n_owned, nxt);
 
       // ---- phase 0: Riemann side data of the tile's own and halo cells -> LDS
       {
@@ -382,12 +387,12 @@ __global__ __launch_bounds__(BLOCK) void swe_rhs_tiled_kernel(const KernelArgs a
         sd_hv[tid] = pu2;
         if (tid < nh) {
           const RiemannSide hs = riemann_side(ph0, ph1, ph2, a.tiny_h, a.h_anuga_sq);
-          sd_h[BLOCK + tid] = hs.h; sd_u[BLOCK + tid] = hs.u; sd_v[BLOCK + tid] = hs.v; sd_sq[BLOCK + tid] = hs.sqh; sd_c[BLOCK + tid] = hs.c;
+          sd_h[TILE + tid] = hs.h; sd_u[TILE + tid] = hs.u; sd_v[TILE + tid] = hs.v; sd_sq[TILE + tid] = hs.sqh; sd_c[TILE + tid] = hs.c;
         }
-        for (int j = tid + BLOCK; j < nh; j += BLOCK) {  // only numberings with poor locality get here
+        for (int j = tid + TILE; j < nh; j += TILE) {  // only numberings with poor locality get here
           const int         hc = a.hcells[td.h_off + j];
           const RiemannSide hs = riemann_side(u[3 * (int64_t)hc + 0], u[3 * (int64_t)hc + 1], u[3 * (int64_t)hc + 2], a.tiny_h, a.h_anuga_sq);
-          sd_h[BLOCK + j] = hs.h; sd_u[BLOCK + j] = hs.u; sd_v[BLOCK + j] = hs.v; sd_sq[BLOCK + j] = hs.sqh; sd_c[BLOCK + j] = hs.c;
+          sd_h[TILE + j] = hs.h; sd_u[TILE + j] = hs.u; sd_v[TILE + j] = hs.v; sd_sq[TILE + j] = hs.sqh; sd_c[TILE + j] = hs.c;
         }
       }
       __syncthreads();
@@ -398,7 +403,7 @@ __global__ __launch_bounds__(BLOCK) void swe_rhs_tiled_kernel(const KernelArgs a
       uint32_t nlr0 = 0, nlr1 = 0;
       double   ncs0 = 0.0, ncs1 = 0.0;
       if (idx1 < hi) {
-        const int o1 = tile1 * BLOCK + tid;
+        const int o1 = tile1 * TILE + tid;
         if (o1 < a.n_owned) {
           const int c1 = a.o2l ? a.o2l[o1] : o1;
           pu0 = u[3 * (int64_t)c1 + 0]; pu1 = u[3 * (int64_t)c1 + 1]; pu2 = u[3 * (int64_t)c1 + 2];
@@ -406,7 +411,7 @@ __global__ __launch_bounds__(BLOCK) void swe_rhs_tiled_kernel(const KernelArgs a
         if (tid < tn1.h_off - td1.h_off) { ph0 = u[3 * (int64_t)hid1 + 0]; ph1 = u[3 * (int64_t)hid1 + 1]; ph2 = u[3 * (int64_t)hid1 + 2]; }
         const int ne1 = tn1.e_off - td1.e_off;
         if (tid < ne1) { nlr0 = a.e_lr[td1.e_off + tid]; ncs0 = a.e_cs[td1.e_off + tid]; }
-        if (tid + BLOCK < ne1) { nlr1 = a.e_lr[td1.e_off + BLOCK + tid]; ncs1 = a.e_cs[td1.e_off + BLOCK + tid]; }
+        if (tid + TILE < ne1) { nlr1 = a.e_lr[td1.e_off + TILE + tid]; ncs1 = a.e_cs[td1.e_off + TILE + tid]; }
         idx2 = next_valid(idx1 + step);
         if (idx2 < hi) {
           tile2 = tile_at(idx2);
@@ -418,8 +423,8 @@ __global__ __launch_bounds__(BLOCK) void swe_rhs_tiled_kernel(const KernelArgs a
 
       // ---- phase 1: every edge of the tile once, operands from LDS only
       // (ApplyInteriorFlux / ApplyBoundaryFlux, swe_petsc.c:215-316, 506-630)
-      for (int e = tid; e < ne; e += BLOCK) {
-        const int      round = e / BLOCK;  // wave-uniform
+      for (int e = tid; e < ne; e += TILE) {
+        const int      round = e / TILE;  // wave-uniform
         const uint32_t lr    = round == 0 ? lr0 : (round == 1 ? lr1 : a.e_lr[td.e_off + e]);
         const double   cs    = round == 0 ? cs0 : (round == 1 ? cs1 : a.e_cs[td.e_off + e]);
         double         cn, sn;
@@ -494,7 +499,7 @@ __global__ __launch_bounds__(BLOCK) void swe_rhs_tiled_kernel(const KernelArgs a
       cur = nxt;
     }
   }
-  block_courant_reduce(a, best, best_slot, best_o);
+  block_courant_reduce<TILE>(a, best, best_slot, best_o);
 }
 
 // ---------------------------------------------------------------------------
@@ -582,7 +587,7 @@ __global__ __launch_bounds__(BLOCK) void swe_rhs_kernel(const KernelArgs a, cons
     cell_epilogue<SRC>(a, o, dt, h, hu, hv, self.u, self.v, acc0, acc1, acc2, a.dzdx[o], a.dzdy[o], a.mannings[o], a.extsrc[3 * (int64_t)o + 0],
                        a.extsrc[3 * (int64_t)o + 1], a.extsrc[3 * (int64_t)o + 2], f);
   }
-  block_courant_reduce(a, best, best_slot, o);
+  block_courant_reduce<BLOCK>(a, best, best_slot, o);
 }
 
 // merges the per-block partials into the persistent diagnostic (reset != 0:
