@@ -104,11 +104,9 @@ struct RDyHipOperator_s {
   DevBuf<double>  d_bvalues, d_bflux, d_baccum, d_bcn, d_bsn, d_pv, d_fdiv, d_blk_max;
   DevBuf<int32_t> d_blk_pos;
   DevBuf<DeviceCourant> d_courant;
-  DevBuf<unsigned int>  d_done;
   int32_t n_halo = 0, n_bghost = 0;
   // tiled kernel (swe_kernels.h)
   bool             use_tiled = true;
-  bool             merge_in_kernel = false;  // Courant partials merged by the last workgroup instead of a finalize launch
   int32_t          ntiles = 0, n_halo_tiles = 0, emax = 0;
   int64_t          nrec = 0;
   int32_t          hmax = 0;
@@ -137,7 +135,7 @@ struct RDyHipOperator_s {
     d_bghost_list.release(); d_cn.release(); d_sn.release(); d_coef.release(); d_dzdx.release(); d_dzdy.release();
     d_mannings.release(); d_extsrc.release(); d_area_local.release(); d_bvalues.release(); d_bflux.release();
     d_baccum.release(); d_bcn.release(); d_bsn.release(); d_pv.release(); d_fdiv.release(); d_blk_max.release();
-    d_blk_pos.release(); d_courant.release(); d_done.release(); d_stage_vals.release(); d_stage_ids.release();
+    d_blk_pos.release(); d_courant.release(); d_stage_vals.release(); d_stage_ids.release();
     d_tiles.release(); d_e_lr.release(); d_hcells.release(); d_tile_bk.release(); d_halo_tiles.release();
     d_e_cs.release(); d_slot_ref.release(); d_slot_ref3.release();
   }
@@ -183,10 +181,6 @@ int launch_rhs(RDyHipOperator op, int32_t phase, int32_t overwrite, int reset_di
   a.fdiv       = op->keep_fdiv ? op->d_fdiv.p : nullptr;
   a.blk_max    = op->d_blk_max.p;
   a.blk_pos    = op->d_blk_pos.p;
-  a.diag       = op->d_courant.p;
-  a.done       = op->d_done.p;
-  a.reset_diag = reset_diag ? 1 : 0;
-  a.merge_in_kernel = op->merge_in_kernel ? 1 : 0;
   a.tiny_h     = op->config.tiny_h;
   a.h_anuga_sq = op->config.h_anuga_regular * op->config.h_anuga_regular;
   a.xq_thresh  = op->config.xq2018_threshold;
@@ -249,10 +243,8 @@ int launch_rhs(RDyHipOperator op, int32_t phase, int32_t overwrite, int reset_di
     }
   }
   HIP_TRY(hipGetLastError());
-  if (!op->merge_in_kernel) {
-    hipLaunchKernelGGL(courant_finalize_kernel, dim3(1), dim3(1024), 0, st, grid, op->d_blk_max.p, op->d_blk_pos.p, op->d_courant.p, reset_diag);
-    HIP_TRY(hipGetLastError());
-  }
+  hipLaunchKernelGGL(courant_finalize_kernel, dim3(1), dim3(1024), 0, st, grid, op->d_blk_max.p, op->d_blk_pos.p, op->d_courant.p, reset_diag);
+  HIP_TRY(hipGetLastError());
   // boundary edges hanging off ghost cells (diagnostic vectors only); once per full apply
   if (op->n_bghost > 0 && phase != RDYHIP_PHASE_INTERIOR) {
     hipLaunchKernelGGL(boundary_ghost_kernel, dim3((op->n_bghost + 63) / 64), dim3(64), 0, st, op->n_bghost, op->d_bghost_list.p, op->d_bleft.p,
@@ -519,8 +511,6 @@ int rdyhip_create(const RDyHipConfig *config, const RDyHipMesh *mesh, int32_t nu
   {
     const char *kenv = getenv("RDYHIP_KERNEL");
     op->use_tiled    = !(kenv && strcmp(kenv, "cell") == 0);
-    const char *menv = getenv("RDYHIP_MERGE_IN_KERNEL");
-    op->merge_in_kernel = op->use_tiled && menv && atoi(menv) != 0;
   }
   int rc         = 0;
   if (hipGetDevice(&op->device) != hipSuccess) {
@@ -605,7 +595,6 @@ int rdyhip_create(const RDyHipConfig *config, const RDyHipMesh *mesh, int32_t nu
   TRY_RC(op->d_blk_max.zeros((size_t)maxgrid));
   TRY_RC(op->d_blk_pos.zeros((size_t)maxgrid));
   TRY_RC(op->d_courant.zeros(1));
-  TRY_RC(op->d_done.zeros(1));
 #undef TRY_RC
   hipLaunchKernelGGL(courant_reset_kernel, dim3(1), dim3(1), 0, 0, op->d_courant.p);
   if (hipDeviceSynchronize() != hipSuccess) {

@@ -18,6 +18,25 @@ constexpr int32_t NBR_EMPTY = INT32_MIN;    // unused slot (triangle in a 4-slot
 constexpr int32_t NBR_GHOST = 1 << 30;      // neighbour is a ghost (non-owned) cell
 constexpr int32_t NBR_MASK  = (1 << 30) - 1;
 
+// Reciprocal by v_rcp_f64 + two Newton steps (the same refinement the IEEE
+// division expansion performs, without its scaling / fix-up wrapper): <= 1 ulp
+// for normal operands; a zero or non-finite operand yields a non-finite
+// result, as the division would (0 -> the IEEE 1/0 = inf becomes NaN, which
+// only occurs on dry-dry edges whose flux is discarded or reported as NaN by
+// the reference too).  -DRDYHIP_IEEE_DIV restores plain divisions.
+__device__ __forceinline__ double rdy_rcp(double x) {
+#ifdef RDYHIP_IEEE_DIV
+  return 1.0 / x;
+#else
+  double r = __builtin_amdgcn_rcp(x);
+  double e = fma(-x, r, 1.0);
+  r        = fma(r, e, r);
+  e        = fma(-x, r, 1.0);
+  r        = fma(r, e, r);
+  return r;
+#endif
+}
+
 struct RoeFlux {
   double f0, f1, f2, amax;
 };
@@ -40,7 +59,7 @@ __device__ __forceinline__ RiemannSide riemann_side(double h, double hu, double 
     s.v = 0.0;
   } else {
     // hu*h/denom and hv*h/denom share one division: r = h/denom
-    const double r = h / (h * h + h_anuga_sq);
+    const double r = h * rdy_rcp(h * h + h_anuga_sq);
     s.u            = hu * r;
     s.v            = hv * r;
   }
@@ -59,7 +78,7 @@ __device__ __forceinline__ void riemann_velocity(double h, double hu, double hv,
     u = 0.0;
     v = 0.0;
   } else {
-    const double r = h / (h * h + h_anuga_sq);
+    const double r = h * rdy_rcp(h * h + h_anuga_sq);
     u              = hu * r;
     v              = hv * r;
   }
@@ -77,7 +96,7 @@ __device__ __forceinline__ RoeFlux roe_flux(const RiemannSide &L, const RiemannS
   const double hl = L.h, ul = L.u, vl = L.v, hr = R.h, ur = R.u, vr = R.v;
   const double duml = L.sqh, dumr = R.sqh, cl = L.c, cr = R.c;
   const double hhat    = duml * dumr;
-  const double inv_sum = 1.0 / (duml + dumr);
+  const double inv_sum = rdy_rcp(duml + dumr);
   const double uhat    = (duml * ul + dumr * ur) * inv_sum;
   const double vhat    = (duml * vl + dumr * vr) * inv_sum;
   const double chat    = sqrt(0.5 * GRAVITY * (hl + hr));
@@ -104,7 +123,7 @@ __device__ __forceinline__ RoeFlux roe_flux(const RiemannSide &L, const RiemannS
   const double da3 = fmax(0.0, 2.0 * ((uperpr + cr) - (uperpl + cl)));
   if (a3 < da3) a3 = 0.5 * (a3 * a3 / da3 + da3);
 
-  const double t   = hhat * duperp / chat;
+  const double t   = hhat * duperp * rdy_rcp(chat);
   const double dw0 = 0.5 * (dh - t);
   const double dw1 = hhat * dupar;
   const double dw2 = 0.5 * (dh + t);
@@ -180,13 +199,13 @@ __device__ __forceinline__ BoundaryFlux boundary_flux(int type, bool left_owned,
 // Friction term of ApplySourceSemiImplicit, src/swe/swe_petsc.c:764-780
 __device__ __forceinline__ void friction_semi_implicit(double h, double hu, double hv, double n, double dt, double fsum_x, double fsum_y, double bedx,
                                                        double bedy, double &tbx, double &tby) {
-  const double inv_h  = 1.0 / h;
+  const double inv_h  = rdy_rcp(h);
   const double u      = hu * inv_h;
   const double v      = hv * inv_h;
   const double Cd     = GRAVITY * (n * n) * rcbrt(h);  // g n^2 h^(-1/3)
   const double vel    = sqrt(u * u + v * v);
   const double tb     = Cd * vel * inv_h;
-  const double factor = tb / (1.0 + dt * tb);
+  const double factor = tb * rdy_rcp(1.0 + dt * tb);
   tbx                 = (hu + dt * fsum_x - dt * bedx) * factor;
   tby                 = (hv + dt * fsum_y - dt * bedy) * factor;
 }
@@ -199,7 +218,7 @@ __device__ __forceinline__ void friction_xq2018(double h, double hu, double hv, 
   const double mx     = hu + Ax * dt;
   const double my     = hv + Ay * dt;
   const double rcb    = rcbrt(h);                // h^(-1/3)
-  const double inv_h  = 1.0 / h;
+  const double inv_h  = rdy_rcp(h);
   const double gn2    = GRAVITY * (n * n);
   const double mxh    = mx * inv_h;
   const double myh    = my * inv_h;
@@ -210,7 +229,7 @@ __device__ __forceinline__ void friction_xq2018(double h, double hu, double hv, 
     qy = my;
   } else {
     const double root = sqrt(1.0 + 4.0 * dt * lambda);
-    const double inv  = 1.0 / (-2.0 * dt * lambda);
+    const double inv  = rdy_rcp(-2.0 * dt * lambda);
     qx                = (mx - mx * root) * inv;
     qy                = (my - my * root) * inv;
   }

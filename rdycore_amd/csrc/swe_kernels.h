@@ -70,10 +70,6 @@ struct KernelArgs {
   double        *fdiv;       // [n_owned][3] or nullptr
   double        *blk_max;    // [grid]
   int32_t       *blk_pos;    // [grid]
-  struct DeviceCourant *diag; // persistent diagnostic
-  unsigned int  *done;       // workgroups that have published their partial (tiled kernel's in-launch merge)
-  int32_t        merge_in_kernel;  // 1: the last workgroup merges the partials into diag (no finalize launch)
-  int32_t        reset_diag;       // 1: diag is reset before the merge (ResetOperatorDiagnostics)
   double         tiny_h, h_anuga_sq, xq_thresh;
   int32_t        phase;      // RDYHIP_PHASE_*
   int32_t        overwrite;  // 1: f = rhs, 0: f += rhs
@@ -149,67 +145,12 @@ __device__ __forceinline__ void block_courant_reduce(const KernelArgs &a, double
   p = wave_min(p);
   if (lane == 0) s_pos[wave] = p;
   __syncthreads();
-  int bp = INT32_MAX;
   if (threadIdx.x == 0) {
-    bp = s_pos[0];
+    int bp = s_pos[0];
 #pragma unroll
     for (int w = 1; w < NT / 64; ++w) bp = min(bp, s_pos[w]);
     a.blk_max[blockIdx.x] = bmax;
     a.blk_pos[blockIdx.x] = (bmax > 0.0) ? bp : -1;
-  }
-  if (!a.merge_in_kernel) return;
-
-  // ---- in-launch merge: the workgroup that publishes last folds every partial
-  // into the persistent diagnostic.  Placement-independent hand-off: partials
-  // are published with an agent-scope release before the counter add, the
-  // last arriver acquires before reading them with L1-bypassing loads.
-  __shared__ int s_last;
-  if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const unsigned prev = __hip_atomic_fetch_add(a.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_last              = (prev == gridDim.x - 1) ? 1 : 0;
-    if (s_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  }
-  __syncthreads();
-  if (!s_last) return;
-  double m = 0.0;
-  int    q = INT32_MAX;
-  for (int i = threadIdx.x; i < (int)gridDim.x; i += NT) {
-    const double v = __hip_atomic_load(a.blk_max + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int    r = __hip_atomic_load(a.blk_pos + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (v > m || (v == m && v > 0.0 && r < q)) {
-      m = v;
-      q = r;
-    }
-  }
-  const double wm = wave_max(m);
-  int          wq = (m == wm && m > 0.0) ? q : INT32_MAX;
-  wq              = wave_min(wq);
-  __syncthreads();  // s_max / s_pos are reused
-  if (lane == 0) {
-    s_max[wave] = wm;
-    s_pos[wave] = wq;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double bm = 0.0;
-    int    bq = INT32_MAX;
-    for (int w = 0; w < NT / 64; ++w) {
-      if (s_max[w] > bm || (s_max[w] == bm && bm > 0.0 && s_pos[w] < bq)) {
-        bm = s_max[w];
-        bq = s_pos[w];
-      }
-    }
-    double cur_max = a.reset_diag ? 0.0 : a.diag->max_courant;
-    int    cur_pos = a.reset_diag ? -1 : a.diag->pos;
-    if (bm > cur_max || (bm == cur_max && bm > 0.0 && bq < cur_pos)) {
-      cur_max = bm;
-      cur_pos = bq;
-    }
-    a.diag->max_courant = cur_max;
-    a.diag->pos         = cur_pos;
-    __hip_atomic_store(a.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch on this stream
   }
 }
 
