@@ -210,12 +210,15 @@ int launch_rhs(RDyHipOperator op, int32_t phase, int32_t overwrite, int reset_di
     } else {
       a.list   = nullptr;
       a.n_work = op->ntiles;
+      // While the interior phase runs, the halo exchange's pack / RCCL / unpack kernels need somewhere
+      // to run: the persistent grid would otherwise fill every SIMD's register file for the whole launch.
+      const int pg = (phase == RDYHIP_PHASE_INTERIOR) ? std::max(8, op->pgrid - op->pgrid / 32) : op->pgrid;
       if (op->tiled_xcd_chunks > 0) {
         a.xcd_chunks = op->tiled_xcd_chunks;
-        grid         = std::min(op->pgrid & ~7, op->tiled_xcd_chunks * 8);
+        grid         = std::min(pg & ~7, op->tiled_xcd_chunks * 8);
       } else {
         a.xcd_chunks = 0;
-        grid         = std::min(op->pgrid, op->ntiles);
+        grid         = std::min(pg, op->ntiles);
       }
     }
     const size_t lds = op->lds_bytes;

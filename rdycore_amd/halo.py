@@ -38,7 +38,7 @@ class HaloExchange:
         self.send_buf: Dict[int, torch.Tensor] = {}
         self.recv_buf: Dict[int, torch.Tensor] = {}
         self._setup()
-        self.comm_stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
+        self.comm_stream = torch.cuda.Stream(device=self.device, priority=-1) if self.device.type == "cuda" else None
 
     # -- pattern discovery (setup only) -----------------------------------
     def _setup(self):

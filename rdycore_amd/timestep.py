@@ -1,0 +1,75 @@
+"""Device-resident explicit time stepping around the RHS operator (SURVEY.md
+section 8.f row 1): what PETSc's TSEULER and RDyAdvance do between RHS
+evaluations, with the state kept on the GPU.
+
+  * forward Euler: F = RHS(t, U); U += dt F   (TSStep_Euler's VecAXPY; the RHS is
+    OperatorRHSFunction, src/rdysetup.c:1120-1172)
+  * RDyAdvance (src/rdyadvance.c:261-383): advance to the next coupling time
+    with the last step shortened to land on it (TS_EXACTFINALTIME_MATCHSTEP),
+    and, when adaptive time stepping is on, rescale dt from the previous
+    interval's maximum Courant number (303-343).
+"""
+from __future__ import annotations
+
+import dataclasses
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+
+@dataclasses.dataclass
+class AdaptiveTime:
+    """RDyTimeAdaptiveSection (include/private/rdyconfigimpl.h): enable,
+    target_courant_number, max_increase_factor."""
+    target_courant_number: float = 0.5
+    max_increase_factor: float = 2.0
+
+
+class EulerStepper:
+    def __init__(self, op, halo=None, adaptive: Optional[AdaptiveTime] = None):
+        self.op = op
+        self.halo = halo
+        self.adaptive = adaptive
+        self.time = 0.0
+        self.step = 0
+        self.max_courant = None      # diagnostics of the last interval, all ranks (None = not updated yet)
+        self._f = None
+
+    def rhs(self, dt, u_local, f_global):
+        if self.halo is not None and self.halo.world > 1:
+            self.halo.rhs_overlapped(self.op, dt, u_local, f_global)
+        else:
+            self.op.rhs_function(dt, u_local, f_global)
+
+    def advance(self, u_local: torch.Tensor, dt: float, interval: float) -> float:
+        """RDyAdvance: integrate from self.time to self.time + interval; returns
+        the dt to use next (changed only by adaptive stepping)."""
+        if self._f is None or self._f.shape[0] != self.op.mesh.num_owned_cells:
+            self._f = torch.empty((self.op.mesh.num_owned_cells, 3), dtype=torch.float64, device=u_local.device)
+        a = self.adaptive
+        if a is not None and self.max_courant is not None and self.max_courant > 0.0:
+            # src/rdyadvance.c:311-332
+            if self.max_courant < a.target_courant_number:
+                dt *= min(a.target_courant_number / self.max_courant, a.max_increase_factor)
+                dt = min(dt, interval)
+            else:
+                dt *= a.target_courant_number / self.max_courant
+        t_end = self.time + interval
+        self.op.reset_diagnostics()
+        while self.time < t_end * (1.0 - 1e-14):
+            h = min(dt, t_end - self.time)       # TS_EXACTFINALTIME_MATCHSTEP
+            self.rhs(h, u_local, self._f)
+            self.op.axpy_owned(h, self._f, u_local)
+            self.time += h
+            self.step += 1
+        if a is not None:
+            # UpdateOperatorDiagnostics: local 16-byte copy + the MPI_Allreduce(max) of src/operator.c:879
+            self.op.update_diagnostics()
+            c = self.op.get_diagnostics().max_courant_num
+            if dist.is_initialized() and dist.get_world_size() > 1:
+                t = torch.tensor([c], dtype=torch.float64, device=u_local.device if dist.get_backend() == "nccl" else "cpu")
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                c = float(t.item())
+            self.max_courant = c
+        return dt

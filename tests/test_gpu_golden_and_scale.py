@@ -159,3 +159,39 @@ def test_full_size_properties(nx, ny):
     op1.apply_phase(2, True, c1.dt, u, f)
     torch.cuda.synchronize()
     assert np.array_equal(f.cpu().numpy(), f1)
+
+
+def test_adaptive_euler_advance_matches_oracle_loop():
+    """RDyAdvance with adaptive dt (src/rdyadvance.c:303-343) on ex2b: the
+    device-resident stepper against the same rules driven by the oracle."""
+    torch = _torch()
+    from rdycore_amd.timestep import AdaptiveTime, EulerStepper
+    case = CS.ex2b_case(os.path.join(ROOT, "tests", "golden", "planar_dam_10x5.msh"))
+    op = CS.create_operator(case)
+    orc = oracle_from_case(case)
+    ad = AdaptiveTime(target_courant_number=0.4, max_increase_factor=1.5)
+    st = EulerStepper(op, adaptive=ad)
+    u = torch.tensor(case.u_local, dtype=torch.float64, device="cuda")
+    uc = case.u_local.copy()
+    dt_g = dt_c = 0.002
+    interval, t_c, cmax = 0.2, 0.0, None
+    for _ in range(12):
+        dt_g = st.advance(u, dt_g, interval)
+        # the same on the CPU
+        if cmax is not None and cmax > 0:
+            if cmax < ad.target_courant_number:
+                dt_c = min(dt_c * min(ad.target_courant_number / cmax, ad.max_increase_factor), interval)
+            else:
+                dt_c *= ad.target_courant_number / cmax
+        t_end = t_c + interval
+        while t_c < t_end * (1.0 - 1e-14):
+            h = min(dt_c, t_end - t_c)
+            orc.reset_diagnostics()
+            uc = uc + h * orc.apply(h, uc)
+            t_c += h
+        cmax = orc.diagnostics()[0]
+        assert abs(dt_g - dt_c) <= 1e-12 * dt_c
+        assert abs(st.max_courant - cmax) <= 1e-10
+    torch.cuda.synchronize()
+    assert st.step > 100 and abs(st.time - 12 * interval) < 1e-9
+    assert rel_linf(u.cpu().numpy(), uc) <= 1e-9
