@@ -37,6 +37,26 @@ __device__ __forceinline__ double rdy_rcp(double x) {
 #endif
 }
 
+// Square root by v_rsq_f64 + one Goldschmidt step + one residual correction
+// (the IEEE expansion minus its denormal-range scaling and its second
+// correction): <= 1 ulp for normal operands, exact for 0 and +inf, NaN for
+// negative operands.  -DRDYHIP_IEEE_SQRT restores plain sqrt().
+__device__ __forceinline__ double rdy_sqrt(double x) {
+#ifdef RDYHIP_IEEE_SQRT
+  return sqrt(x);
+#else
+  const double y = __builtin_amdgcn_rsq(x);
+  double       g = x * y;
+  double       h = 0.5 * y;
+  const double r = fma(-h, g, 0.5);
+  g              = fma(g, r, g);
+  h              = fma(h, r, h);
+  const double d = fma(-g, g, x);
+  g              = fma(d, h, g);
+  return (x == 0.0 || x == __builtin_inf()) ? x : g;
+#endif
+}
+
 struct RoeFlux {
   double f0, f1, f2, amax;
 };
@@ -66,8 +86,8 @@ __device__ __forceinline__ RiemannSide riemann_side(double h, double hu, double 
 #ifdef RDYHIP_STUB_FLUX
   s.sqh = h; s.c = h;
 #else
-  s.sqh = sqrt(h);
-  s.c   = sqrt(GRAVITY * h);
+  s.sqh = rdy_sqrt(h);
+  s.c   = rdy_sqrt(GRAVITY * h);
 #endif
   return s;
 }
@@ -99,7 +119,7 @@ __device__ __forceinline__ RoeFlux roe_flux(const RiemannSide &L, const RiemannS
   const double inv_sum = rdy_rcp(duml + dumr);
   const double uhat    = (duml * ul + dumr * ur) * inv_sum;
   const double vhat    = (duml * vl + dumr * vr) * inv_sum;
-  const double chat    = sqrt(0.5 * GRAVITY * (hl + hr));
+  const double chat    = rdy_sqrt(0.5 * GRAVITY * (hl + hr));
   const double uperp   = uhat * cn + vhat * sn;
 
   const double dh     = hr - hl;
@@ -183,8 +203,8 @@ __device__ __forceinline__ BoundaryFlux boundary_flux(int type, bool left_owned,
       } else {
         const double q = L.h * fabs(uperp);
         R.h            = cbrt(q * q / GRAVITY);
-        R.sqh          = sqrt(R.h);
-        R.c            = sqrt(GRAVITY * R.h);
+        R.sqh          = rdy_sqrt(R.h);
+        R.c            = rdy_sqrt(GRAVITY * R.h);
         R.u            = R.c * cn;
         R.v            = R.c * sn;
       }
@@ -203,7 +223,7 @@ __device__ __forceinline__ void friction_semi_implicit(double h, double hu, doub
   const double u      = hu * inv_h;
   const double v      = hv * inv_h;
   const double Cd     = GRAVITY * (n * n) * rcbrt(h);  // g n^2 h^(-1/3)
-  const double vel    = sqrt(u * u + v * v);
+  const double vel    = rdy_sqrt(u * u + v * v);
   const double tb     = Cd * vel * inv_h;
   const double factor = tb * rdy_rcp(1.0 + dt * tb);
   tbx                 = (hu + dt * fsum_x - dt * bedx) * factor;
@@ -222,18 +242,18 @@ __device__ __forceinline__ void friction_xq2018(double h, double hu, double hv, 
   const double gn2    = GRAVITY * (n * n);
   const double mxh    = mx * inv_h;
   const double myh    = my * inv_h;
-  const double lambda = gn2 * (inv_h * rcb) * sqrt(mxh * mxh + myh * myh);  // h^(-4/3)
+  const double lambda = gn2 * (inv_h * rcb) * rdy_sqrt(mxh * mxh + myh * myh);  // h^(-4/3)
   double       qx, qy;
   if (dt * lambda < thresh) {
     qx = mx;
     qy = my;
   } else {
-    const double root = sqrt(1.0 + 4.0 * dt * lambda);
+    const double root = rdy_sqrt(1.0 + 4.0 * dt * lambda);
     const double inv  = rdy_rcp(-2.0 * dt * lambda);
     qx                = (mx - mx * root) * inv;
     qy                = (my - my * root) * inv;
   }
-  const double qmag = sqrt(qx * qx + qy * qy);
+  const double qmag = rdy_sqrt(qx * qx + qy * qy);
   const double hm73 = inv_h * inv_h * rcb;  // h^(-7/3)
   tbx               = gn2 * hm73 * qx * qmag;
   tby               = gn2 * hm73 * qy * qmag;

@@ -183,7 +183,7 @@ constexpr uint32_t EDGE_OTHER_NEG    = 1u << 24;  // the reconstructed component
 constexpr uint32_t REF3_EMPTY = 0x3FF;
 
 __device__ __forceinline__ void edge_normal(uint32_t lr, double cs, double &cn, double &sn) {
-  double other = sqrt(fma(-cs, cs, 1.0));
+  double other = rdy_sqrt(fma(-cs, cs, 1.0));
   if (lr & EDGE_OTHER_NEG) other = -other;
   const bool is_cn = lr & EDGE_CS_IS_CN;
   cn               = is_cn ? cs : other;
