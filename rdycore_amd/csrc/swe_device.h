@@ -57,24 +57,6 @@ __device__ __forceinline__ double rdy_sqrt(double x) {
 #endif
 }
 
-// x^(-1/3) for x > 0 (only called for wet cells, x >= tiny_h): a single-precision
-// seed exp2(-log2(x)/3) (v_log_f32 / v_exp_f32, ~22 bits) refined by two Newton
-// steps y <- y (4 - x y^3) / 3 in double precision (~1 ulp).
-// -DRDYHIP_OCML_CBRT restores rcbrt().
-__device__ __forceinline__ double rdy_rcbrt(double x) {
-#ifdef RDYHIP_OCML_CBRT
-  return rcbrt(x);
-#else
-  double y = (double)__builtin_amdgcn_exp2f(__builtin_amdgcn_logf((float)x) * (-1.0f / 3.0f));
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const double y3 = y * y * y;
-    y               = y * fma(-x, y3, 4.0) * (1.0 / 3.0);
-  }
-  return y;
-#endif
-}
-
 struct RoeFlux {
   double f0, f1, f2, amax;
 };
@@ -240,7 +222,7 @@ __device__ __forceinline__ void friction_semi_implicit(double h, double hu, doub
   const double inv_h  = rdy_rcp(h);
   const double u      = hu * inv_h;
   const double v      = hv * inv_h;
-  const double Cd     = GRAVITY * (n * n) * rdy_rcbrt(h);  // g n^2 h^(-1/3)
+  const double Cd     = GRAVITY * (n * n) * rcbrt(h);  // g n^2 h^(-1/3)
   const double vel    = rdy_sqrt(u * u + v * v);
   const double tb     = Cd * vel * inv_h;
   const double factor = tb * rdy_rcp(1.0 + dt * tb);
@@ -255,7 +237,7 @@ __device__ __forceinline__ void friction_xq2018(double h, double hu, double hv, 
   const double Ay     = fsum_y - bedy;
   const double mx     = hu + Ax * dt;
   const double my     = hv + Ay * dt;
-  const double rcb    = rdy_rcbrt(h);                // h^(-1/3)
+  const double rcb    = rcbrt(h);                // h^(-1/3)
   const double inv_h  = rdy_rcp(h);
   const double gn2    = GRAVITY * (n * n);
   const double mxh    = mx * inv_h;
