@@ -43,22 +43,28 @@ def parse():
     p.add_argument("--ny", type=int, default=2000, help="squares along y")
     p.add_argument("--order", default="tiled", choices=["rowmajor", "tiled"], help="cell numbering of the synthetic mesh")
     p.add_argument("--source", default="semi_implicit", choices=["semi_implicit", "implicit_xq2018"])
+    p.add_argument("--workload", default="c3", choices=["c3", "c2"],
+                   help="c3: friction + bed slope + all BC types (default; use --nx 2500 --ny 2000); "
+                        "c2: flat-bed dam break, all reflecting (BASELINE configs[1]: --nx 1000 --ny 500)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--kernel", default=None, choices=["tiled", "cell"], help="kernel variant (default: library default = tiled)")
     p.add_argument("--cpu-sample", default="1000x500", help="nx x ny of the CPU-baseline sample mesh")
     return p.parse_args()
 
 
-def build_case(nx, ny, rank, world, order, source):
+def build_case(nx, ny, rank, world, order, source, workload="c3"):
     from rdycore_amd import cases as CS
     from rdycore_amd import mesh as M
     from rdycore_amd.operator import SOURCE_IMPLICIT_XQ2018, SOURCE_SEMI_IMPLICIT
     K = 2 * np.pi / 200.0
     src = SOURCE_SEMI_IMPLICIT if source == "semi_implicit" else SOURCE_IMPLICIT_XQ2018
+    zf = CS.mms_bathymetry(K=K) if workload == "c3" else None
     if world == 1:
-        mesh = M.structured_tri_mesh(nx, ny, 1.0, zfunc=CS.mms_bathymetry(K=K), order=order)
+        mesh = M.structured_tri_mesh(nx, ny, 1.0, zfunc=zf, order=order)
     else:
-        mesh = M.strip_partition_tri_mesh(nx, ny, rank, world, 1.0, zfunc=CS.mms_bathymetry(K=K), order=order)
+        mesh = M.strip_partition_tri_mesh(nx, ny, rank, world, 1.0, zfunc=zf, order=order)
+    if workload == "c2":
+        return CS.dam_break_case(mesh, nx * world * 1.0, dt=1e-3, source_method=src)
     return CS.friction_slope_case(mesh, nx * world * 1.0, ny * 1.0, dt=1e-3, source_method=src, K=K)
 
 
@@ -110,17 +116,23 @@ def main():
             raise SystemExit("launch with torch.distributed.run for --gpus > 1")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    backend = os.environ.get("BENCH_BACKEND", "nccl")   # "gloo": rehearsal of several ranks on one GPU (host-staged halo)
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank if backend == "nccl" else local_rank % max(ndev, 1)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from rdycore_amd import cases as CS
     from rdycore_amd.halo import HaloExchange
 
     t0 = time.time()
-    case = build_case(args.nx, args.ny, rank, world, args.order, args.source)
+    case = build_case(args.nx, args.ny, rank, world, args.order, args.source, args.workload)
     mesh = case.mesh
     op = CS.create_operator(case)
     halo = HaloExchange(mesh, dev) if world > 1 else None
@@ -150,10 +162,11 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t_start
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        rdev = dev if backend == "nccl" else torch.device("cpu")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        tot = torch.tensor([n_owned], dtype=torch.int64, device=dev)
+        tot = torch.tensor([n_owned], dtype=torch.int64, device=rdev)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         total_cells = int(tot.item())
     else:
@@ -181,9 +194,13 @@ def main():
         value = total_cells / (elapsed / args.steps) / 1e6
         achieved = n_owned * ALG_BYTES_PER_CELL / (kern_ms * 1e-3) / 1e9
         info = op.layout_info()
-        workload = (f"C3: synthetic {args.nx * world}x{args.ny}x2 = {total_cells}-cell triangle mesh "
-                    f"({n_owned} cells/GPU), MMS-style state over sinusoidal bathymetry, Manning field, rain source, "
-                    f"dry disc, Dirichlet + critical-outflow + reflecting boundaries, {args.source} friction, dt=1e-3")
+        if args.workload == "c3":
+            workload = (f"C3: synthetic {args.nx * world}x{args.ny}x2 = {total_cells}-cell triangle mesh "
+                        f"({n_owned} cells/GPU), MMS-style state over sinusoidal bathymetry, Manning field, rain source, "
+                        f"dry disc, Dirichlet + critical-outflow + reflecting boundaries, {args.source} friction, dt=1e-3")
+        else:
+            workload = (f"C2: synthetic {args.nx * world}x{args.ny}x2 = {total_cells}-cell triangle mesh ({n_owned} cells/GPU), "
+                        f"flat-bed dam break h = 10 / 5 with perturbed momenta, Manning 0.015, reflecting walls, {args.source} friction, dt=1e-3")
         out = {
             "metric": "M cell-updates/s (SWE RHS eval)",
             "value": round(value, 1),
@@ -203,7 +220,7 @@ def main():
                        "setup_seconds": round(setup_s, 1), "max_courant": courant, "finite": finite},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                         "traffic": load_traffic(f"{args.nx}x{args.ny}_{args.order}_{args.source}"),
+                         "traffic": load_traffic(f"{args.nx}x{args.ny}_{args.order}_{args.source}") if args.workload == "c3" else None,
                          "kernel": "%s<3,%d>" % ("swe_rhs_tiled_kernel" if info["tiled_kernel"] else "swe_rhs_kernel",
                                                  0 if args.source == "semi_implicit" else 1),
                          "tile_edge_records_per_cell": round(info["num_edge_records"] / max(n_owned, 1), 4),
