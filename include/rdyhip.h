@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RDYHIP_VERSION 100
+#define RDYHIP_VERSION 101
 
 /* error codes = PETSc's values */
 #define RDYHIP_SUCCESS 0
@@ -49,12 +49,17 @@ extern "C" {
 #define RDYHIP_SOURCE_SEMI_IMPLICIT 0
 #define RDYHIP_SOURCE_IMPLICIT_XQ2018 1
 
+/* RDyWellBalanceMethod (include/private/rdyconfigimpl.h:58-62).  BS2002 exists only in
+ * the reference's CEED backend (src/operator.c:388) and is rejected here too. */
+#define RDYHIP_WELL_BALANCING_NONE 0
+#define RDYHIP_WELL_BALANCING_HR 2
+
 /* RDyNumericsRiemann (include/private/rdyconfigimpl.h:118-122); only Roe exists
  * in the reference (src/swe/swe_petsc.c:264-270) */
 #define RDYHIP_RIEMANN_ROE 0
 
-/* The six scalars of RDyConfig that reach the kernels
- * (config.physics.flow.{tiny_h,h_anuga_regular,source.method,source.xq2018_threshold},
+/* The scalars of RDyConfig that reach the kernels
+ * (config.physics.flow.{tiny_h,h_anuga_regular,source.method,source.xq2018_threshold,well_balancing},
  *  config.numerics.riemann; include/private/rdyconfigimpl.h:73-85,125-132). */
 typedef struct {
   double  tiny_h;
@@ -62,6 +67,11 @@ typedef struct {
   double  xq2018_threshold;
   int32_t source_method; /* RDYHIP_SOURCE_* */
   int32_t riemann;       /* RDYHIP_RIEMANN_ROE */
+  int32_t well_balancing; /* RDYHIP_WELL_BALANCING_*: HR = ApplyInteriorFluxHR + bed-slope-free source
+                             (src/swe/swe_petsc.c:1000-1263); the mesh must then carry cell_zc and, as the
+                             reference does (RDyMeshOverride2DProjection, src/rdymesh.c:1478-1509), x-y
+                             projected edge lengths and cell areas */
+  int32_t reserved;
 } RDyHipConfig;
 
 /* The RDyMesh arrays the SWE operators read (include/private/rdymeshimpl.h:26-202).
@@ -83,6 +93,8 @@ typedef struct {
   const double  *edge_lengths;        /* edges.lengths        [num_edges] */
   const double  *edge_cn;             /* edges.cn             [num_edges] */
   const double  *edge_sn;             /* edges.sn             [num_edges] */
+  const double  *cell_zc;             /* vertex-averaged bed elevation per cell [num_cells] (InteriorFluxHROperator.zc,
+                                         src/swe/swe_petsc.c:1209-1224); may be NULL unless well_balancing == HR */
 } RDyHipMesh;
 
 /* RDyBoundary (include/private/rdyboundaryimpl.h:7-14) + the flow condition

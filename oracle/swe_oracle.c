@@ -216,6 +216,88 @@ static void apply_interior_flux(OracleOperator *op, double dt, const double *u, 
   }
 }
 
+
+/* ApplyInteriorFluxHR, src/swe/swe_petsc.c:1000-1161: hydrostatic reconstruction
+ * of the two depths of every interior edge, Roe flux on the reconstructed
+ * states, and the hydrostatic pressure correction. */
+static void apply_interior_flux_hr(OracleOperator *op, double dt, const double *u, double *f) {
+  const OracleMesh *m      = &op->mesh;
+  const double      tiny_h = op->config.tiny_h, h_anuga = op->config.h_anuga_regular;
+  const double     *zc = m->zc;
+  Side             *L = &op->left, *R = &op->right;
+  Batch            *E = &op->edges;
+
+  /* reconstruction (1031-1074) */
+  for (int e = 0; e < m->num_internal_edges; ++e) {
+    int edge = m->internal_edge_ids[e];
+    int l    = m->cell_ids[2 * edge];
+    int r    = m->cell_ids[2 * edge + 1];
+    if (r == -1) continue;
+    double h_L = u[3 * l + 0], hu_L = u[3 * l + 1], hv_L = u[3 * l + 2];
+    double h_R = u[3 * r + 0], hu_R = u[3 * r + 1], hv_R = u[3 * r + 2];
+    double zc_L = zc[l], zc_R = zc[r];
+    double eta_L = h_L + zc_L, eta_R = h_R + zc_R;
+    double z_max = fmax(zc_L, zc_R);
+    double hL_rec = fmax(0.0, eta_L - z_max);
+    double hR_rec = fmax(0.0, eta_R - z_max);
+    double denom_L = sq(h_L) + sq(h_anuga);
+    double denom_R = sq(h_R) + sq(h_anuga);
+    L->h[e] = hL_rec;
+    L->u[e] = (h_L > tiny_h) ? hu_L * h_L / denom_L : 0.0;
+    L->v[e] = (h_L > tiny_h) ? hv_L * h_L / denom_L : 0.0;
+    R->h[e] = hR_rec;
+    R->u[e] = (h_R > tiny_h) ? hu_R * h_R / denom_R : 0.0;
+    R->v[e] = (h_R > tiny_h) ? hv_R * h_R / denom_R : 0.0;
+  }
+  roe_batch(L, R, E, E->flux);
+
+  /* accumulation + pressure correction (1085-1153) */
+  for (int e = 0; e < m->num_internal_edges; ++e) {
+    int edge = m->internal_edge_ids[e];
+    int l    = m->cell_ids[2 * edge];
+    int r    = m->cell_ids[2 * edge + 1];
+    if (r == -1) continue;
+    double h_L = u[3 * l + 0];
+    double h_R = u[3 * r + 0];
+    if (!(h_R < tiny_h && h_L < tiny_h)) {
+      double len = m->lengths[edge];
+      double areal = m->areas[l], arear = m->areas[r];
+      double zc_L = zc[l], zc_R = zc[r];
+      double eta_L = h_L + zc_L, eta_R = h_R + zc_R;
+      double z_max = fmax(zc_L, zc_R);
+      double hL_rec = fmax(0.0, eta_L - z_max);
+      double hR_rec = fmax(0.0, eta_R - z_max);
+      double scale_l = -len / areal;
+      double scale_r = len / arear;
+      if (hL_rec > tiny_h || hR_rec > tiny_h) {
+        double cnum = E->amax[e] * len / fmin(areal, arear) * dt;
+        if (cnum > op->courant.max_courant_num) {
+          op->courant.max_courant_num = cnum;
+          op->courant.global_edge_id  = m->edge_global_ids[edge];
+          op->courant.global_cell_id  = (areal < arear) ? m->cell_global_ids[l] : m->cell_global_ids[r];
+        }
+        for (int c = 0; c < 3; ++c) {
+          if (m->is_owned[l]) f[3 * m->local_to_owned[l] + c] += E->flux[3 * e + c] * scale_l;
+          if (m->is_owned[r]) f[3 * m->local_to_owned[r] + c] += E->flux[3 * e + c] * scale_r;
+        }
+      }
+      double corr_L = 0.5 * G * (sq(h_L) - sq(hL_rec));
+      double corr_R = 0.5 * G * (sq(h_R) - sq(hR_rec));
+      double cn = E->cn[e], sn = E->sn[e];
+      if (m->is_owned[l]) {
+        int lo = m->local_to_owned[l];
+        f[3 * lo + 1] += corr_L * cn * scale_l;
+        f[3 * lo + 2] += corr_L * sn * scale_l;
+      }
+      if (m->is_owned[r]) {
+        int ro = m->local_to_owned[r];
+        f[3 * ro + 1] += corr_R * cn * scale_r;
+        f[3 * ro + 2] += corr_R * sn * scale_r;
+      }
+    }
+  }
+}
+
 /* ApplyReflectingBC, src/swe/swe_petsc.c:434-461 */
 static void reflecting_bc(const OracleMesh *m, BoundaryOp *b) {
   for (int e = 0; e < b->desc.num_edges; ++e) {
@@ -317,6 +399,9 @@ static void apply_source_semi_implicit(OracleOperator *op, double dt, const doub
   const double      tiny_h = op->config.tiny_h, h_anuga = op->config.h_anuga_regular;
   const double     *src = op->external_sources, *mat = op->material_properties, *fdiv = op->flux_divergence;
   double           *pv = op->primitive_variables;
+  /* SourceOperator.include_bed_slope: false under HR, where the flux's pressure
+   * correction carries the bed slope (src/swe/swe_petsc.c:700, 1243) */
+  const int bed_slope = op->config.well_balancing != ORACLE_WB_HR;
   for (int c = 0; c < m->num_cells; ++c) {
     if (!m->is_owned[c]) continue;
     int    o  = m->local_to_owned[c];
@@ -324,8 +409,11 @@ static void apply_source_semi_implicit(OracleOperator *op, double dt, const doub
     double hu = u[3 * c + 1];
     double hv = u[3 * c + 2];
 
-    double bedx = m->dz_dx[c] * G * h;
-    double bedy = m->dz_dy[c] * G * h;
+    double bedx = 0.0, bedy = 0.0;
+    if (bed_slope) {
+      bedx = m->dz_dx[c] * G * h;
+      bedy = m->dz_dy[c] * G * h;
+    }
 
     double Fsum_x = fdiv[3 * o + 1];
     double Fsum_y = fdiv[3 * o + 2];
@@ -361,6 +449,9 @@ static void apply_source_xq2018(OracleOperator *op, double dt, const double *u, 
   const double      thresh = op->config.xq2018_threshold;
   const double     *src = op->external_sources, *mat = op->material_properties, *fdiv = op->flux_divergence;
   double           *pv = op->primitive_variables;
+  /* SourceOperator.include_bed_slope: false under HR, where the flux's pressure
+   * correction carries the bed slope (src/swe/swe_petsc.c:700, 1243) */
+  const int bed_slope = op->config.well_balancing != ORACLE_WB_HR;
   for (int c = 0; c < m->num_cells; ++c) {
     if (!m->is_owned[c]) continue;
     int    o  = m->local_to_owned[c];
@@ -368,8 +459,11 @@ static void apply_source_xq2018(OracleOperator *op, double dt, const double *u, 
     double hu = u[3 * c + 1];
     double hv = u[3 * c + 2];
 
-    double bedx = m->dz_dx[c] * G * h;
-    double bedy = m->dz_dy[c] * G * h;
+    double bedx = 0.0, bedy = 0.0;
+    if (bed_slope) {
+      bedx = m->dz_dx[c] * G * h;
+      bedy = m->dz_dy[c] * G * h;
+    }
 
     double tbx = 0.0, tby = 0.0;
     if (h >= tiny_h) {
@@ -477,7 +571,9 @@ void oracle_destroy(OracleOperator *op) {
  * one sub-operator per boundary, src/operator_fluxes_petsc.c:17-53), copy of
  * f into flux_divergence, source composite. */
 int oracle_apply(OracleOperator *op, double dt, const double *u_local, double *f_global) {
-  apply_interior_flux(op, dt, u_local, f_global);
+  /* CreatePetscFluxOperator vs CreatePetscFluxHROperator (src/operator.c:186-200, src/operator_fluxes_petsc.c:17-95) */
+  if (op->config.well_balancing == ORACLE_WB_HR) apply_interior_flux_hr(op, dt, u_local, f_global);
+  else apply_interior_flux(op, dt, u_local, f_global);
   for (int b = 0; b < op->num_boundaries; ++b) apply_boundary_flux(op, &op->boundaries[b], dt, u_local, f_global);
   memcpy(op->flux_divergence, f_global, sizeof(double) * 3 * (size_t)op->mesh.num_owned_cells);
   switch (op->config.source_method) {

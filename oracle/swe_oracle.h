@@ -26,6 +26,7 @@ extern "C" {
 enum { ORACLE_BC_DIRICHLET = 0, ORACLE_BC_REFLECTING = 2, ORACLE_BC_CRITICAL_OUTFLOW = 3 };
 /* RDyFlowSourceMethod, include/private/rdyconfigimpl.h:52-56 */
 enum { ORACLE_SOURCE_SEMI_IMPLICIT = 0, ORACLE_SOURCE_IMPLICIT_XQ2018 = 1 };
+enum { ORACLE_WB_NONE = 0, ORACLE_WB_HR = 2 };
 
 /* the RDyMesh fields the operators read (include/private/rdymeshimpl.h) */
 typedef struct {
@@ -35,6 +36,7 @@ typedef struct {
   const long long *cell_global_ids;   /* cells.global_ids      [num_cells] */
   const double    *areas;             /* cells.areas           [num_cells] */
   const double    *dz_dx, *dz_dy;     /* cells.dz_dx/dz_dy     [num_cells] */
+  const double    *zc;                /* vertex-averaged bed elevation per cell (HR only; src/swe/swe_petsc.c:1209-1224) */
   const int       *cell_ids;          /* edges.cell_ids        [2*num_edges] */
   const int       *internal_edge_ids; /* edges.internal_edge_ids [num_internal_edges] */
   const long long *edge_global_ids;   /* edges.global_ids      [num_edges] */
@@ -50,6 +52,7 @@ typedef struct {
 typedef struct {
   double tiny_h, h_anuga_regular, xq2018_threshold; /* RDyPhysicsFlow, rdyconfigimpl.h:74-85 */
   int    source_method;
+  int    well_balancing; /* RDyWellBalanceMethod: 0 none, 2 hydrostatic reconstruction (rdyconfigimpl.h:58-62) */
 } OracleConfig;
 
 /* CourantNumberDiagnostics, include/private/rdyoperatorimpl.h:21-25 */

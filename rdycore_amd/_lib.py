@@ -18,7 +18,7 @@ c_int64_p = C.POINTER(C.c_int64)
 
 class RDyHipConfig(C.Structure):
     _fields_ = [("tiny_h", C.c_double), ("h_anuga_regular", C.c_double), ("xq2018_threshold", C.c_double),
-                ("source_method", C.c_int32), ("riemann", C.c_int32)]
+                ("source_method", C.c_int32), ("riemann", C.c_int32), ("well_balancing", C.c_int32), ("reserved", C.c_int32)]
 
 
 class RDyHipMesh(C.Structure):
@@ -27,7 +27,7 @@ class RDyHipMesh(C.Structure):
         ("cell_is_owned", c_int32_p), ("cell_local_to_owned", c_int32_p), ("cell_global_ids", c_int64_p),
         ("cell_areas", c_double_p), ("cell_dz_dx", c_double_p), ("cell_dz_dy", c_double_p),
         ("edge_cell_ids", c_int32_p), ("edge_internal_ids", c_int32_p), ("edge_global_ids", c_int64_p),
-        ("edge_lengths", c_double_p), ("edge_cn", c_double_p), ("edge_sn", c_double_p),
+        ("edge_lengths", c_double_p), ("edge_cn", c_double_p), ("edge_sn", c_double_p), ("cell_zc", c_double_p),
     ]
 
 

@@ -107,6 +107,8 @@ struct RDyHipOperator_s {
   int32_t n_halo = 0, n_bghost = 0;
   // tiled kernel (swe_kernels.h)
   bool             use_tiled = true;
+  bool             hr = false;   // hydrostatic reconstruction
+  DevBuf<double>   d_zc_local;
   int32_t          ntiles = 0, n_halo_tiles = 0, emax = 0;
   int64_t          nrec = 0;
   int32_t          hmax = 0;
@@ -137,7 +139,7 @@ struct RDyHipOperator_s {
     d_baccum.release(); d_bcn.release(); d_bsn.release(); d_pv.release(); d_fdiv.release(); d_blk_max.release();
     d_blk_pos.release(); d_courant.release(); d_stage_vals.release(); d_stage_ids.release();
     d_tiles.release(); d_e_lr.release(); d_hcells.release(); d_tile_bk.release(); d_halo_tiles.release();
-    d_e_cs.release(); d_slot_ref.release(); d_slot_ref3.release();
+    d_e_cs.release(); d_slot_ref.release(); d_slot_ref3.release(); d_zc_local.release();
   }
 };
 
@@ -146,14 +148,16 @@ namespace {
 using TiledKernelFn = void (*)(const KernelArgs, const double, const double *, double *);
 
 // the instantiation of the tiled kernel for (slots per cell, source method, overwrite)
-TiledKernelFn tiled_kernel_fn(int S, int src, bool ovw) {
+template <bool HR>
+TiledKernelFn tiled_kernel_fn_hr(int S, int src, bool ovw) {
   if (S == 3) {
-    if (src) return ovw ? swe_rhs_tiled_kernel<3, 1, true> : swe_rhs_tiled_kernel<3, 1, false>;
-    return ovw ? swe_rhs_tiled_kernel<3, 0, true> : swe_rhs_tiled_kernel<3, 0, false>;
+    if (src) return ovw ? swe_rhs_tiled_kernel<3, 1, true, HR> : swe_rhs_tiled_kernel<3, 1, false, HR>;
+    return ovw ? swe_rhs_tiled_kernel<3, 0, true, HR> : swe_rhs_tiled_kernel<3, 0, false, HR>;
   }
-  if (src) return ovw ? swe_rhs_tiled_kernel<4, 1, true> : swe_rhs_tiled_kernel<4, 1, false>;
-  return ovw ? swe_rhs_tiled_kernel<4, 0, true> : swe_rhs_tiled_kernel<4, 0, false>;
+  if (src) return ovw ? swe_rhs_tiled_kernel<4, 1, true, HR> : swe_rhs_tiled_kernel<4, 1, false, HR>;
+  return ovw ? swe_rhs_tiled_kernel<4, 0, true, HR> : swe_rhs_tiled_kernel<4, 0, false, HR>;
 }
+TiledKernelFn tiled_kernel_fn(int S, int src, bool ovw, bool hr) { return hr ? tiled_kernel_fn_hr<true>(S, src, ovw) : tiled_kernel_fn_hr<false>(S, src, ovw); }
 
 int launch_rhs(RDyHipOperator op, int32_t phase, int32_t overwrite, int reset_diag, double dt, const double *u, double *f, hipStream_t st) {
   if (!op) return fail(RDYHIP_ERR_USER, "null operator");
@@ -193,6 +197,7 @@ int launch_rhs(RDyHipOperator op, int32_t phase, int32_t overwrite, int reset_di
   a.hcells   = op->d_hcells.p;
   a.tile_bk  = op->d_tile_bk.p;
   a.slot_ref = op->S == 3 ? (const void *)op->d_slot_ref3.p : (const void *)op->d_slot_ref.p;
+  a.zc_local = op->d_zc_local.p;
   a.emax     = op->emax;
   a.hmax     = op->hmax;
 
@@ -222,7 +227,7 @@ int launch_rhs(RDyHipOperator op, int32_t phase, int32_t overwrite, int reset_di
       }
     }
     const size_t lds = op->lds_bytes;
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(tiled_kernel_fn(op->S, xq ? 1 : 0, overwrite != 0)), dim3(grid), dim3(TILE), lds, st, a, dt, u, f);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(tiled_kernel_fn(op->S, xq ? 1 : 0, overwrite != 0, op->hr)), dim3(grid), dim3(TILE), lds, st, a, dt, u, f);
   } else {
     if (phase == RDYHIP_PHASE_HALO) {
       if (op->n_halo == 0) return 0;
@@ -272,6 +277,10 @@ int rdyhip_create(const RDyHipConfig *config, const RDyHipMesh *mesh, int32_t nu
   if (config->riemann != RDYHIP_RIEMANN_ROE) return fail(RDYHIP_ERR_USER, "Unsupported Riemann solver");  // swe_petsc.c:269
   if (config->source_method != RDYHIP_SOURCE_SEMI_IMPLICIT && config->source_method != RDYHIP_SOURCE_IMPLICIT_XQ2018)
     return fail(RDYHIP_ERR_USER, "Only semi_implicit and implicit_xq2018 are supported");  // swe_petsc.c:973
+  if (config->well_balancing != RDYHIP_WELL_BALANCING_NONE && config->well_balancing != RDYHIP_WELL_BALANCING_HR)
+    return fail(RDYHIP_ERR_USER, "Only well_balancing = none or hydrostatic_reconstruction is supported in the PETSc version");  // operator.c:388
+  if (config->well_balancing == RDYHIP_WELL_BALANCING_HR && !mesh->cell_zc)
+    return fail(RDYHIP_ERR_USER, "hydrostatic reconstruction needs the per-cell bed elevation (RDyHipMesh.cell_zc)");
   const int32_t nc = mesh->num_cells, no = mesh->num_owned_cells, ne = mesh->num_edges, ni = mesh->num_internal_edges;
   if (nc < 0 || no < 0 || no > nc || ne < 0 || ni < 0 || ni > ne) return fail(RDYHIP_ERR_ARG_SIZ, "inconsistent mesh sizes");
   if (nc >= NBR_GHOST) return fail(RDYHIP_ERR_ARG_SIZ, "too many local cells (%d) for the 30-bit neighbour encoding", nc);
@@ -468,7 +477,8 @@ int rdyhip_create(const RDyHipConfig *config, const RDyHipMesh *mesh, int32_t nu
     tiles[ntiles].halo  = 0;
     // a tile has at most 4*256 edges, so 256 + hmax <= 1280 slots < 2^11 and <= 1024 boundary edges
   }
-  const size_t lds_bytes = sizeof(double) * (5 * ((size_t)TILE + hmax) + 2 * (size_t)TILE + 4 * (size_t)emax);
+  const bool   hr_on     = config->well_balancing == RDYHIP_WELL_BALANCING_HR;
+  const size_t lds_bytes = sizeof(double) * ((hr_on ? 6 : 5) * ((size_t)TILE + hmax) + 2 * (size_t)TILE + (hr_on ? 8 : 4) * (size_t)emax);
   if (lds_bytes > 160 * 1024) return fail(RDYHIP_ERR_USER, "tile working set (%zu B of LDS) too large: the cell numbering has no locality", lds_bytes);
 
   // ---- per-owned-cell geometry --------------------------------------------
@@ -503,7 +513,7 @@ int rdyhip_create(const RDyHipConfig *config, const RDyHipMesh *mesh, int32_t nu
     for (int ovw = 0; ovw < 2; ++ovw)
       for (int src = 0; src < 2; ++src)
         for (int sl = 3; sl <= 4; ++sl)
-          ok = ok && hipFuncSetAttribute((const void *)tiled_kernel_fn(sl, src, ovw != 0), hipFuncAttributeMaxDynamicSharedMemorySize, nb) == hipSuccess;
+          ok = ok && hipFuncSetAttribute((const void *)tiled_kernel_fn(sl, src, ovw != 0, hr_on), hipFuncAttributeMaxDynamicSharedMemorySize, nb) == hipSuccess;
     if (!ok) {
       delete op;
       return fail(RDYHIP_ERR_LIB, "cannot reserve %d bytes of LDS per workgroup", nb);
@@ -514,6 +524,11 @@ int rdyhip_create(const RDyHipConfig *config, const RDyHipMesh *mesh, int32_t nu
   {
     const char *kenv = getenv("RDYHIP_KERNEL");
     op->use_tiled    = !(kenv && strcmp(kenv, "cell") == 0);
+    op->hr           = hr_on;
+    if (hr_on && !op->use_tiled) {
+      delete op;
+      return fail(RDYHIP_ERR_USER, "hydrostatic reconstruction is implemented by the tiled kernel only (unset RDYHIP_KERNEL=cell)");
+    }
   }
   int rc         = 0;
   if (hipGetDevice(&op->device) != hipSuccess) {
@@ -532,7 +547,7 @@ int rdyhip_create(const RDyHipConfig *config, const RDyHipMesh *mesh, int32_t nu
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, op->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
     int q = 0;
-    const void *kfn = (const void *)tiled_kernel_fn(S, config->source_method == RDYHIP_SOURCE_IMPLICIT_XQ2018 ? 1 : 0, true);
+    const void *kfn = (const void *)tiled_kernel_fn(S, config->source_method == RDYHIP_SOURCE_IMPLICIT_XQ2018 ? 1 : 0, true, hr_on);
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, kfn, TILE, lds_bytes) == hipSuccess && q > 0) per_cu = q;
     if (const char *e2 = getenv("RDYHIP_BLOCKS_PER_CU")) {
       if (atoi(e2) > 0) per_cu = atoi(e2);
@@ -588,6 +603,10 @@ int rdyhip_create(const RDyHipConfig *config, const RDyHipMesh *mesh, int32_t nu
     TRY_RC(op->d_slot_ref3.upload(ref3));
   } else {
     TRY_RC(op->d_slot_ref.upload(slot_ref));
+  }
+  if (hr_on) {
+    std::vector<double> zc(mesh->cell_zc, mesh->cell_zc + nc);
+    TRY_RC(op->d_zc_local.upload(zc));
   }
   TRY_RC(op->d_mannings.zeros((size_t)no));
   TRY_RC(op->d_extsrc.zeros((size_t)3 * no));

@@ -82,6 +82,7 @@ struct KernelArgs {
   const int32_t  *tile_bk;   // boundary-edge ids k of each tile's boundary edges
   const void     *slot_ref;  // index of each slot's edge in the tile's edge list: S == 3: uint32[n_owned] (3 x 10 bits),
                              // S == 4: uint16[n_owned][4]
+  const double   *zc_local;  // [num_cells] vertex-averaged bed elevation (hydrostatic reconstruction only)
   int32_t         emax;      // largest edge count of a tile (LDS sizing)
   int32_t         hmax;      // largest halo-cell count of a tile (LDS sizing)
 };
@@ -206,7 +207,7 @@ struct CellStreams {
   double   dzdx, dzdy, nman, s0, s1, s2;
 };
 
-template <int S>
+template <int S, bool HR>
 __device__ __forceinline__ void load_streams(const KernelArgs &a, int o, bool active, CellStreams<S> &c) {
   c.r0 = c.r1 = 0xFFFFFFFFu;
 #pragma unroll
@@ -222,8 +223,10 @@ __device__ __forceinline__ void load_streams(const KernelArgs &a, int o, bool ac
     }
 #pragma unroll
     for (int s = 0; s < S; ++s) c.coef[s] = a.coef[s * a.stride + o];
-    c.dzdx = a.dzdx[o];
-    c.dzdy = a.dzdy[o];
+    if (!HR) {  // under HR the pressure correction of the flux carries the bed slope
+      c.dzdx = a.dzdx[o];
+      c.dzdy = a.dzdy[o];
+    }
     c.nman = a.mannings[o];
     c.s0   = a.extsrc[3 * (int64_t)o + 0];
     c.s1   = a.extsrc[3 * (int64_t)o + 1];
@@ -238,7 +241,12 @@ __device__ __forceinline__ void load_streams(const KernelArgs &a, int o, bool ac
 // T, its cell states and edge records after T's first barrier.  A tile never
 // waits for a dependent chain of global loads, and every load has about one
 // tile time to complete, which is what keeps HBM busy at 3 workgroups per CU.
-template <int S, int SRC, bool OVW>
+//
+// HR = hydrostatic reconstruction (ApplyInteriorFluxHR, src/swe/swe_petsc.c:1000-1161):
+// each interior edge's two depths are reconstructed against max(zc_l, zc_r) before
+// the Roe solver, a pressure correction 0.5 g (h^2 - h_rec^2) (cn, sn) is added per
+// side, and the source term drops the bed slope (CreatePetscSWESourceHROperator, 1229-1263).
+template <int S, int SRC, bool OVW, bool HR>
 __global__ __launch_bounds__(TILE) void swe_rhs_tiled_kernel(const KernelArgs a, const double dt, const double *__restrict__ u,
                                                               double *__restrict__ f) {
   extern __shared__ double lds[];
@@ -246,6 +254,8 @@ __global__ __launch_bounds__(TILE) void swe_rhs_tiled_kernel(const KernelArgs a,
   double   *sd_h = lds, *sd_u = lds + nside, *sd_v = lds + 2 * nside, *sd_sq = lds + 3 * nside, *sd_c = lds + 4 * nside;
   double   *sd_hu = lds + 5 * nside, *sd_hv = sd_hu + TILE;
   double   *ef0 = sd_hv + TILE, *ef1 = ef0 + a.emax, *ef2 = ef1 + a.emax, *eam = ef2 + a.emax;
+  // HR only: bed elevation per slot; per edge the two pressure corrections and the normal
+  double   *sd_zc = eam + a.emax, *ecl = sd_zc + nside, *ecr = ecl + a.emax, *ecn = ecr + a.emax, *esn = ecn + a.emax;
   const int tid = threadIdx.x;
 
   // ---- this workgroup's tile sequence.  Block ids are dealt round-robin to the
@@ -281,6 +291,7 @@ __global__ __launch_bounds__(TILE) void swe_rhs_tiled_kernel(const KernelArgs a,
     TileDesc td = a.tiles[tile], tn = a.tiles[tile + 1];
     double   pu0 = 0.0, pu1 = 0.0, pu2 = 0.0;  // own cell state of the tile being started
     double   ph0 = 0.0, ph1 = 0.0, ph2 = 0.0;  // state of this thread's halo cell
+    double   pz = 0.0, phz = 0.0;              // HR: bed elevation of the own / halo cell
     uint32_t lr0 = 0, lr1 = 0;                 // first two rounds of edge records
     double   cs0 = 0.0, cs1 = 0.0;
     CellStreams<S> cur;
@@ -289,15 +300,17 @@ __global__ __launch_bounds__(TILE) void swe_rhs_tiled_kernel(const KernelArgs a,
       if (o < a.n_owned) {
         const int c = a.o2l ? a.o2l[o] : o;
         pu0 = u[3 * (int64_t)c + 0]; pu1 = u[3 * (int64_t)c + 1]; pu2 = u[3 * (int64_t)c + 2];
+        if (HR) pz = a.zc_local[c];
       }
       if (tid < tn.h_off - td.h_off) {
         const int hc = a.hcells[td.h_off + tid];
         ph0 = u[3 * (int64_t)hc + 0]; ph1 = u[3 * (int64_t)hc + 1]; ph2 = u[3 * (int64_t)hc + 2];
+        if (HR) phz = a.zc_local[hc];
       }
       const int ne = tn.e_off - td.e_off;
       if (tid < ne) { lr0 = a.e_lr[td.e_off + tid]; cs0 = a.e_cs[td.e_off + tid]; }
       if (tid + TILE < ne) { lr1 = a.e_lr[td.e_off + TILE + tid]; cs1 = a.e_cs[td.e_off + TILE + tid]; }
-      load_streams<S>(a, o, o < a.n_owned, cur);
+      load_streams<S, HR>(a, o, o < a.n_owned, cur);
     }
     int      idx1 = next_valid(idx + step);
     int      tile1 = 0, hid1 = 0;
@@ -316,7 +329,7 @@ __global__ __launch_bounds__(TILE) void swe_rhs_tiled_kernel(const KernelArgs a,
 
       // ---- software pipeline (1): the next tile's per-cell streams, a full tile ahead
       CellStreams<S> nxt;
-      load_streams<S>(a, tile1 * TILE + tid, idx1 < hi && tile1 * TILE + tid < a.n_owned, nxt);
+      load_streams<S, HR>(a, tile1 * TILE + tid, idx1 < hi && tile1 * TILE + tid < a.n_owned, nxt);
 
       // ---- phase 0: Riemann side data of the tile's own and halo cells -> LDS
       {
@@ -326,14 +339,17 @@ __global__ __launch_bounds__(TILE) void swe_rhs_tiled_kernel(const KernelArgs a,
         sd_h[tid] = self.h; sd_u[tid] = self.u; sd_v[tid] = self.v; sd_sq[tid] = self.sqh; sd_c[tid] = self.c;
         sd_hu[tid] = pu1;
         sd_hv[tid] = pu2;
+        if (HR) sd_zc[tid] = pz;
         if (tid < nh) {
           const RiemannSide hs = riemann_side(ph0, ph1, ph2, a.tiny_h, a.h_anuga_sq);
           sd_h[TILE + tid] = hs.h; sd_u[TILE + tid] = hs.u; sd_v[TILE + tid] = hs.v; sd_sq[TILE + tid] = hs.sqh; sd_c[TILE + tid] = hs.c;
+          if (HR) sd_zc[TILE + tid] = phz;
         }
         for (int j = tid + TILE; j < nh; j += TILE) {  // only numberings with poor locality get here
           const int         hc = a.hcells[td.h_off + j];
           const RiemannSide hs = riemann_side(u[3 * (int64_t)hc + 0], u[3 * (int64_t)hc + 1], u[3 * (int64_t)hc + 2], a.tiny_h, a.h_anuga_sq);
           sd_h[TILE + j] = hs.h; sd_u[TILE + j] = hs.u; sd_v[TILE + j] = hs.v; sd_sq[TILE + j] = hs.sqh; sd_c[TILE + j] = hs.c;
+          if (HR) sd_zc[TILE + j] = a.zc_local[hc];
         }
       }
       __syncthreads();
@@ -348,8 +364,12 @@ __global__ __launch_bounds__(TILE) void swe_rhs_tiled_kernel(const KernelArgs a,
         if (o1 < a.n_owned) {
           const int c1 = a.o2l ? a.o2l[o1] : o1;
           pu0 = u[3 * (int64_t)c1 + 0]; pu1 = u[3 * (int64_t)c1 + 1]; pu2 = u[3 * (int64_t)c1 + 2];
+          if (HR) pz = a.zc_local[c1];
         }
-        if (tid < tn1.h_off - td1.h_off) { ph0 = u[3 * (int64_t)hid1 + 0]; ph1 = u[3 * (int64_t)hid1 + 1]; ph2 = u[3 * (int64_t)hid1 + 2]; }
+        if (tid < tn1.h_off - td1.h_off) {
+          ph0 = u[3 * (int64_t)hid1 + 0]; ph1 = u[3 * (int64_t)hid1 + 1]; ph2 = u[3 * (int64_t)hid1 + 2];
+          if (HR) phz = a.zc_local[hid1];
+        }
         const int ne1 = tn1.e_off - td1.e_off;
         if (tid < ne1) { nlr0 = a.e_lr[td1.e_off + tid]; ncs0 = a.e_cs[td1.e_off + tid]; }
         if (tid + TILE < ne1) { nlr1 = a.e_lr[td1.e_off + TILE + tid]; ncs1 = a.e_cs[td1.e_off + TILE + tid]; }
@@ -379,9 +399,36 @@ __global__ __launch_bounds__(TILE) void swe_rhs_tiled_kernel(const KernelArgs a,
           const int   jr = (lr >> EDGE_R_SHIFT) & EDGE_SLOT_MASK;
           RiemannSide R;
           R.h = sd_h[jr]; R.u = sd_u[jr]; R.v = sd_v[jr]; R.sqh = sd_sq[jr]; R.c = sd_c[jr];
-          fl  = roe_flux(L, R, sn, cn);
-          wet = !(R.h < a.tiny_h && L.h < a.tiny_h);
+          if (!HR) {
+            fl  = roe_flux(L, R, sn, cn);
+            wet = !(R.h < a.tiny_h && L.h < a.tiny_h);
+          } else {
+            // hydrostatic reconstruction (swe_petsc.c:1046-1071); velocities are kept, with the strict
+            // "h > tiny_h" wet test of the HR operator (1061-1064)
+            const double zl = sd_zc[jl], zr = sd_zc[jr];
+            const double z_max = fmax(zl, zr);
+            RiemannSide  Lr, Rr;
+            Lr.h   = fmax(0.0, (L.h + zl) - z_max);
+            Rr.h   = fmax(0.0, (R.h + zr) - z_max);
+            Lr.u   = (L.h > a.tiny_h) ? L.u : 0.0;
+            Lr.v   = (L.h > a.tiny_h) ? L.v : 0.0;
+            Rr.u   = (R.h > a.tiny_h) ? R.u : 0.0;
+            Rr.v   = (R.h > a.tiny_h) ? R.v : 0.0;
+            Lr.sqh = rdy_sqrt(Lr.h);
+            Rr.sqh = rdy_sqrt(Rr.h);
+            Lr.c   = rdy_sqrt(GRAVITY * Lr.h);
+            Rr.c   = rdy_sqrt(GRAVITY * Rr.h);
+            fl     = roe_flux(Lr, Rr, sn, cn);
+            const bool outer = !(R.h < a.tiny_h && L.h < a.tiny_h);       // 1094
+            wet              = outer && (Lr.h > a.tiny_h || Rr.h > a.tiny_h);  // inner guard, 1112
+            // pressure correction, applied whenever the outer guard holds (1136-1152)
+            ecl[e] = outer ? 0.5 * GRAVITY * (L.h * L.h - Lr.h * Lr.h) : 0.0;
+            ecr[e] = outer ? 0.5 * GRAVITY * (R.h * R.h - Rr.h * Rr.h) : 0.0;
+            ecn[e] = cn;
+            esn[e] = sn;
+          }
         } else {
+          if (HR) { ecl[e] = 0.0; ecr[e] = 0.0; ecn[e] = cn; esn[e] = sn; }  // boundary edges: HR is a no-op (operator_fluxes_petsc.c:57-58)
           const int    k  = a.tile_bk[td.b_off + ((lr >> EDGE_R_SHIFT) & EDGE_SLOT_MASK)];
           BoundaryFlux bf = boundary_flux(a.btype[k], true, L, a.bvalues + 3 * (int64_t)k, sn, cn, a.tiny_h, a.h_anuga_sq);
           fl              = bf.flux;
@@ -427,6 +474,12 @@ __global__ __launch_bounds__(TILE) void swe_rhs_tiled_kernel(const KernelArgs a,
               best_slot = s;
               best_o    = o;
             }
+          }
+          if (HR) {
+            const double k    = cur.coef[s];
+            const double corr = (k < 0.0) ? ecl[ref] : ecr[ref];  // this cell is the edge's left (k < 0) or right cell
+            acc1 += corr * ecn[ref] * k;
+            acc2 += corr * esn[ref] * k;
           }
         }
         cell_epilogue<SRC>(a, o, dt, sd_h[tid], sd_hu[tid], sd_hv[tid], sd_u[tid], sd_v[tid], acc0, acc1, acc2, cur.dzdx, cur.dzdy, cur.nman, cur.s0,

@@ -69,6 +69,7 @@ class RDyMesh:
     cell_areas: np.ndarray           # [Nc]
     cell_dz_dx: np.ndarray           # [Nc]
     cell_dz_dy: np.ndarray           # [Nc]
+    cell_zc: np.ndarray              # [Nc] vertex-averaged bed elevation (hydrostatic reconstruction, swe_petsc.c:1209-1224)
     # edges (local index)
     edge_cell_ids: np.ndarray        # [2*Ne] int32
     edge_vertex_ids: np.ndarray      # [Ne,2] int32 (oriented)
@@ -179,6 +180,7 @@ def build_mesh(xyz: np.ndarray, conn: np.ndarray,
                cell_global_ids: Optional[np.ndarray] = None,
                num_cells_global: Optional[int] = None,
                boundary_classifier: Optional[Callable[["RDyMesh"], List[RDyBoundary]]] = None,
+               project_2d: bool = False,
                ) -> RDyMesh:
     """Build the RDyMesh arrays from vertices + cell->vertex connectivity.
 
@@ -196,6 +198,18 @@ def build_mesh(xyz: np.ndarray, conn: np.ndarray,
     nverts = (conn >= 0).sum(axis=1).astype(np.int32)
 
     cent, area, dzdx, dzdy = _cell_geometry(xyz, conn, nverts)
+    # vertex-averaged bed elevation per cell (CreatePetscSWEInteriorFluxHROperator, swe_petsc.c:1209-1224)
+    zsum = np.where(conn >= 0, xyz[np.maximum(conn, 0), 2], 0.0).sum(axis=1)
+    zc = zsum / nverts
+    if project_2d:
+        # RDyMeshOverride2DProjection (src/rdymesh.c:1478-1509): x-y projected areas (shoelace)
+        xy = np.where((conn >= 0)[:, :, None], xyz[np.maximum(conn, 0), :2], 0.0)
+        nxt_i = (np.arange(4)[None, :] + 1) % nverts[:, None]
+        xn = np.take_along_axis(xy[:, :, 0], nxt_i, axis=1)
+        yn = np.take_along_axis(xy[:, :, 1], nxt_i, axis=1)
+        valid_v = conn >= 0
+        twice = np.where(valid_v, xy[:, :, 0] * yn - xn * xy[:, :, 1], 0.0).sum(axis=1)
+        area = np.abs(twice) / 2.0
 
     # ---- sides -> edges --------------------------------------------------
     j = np.arange(4)
@@ -252,7 +266,7 @@ def build_mesh(xyz: np.ndarray, conn: np.ndarray,
     ds = np.sqrt(dx * dx + dy * dy)
     sn = -dx / ds
     cn = dy / ds
-    lengths = np.linalg.norm(xyz[v2f] - xyz[v1f], axis=1)
+    lengths = ds.copy() if project_2d else np.linalg.norm(xyz[v2f] - xyz[v1f], axis=1)
 
     cell_ids = np.empty(2 * ne, dtype=np.int32)
     cell_ids[0::2] = left
@@ -281,7 +295,7 @@ def build_mesh(xyz: np.ndarray, conn: np.ndarray,
         xyz=xyz, cell_conn=conn, cell_nverts=nverts, cell_is_owned=is_owned,
         cell_local_to_owned=l2o, cell_owned_to_local=owned,
         cell_global_ids=np.ascontiguousarray(cell_global_ids, dtype=np.int64),
-        cell_centroids=cent, cell_areas=area, cell_dz_dx=dzdx, cell_dz_dy=dzdy,
+        cell_centroids=cent, cell_areas=area, cell_dz_dx=dzdx, cell_dz_dy=dzdy, cell_zc=zc,
         edge_cell_ids=cell_ids,
         edge_vertex_ids=np.stack([v1f, v2f], axis=1).astype(np.int32),
         edge_internal_ids=internal_ids, edge_boundary_ids=boundary_ids,
@@ -379,17 +393,17 @@ def structured_tri_connectivity(nx: int, ny: int, d: float = 1.0, i0: int = 0,
 def structured_tri_mesh(nx: int, ny: int, d: float = 1.0,
                         zfunc: Optional[Callable[[np.ndarray, np.ndarray], np.ndarray]] = None,
                         order: str = "rowmajor", tile: int = 16,
-                        boundaries: str = "sides") -> RDyMesh:
+                        boundaries: str = "sides", project_2d: bool = False) -> RDyMesh:
     """Single-rank synthetic triangle mesh on [0,nx*d] x [0,ny*d]."""
     xyz, conn, _, _ = structured_tri_connectivity(nx, ny, d, order=order, tile=tile)
     if zfunc is not None:
         xyz[:, 2] = zfunc(xyz[:, 0], xyz[:, 1])
     cls = box_side_boundaries(0.0, nx * d, 0.0, ny * d) if boundaries == "sides" else single_boundary()
-    return build_mesh(xyz, conn, boundary_classifier=cls)
+    return build_mesh(xyz, conn, boundary_classifier=cls, project_2d=project_2d)
 
 
 def structured_quad_mesh(nx: int, ny: int, dx: float = 1.0, dy: float = 1.0,
-                         zfunc=None, boundaries: str = "sides") -> RDyMesh:
+                         zfunc=None, boundaries: str = "sides", project_2d: bool = False) -> RDyMesh:
     ii, jj = np.meshgrid(np.arange(nx + 1), np.arange(ny + 1), indexing="xy")
     xyz = np.zeros(((nx + 1) * (ny + 1), 3))
     xyz[:, 0] = ii.ravel() * dx
@@ -402,7 +416,7 @@ def structured_quad_mesh(nx: int, ny: int, dx: float = 1.0, dy: float = 1.0,
     v = lambda i, j: j * (nx + 1) + i
     conn = np.stack([v(qi, qj), v(qi + 1, qj), v(qi + 1, qj + 1), v(qi, qj + 1)], 1).astype(np.int32)
     cls = box_side_boundaries(0.0, nx * dx, 0.0, ny * dy) if boundaries == "sides" else single_boundary()
-    return build_mesh(xyz, conn, boundary_classifier=cls)
+    return build_mesh(xyz, conn, boundary_classifier=cls, project_2d=project_2d)
 
 
 def refine_triangles(xyz: np.ndarray, conn: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
@@ -439,7 +453,7 @@ def extract_local_mesh(xyz: np.ndarray, conn: np.ndarray, owned_mask: np.ndarray
                        cell_global_ids: Optional[np.ndarray] = None,
                        num_cells_global: Optional[int] = None,
                        boundary_classifier=None,
-                       ghosts: str = "tail") -> RDyMesh:
+                       ghosts: str = "tail", project_2d: bool = False) -> RDyMesh:
     """Local mesh of one rank: the cells flagged in `owned_mask` plus every
     cell sharing an edge with one of them (the 1-cell overlap of
     DMPlexDistributeOverlap(dm, 1, ...), src/rdydm.c:145-157, under edge
@@ -487,7 +501,7 @@ def extract_local_mesh(xyz: np.ndarray, conn: np.ndarray, owned_mask: np.ndarray
     return build_mesh(xyz[used], sub_conn, is_owned=owned_mask[sel].astype(np.int32),
                       cell_global_ids=gids[sel],
                       num_cells_global=num_cells_global if num_cells_global is not None else nc,
-                      boundary_classifier=boundary_classifier)
+                      boundary_classifier=boundary_classifier, project_2d=project_2d)
 
 
 def strip_partition_tri_mesh(nx_per_rank: int, ny: int, rank: int, nranks: int, d: float = 1.0,

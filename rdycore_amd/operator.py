@@ -23,6 +23,8 @@ from .mesh import (CONDITION_CRITICAL_OUTFLOW, CONDITION_DIRICHLET, CONDITION_RE
 SOURCE_SEMI_IMPLICIT = 0     # RDyFlowSourceMethod, include/private/rdyconfigimpl.h:52-56
 SOURCE_IMPLICIT_XQ2018 = 1
 RIEMANN_ROE = 0
+WELL_BALANCING_NONE = 0      # RDyWellBalanceMethod, include/private/rdyconfigimpl.h:58-62
+WELL_BALANCING_HR = 2        # hydrostatic reconstruction
 
 PHASE_ALL, PHASE_INTERIOR, PHASE_HALO = 0, 1, 2
 
@@ -36,6 +38,7 @@ class RDyFlowConfig:
     xq2018_threshold: float = 1e-10
     source_method: int = SOURCE_SEMI_IMPLICIT
     riemann: int = RIEMANN_ROE
+    well_balancing: int = WELL_BALANCING_NONE
 
 
 @dataclasses.dataclass
@@ -108,13 +111,14 @@ class Operator:
         m.edge_lengths = arr(mesh.edge_lengths, np.float64).ctypes.data_as(_lib.c_double_p)
         m.edge_cn = arr(mesh.edge_cn, np.float64).ctypes.data_as(_lib.c_double_p)
         m.edge_sn = arr(mesh.edge_sn, np.float64).ctypes.data_as(_lib.c_double_p)
+        m.cell_zc = arr(mesh.cell_zc, np.float64).ctypes.data_as(_lib.c_double_p)
         barr = (_lib.RDyHipBoundary * max(nb, 1))()
         for i, b in enumerate(mesh.boundaries):
             barr[i].num_edges = b.num_edges
             barr[i].edge_ids = arr(b.edge_ids, np.int32).ctypes.data_as(_lib.c_int32_p)
             barr[i].condition_type = int(condition_types[i])
         cfg = _lib.RDyHipConfig(config.tiny_h, config.h_anuga_regular, config.xq2018_threshold,
-                                int(config.source_method), int(config.riemann))
+                                int(config.source_method), int(config.riemann), int(config.well_balancing), 0)
         h = C.c_void_p()
         _lib.check(lib.rdyhip_create(C.byref(cfg), C.byref(m), nb, barr, C.byref(h)))
         return cls(h, mesh, config, condition_types)

@@ -6,7 +6,7 @@ from oracle import oracle as O
 
 def oracle_from_case(case):
     cfg = case.config
-    orc = O.OracleOperator(case.mesh, case.condition_types, cfg.tiny_h, cfg.h_anuga_regular, cfg.xq2018_threshold, cfg.source_method)
+    orc = O.OracleOperator(case.mesh, case.condition_types, cfg.tiny_h, cfg.h_anuga_regular, cfg.xq2018_threshold, cfg.source_method, cfg.well_balancing)
     orc.mannings[:] = case.mannings
     orc.external_sources[:] = case.ext_src
     for b, vals in case.boundary_values.items():

@@ -251,3 +251,69 @@ def test_random_cell_numbering(kind):
     info = op.layout_info()
     if info["tiled_kernel"]:
         assert info["max_tile_halo_cells"] > 256
+
+
+# ---------------------------------------------------------------------------
+# hydrostatic reconstruction (src/swe/swe_petsc.c:1000-1263)
+# ---------------------------------------------------------------------------
+def hr_case(kind, source_method):
+    from rdycore_amd.operator import WELL_BALANCING_HR
+    K = 2 * np.pi / 19
+    z = lambda x, y: 0.6 * np.sin(K * x) * np.sin(K * y) + 0.02 * x      # bumps tall enough to leave islands
+    if kind == "tri":
+        mesh = M.structured_tri_mesh(33, 21, 1.0, zfunc=z, order="tiled", tile=4, project_2d=True)
+        lx, ly = 33, 21
+    else:
+        mesh = M.structured_quad_mesh(21, 13, 1.0, 1.5, zfunc=z, project_2d=True)
+        lx, ly = 21, 19.5
+    case = CS.friction_slope_case(mesh, lx, ly, dt=1e-2, source_method=source_method, K=K, dry_disc=True)
+    # shallow water over the bumps: some cells dry, some reconstructed depths clipped to zero
+    eta = 0.45
+    h = np.maximum(0.0, eta - mesh.cell_zc) * (1 + 0.2 * np.sin(0.7 * mesh.cell_centroids[:, 0]))
+    uu = case.u_local[:, 1] / np.maximum(case.u_local[:, 0], 1e-12)
+    vv = case.u_local[:, 2] / np.maximum(case.u_local[:, 0], 1e-12)
+    case.u_local = np.stack([h, h * uu, h * vv], axis=1)
+    case.config.well_balancing = WELL_BALANCING_HR
+    return case
+
+
+@pytest.mark.parametrize("kind", ["tri", "quad"])
+@pytest.mark.parametrize("source_method", [SOURCE_SEMI_IMPLICIT, SOURCE_IMPLICIT_XQ2018])
+def test_hydrostatic_reconstruction_parity(kind, source_method, rdyhip_kernel):
+    if rdyhip_kernel == "cell":
+        from rdycore_amd.operator import RDyHipError
+        with pytest.raises(RDyHipError):
+            CS.create_operator(hr_case(kind, source_method))     # HR lives in the tiled kernel only
+        return
+    case = hr_case(kind, source_method)
+    assert (case.u_local[:, 0] == 0).any() and (case.u_local[:, 0] > 0.1).any()
+    f, fr, op, orc = run_both(case)
+    check_all(case, f, fr, op, orc)
+    # accumulate semantics too
+    f0 = np.random.default_rng(11).normal(size=fr.shape) * 0.01
+    f2, fr2, op2, orc2 = run_both(case, accumulate_from=f0)
+    assert rel_linf(f2, fr2) <= TOL
+
+
+def test_hydrostatic_reconstruction_lake_at_rest(rdyhip_kernel):
+    if rdyhip_kernel == "cell":
+        pytest.skip("HR lives in the tiled kernel")
+    torch = _torch()
+    from rdycore_amd.operator import WELL_BALANCING_HR
+    K = 2 * np.pi / 9
+    mesh = M.structured_tri_mesh(40, 30, 1.0, zfunc=lambda x, y: 0.3 * np.sin(K * x) * np.cos(K * y), order="tiled", tile=4, project_2d=True)
+    case = CS.dam_break_case(mesh, 1e9, perturb=0.0)
+    case.u_local[:, 0] = 2.0 - mesh.cell_zc
+    case.config.well_balancing = WELL_BALANCING_HR
+    op = CS.create_operator(case)
+    u = torch.tensor(case.u_local, dtype=torch.float64, device="cuda")
+    f = torch.empty((mesh.num_owned_cells, 3), dtype=torch.float64, device="cuda")
+    op.rhs_function(case.dt, u, f)
+    assert float(f.abs().max()) < 1e-12
+
+
+def test_unsupported_well_balancing_is_rejected():
+    from rdycore_amd.operator import Operator, RDyFlowConfig, RDyHipError
+    _torch()
+    with pytest.raises(RDyHipError):
+        Operator.create(RDyFlowConfig(well_balancing=1), M.structured_tri_mesh(4, 3))   # BS2002: CEED only (src/operator.c:388)

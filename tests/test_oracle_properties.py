@@ -58,3 +58,20 @@ def test_dt_enters_the_rhs_through_friction_and_courant():
     assert np.abs(f1[:, 1] - f2[:, 1]).max() > 1e-6
     assert np.array_equal(f1[:, 0], f2[:, 0])
     assert abs(o2.diagnostics()[0] / o1.diagnostics()[0] - 100.0) < 1e-9
+
+
+def test_hydrostatic_reconstruction_keeps_a_lake_at_rest():
+    # the defining property of HR well-balancing: flat free surface over a bumpy
+    # bed is a steady state (docs/theory/second_order_hydrostatic_reconstruction.md);
+    # without HR the first-order scheme is not.
+    from rdycore_amd.operator import WELL_BALANCING_HR
+    K = 2 * np.pi / 9
+    mesh = M.structured_tri_mesh(14, 10, 1.0, zfunc=lambda x, y: 0.3 * np.sin(K * x) * np.cos(K * y), project_2d=True)
+    case = CS.dam_break_case(mesh, 1e9, perturb=0.0)
+    case.u_local[:, 0] = 2.0 - mesh.cell_zc            # eta = h + zc = 2 everywhere
+    case.config.well_balancing = WELL_BALANCING_HR
+    f = oracle_from_case(case).apply(case.dt, case.u_local)
+    assert np.abs(f).max() < 1e-12
+    case.config.well_balancing = 0
+    f0 = oracle_from_case(case).apply(case.dt, case.u_local)
+    assert np.abs(f0).max() > 1e-3
