@@ -46,13 +46,14 @@ def parse():
     p.add_argument("--workload", default="c3", choices=["c3", "c2"],
                    help="c3: friction + bed slope + all BC types (default; use --nx 2500 --ny 2000); "
                         "c2: flat-bed dam break, all reflecting (BASELINE configs[1]: --nx 1000 --ny 500)")
+    p.add_argument("--hr", action="store_true", help="hydrostatic-reconstruction variant of the operator (SURVEY 8.f row 2)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--kernel", default=None, choices=["tiled", "cell"], help="kernel variant (default: library default = tiled)")
     p.add_argument("--cpu-sample", default="1000x500", help="nx x ny of the CPU-baseline sample mesh")
     return p.parse_args()
 
 
-def build_case(nx, ny, rank, world, order, source, workload="c3"):
+def build_case(nx, ny, rank, world, order, source, workload="c3", hr=False):
     from rdycore_amd import cases as CS
     from rdycore_amd import mesh as M
     from rdycore_amd.operator import SOURCE_IMPLICIT_XQ2018, SOURCE_SEMI_IMPLICIT
@@ -60,22 +61,27 @@ def build_case(nx, ny, rank, world, order, source, workload="c3"):
     src = SOURCE_SEMI_IMPLICIT if source == "semi_implicit" else SOURCE_IMPLICIT_XQ2018
     zf = CS.mms_bathymetry(K=K) if workload == "c3" else None
     if world == 1:
-        mesh = M.structured_tri_mesh(nx, ny, 1.0, zfunc=zf, order=order)
+        mesh = M.structured_tri_mesh(nx, ny, 1.0, zfunc=zf, order=order, project_2d=hr)
     else:
         mesh = M.strip_partition_tri_mesh(nx, ny, rank, world, 1.0, zfunc=zf, order=order)
     if workload == "c2":
-        return CS.dam_break_case(mesh, nx * world * 1.0, dt=1e-3, source_method=src)
-    return CS.friction_slope_case(mesh, nx * world * 1.0, ny * 1.0, dt=1e-3, source_method=src, K=K)
+        case = CS.dam_break_case(mesh, nx * world * 1.0, dt=1e-3, source_method=src)
+    else:
+        case = CS.friction_slope_case(mesh, nx * world * 1.0, ny * 1.0, dt=1e-3, source_method=src, K=K)
+    if hr:
+        from rdycore_amd.operator import WELL_BALANCING_HR
+        case.config.well_balancing = WELL_BALANCING_HR
+    return case
 
 
-def cpu_baseline(sample: str, source: str):
+def cpu_baseline(sample: str, source: str, workload: str = "c3", hr: bool = False):
     """The CPU oracle (a plain-C restatement of the reference's PETSc path, one
     core) timed on a bounded sample of the same workload."""
     from oracle import oracle as O  # test infrastructure; used here only as the timed CPU baseline
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from helpers import oracle_from_case
     nx, ny = map(int, sample.split("x"))
-    case = build_case(nx, ny, 0, 1, "rowmajor", source)
+    case = build_case(nx, ny, 0, 1, "rowmajor", source, workload, hr)
     orc = oracle_from_case(case)
     f = np.zeros((case.mesh.num_owned_cells, 3))
     orc.apply(case.dt, case.u_local, f)  # warm
@@ -132,7 +138,7 @@ def main():
     from rdycore_amd.halo import HaloExchange
 
     t0 = time.time()
-    case = build_case(args.nx, args.ny, rank, world, args.order, args.source, args.workload)
+    case = build_case(args.nx, args.ny, rank, world, args.order, args.source, args.workload, args.hr)
     mesh = case.mesh
     op = CS.create_operator(case)
     halo = HaloExchange(mesh, dev) if world > 1 else None
@@ -216,6 +222,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": workload, "cells_per_gpu": n_owned, "cell_order": args.order,
                        "partition": "single" if world == 1 else f"strips_x{world}",
+                       "well_balancing": "hydrostatic_reconstruction" if args.hr else "none",
                        "halo_bytes_per_rank": halo.bytes_sent_per_exchange if halo else 0,
                        "setup_seconds": round(setup_s, 1), "max_courant": courant, "finite": finite},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -229,7 +236,7 @@ def main():
                          "layout_bytes_per_launch": int(info["bytes_per_apply"])},
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.source)
+            out["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.source, args.workload, args.hr)
         print(json.dumps(out), flush=True)
     op.destroy()
     if world > 1:
