@@ -100,7 +100,7 @@ struct RDyHipOperator_s {
   bool         keep_fdiv = false;
 
   DevBuf<int32_t> d_o2l, d_nbr, d_pos, d_halo_list, d_btype, d_bleft, d_bghost_list;
-  DevBuf<double>  d_cn, d_sn, d_coef, d_dzdx, d_dzdy, d_mannings, d_extsrc, d_area_local;
+  DevBuf<double>  d_cn, d_sn, d_coef, d_dzdx, d_dzdy, d_mannings, d_extsrc;
   DevBuf<double>  d_bvalues, d_bflux, d_baccum, d_bcn, d_bsn, d_pv, d_fdiv, d_blk_max;
   DevBuf<int32_t> d_blk_pos;
   DevBuf<DeviceCourant> d_courant;
@@ -135,7 +135,7 @@ struct RDyHipOperator_s {
   ~RDyHipOperator_s() {
     d_o2l.release(); d_nbr.release(); d_pos.release(); d_halo_list.release(); d_btype.release(); d_bleft.release();
     d_bghost_list.release(); d_cn.release(); d_sn.release(); d_coef.release(); d_dzdx.release(); d_dzdy.release();
-    d_mannings.release(); d_extsrc.release(); d_area_local.release(); d_bvalues.release(); d_bflux.release();
+    d_mannings.release(); d_extsrc.release(); d_bvalues.release(); d_bflux.release();
     d_baccum.release(); d_bcn.release(); d_bsn.release(); d_pv.release(); d_fdiv.release(); d_blk_max.release();
     d_blk_pos.release(); d_courant.release(); d_stage_vals.release(); d_stage_ids.release();
     d_tiles.release(); d_e_lr.release(); d_hcells.release(); d_tile_bk.release(); d_halo_tiles.release();
@@ -176,7 +176,6 @@ int launch_rhs(RDyHipOperator op, int32_t phase, int32_t overwrite, int reset_di
   a.dzdy       = op->d_dzdy.p;
   a.mannings   = op->d_mannings.p;
   a.extsrc     = op->d_extsrc.p;
-  a.area_local = op->d_area_local.p;
   a.btype      = op->d_btype.p;
   a.bvalues    = op->d_bvalues.p;
   a.bflux      = op->d_bflux.p;
@@ -581,7 +580,6 @@ int rdyhip_create(const RDyHipConfig *config, const RDyHipMesh *mesh, int32_t nu
   TRY_RC(op->d_bsn.upload(bsn));
   {
     std::vector<double> area(mesh->cell_areas, mesh->cell_areas + nc);
-    TRY_RC(op->d_area_local.upload(area));
     op->h_area.swap(area);
   }
   TRY_RC(op->d_tiles.upload(tiles));
@@ -632,7 +630,7 @@ int rdyhip_create(const RDyHipConfig *config, const RDyHipMesh *mesh, int32_t nu
   if (mesh->edge_global_ids) op->h_edge_gid.assign(mesh->edge_global_ids, mesh->edge_global_ids + ne);
 
   op->device_bytes = op->d_o2l.bytes() + op->d_nbr.bytes() + op->d_pos.bytes() + op->d_cn.bytes() + op->d_sn.bytes() + op->d_coef.bytes() +
-                     op->d_dzdx.bytes() + op->d_dzdy.bytes() + op->d_mannings.bytes() + op->d_extsrc.bytes() + op->d_area_local.bytes() +
+                     op->d_dzdx.bytes() + op->d_dzdy.bytes() + op->d_mannings.bytes() + op->d_extsrc.bytes() +
                      op->d_pv.bytes() + op->d_bvalues.bytes() + op->d_bflux.bytes() + op->d_baccum.bytes() + op->d_blk_max.bytes() +
                      op->d_blk_pos.bytes() + op->d_tiles.bytes() + op->d_e_lr.bytes() + op->d_hcells.bytes() + op->d_tile_bk.bytes() +
                      op->d_e_cs.bytes() + op->d_slot_ref.bytes() + op->d_slot_ref3.bytes();

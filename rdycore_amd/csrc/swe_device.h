@@ -1,10 +1,13 @@
 // Device-side arithmetic of the SWE right-hand side for gfx950.
 //
-// Each function keeps the operand order of the reference expression it stands
-// for, so that the only differences from the CPU path are (a) FMA contraction,
-// (b) sqrt()/cbrt() in place of pow(x,0.5)/pow(x,+-k/3) and (c) the order in
-// which a cell's edge contributions are summed -- which is made the same as the
-// reference's edge-loop order by the slot ordering built in rdyhip_api.hip.
+// Each function keeps the formulas and operand order of the reference
+// expression it stands for; the differences from the CPU path are (a) FMA
+// contraction, (b) square / cube roots and reciprocals computed from
+// v_rsq_f64 / v_rcp_f64 with Newton refinement (<= 1 ulp) instead of
+// pow(x,0.5), pow(x,+-k/3) and IEEE division, with divisions that share a
+// denominator sharing one reciprocal.  All of it stays ~1e-15 relative; the
+// parity bar is 1e-10 (tests/test_gpu_parity.py).  A cell's edge contributions
+// are summed in the reference's edge-loop order (slot ordering, rdyhip_api.hip).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -12,7 +15,8 @@
 namespace rdyhip {
 
 // src/swe/swe_types_petsc.h:7
-constexpr double GRAVITY = 9.806;
+constexpr double GRAVITY      = 9.806;
+constexpr double SQRT_GRAVITY = 3.1314533367112465;  // sqrt(9.806) correctly rounded
 
 constexpr int32_t NBR_EMPTY = INT32_MIN;    // unused slot (triangle in a 4-slot layout)
 constexpr int32_t NBR_GHOST = 1 << 30;      // neighbour is a ghost (non-owned) cell
@@ -87,21 +91,13 @@ __device__ __forceinline__ RiemannSide riemann_side(double h, double hu, double 
   s.sqh = h; s.c = h;
 #else
   s.sqh = rdy_sqrt(h);
+#ifdef RDYHIP_EXP_TWO_SQRT
   s.c   = rdy_sqrt(GRAVITY * h);
+#else
+  s.c   = SQRT_GRAVITY * s.sqh;  // sqrt(g h) = sqrt(g) sqrt(h): one multiply instead of a second square root
+#endif
 #endif
   return s;
-}
-
-// ComputeRiemannVelocities for a state given as (h, hu, hv) only
-__device__ __forceinline__ void riemann_velocity(double h, double hu, double hv, double tiny_h, double h_anuga_sq, double &u, double &v) {
-  if (h < tiny_h) {
-    u = 0.0;
-    v = 0.0;
-  } else {
-    const double r = h * rdy_rcp(h * h + h_anuga_sq);
-    u              = hu * r;
-    v              = hv * r;
-  }
 }
 
 // ComputeSWERoeEigenspectrum + ComputeSWERoeFlux for one edge,
@@ -204,7 +200,7 @@ __device__ __forceinline__ BoundaryFlux boundary_flux(int type, bool left_owned,
         const double q = L.h * fabs(uperp);
         R.h            = cbrt(q * q / GRAVITY);
         R.sqh          = rdy_sqrt(R.h);
-        R.c            = rdy_sqrt(GRAVITY * R.h);
+        R.c            = SQRT_GRAVITY * R.sqh;
         R.u            = R.c * cn;
         R.v            = R.c * sn;
       }

@@ -61,7 +61,6 @@ struct KernelArgs {
   const double  *dzdx, *dzdy;  // [n_owned]
   const double  *mannings;   // [n_owned]
   const double  *extsrc;     // [n_owned][3]
-  const double  *area_local; // [num_cells]
   const int32_t *btype;      // [K] condition type of boundary edge k
   const double  *bvalues;    // [K][3]
   double        *bflux;      // [K][3]
@@ -416,8 +415,8 @@ __global__ __launch_bounds__(TILE) void swe_rhs_tiled_kernel(const KernelArgs a,
             Rr.v   = (R.h > a.tiny_h) ? R.v : 0.0;
             Lr.sqh = rdy_sqrt(Lr.h);
             Rr.sqh = rdy_sqrt(Rr.h);
-            Lr.c   = rdy_sqrt(GRAVITY * Lr.h);
-            Rr.c   = rdy_sqrt(GRAVITY * Rr.h);
+            Lr.c   = SQRT_GRAVITY * Lr.sqh;
+            Rr.c   = SQRT_GRAVITY * Rr.sqh;
             fl     = roe_flux(Lr, Rr, sn, cn);
             const bool outer = !(R.h < a.tiny_h && L.h < a.tiny_h);       // 1094
             wet              = outer && (Lr.h > a.tiny_h || Rr.h > a.tiny_h);  // inner guard, 1112
