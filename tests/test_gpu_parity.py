@@ -317,3 +317,80 @@ def test_unsupported_well_balancing_is_rejected():
     _torch()
     with pytest.raises(RDyHipError):
         Operator.create(RDyFlowConfig(well_balancing=1), M.structured_tri_mesh(4, 3))   # BS2002: CEED only (src/operator.c:388)
+
+
+# ---------------------------------------------------------------------------
+# edge cases: empty and ragged inputs
+# ---------------------------------------------------------------------------
+def test_rank_with_no_owned_cells():
+    # a rank may own nothing (more ranks than cells): every call is a no-op
+    torch = _torch()
+    from rdycore_amd.operator import Operator, RDyFlowConfig
+    xyz, conn, _, _ = M.structured_tri_connectivity(3, 2)
+    mesh = M.build_mesh(xyz, conn, is_owned=np.zeros(conn.shape[0], dtype=np.int32), boundary_classifier=M.box_side_boundaries(0, 3, 0, 2))
+    assert mesh.num_owned_cells == 0 and mesh.num_cells == 12
+    op = Operator.create(RDyFlowConfig(), mesh)
+    u = torch.ones((mesh.num_cells, 3), dtype=torch.float64, device="cuda")
+    f = torch.zeros((0, 3), dtype=torch.float64, device="cuda")
+    op.rhs_function(0.1, u, f)
+    op.apply(0.1, u, f)
+    op.update_diagnostics()
+    d = op.get_diagnostics()
+    assert (d.max_courant_num, d.global_edge_id, d.global_cell_id) == (0.0, -1, -1)   # ResetOperatorDiagnostics values
+    assert op.primitive_variables.shape[0] == 0
+    op.destroy()
+
+
+def test_single_cell_and_empty_boundaries():
+    # one triangle: three boundary edges spread over boundaries of 2, 1 and 0 edges
+    xyz = np.array([[0.0, 0.0, 0.0], [2.0, 0.0, 0.1], [0.0, 1.0, 0.3]])
+    conn = np.array([[0, 1, 2]], dtype=np.int32)
+
+    def cls(mesh):
+        be = mesh.edge_boundary_ids
+        return [M.RDyBoundary(1, "two", be[:2].astype(np.int32)), M.RDyBoundary(2, "one", be[2:].astype(np.int32)),
+                M.RDyBoundary(3, "none", np.zeros(0, dtype=np.int32))]
+
+    mesh = M.build_mesh(xyz, conn, boundary_classifier=cls)
+    from rdycore_amd.operator import RDyFlowConfig
+    case = CS.Case("one_cell", mesh, RDyFlowConfig(source_method=SOURCE_IMPLICIT_XQ2018),
+                   [M.CONDITION_REFLECTING, M.CONDITION_DIRICHLET, M.CONDITION_CRITICAL_OUTFLOW],
+                   np.array([[1.3, 0.4, -0.2]]), np.array([0.03]), np.array([[1e-4, 0.0, 2e-4]]),
+                   {1: np.array([[0.9, 0.1, 0.05]])}, 0.01)
+    f, fr, op, orc = run_both(case)
+    check_all(case, f, fr, op, orc)
+    assert op.boundary_fluxes(2).shape == (0, 3)
+
+
+def test_nan_state_propagates_like_the_reference():
+    # a NaN depth is "not dry" for every guard (!(h < tiny_h)): it poisons exactly the cells the reference poisons
+    mesh = M.structured_tri_mesh(12, 8)
+    case = CS.dam_break_case(mesh, 12.0)
+    case.u_local[37, 0] = np.nan
+    f, fr, op, orc = run_both(case)
+    assert np.array_equal(np.isnan(f), np.isnan(fr))
+    ok = ~np.isnan(fr)
+    assert np.isnan(fr).any() and rel_linf(f[ok], fr[ok]) <= TOL
+
+
+def test_repeated_applies_and_persistent_diagnostics():
+    # diagnostics persist across applies until reset (src/operator.c:772-784); boundary accumulations add up
+    torch = _torch()
+    case = tri_mms_case(19, 11, SOURCE_SEMI_IMPLICIT)
+    op = CS.create_operator(case)
+    orc = oracle_from_case(case)
+    u1 = case.u_local.copy()
+    u2 = case.u_local.copy()
+    u2[:, 1:] *= 3.0                                  # faster flow: larger Courant number
+    f = torch.zeros((case.mesh.num_owned_cells, 3), dtype=torch.float64, device="cuda")
+    op.reset_diagnostics()
+    for uu in (u2, u1):                               # the larger value comes first and must survive the second apply
+        f.zero_()
+        op.apply(case.dt, torch.tensor(uu, dtype=torch.float64, device="cuda"), f)
+        orc.apply(case.dt, uu)
+    op.update_diagnostics()
+    d = op.get_diagnostics()
+    cmax, ce, cc = orc.diagnostics()
+    assert abs(d.max_courant_num - cmax) <= 1e-12 and (d.global_edge_id, d.global_cell_id) == (ce, cc)
+    for b in range(len(case.mesh.boundaries)):
+        assert rel_linf(np.nan_to_num(op.boundary_fluxes(b, accumulated=True)), np.nan_to_num(orc.boundary_fluxes_accum[b])) <= TOL
