@@ -161,8 +161,8 @@ TiledKernelFn tiled_kernel_fn(int S, int src, bool ovw, bool hr) { return hr ? t
 
 int launch_rhs(RDyHipOperator op, int32_t phase, int32_t overwrite, int reset_diag, double dt, const double *u, double *f, hipStream_t st) {
   if (!op) return fail(RDYHIP_ERR_USER, "null operator");
+  if (op->n_owned == 0) return reset_diag ? rdyhip_reset_diagnostics(op, (void *)st) : 0;  // a rank may own nothing (f_global is then empty)
   if (!u || !f) return fail(RDYHIP_ERR_USER, "null u_local / f_global");
-  if (op->n_owned == 0) return reset_diag ? rdyhip_reset_diagnostics(op, (void *)st) : 0;
   KernelArgs a{};
   a.n_owned    = op->n_owned;
   a.stride     = op->stride;
