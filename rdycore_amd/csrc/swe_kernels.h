@@ -86,6 +86,15 @@ struct KernelArgs {
   int32_t         hmax;      // largest halo-cell count of a tile (LDS sizing)
 };
 
+// Wave-uniform loads of read-only index data through the constant address space,
+// so that hipcc emits scalar loads (s_load, counted by lgkmcnt) instead of vector
+// loads whose s_waitcnt vmcnt(0) would also wait for every prefetch in flight.
+template <typename T>
+__device__ __forceinline__ T load_uniform(const T *p, int i) {
+  typedef const __attribute__((address_space(4))) T *ConstPtr;
+  return ((ConstPtr)(uintptr_t)p)[i];
+}
+
 __device__ __forceinline__ double wave_max(double v) {
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
@@ -124,6 +133,36 @@ __device__ __forceinline__ void cell_epilogue(const KernelArgs &a, int o, double
   a.pv[3 * (int64_t)o + 0] = h;
   a.pv[3 * (int64_t)o + 1] = pu;
   a.pv[3 * (int64_t)o + 2] = pv_;
+}
+
+// cell_epilogue split in two for the pipelined kernel: the arithmetic ...
+template <int SRC>
+__device__ __forceinline__ void cell_results(const KernelArgs &a, double dt, double h, double hu, double hv, double acc0, double acc1, double acc2,
+                                             double dzdx, double dzdy, double n, double s0, double s1, double s2, double *out) {
+  const double bedx = dzdx * GRAVITY * h;
+  const double bedy = dzdy * GRAVITY * h;
+  double       tbx = 0.0, tby = 0.0;
+  if (h >= a.tiny_h) {
+    if (SRC == RDYHIP_SOURCE_SEMI_IMPLICIT) friction_semi_implicit(h, hu, hv, n, dt, acc1, acc2, bedx, bedy, tbx, tby);
+    else friction_xq2018(h, hu, hv, n, dt, a.xq_thresh, acc1, acc2, bedx, bedy, tbx, tby);
+  }
+  out[0] = acc0 + s0;
+  out[1] = acc1 + (-bedx - tbx + s1);
+  out[2] = acc2 + (-bedy - tby + s2);
+}
+// ... and the stores of F, the primitive variables and (optionally) the flux divergence
+__device__ __forceinline__ void cell_store(const KernelArgs &a, int o, const double *fdiv, const double *out, double *__restrict__ f) {
+  if (a.fdiv) {
+    a.fdiv[3 * (int64_t)o + 0] = fdiv[0];
+    a.fdiv[3 * (int64_t)o + 1] = fdiv[1];
+    a.fdiv[3 * (int64_t)o + 2] = fdiv[2];
+  }
+  f[3 * (int64_t)o + 0]    = out[0];
+  f[3 * (int64_t)o + 1]    = out[1];
+  f[3 * (int64_t)o + 2]    = out[2];
+  a.pv[3 * (int64_t)o + 0] = out[3];
+  a.pv[3 * (int64_t)o + 1] = out[4];
+  a.pv[3 * (int64_t)o + 2] = out[5];
 }
 
 // Block reduction of the Courant number: max value, then the smallest loop
@@ -272,10 +311,17 @@ __global__ __launch_bounds__(TILE) void swe_rhs_tiled_kernel(const KernelArgs a,
     step = gridDim.x;
     hi   = a.n_work;
   }
-  auto tile_at = [&](int i) -> int { return a.list ? a.list[i] : i; };
+  auto tile_at = [&](int i) -> int { return __builtin_amdgcn_readfirstlane(a.list ? load_uniform(a.list, i) : i); };
+  auto tile_desc = [&](int t) -> TileDesc {
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    const v4i v = load_uniform(reinterpret_cast<const v4i *>(a.tiles), t);
+    TileDesc  d;
+    d.e_off = v.x; d.h_off = v.y; d.b_off = v.z; d.halo = v.w;
+    return d;
+  };
   auto next_valid = [&](int i) -> int {  // INTERIOR phase skips tiles with ghost-adjacent cells (wave-uniform)
     if (a.phase == RDYHIP_PHASE_INTERIOR) {
-      while (i < hi && a.tiles[tile_at(i)].halo) i += step;
+      while (i < hi && tile_desc(tile_at(i)).halo) i += step;
     }
     return i;
   };
@@ -287,7 +333,7 @@ __global__ __launch_bounds__(TILE) void swe_rhs_tiled_kernel(const KernelArgs a,
   if (idx < hi) {
     // ---- prologue: everything tile T0 needs, and the halo ids of T1
     int      tile = tile_at(idx);
-    TileDesc td = a.tiles[tile], tn = a.tiles[tile + 1];
+    TileDesc td = tile_desc(tile), tn = tile_desc(tile + 1);
     double   pu0 = 0.0, pu1 = 0.0, pu2 = 0.0;  // own cell state of the tile being started
     double   ph0 = 0.0, ph1 = 0.0, ph2 = 0.0;  // state of this thread's halo cell
     double   pz = 0.0, phz = 0.0;              // HR: bed elevation of the own / halo cell
@@ -312,23 +358,21 @@ __global__ __launch_bounds__(TILE) void swe_rhs_tiled_kernel(const KernelArgs a,
       load_streams<S, HR>(a, o, o < a.n_owned, cur);
     }
     int      idx1 = next_valid(idx + step);
-    int      tile1 = 0, hid1 = 0;
+    int      tile1 = 0, hid1 = 0, c1 = 0;  // next tile: this thread's halo cell and own cell (local ids)
     TileDesc td1 = td, tn1 = tn;
     if (idx1 < hi) {
       tile1 = tile_at(idx1);
-      td1   = a.tiles[tile1];
-      tn1   = a.tiles[tile1 + 1];
+      td1   = tile_desc(tile1);
+      tn1   = tile_desc(tile1 + 1);
       if (tid < tn1.h_off - td1.h_off) hid1 = a.hcells[td1.h_off + tid];
+      const int o1 = tile1 * TILE + tid;
+      c1           = (a.o2l && o1 < a.n_owned) ? a.o2l[o1] : o1;
     }
 
     while (true) {
       const int  ne = tn.e_off - td.e_off, nh = tn.h_off - td.h_off;
       const int  o      = tile * TILE + tid;
       const bool active = o < a.n_owned;
-
-      // ---- software pipeline (1): the next tile's per-cell streams, a full tile ahead
-      CellStreams<S> nxt;
-      load_streams<S, HR>(a, tile1 * TILE + tid, idx1 < hi && tile1 * TILE + tid < a.n_owned, nxt);
 
       // ---- phase 0: Riemann side data of the tile's own and halo cells -> LDS
       {
@@ -353,15 +397,32 @@ __global__ __launch_bounds__(TILE) void swe_rhs_tiled_kernel(const KernelArgs a,
       }
       __syncthreads();
 
-      // ---- software pipeline (2): cell states and edge records of the next tile, halo ids of the one after
-      int      idx2 = hi, tile2 = 0, hid2 = 0;
+      // ---- software pipeline: EVERY global load of the next tile (cell states, edge records, per-cell
+      // streams) and the halo ids of the one after are issued here in one batch.  hipcc waits with
+      // s_waitcnt vmcnt(0) wherever a loaded register is first used, so the batch must not be followed
+      // by any such use until the end of the tile: phases 1 and 2 below touch only registers whose
+      // loads completed a tile ago, and the first use of this batch is the register rotation at the
+      // very end (one wait per tile, a whole flux phase after the loads were issued).
+      // (a) which tile comes after the next, and the ids it needs (the only dependent loads: first)
+      int      idx2 = hi, tile2 = 0, hid2 = 0, c2 = 0;
       TileDesc td2 = td1, tn2 = tn1;
+      if (idx1 < hi) {
+        idx2 = next_valid(idx1 + step);
+        if (idx2 < hi) {
+          tile2 = tile_at(idx2);
+          td2   = tile_desc(tile2);
+          tn2   = tile_desc(tile2 + 1);
+          if (tid < tn2.h_off - td2.h_off) hid2 = a.hcells[td2.h_off + tid];
+          const int o2 = tile2 * TILE + tid;
+          c2           = (a.o2l && o2 < a.n_owned) ? a.o2l[o2] : o2;
+        }
+      }
+      // (b) the next tile's cell states, edge records and per-cell streams
       uint32_t nlr0 = 0, nlr1 = 0;
       double   ncs0 = 0.0, ncs1 = 0.0;
+      CellStreams<S> nxt;
       if (idx1 < hi) {
-        const int o1 = tile1 * TILE + tid;
-        if (o1 < a.n_owned) {
-          const int c1 = a.o2l ? a.o2l[o1] : o1;
+        if (tile1 * TILE + tid < a.n_owned) {
           pu0 = u[3 * (int64_t)c1 + 0]; pu1 = u[3 * (int64_t)c1 + 1]; pu2 = u[3 * (int64_t)c1 + 2];
           if (HR) pz = a.zc_local[c1];
         }
@@ -372,22 +433,13 @@ __global__ __launch_bounds__(TILE) void swe_rhs_tiled_kernel(const KernelArgs a,
         const int ne1 = tn1.e_off - td1.e_off;
         if (tid < ne1) { nlr0 = a.e_lr[td1.e_off + tid]; ncs0 = a.e_cs[td1.e_off + tid]; }
         if (tid + TILE < ne1) { nlr1 = a.e_lr[td1.e_off + TILE + tid]; ncs1 = a.e_cs[td1.e_off + TILE + tid]; }
-        idx2 = next_valid(idx1 + step);
-        if (idx2 < hi) {
-          tile2 = tile_at(idx2);
-          td2   = a.tiles[tile2];
-          tn2   = a.tiles[tile2 + 1];
-          if (tid < tn2.h_off - td2.h_off) hid2 = a.hcells[td2.h_off + tid];
-        }
       }
+      load_streams<S, HR>(a, tile1 * TILE + tid, idx1 < hi && tile1 * TILE + tid < a.n_owned, nxt);
 
       // ---- phase 1: every edge of the tile once, operands from LDS only
       // (ApplyInteriorFlux / ApplyBoundaryFlux, swe_petsc.c:215-316, 506-630)
-      for (int e = tid; e < ne; e += TILE) {
-        const int      round = e / TILE;  // wave-uniform
-        const uint32_t lr    = round == 0 ? lr0 : (round == 1 ? lr1 : a.e_lr[td.e_off + e]);
-        const double   cs    = round == 0 ? cs0 : (round == 1 ? cs1 : a.e_cs[td.e_off + e]);
-        double         cn, sn;
+      auto do_edge = [&](int e, uint32_t lr, double cs) {
+        double cn, sn;
         edge_normal(lr, cs, cn, sn);
         const int   jl = lr & EDGE_SLOT_MASK;
         RiemannSide L;
@@ -438,10 +490,22 @@ __global__ __launch_bounds__(TILE) void swe_rhs_tiled_kernel(const KernelArgs a,
         ef1[e] = fl.f1;
         ef2[e] = fl.f2;
         eam[e] = wet ? fl.amax : -1.0;  // -1 marks a dry-dry edge (skipped, swe_petsc.c:285)
+      };
+      // Rounds 0 and 1 take their records from registers.  This loop must contain no global load on any
+      // path: hipcc would put an s_waitcnt vmcnt(0) at the merge, and every round would then wait for
+      // the whole prefetch batch issued above.
+#pragma unroll 1
+      for (int r = 0; r < 2; ++r) {
+        const int e = tid + r * TILE;
+        if (e < ne) do_edge(e, r == 0 ? lr0 : lr1, r == 0 ? cs0 : cs1);
       }
+      // further rounds (quads, or numberings with poor locality) load their records here
+      for (int e = tid + 2 * TILE; e < ne; e += TILE) do_edge(e, a.e_lr[td.e_off + e], a.e_cs[td.e_off + e]);
       __syncthreads();
 
-      // ---- phase 2: per-cell sum in the reference's edge order, source terms, stores
+      // ---- phase 2: per-cell sum in the reference's edge order, source terms; the stores come last
+      double out[6]      = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};  // F[3], then the primitive variables (h, u, v)
+      double acc_fdiv[3] = {0.0, 0.0, 0.0};
       if (active) {
         double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
         if (!OVW) {  // ApplyOperator semantics: add into f (and let the friction term see it)
@@ -481,15 +545,30 @@ __global__ __launch_bounds__(TILE) void swe_rhs_tiled_kernel(const KernelArgs a,
             acc2 += corr * esn[ref] * k;
           }
         }
-        cell_epilogue<SRC>(a, o, dt, sd_h[tid], sd_hu[tid], sd_hv[tid], sd_u[tid], sd_v[tid], acc0, acc1, acc2, cur.dzdx, cur.dzdy, cur.nman, cur.s0,
-                           cur.s1, cur.s2, f);
+        acc_fdiv[0] = acc0;
+        acc_fdiv[1] = acc1;
+        acc_fdiv[2] = acc2;
+        cell_results<SRC>(a, dt, sd_h[tid], sd_hu[tid], sd_hv[tid], acc0, acc1, acc2, cur.dzdx, cur.dzdy, cur.nman, cur.s0, cur.s1, cur.s2, out);
+        out[3] = sd_h[tid];
+        out[4] = sd_u[tid];
+        out[5] = sd_v[tid];
       }
-
-      if (idx1 >= hi) break;
+      const bool last = idx1 >= hi;
+      // The tile's single wait on global loads: the youngest load of the prefetch batch is "used" here, before
+      // this tile's stores are issued (vmcnt counts stores too, and the register rotation below is
+      // materialised at the very end of the loop body).
+      asm volatile("" ::"v"(pu0), "v"(pu1), "v"(pu2), "v"(ph0), "v"(ph1), "v"(ph2), "v"(pz), "v"(phz), "v"(nlr0), "v"(nlr1), "v"(ncs0), "v"(ncs1),
+                   "v"(hid2), "v"(c2));
+      asm volatile("" ::"v"(nxt.r0), "v"(nxt.r1), "v"(nxt.coef[0]), "v"(nxt.coef[1]), "v"(nxt.coef[2]), "v"(nxt.coef[S - 1]), "v"(nxt.dzdx),
+                   "v"(nxt.dzdy), "v"(nxt.nman), "v"(nxt.s0), "v"(nxt.s1), "v"(nxt.s2));
+      // rotate the pipeline registers, store
       idx = idx1; tile = tile1; td = td1; tn = tn1;
-      idx1 = idx2; tile1 = tile2; td1 = td2; tn1 = tn2; hid1 = hid2;
+      idx1 = idx2; tile1 = tile2; td1 = td2; tn1 = tn2; hid1 = hid2; c1 = c2;
       lr0 = nlr0; lr1 = nlr1; cs0 = ncs0; cs1 = ncs1;
       cur = nxt;
+      __builtin_amdgcn_sched_barrier(0);
+      if (active) cell_store(a, o, acc_fdiv, out, f);
+      if (last) break;
     }
   }
   block_courant_reduce<TILE>(a, best, best_slot, best_o);
