@@ -165,10 +165,14 @@ int rdyhip_rhs_function(RDyHipOperator op, double dt, const double *u_local, dou
 
 /* The same as rdyhip_rhs_function restricted to a subset of the owned cells, so
  * that a caller can overlap the halo exchange with the interior cells:
- *   reset_diagnostics; apply_phase(INTERIOR) || exchange; apply_phase(HALO).
- * `overwrite` != 0 gives rdyhip_rhs_function semantics, 0 gives rdyhip_apply's.
- * Does not reset diagnostics. */
-int rdyhip_apply_phase(RDyHipOperator op, int32_t phase, int32_t overwrite, double dt, const double *u_local, double *f_global,
+ *   apply_phase(INTERIOR, RDYHIP_PHASE_OVERWRITE | RDYHIP_PHASE_RESET_DIAGNOSTICS) || exchange;
+ *   apply_phase(HALO, RDYHIP_PHASE_OVERWRITE).
+ * `flags`: RDYHIP_PHASE_OVERWRITE gives rdyhip_rhs_function semantics (f = F(u)),
+ * without it rdyhip_apply's (f += F(u)); RDYHIP_PHASE_RESET_DIAGNOSTICS resets the
+ * Courant diagnostic first (no extra launch). */
+#define RDYHIP_PHASE_OVERWRITE 1
+#define RDYHIP_PHASE_RESET_DIAGNOSTICS 2
+int rdyhip_apply_phase(RDyHipOperator op, int32_t phase, int32_t flags, double dt, const double *u_local, double *f_global,
                        void *stream);
 
 /* ---- operator data (host-side setters, as in the reference) -----------------

@@ -659,9 +659,16 @@ int rdyhip_rhs_function(RDyHipOperator op, double dt, const double *u_local, dou
   return launch_rhs(op, RDYHIP_PHASE_ALL, 1, 1, dt, u_local, f_global, (hipStream_t)stream);
 }
 
-int rdyhip_apply_phase(RDyHipOperator op, int32_t phase, int32_t overwrite, double dt, const double *u_local, double *f_global, void *stream) {
+int rdyhip_apply_phase(RDyHipOperator op, int32_t phase, int32_t flags, double dt, const double *u_local, double *f_global, void *stream) {
   if (phase != RDYHIP_PHASE_ALL && phase != RDYHIP_PHASE_INTERIOR && phase != RDYHIP_PHASE_HALO) return fail(RDYHIP_ERR_USER, "bad phase %d", phase);
-  return launch_rhs(op, phase, overwrite, 0, dt, u_local, f_global, (hipStream_t)stream);
+  if (!op) return fail(RDYHIP_ERR_USER, "null operator");
+  const int reset = (flags & RDYHIP_PHASE_RESET_DIAGNOSTICS) ? 1 : 0;
+  if (reset) op->courant = RDyHipCourant{0.0, -1, -1};
+  if (reset && phase == RDYHIP_PHASE_HALO && (op->use_tiled ? op->n_halo_tiles == 0 : op->n_halo == 0)) {
+    int rc = rdyhip_reset_diagnostics(op, stream);  // nothing to launch in this phase: reset on its own
+    if (rc) return rc;
+  }
+  return launch_rhs(op, phase, (flags & RDYHIP_PHASE_OVERWRITE) ? 1 : 0, reset, dt, u_local, f_global, (hipStream_t)stream);
 }
 
 int rdyhip_set_boundary_values(RDyHipOperator op, int32_t boundary, int32_t comp_offset, int32_t num_comp, int32_t num_edges, const double *values) {

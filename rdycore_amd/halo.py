@@ -85,14 +85,30 @@ class HaloExchange:
                 covered += got.size
         if covered != ghost_local.size:
             raise RuntimeError(f"rank {self.rank}: {ghost_local.size - covered} ghost cells have no owner")
-        for peer, ids in self.send_ids.items():
-            self.send_buf[peer] = torch.empty((ids.numel(), 3), dtype=torch.float64, device=self.device)
-        for peer, ids in self.recv_ids.items():
-            self.recv_buf[peer] = torch.empty((ids.numel(), 3), dtype=torch.float64, device=self.device)
+        # one contiguous send and one contiguous receive buffer (a slice per peer), so that a ghost
+        # update costs one pack and one unpack launch whatever the number of neighbours
+        peers_s, peers_r = sorted(self.send_ids), sorted(self.recv_ids)
+        ns = sum(int(self.send_ids[p].numel()) for p in peers_s)
+        nr = sum(int(self.recv_ids[p].numel()) for p in peers_r)
+        self.send_all = torch.empty((ns, 3), dtype=torch.float64, device=self.device)
+        self.recv_all = torch.empty((nr, 3), dtype=torch.float64, device=self.device)
+        self.send_ids_all = torch.cat([self.send_ids[p] for p in peers_s]) if peers_s else torch.zeros(0, dtype=torch.int32, device=self.device)
+        self.recv_ids_all = torch.cat([self.recv_ids[p] for p in peers_r]) if peers_r else torch.zeros(0, dtype=torch.int32, device=self.device)
+        o = 0
+        for p in peers_s:
+            n = int(self.send_ids[p].numel())
+            self.send_buf[p] = self.send_all[o:o + n]
+            o += n
+        o = 0
+        for p in peers_r:
+            n = int(self.recv_ids[p].numel())
+            self.recv_buf[p] = self.recv_all[o:o + n]
+            o += n
+        self._p2p_ops = None
 
     @property
     def bytes_sent_per_exchange(self) -> int:
-        return sum(int(b.numel()) * 8 for b in self.send_buf.values())
+        return int(self.send_all.numel()) * 8 if self.world > 1 else 0
 
     # -- one ghost update on the current stream ----------------------------
     def exchange(self, u_local: torch.Tensor):
@@ -104,30 +120,37 @@ class HaloExchange:
         via_host = cuda and dist.get_backend(self.group) == "gloo"
         if cuda:
             from .operator import pack_cells, unpack_cells
-        ops = []
-        wire_send, wire_recv = {}, {}
-        for peer, ids in self.send_ids.items():
-            if cuda:
-                pack_cells(u_local, ids, self.send_buf[peer])
-            else:
-                self.send_buf[peer].copy_(u_local.view(-1, 3)[ids.long()])
-            wire_send[peer] = self.send_buf[peer].cpu() if via_host else self.send_buf[peer]
-        for peer in self.recv_ids:
-            wire_recv[peer] = torch.empty_like(self.recv_buf[peer], device="cpu") if via_host else self.recv_buf[peer]
-        for peer in sorted(set(self.send_ids) | set(self.recv_ids)):
-            if peer in self.send_ids:
-                ops.append(dist.P2POp(dist.isend, wire_send[peer], peer, group=self.group))
-            if peer in self.recv_ids:
-                ops.append(dist.P2POp(dist.irecv, wire_recv[peer], peer, group=self.group))
+            if self.send_ids_all.numel():
+                pack_cells(u_local, self.send_ids_all, self.send_all)
+        elif self.send_ids_all.numel():
+            self.send_all.copy_(u_local.view(-1, 3)[self.send_ids_all.long()])
+        if via_host:
+            wire_send = {p: self.send_buf[p].cpu() for p in self.send_ids}
+            wire_recv = {p: torch.empty_like(self.recv_buf[p], device="cpu") for p in self.recv_ids}
+            ops = self._make_ops(wire_send, wire_recv)
+        else:
+            if self._p2p_ops is None:           # the buffers are persistent: build the op list once
+                self._p2p_ops = self._make_ops(self.send_buf, self.recv_buf)
+            ops = self._p2p_ops
         for w in dist.batch_isend_irecv(ops):
             w.wait()
-        for peer, ids in self.recv_ids.items():
-            if via_host:
-                self.recv_buf[peer].copy_(wire_recv[peer])
-            if cuda:
-                unpack_cells(u_local, ids, self.recv_buf[peer])
-            else:
-                u_local.view(-1, 3)[ids.long()] = self.recv_buf[peer]
+        if via_host:
+            for p in self.recv_ids:
+                self.recv_buf[p].copy_(wire_recv[p])
+        if cuda:
+            if self.recv_ids_all.numel():
+                unpack_cells(u_local, self.recv_ids_all, self.recv_all)
+        elif self.recv_ids_all.numel():
+            u_local.view(-1, 3)[self.recv_ids_all.long()] = self.recv_all
+
+    def _make_ops(self, send, recv):
+        ops = []
+        for peer in sorted(set(self.send_ids) | set(self.recv_ids)):
+            if peer in self.send_ids:
+                ops.append(dist.P2POp(dist.isend, send[peer], peer, group=self.group))
+            if peer in self.recv_ids:
+                ops.append(dist.P2POp(dist.irecv, recv[peer], peer, group=self.group))
+        return ops
 
     # -- RHS with the exchange hidden behind the interior cells -----------
     def rhs_overlapped(self, op, dt: float, u_local: torch.Tensor, f_global: torch.Tensor):
@@ -141,7 +164,6 @@ class HaloExchange:
         self.comm_stream.wait_stream(main)           # u_local's owned part is final
         with torch.cuda.stream(self.comm_stream):
             self.exchange(u_local)
-        op.reset_diagnostics()
-        op.apply_phase(1, True, dt, u_local, f_global)      # RDYHIP_PHASE_INTERIOR
+        op.apply_phase(1, True, dt, u_local, f_global, reset_diagnostics=True)   # RDYHIP_PHASE_INTERIOR (+ diagnostics reset)
         main.wait_stream(self.comm_stream)
-        op.apply_phase(2, True, dt, u_local, f_global)      # RDYHIP_PHASE_HALO
+        op.apply_phase(2, True, dt, u_local, f_global)                           # RDYHIP_PHASE_HALO

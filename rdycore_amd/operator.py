@@ -154,9 +154,11 @@ class Operator:
         self._check_vecs(u_local, f_global)
         _lib.check(_lib.load().rdyhip_rhs_function(self._h, float(dt), _ptr(u_local), _ptr(f_global), _stream()))
 
-    def apply_phase(self, phase: int, overwrite: bool, dt: float, u_local: torch.Tensor, f_global: torch.Tensor):
+    def apply_phase(self, phase: int, overwrite: bool, dt: float, u_local: torch.Tensor, f_global: torch.Tensor,
+                    reset_diagnostics: bool = False):
         self._check_vecs(u_local, f_global)
-        _lib.check(_lib.load().rdyhip_apply_phase(self._h, int(phase), 1 if overwrite else 0, float(dt), _ptr(u_local),
+        flags = (1 if overwrite else 0) | (2 if reset_diagnostics else 0)
+        _lib.check(_lib.load().rdyhip_apply_phase(self._h, int(phase), flags, float(dt), _ptr(u_local),
                                                  _ptr(f_global), _stream()))
 
     # -- SetOperatorBoundaryValues (src/operator.c:1045-1061) --------------
