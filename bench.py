@@ -48,6 +48,7 @@ def parse():
                         "c2: flat-bed dam break, all reflecting (BASELINE configs[1]: --nx 1000 --ny 500)")
     p.add_argument("--hr", action="store_true", help="hydrostatic-reconstruction variant of the operator (SURVEY 8.f row 2)")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-cpu-all-cores", action="store_true", help="skip the all-host-cores CPU figure (the 1-core cpu_baseline stays)")
     p.add_argument("--kernel", default=None, choices=["tiled", "cell"], help="kernel variant (default: library default = tiled)")
     p.add_argument("--cpu-sample", default="1000x500", help="nx x ny of the CPU-baseline sample mesh")
     return p.parse_args()
@@ -97,6 +98,43 @@ def cpu_baseline(sample: str, source: str, workload: str = "c3", hr: bool = Fals
     return {"value": round(nc / med / 1e6, 3), "unit": "M cell-updates/s", "cores": 1, "kind": "port",
             "sample": f"{len(times)} RHS evaluations of the same workload on a {nx}x{ny}x2 = {nc}-cell mesh, "
                       f"oracle/swe_oracle.c (gcc -O2, 1 thread), median {med * 1e3:.1f} ms/RHS"}
+
+
+def _cpu_strip_worker(args):
+    """One host core: the oracle on one strip (with its ghost cells) of the sample mesh."""
+    nx, ny, rank, world, source, workload, hr, reps = args
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import oracle_from_case
+    case = build_case(nx, ny, rank, world, "rowmajor", source, workload, hr)
+    orc = oracle_from_case(case)
+    f = np.zeros((case.mesh.num_owned_cells, 3))
+    orc.apply(case.dt, case.u_local, f)
+    ts = []
+    for _ in range(reps):
+        f[:] = 0.0
+        t0 = time.perf_counter()
+        orc.apply(case.dt, case.u_local, f)
+        ts.append(time.perf_counter() - t0)
+    return case.mesh.num_owned_cells, float(np.median(ts))
+
+
+def cpu_baseline_all_cores(sample: str, source: str, workload: str, hr: bool):
+    """no MPI launcher exists here, so P independent oracle processes run on P strip
+    partitions of the sample mesh (ghost cells present, not exchanged) -- an upper bound on what the
+    MPI-parallel reference could do on these host cores."""
+    import multiprocessing as mp
+    nx, ny = map(int, sample.split("x"))
+    cores = len(os.sched_getaffinity(0))
+    p = max(1, min(cores, 32))
+    while nx % p:
+        p -= 1
+    with mp.get_context("spawn").Pool(p) as pool:
+        res = pool.map(_cpu_strip_worker, [(nx // p, ny, r, p, source, workload, hr, 5) for r in range(p)])
+    cells = sum(r[0] for r in res)
+    tmax = max(r[1] for r in res)
+    return {"value": round(cells / tmax / 1e6, 2), "unit": "M cell-updates/s", "cores": p, "kind": "port",
+            "sample": f"{p} independent oracle processes, one x-strip each of the {nx}x{ny}x2-cell sample mesh, no halo exchange "
+                      f"(upper bound on an MPI run), slowest strip {tmax * 1e3:.1f} ms/RHS"}
 
 
 def load_traffic(workload_key: str):
@@ -237,6 +275,11 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.source, args.workload, args.hr)
+            if not args.no_cpu_all_cores:
+                try:
+                    out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(args.cpu_sample, args.source, args.workload, args.hr)
+                except Exception as exc:  # a reported extra, never a reason to lose the bench line
+                    out["cpu_baseline_all_cores"] = {"error": repr(exc)}
         print(json.dumps(out), flush=True)
     op.destroy()
     if world > 1:
