@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RDYHIP_VERSION 101
+#define RDYHIP_VERSION 102
 
 /* error codes = PETSc's values */
 #define RDYHIP_SUCCESS 0
@@ -195,6 +195,38 @@ int rdyhip_set_external_source(RDyHipOperator op, int32_t comp, int32_t n, const
 /* Get/RestoreOperator{Regional,Domain}MaterialProperties (rdyoperatorimpl.h:263-266)
  *   as used by RDySet{Regional,Domain}ManningsN (src/rdydata.c:506-539). */
 int rdyhip_set_mannings(RDyHipOperator op, int32_t n, const int32_t *owned_cell_ids, const double *values);
+
+/* ---- forcing ingestion on the device -----------------------------------------
+ * The per-step fill loops of RDyApplyForcing (src/forcing/rdyforcing.c:688-770)
+ * with the dataset, the data->mesh map and the region's cell list resident in
+ * HBM: nothing crosses PCIe between RHS evaluations.  All pointers are DEVICE
+ * pointers; the calls are enqueued on `stream` and do not synchronise.
+ * `d_owned_cell_ids` (the region's owned-cell indices, RDyRegion.owned_cell_ids;
+ * NULL = owned cells 0..n-1) must hold valid indices: they cannot be range-checked
+ * on the host.  The scalar time lookup (RDyForcingGetCurrentData,
+ * src/forcing/rdyforcing_dataset.c:32-67) stays on the host (rdycore_amd/forcing.py).
+ *
+ * fill_source:     RDyForcingSetConstantRainfall / RDyForcingSetHomogeneousData (rdyforcing_dataset.c:282-288,
+ *                  320-344) + RDySetRegionalWaterSource / RDySetHomogeneousRegionalWaterSource (src/rdydata.c:253-309):
+ *                  ext[id[i]][comp] = value
+ * gather_source:   RDyForcingSetRasterData (rdyforcing_dataset.c:295-314: stride 1, offset = header_offset,
+ *                  scale = 1/(1000*3600)) and RDyForcingSetUnstructuredData (350-373: offset 2, scale 1):
+ *                  ext[id[i]][comp] = data[data2mesh_idx[i]*stride + offset] * scale
+ * fill_boundary:   RDyForcingSetHomogeneousBoundary (380-406) + RDySetFlowDirichletBoundaryValues: bvalues[e] = [h,0,0]
+ * gather_boundary: RDyForcingSetUnstructuredData on a boundary dataset (stride 3):
+ *                  bvalues[e][c] = data[data2mesh_idx[e]*stride + c + offset]
+ * nearest_map:     RDyForcingCreateRasterDatasetMapping (src/forcing/rdyforcing_map.c:111-141; min_dist0 =
+ *                  (max(ncols,nrows)+1)*cellsize, entries with no point nearer than that are left untouched) and
+ *                  RDyForcingCreateUnstructuredDatasetMap (77-104; pass min_dist0 < 0): brute-force nearest
+ *                  data point, first index wins ties. */
+int rdyhip_forcing_fill_source(RDyHipOperator op, int32_t comp, int32_t n, const int32_t *d_owned_cell_ids, double value, void *stream);
+int rdyhip_forcing_gather_source(RDyHipOperator op, int32_t comp, int32_t n, const int32_t *d_owned_cell_ids, const double *d_data,
+                                 const int32_t *d_data2mesh_idx, int64_t stride, int64_t offset, double scale, void *stream);
+int rdyhip_forcing_fill_boundary(RDyHipOperator op, int32_t boundary, int32_t num_edges, double h, void *stream);
+int rdyhip_forcing_gather_boundary(RDyHipOperator op, int32_t boundary, int32_t num_edges, const double *d_data,
+                                   const int32_t *d_data2mesh_idx, int64_t stride, int64_t offset, void *stream);
+int rdyhip_forcing_nearest_map(int32_t n, const double *d_xc, const double *d_yc, int32_t ndata, const double *d_data_xc,
+                               const double *d_data_yc, double min_dist0, int32_t *d_map, void *stream);
 
 /* In-place access to the device-resident fields (no copy): e.g. a forcing
  * kernel can write the external source on the GPU, an output routine can read

@@ -45,8 +45,8 @@ class OracleCourant(C.Structure):
 
 def build(force: bool = False) -> str:
     so = os.path.join(_HERE, "libswe_oracle.so")
-    src = os.path.join(_HERE, "swe_oracle.c")
-    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("swe_oracle.c", "forcing_oracle.c", "swe_oracle.h")]
+    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-B", "libswe_oracle.so"], stdout=subprocess.DEVNULL)
     return so
 
@@ -183,3 +183,45 @@ class OracleOperator:
             self.close()
         except Exception:
             pass
+
+
+# ---- forcing loops (oracle/forcing_oracle.c) ---------------------------------
+def forcing_current_data(table, cur_time, temporally_interpolate):
+    t = np.ascontiguousarray(table, dtype=np.float64).ravel()
+    idx, val = C.c_int(-1), C.c_double(0.0)
+    lib().oracle_forcing_current_data(_dp(t), C.c_int(t.size // 2), C.c_double(cur_time), C.c_int(int(temporally_interpolate)),
+                                      C.byref(idx), C.byref(val))
+    return idx.value, val.value
+
+
+def forcing_set_raster(data_vec, offset, data2mesh_idx):
+    d = np.ascontiguousarray(data_vec, dtype=np.float64)
+    m = np.ascontiguousarray(data2mesh_idx, dtype=np.int32)
+    out = np.zeros(m.size)
+    lib().oracle_forcing_set_raster(_dp(d), C.c_int(offset), _ip(m), C.c_int(m.size), _dp(out))
+    return out
+
+
+def forcing_set_unstructured(data_vec, stride, data2mesh_idx):
+    d = np.ascontiguousarray(data_vec, dtype=np.float64)
+    m = np.ascontiguousarray(data2mesh_idx, dtype=np.int32)
+    out = np.zeros(m.size * stride)
+    lib().oracle_forcing_set_unstructured(_dp(d), C.c_int(stride), _ip(m), C.c_int(m.size), _dp(out))
+    return out.reshape(m.size, stride)
+
+
+def forcing_raster_map(mesh_xc, mesh_yc, ncols, nrows, cellsize, data_xc, data_yc):
+    x, y = (np.ascontiguousarray(a, dtype=np.float64) for a in (mesh_xc, mesh_yc))
+    px, py = (np.ascontiguousarray(a, dtype=np.float64) for a in (data_xc, data_yc))
+    out = np.zeros(x.size, dtype=np.int32)
+    lib().oracle_forcing_raster_map(C.c_int(x.size), _dp(x), _dp(y), C.c_int(ncols), C.c_int(nrows), C.c_double(cellsize), _dp(px), _dp(py),
+                                    _ip(out))
+    return out
+
+
+def forcing_unstructured_map(mesh_xc, mesh_yc, data_xc, data_yc):
+    x, y = (np.ascontiguousarray(a, dtype=np.float64) for a in (mesh_xc, mesh_yc))
+    px, py = (np.ascontiguousarray(a, dtype=np.float64) for a in (data_xc, data_yc))
+    out = np.zeros(x.size, dtype=np.int32)
+    lib().oracle_forcing_unstructured_map(C.c_int(x.size), _dp(x), _dp(y), C.c_int(px.size), _dp(px), _dp(py), _ip(out))
+    return out

@@ -63,6 +63,13 @@ SYMBOLS = {
     "rdyhip_reset_boundary_fluxes_accum": (C.c_int, [_H]),
     "rdyhip_set_external_source": (C.c_int, [_H, C.c_int32, C.c_int32, c_int32_p, c_double_p]),
     "rdyhip_set_mannings": (C.c_int, [_H, C.c_int32, c_int32_p, c_double_p]),
+    "rdyhip_forcing_fill_source": (C.c_int, [_H, C.c_int32, C.c_int32, C.c_void_p, C.c_double, C.c_void_p]),
+    "rdyhip_forcing_gather_source": (C.c_int, [_H, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
+                                               C.c_double, C.c_void_p]),
+    "rdyhip_forcing_fill_boundary": (C.c_int, [_H, C.c_int32, C.c_int32, C.c_double, C.c_void_p]),
+    "rdyhip_forcing_gather_boundary": (C.c_int, [_H, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
+    "rdyhip_forcing_nearest_map": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p,
+                                             C.c_void_p]),
     "rdyhip_field_ptr": (C.c_int, [_H, C.c_int, C.POINTER(C.c_void_p), c_int64_p]),
     "rdyhip_enable_flux_divergence": (C.c_int, [_H, C.c_int32]),
     "rdyhip_reset_diagnostics": (C.c_int, [_H, C.c_void_p]),

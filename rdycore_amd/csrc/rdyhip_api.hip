@@ -33,6 +33,7 @@
 #include "rdyhip.h"
 #include "swe_device.h"
 #include "swe_kernels.h"
+#include "forcing_kernels.h"
 
 using namespace rdyhip;
 
@@ -747,6 +748,82 @@ int rdyhip_set_external_source(RDyHipOperator op, int32_t comp, int32_t n, const
 int rdyhip_set_mannings(RDyHipOperator op, int32_t n, const int32_t *owned_cell_ids, const double *values) {
   if (!op) return fail(RDYHIP_ERR_USER, "null operator");
   return scatter_component(op, op->d_mannings.p, 1, 0, n, owned_cell_ids, values);
+}
+
+// ---- device-side forcing ingestion (forcing_kernels.h) -------------------------------------------------
+static int forcing_grid(int64_t n) { return (int)std::min<int64_t>((n + 255) / 256, 2048); }
+
+static int forcing_source_args(RDyHipOperator op, int32_t comp, int32_t n) {
+  if (!op) return fail(RDYHIP_ERR_USER, "null operator");
+  if (comp < 0 || comp > 2) return fail(RDYHIP_ERR_USER, "bad source component %d", comp);
+  if (n < 0 || n > op->n_owned) return fail(RDYHIP_ERR_ARG_SIZ, "n (%d) exceeds the number of owned cells (%d)", n, op->n_owned);
+  return 0;
+}
+
+int rdyhip_forcing_fill_source(RDyHipOperator op, int32_t comp, int32_t n, const int32_t *d_owned_cell_ids, double value, void *stream) {
+  int rc = forcing_source_args(op, comp, n);
+  if (rc || n == 0) return rc;
+  hipLaunchKernelGGL(forcing_fill_kernel, dim3(forcing_grid(n)), dim3(256), 0, (hipStream_t)stream, n, d_owned_cell_ids, value, op->d_extsrc.p, 3, comp);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int rdyhip_forcing_gather_source(RDyHipOperator op, int32_t comp, int32_t n, const int32_t *d_owned_cell_ids, const double *d_data,
+                                 const int32_t *d_data2mesh_idx, int64_t stride, int64_t offset, double scale, void *stream) {
+  int rc = forcing_source_args(op, comp, n);
+  if (rc || n == 0) return rc;
+  if (!d_data || !d_data2mesh_idx) return fail(RDYHIP_ERR_USER, "null dataset or map");
+  if (stride < 1 || offset < 0) return fail(RDYHIP_ERR_USER, "bad stride/offset (%lld, %lld)", (long long)stride, (long long)offset);
+  if (scale == 1.0)
+    hipLaunchKernelGGL(forcing_gather_kernel<false>, dim3(forcing_grid(n)), dim3(256), 0, (hipStream_t)stream, n, d_owned_cell_ids, d_data,
+                       d_data2mesh_idx, stride, offset, scale, op->d_extsrc.p, 3, comp);
+  else
+    hipLaunchKernelGGL(forcing_gather_kernel<true>, dim3(forcing_grid(n)), dim3(256), 0, (hipStream_t)stream, n, d_owned_cell_ids, d_data,
+                       d_data2mesh_idx, stride, offset, scale, op->d_extsrc.p, 3, comp);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+static int forcing_boundary_args(RDyHipOperator op, int32_t boundary, int32_t num_edges, int32_t *n) {
+  if (!op) return fail(RDYHIP_ERR_USER, "null operator");
+  if (boundary < 0 || boundary + 1 >= (int32_t)op->h_boff.size()) return fail(RDYHIP_ERR_USER, "Invalid boundary index %d", boundary);
+  *n = op->h_boff[boundary + 1] - op->h_boff[boundary];
+  if (*n != num_edges) return fail(RDYHIP_ERR_USER, "num_edges (%d) does not match boundary.num_edges (%d)", num_edges, *n);
+  return 0;
+}
+
+int rdyhip_forcing_fill_boundary(RDyHipOperator op, int32_t boundary, int32_t num_edges, double h, void *stream) {
+  int32_t n  = 0;
+  int     rc = forcing_boundary_args(op, boundary, num_edges, &n);
+  if (rc || n == 0) return rc;
+  hipLaunchKernelGGL(forcing_fill_boundary_kernel, dim3(forcing_grid(3 * (int64_t)n)), dim3(256), 0, (hipStream_t)stream, n, h,
+                     op->d_bvalues.p + 3 * (size_t)op->h_boff[boundary]);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int rdyhip_forcing_gather_boundary(RDyHipOperator op, int32_t boundary, int32_t num_edges, const double *d_data, const int32_t *d_data2mesh_idx,
+                                   int64_t stride, int64_t offset, void *stream) {
+  int32_t n  = 0;
+  int     rc = forcing_boundary_args(op, boundary, num_edges, &n);
+  if (rc || n == 0) return rc;
+  if (!d_data || !d_data2mesh_idx) return fail(RDYHIP_ERR_USER, "null dataset or map");
+  if (stride < 3 || offset < 0) return fail(RDYHIP_ERR_USER, "bad stride/offset (%lld, %lld)", (long long)stride, (long long)offset);
+  hipLaunchKernelGGL(forcing_gather_boundary_kernel, dim3(forcing_grid(3 * (int64_t)n)), dim3(256), 0, (hipStream_t)stream, n, d_data,
+                     d_data2mesh_idx, stride, offset, op->d_bvalues.p + 3 * (size_t)op->h_boff[boundary]);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int rdyhip_forcing_nearest_map(int32_t n, const double *d_xc, const double *d_yc, int32_t ndata, const double *d_data_xc, const double *d_data_yc,
+                               double min_dist0, int32_t *d_map, void *stream) {
+  if (n < 0 || ndata < 0) return fail(RDYHIP_ERR_ARG_SIZ, "negative count");
+  if (n == 0 || ndata == 0) return 0;
+  if (!d_xc || !d_yc || !d_data_xc || !d_data_yc || !d_map) return fail(RDYHIP_ERR_USER, "null argument");
+  hipLaunchKernelGGL(forcing_nearest_kernel, dim3((n + NN_BLOCK - 1) / NN_BLOCK), dim3(NN_BLOCK), 0, (hipStream_t)stream, n, d_xc, d_yc, ndata,
+                     d_data_xc, d_data_yc, min_dist0, d_map);
+  HIP_TRY(hipGetLastError());
+  return 0;
 }
 
 int rdyhip_field_ptr(RDyHipOperator op, RDyHipField field, double **device_ptr, int64_t *num_values) {
