@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RDYHIP_VERSION 102
+#define RDYHIP_VERSION 103
 
 /* error codes = PETSc's values */
 #define RDYHIP_SUCCESS 0
@@ -54,6 +54,11 @@ extern "C" {
 #define RDYHIP_WELL_BALANCING_NONE 0
 #define RDYHIP_WELL_BALANCING_HR 2
 
+/* RDyLimiterType (include/private/rdyconfigimpl.h:64-71): slope limiter of the second-order reconstruction */
+#define RDYHIP_LIMITER_MINMOD 0
+#define RDYHIP_LIMITER_NONE 1
+#define RDYHIP_LIMITER_VANLEER 2
+
 /* RDyNumericsRiemann (include/private/rdyconfigimpl.h:118-122); only Roe exists
  * in the reference (src/swe/swe_petsc.c:264-270) */
 #define RDYHIP_RIEMANN_ROE 0
@@ -71,6 +76,11 @@ typedef struct {
                              (src/swe/swe_petsc.c:1000-1263); the mesh must then carry cell_zc and, as the
                              reference does (RDyMeshOverride2DProjection, src/rdymesh.c:1478-1509), x-y
                              projected edge lengths and cell areas */
+  int32_t second_order;  /* config.numerics.second_order (rdyconfigimpl.h:129): MUSCL reconstruction of the interior
+                            face states, ApplyInteriorFlux2R (src/swe/swe_petsc.c:98-213); the mesh must then carry
+                            cell_centroids, edge_vertex_ids and vertex_points; not combinable with HR (src/operator.c:388-389) */
+  int32_t limiter;       /* RDYHIP_LIMITER_* (config.numerics.limiter after the -no_limiter / -van_leer overrides,
+                            src/swe/swe_petsc.c:357-367); read only if second_order */
   int32_t reserved;
 } RDyHipConfig;
 
@@ -95,6 +105,12 @@ typedef struct {
   const double  *edge_sn;             /* edges.sn             [num_edges] */
   const double  *cell_zc;             /* vertex-averaged bed elevation per cell [num_cells] (InteriorFluxHROperator.zc,
                                          src/swe/swe_petsc.c:1209-1224); may be NULL unless well_balancing == HR */
+  /* second_order only (may be NULL / 0 otherwise): what PrecomputeLSGradCoeffs and ReconstructFaceValues read
+   * (src/operator_fluxes_ceed.c:884-980, 1155-1206) */
+  int32_t        num_vertices;        /* mesh->num_vertices */
+  const double  *cell_centroids;      /* cells.centroids      [num_cells][3]    (RDyPoint.X) */
+  const int32_t *edge_vertex_ids;     /* edges.vertex_ids     [2*num_edges] */
+  const double  *vertex_points;       /* vertices.points      [num_vertices][3] (RDyPoint.X) */
 } RDyHipMesh;
 
 /* RDyBoundary (include/private/rdyboundaryimpl.h:7-14) + the flow condition
@@ -122,6 +138,10 @@ typedef enum {
   RDYHIP_FIELD_EXTERNAL_SOURCES    = 1, /* Operator.petsc.external_sources [owned][3]; in; also src_inst */
   RDYHIP_FIELD_MANNINGS            = 2, /* Operator.petsc.material_properties [owned][1]; in */
   RDYHIP_FIELD_FLUX_DIVERGENCE     = 3, /* Operator.flux_divergence [owned][3]; out, only if enabled */
+  RDYHIP_FIELD_GRADIENTS           = 4, /* second order: InteriorFluxOperator.grad_h/grad_hu/grad_hv interleaved,
+                                           [num_cells][6] = (dh/dx, dh/dy, dhu/dx, dhu/dy, dhv/dx, dhv/dy), LOCAL cell index:
+                                           owned rows are written by rdyhip_compute_gradients, ghost rows by the caller's
+                                           halo exchange (CommunicateCellGradients, src/operator_fluxes_ceed.c:1058-1107) */
 } RDyHipField;
 
 /* which cells a partial apply covers (multi-GPU overlap, see rdyhip_apply_phase) */
@@ -172,8 +192,25 @@ int rdyhip_rhs_function(RDyHipOperator op, double dt, const double *u_local, dou
  * Courant diagnostic first (no extra launch). */
 #define RDYHIP_PHASE_OVERWRITE 1
 #define RDYHIP_PHASE_RESET_DIAGNOSTICS 2
+#define RDYHIP_PHASE_GRADIENTS_READY 4 /* second order: use the gradient field as it is (the caller has run
+                                          rdyhip_compute_gradients and filled the ghost rows) */
 int rdyhip_apply_phase(RDyHipOperator op, int32_t phase, int32_t flags, double dt, const double *u_local, double *f_global,
                        void *stream);
+
+/* ---- second order (config.second_order) -------------------------------------
+ * rdyhip_apply / rdyhip_rhs_function then run ApplyInteriorFlux2R (src/swe/swe_petsc.c:98-213):
+ * least-squares gradients of the owned cells, limited reconstruction of both face states of every
+ * interior edge, Roe flux on the reconstructed states; boundary edges and sources are unchanged.
+ * On one rank nothing else is needed.  With ghost cells the gradients of the ghosts must come from
+ * their owners (CommunicateCellGradients) before the fluxes are taken:
+ *   [halo update of u_local]
+ *   rdyhip_compute_gradients(op, RDYHIP_PHASE_ALL, u_local, stream)     ComputeLeastSquaresGradients, owned cells
+ *   [halo update of the RDYHIP_FIELD_GRADIENTS rows, 6 values per cell: rdyhip_pack_rows / rdyhip_unpack_rows]
+ *   rdyhip_apply_phase(op, RDYHIP_PHASE_ALL, flags | RDYHIP_PHASE_GRADIENTS_READY, ...)
+ * Every rank then evaluates all edges of its owned cells itself (a cut edge on both ranks, from
+ * identical operands), so the reference's reverse DMLocalToGlobal(ADD_VALUES) has no counterpart.
+ * PHASE_INTERIOR / PHASE_HALO select owned cells without / with a ghost neighbour, for overlap. */
+int rdyhip_compute_gradients(RDyHipOperator op, int32_t phase, const double *u_local, void *stream);
 
 /* ---- operator data (host-side setters, as in the reference) -----------------
  * SetOperatorBoundaryValues(Operator*, RDyBoundary, comp_offset, num_comp, num_edges, values[num_comp*e+c])
@@ -251,6 +288,9 @@ int rdyhip_get_diagnostics(RDyHipOperator op, RDyHipCourant *courant);
  * all device pointers; the transport between ranks (RCCL) is the caller's. */
 int rdyhip_pack_cells(const double *u_local, const int32_t *cell_ids, int32_t n, double *buf, void *stream);
 int rdyhip_unpack_cells(double *u_local, const int32_t *cell_ids, int32_t n, const double *buf, void *stream);
+/* the same for rows of `ncomp` values (the [num_cells][6] gradient field): buf[i][:] = src[ids[i]][:] and back */
+int rdyhip_pack_rows(const double *src, int32_t ncomp, const int32_t *row_ids, int32_t n, double *buf, void *stream);
+int rdyhip_unpack_rows(double *dst, int32_t ncomp, const int32_t *row_ids, int32_t n, const double *buf, void *stream);
 
 /* ---- explicit update kept on the device (what TSEULER does between RHS calls)
  * u_local[owned cell o] += dt * f_global[o]   (PETSc TSStep_Euler VecAXPY; the

@@ -27,6 +27,8 @@ class OracleMesh(C.Structure):
         ("areas", c_double_p), ("dz_dx", c_double_p), ("dz_dy", c_double_p), ("zc", c_double_p),
         ("cell_ids", c_int_p), ("internal_edge_ids", c_int_p), ("edge_global_ids", c_ll_p),
         ("lengths", c_double_p), ("cn", c_double_p), ("sn", c_double_p),
+        ("num_vertices", C.c_int), ("centroids", c_double_p), ("vertex_ids", c_int_p), ("points", c_double_p),
+        ("edge_is_owned", c_int_p),
     ]
 
 
@@ -36,7 +38,7 @@ class OracleBoundary(C.Structure):
 
 class OracleConfig(C.Structure):
     _fields_ = [("tiny_h", C.c_double), ("h_anuga_regular", C.c_double), ("xq2018_threshold", C.c_double),
-                ("source_method", C.c_int), ("well_balancing", C.c_int)]
+                ("source_method", C.c_int), ("well_balancing", C.c_int), ("second_order", C.c_int), ("limiter", C.c_int)]
 
 
 class OracleCourant(C.Structure):
@@ -58,13 +60,21 @@ def lib():
         L.oracle_create.restype = C.c_void_p
         L.oracle_create.argtypes = [C.POINTER(OracleMesh), C.POINTER(OracleConfig), C.c_int, C.POINTER(OracleBoundary)]
         L.oracle_destroy.argtypes = [C.c_void_p]
-        L.oracle_apply.argtypes = [C.c_void_p, C.c_double, c_double_p, c_double_p]
-        L.oracle_apply.restype = C.c_int
+        for name in ("oracle_apply", "oracle_apply_interior", "oracle_apply_rest"):
+            getattr(L, name).argtypes = [C.c_void_p, C.c_double, c_double_p, c_double_p]
+            getattr(L, name).restype = C.c_int
         for name in ("oracle_boundary_values", "oracle_boundary_fluxes", "oracle_boundary_fluxes_accum"):
             getattr(L, name).restype = c_double_p
             getattr(L, name).argtypes = [C.c_void_p, C.c_int]
         for name in ("oracle_external_sources", "oracle_material_properties", "oracle_flux_divergence",
                      "oracle_primitive_variables"):
+            getattr(L, name).restype = c_double_p
+            getattr(L, name).argtypes = [C.c_void_p]
+        L.oracle_compute_gradients.argtypes = [C.c_void_p, c_double_p]
+        L.oracle_set_gradients_ready.argtypes = [C.c_void_p, C.c_int]
+        L.oracle_gradients.restype = c_double_p
+        L.oracle_gradients.argtypes = [C.c_void_p, C.c_int]
+        for name in ("oracle_rhs_local", "oracle_ls_grad_coeffs"):
             getattr(L, name).restype = c_double_p
             getattr(L, name).argtypes = [C.c_void_p]
         L.oracle_reset_diagnostics.argtypes = [C.c_void_p]
@@ -97,7 +107,7 @@ class OracleOperator:
     """CPU oracle for ApplyOperator on one rank's mesh (mesh: rdycore_amd.mesh.RDyMesh)."""
 
     def __init__(self, mesh, bc_types: Sequence[int], tiny_h=1e-7, h_anuga_regular=0.0, xq2018_threshold=1e-10,
-                 source_method=0, well_balancing=0):
+                 source_method=0, well_balancing=0, second_order=False, limiter=0):
         L = lib()
         self.mesh = mesh
         self._keep = []
@@ -123,6 +133,12 @@ class OracleOperator:
         m.lengths = _dp(keep(mesh.edge_lengths, np.float64))
         m.cn = _dp(keep(mesh.edge_cn, np.float64))
         m.sn = _dp(keep(mesh.edge_sn, np.float64))
+        if second_order:
+            m.num_vertices = mesh.num_vertices
+            m.centroids = _dp(keep(mesh.cell_centroids, np.float64))
+            m.vertex_ids = _ip(keep(mesh.edge_vertex_ids, np.int32))
+            m.points = _dp(keep(mesh.xyz, np.float64))
+            m.edge_is_owned = _ip(keep(mesh.edge_is_owned(), np.int32))
         nb = len(mesh.boundaries)
         assert len(bc_types) == nb
         barr = (OracleBoundary * max(nb, 1))()
@@ -130,7 +146,9 @@ class OracleOperator:
             barr[i].num_edges = b.num_edges
             barr[i].edge_ids = _ip(keep(b.edge_ids, np.int32))
             barr[i].bc_type = int(bc_types[i])
-        cfg = OracleConfig(tiny_h, h_anuga_regular, xq2018_threshold, int(source_method), int(well_balancing))
+        cfg = OracleConfig(tiny_h, h_anuga_regular, xq2018_threshold, int(source_method), int(well_balancing), int(bool(second_order)),
+                           int(limiter))
+        self.second_order = bool(second_order)
         self._h = L.oracle_create(C.byref(m), C.byref(cfg), nb, barr)
         self._keep.append((m, barr, cfg))
         self.num_boundaries = nb
@@ -143,6 +161,11 @@ class OracleOperator:
         self.mannings = view(L.oracle_material_properties(self._h), no)
         self.flux_divergence = view(L.oracle_flux_divergence(self._h), 3 * no).reshape(no, 3)
         self.primitive_variables = view(L.oracle_primitive_variables(self._h), 3 * no).reshape(no, 3)
+        if second_order:
+            nc, ni = mesh.num_cells, mesh.num_internal_edges
+            self.gradients = [view(L.oracle_gradients(self._h, k), 2 * nc).reshape(nc, 2) for k in range(3)]
+            self.rhs_local = view(L.oracle_rhs_local(self._h), 3 * nc).reshape(nc, 3)
+            self.ls_grad_coeffs = view(L.oracle_ls_grad_coeffs(self._h), 4 * ni).reshape(ni, 4)
         self.boundary_values = []
         self.boundary_fluxes = []
         self.boundary_fluxes_accum = []
@@ -152,7 +175,7 @@ class OracleOperator:
             self.boundary_fluxes.append(view(L.oracle_boundary_fluxes(self._h, i), 3 * n).reshape(n, 3))
             self.boundary_fluxes_accum.append(view(L.oracle_boundary_fluxes_accum(self._h, i), 3 * n).reshape(n, 3))
 
-    def apply(self, dt: float, u_local: np.ndarray, f_global: Optional[np.ndarray] = None) -> np.ndarray:
+    def apply(self, dt: float, u_local: np.ndarray, f_global: Optional[np.ndarray] = None, stage: str = "") -> np.ndarray:
         """f_global += RHS(u_local); a zeroed f_global is made when none is given
         (the caller's VecZeroEntries, src/rdysetup.c:1130)."""
         u = np.ascontiguousarray(u_local, dtype=np.float64)
@@ -160,10 +183,28 @@ class OracleOperator:
         if f_global is None:
             f_global = np.zeros((self.mesh.num_owned_cells, 3))
         assert f_global.flags.c_contiguous and f_global.size == 3 * self.mesh.num_owned_cells
-        rc = lib().oracle_apply(self._h, float(dt), _dp(u), _dp(f_global))
+        rc = getattr(lib(), "oracle_apply" + stage)(self._h, float(dt), _dp(u), _dp(f_global))
         if rc != 0:
             raise RuntimeError("oracle_apply failed")
         return f_global
+
+    def apply_interior(self, dt, u_local, f_global=None):
+        return self.apply(dt, u_local, f_global, stage="_interior")
+
+    def apply_rest(self, dt, u_local, f_global):
+        return self.apply(dt, u_local, f_global, stage="_rest")
+
+    def compute_gradients(self, u_local: np.ndarray):
+        """ComputeLeastSquaresGradients into self.gradients (ghost rows incomplete, as in the reference)."""
+        u = np.ascontiguousarray(u_local, dtype=np.float64)
+        lib().oracle_compute_gradients(self._h, _dp(u))
+
+    def set_gradients_ready(self, ready: bool):
+        lib().oracle_set_gradients_ready(self._h, int(ready))
+
+    def gradients6(self) -> np.ndarray:
+        """[num_cells, 6] = (dh/dx, dh/dy, dhu/dx, dhu/dy, dhv/dx, dhv/dy): the layout of the HIP operator's gradient array"""
+        return np.concatenate(self.gradients, axis=1)
 
     def reset_diagnostics(self):
         lib().oracle_reset_diagnostics(self._h)

@@ -78,6 +78,14 @@ struct OracleOperator {
   BoundaryOp *boundaries;
   /* operator-owned vectors */
   double *external_sources, *material_properties, *flux_divergence, *primitive_variables;
+  /* second order: the MUSCL members of InteriorFluxOperator (src/swe/swe_petsc.c:87-93) */
+  int     num_owned_internal_edges, gradients_ready;
+  double *ls_grad_coeffs;   /* [num_internal_edges][4] */
+  double *grad[3];          /* grad_h, grad_hu, grad_hv: [num_cells][2] */
+  double *q_reconstructed;  /* [num_owned_internal_edges][6] */
+  double *rhs_local;        /* [num_cells][3] */
+  Side    left2, right2;    /* Riemann batch of the owned internal edges */
+  Batch   edges2;
 };
 
 /* ------------------------------------------------------------------------ */
@@ -498,6 +506,187 @@ static void apply_source_xq2018(OracleOperator *op, double dt, const double *u, 
   }
 }
 
+
+/* ------------------------------------------------------------------------ */
+/* Second-order MUSCL path.                                                  */
+
+static int edge_owned(const OracleMesh *m, int edge) { return m->edge_is_owned ? m->edge_is_owned[edge] : 1; }
+
+/* PrecomputeLSGradCoeffs, src/operator_fluxes_ceed.c:884-980: inverse-distance weighted
+ * least squares; per cell the 2x2 normal matrix M = sum w [dx dx, dx dy; dx dy, dy dy] over
+ * its internal edges, per edge the two columns inv(M_cell) * w (dx, dy). */
+static void precompute_ls_grad_coeffs(const OracleMesh *m, double *coeffs) {
+  int     nc = m->num_cells;
+  double *M  = calloc((size_t)(nc > 0 ? nc : 1) * 3, sizeof(double));
+  for (int ie = 0; ie < m->num_internal_edges; ++ie) {
+    int    e  = m->internal_edge_ids[ie];
+    int    cl = m->cell_ids[2 * e], cr = m->cell_ids[2 * e + 1];
+    double dx = m->centroids[3 * cr + 0] - m->centroids[3 * cl + 0];
+    double dy = m->centroids[3 * cr + 1] - m->centroids[3 * cl + 1];
+    double d  = sqrt(dx * dx + dy * dy);
+    double w  = (d > 0.0) ? 1.0 / d : 0.0;
+    M[cl * 3 + 0] += w * dx * dx;
+    M[cl * 3 + 1] += w * dx * dy;
+    M[cl * 3 + 2] += w * dy * dy;
+    M[cr * 3 + 0] += w * dx * dx;
+    M[cr * 3 + 1] += w * dx * dy;
+    M[cr * 3 + 2] += w * dy * dy;
+  }
+  double *inv = calloc((size_t)(nc > 0 ? nc : 1) * 4, sizeof(double));
+  for (int c = 0; c < nc; ++c) {
+    double m00 = M[c * 3 + 0], m01 = M[c * 3 + 1], m11 = M[c * 3 + 2];
+    double det = m00 * m11 - m01 * m01;
+    if (fabs(det) < 1e-15) { /* degenerate stencil: zero gradient (926-933) */
+      inv[c * 4 + 0] = inv[c * 4 + 1] = inv[c * 4 + 2] = inv[c * 4 + 3] = 0.0;
+    } else {
+      double inv_det = 1.0 / det;
+      inv[c * 4 + 0] = m11 * inv_det;
+      inv[c * 4 + 1] = -m01 * inv_det;
+      inv[c * 4 + 2] = -m01 * inv_det;
+      inv[c * 4 + 3] = m00 * inv_det;
+    }
+  }
+  free(M);
+  for (int ie = 0; ie < m->num_internal_edges; ++ie) {
+    int    e  = m->internal_edge_ids[ie];
+    int    cl = m->cell_ids[2 * e], cr = m->cell_ids[2 * e + 1];
+    double dx = m->centroids[3 * cr + 0] - m->centroids[3 * cl + 0];
+    double dy = m->centroids[3 * cr + 1] - m->centroids[3 * cl + 1];
+    double d  = sqrt(dx * dx + dy * dy);
+    double w  = (d > 0.0) ? 1.0 / d : 0.0;
+    double wdx = w * dx, wdy = w * dy;
+    coeffs[ie * 4 + 0] = inv[cl * 4 + 0] * wdx + inv[cl * 4 + 1] * wdy;
+    coeffs[ie * 4 + 1] = inv[cl * 4 + 2] * wdx + inv[cl * 4 + 3] * wdy;
+    coeffs[ie * 4 + 2] = inv[cr * 4 + 0] * wdx + inv[cr * 4 + 1] * wdy;
+    coeffs[ie * 4 + 3] = inv[cr * 4 + 2] * wdx + inv[cr * 4 + 3] * wdy;
+  }
+  free(inv);
+}
+
+/* ComputeLeastSquaresGradients, src/operator_fluxes_ceed.c:998-1042 */
+void oracle_compute_gradients(OracleOperator *op, const double *q) {
+  const OracleMesh *m = &op->mesh;
+  for (int k = 0; k < 3; ++k) memset(op->grad[k], 0, sizeof(double) * 2 * (size_t)m->num_cells);
+  for (int ie = 0; ie < m->num_internal_edges; ++ie) {
+    int           e  = m->internal_edge_ids[ie];
+    int           cl = m->cell_ids[2 * e], cr = m->cell_ids[2 * e + 1];
+    const double *c  = &op->ls_grad_coeffs[ie * 4];
+    for (int k = 0; k < 3; ++k) {
+      double dq = q[cr * 3 + k] - q[cl * 3 + k];
+      op->grad[k][cl * 2 + 0] += c[0] * dq;
+      op->grad[k][cl * 2 + 1] += c[1] * dq;
+      op->grad[k][cr * 2 + 0] += c[2] * dq;
+      op->grad[k][cr * 2 + 1] += c[3] * dq;
+    }
+  }
+}
+
+/* Minmod / VanLeer / LimitSlope, src/operator_fluxes_ceed.c:1110-1138 */
+static double minmod(double a, double b) {
+  if (a * b <= 0.0) return 0.0;
+  return fabs(a) < fabs(b) ? a : b;
+}
+static double vanleer(double a, double b) {
+  if (a * b <= 0.0) return 0.0;
+  return 2.0 * a * b / (a + b);
+}
+static double limit_slope(int limiter, double extrap, double half_dq) {
+  switch (limiter) {
+    case ORACLE_LIMITER_NONE: return extrap;
+    case ORACLE_LIMITER_VANLEER: return vanleer(extrap, half_dq);
+    default: return minmod(extrap, half_dq);
+  }
+}
+
+/* ReconstructFaceValues, src/operator_fluxes_ceed.c:1155-1206 */
+static void reconstruct_face_values(OracleOperator *op, const double *q) {
+  const OracleMesh *m       = &op->mesh;
+  double           *q_face  = op->q_reconstructed;
+  int               owned_e = 0;
+  for (int ie = 0; ie < m->num_internal_edges; ++ie) {
+    int e = m->internal_edge_ids[ie];
+    if (!edge_owned(m, e)) continue;
+    int    cl = m->cell_ids[2 * e], cr = m->cell_ids[2 * e + 1];
+    int    v0 = m->vertex_ids[2 * e], v1 = m->vertex_ids[2 * e + 1];
+    double x_mid = 0.5 * (m->points[3 * v0 + 0] + m->points[3 * v1 + 0]);
+    double y_mid = 0.5 * (m->points[3 * v0 + 1] + m->points[3 * v1 + 1]);
+    double dx_l = x_mid - m->centroids[3 * cl + 0], dy_l = y_mid - m->centroids[3 * cl + 1];
+    double dx_r = x_mid - m->centroids[3 * cr + 0], dy_r = y_mid - m->centroids[3 * cr + 1];
+    for (int k = 0; k < 3; ++k) {
+      double extrap_l = op->grad[k][cl * 2 + 0] * dx_l + op->grad[k][cl * 2 + 1] * dy_l;
+      double extrap_r = op->grad[k][cr * 2 + 0] * dx_r + op->grad[k][cr * 2 + 1] * dy_r;
+      double dq       = q[cr * 3 + k] - q[cl * 3 + k];
+      q_face[owned_e * 6 + k]     = q[cl * 3 + k] + limit_slope(op->config.limiter, extrap_l, 0.5 * dq);
+      q_face[owned_e * 6 + 3 + k] = q[cr * 3 + k] + limit_slope(op->config.limiter, extrap_r, -0.5 * dq);
+    }
+    q_face[owned_e * 6 + 0] = fmax(0.0, q_face[owned_e * 6 + 0]);
+    q_face[owned_e * 6 + 3] = fmax(0.0, q_face[owned_e * 6 + 3]);
+    owned_e++;
+  }
+}
+
+/* ApplyInteriorFlux2R, src/swe/swe_petsc.c:98-213 */
+static void apply_interior_flux_2r(OracleOperator *op, double dt, const double *u, double *f) {
+  const OracleMesh *m      = &op->mesh;
+  const double      tiny_h = op->config.tiny_h;
+  Side             *L = &op->left2, *R = &op->right2;
+  Batch            *E = &op->edges2;
+
+  if (!op->gradients_ready) oracle_compute_gradients(op, u); /* + CommunicateCellGradients: the identity on one rank */
+  reconstruct_face_values(op, u);
+
+  int owned_e = 0;
+  for (int ie = 0; ie < m->num_internal_edges; ++ie) {
+    if (!edge_owned(m, m->internal_edge_ids[ie])) continue;
+    const double *qf = &op->q_reconstructed[owned_e * 6];
+    L->h[owned_e]  = fmax(0.0, qf[0]);
+    L->hu[owned_e] = qf[1];
+    L->hv[owned_e] = qf[2];
+    R->h[owned_e]  = fmax(0.0, qf[3]);
+    R->hu[owned_e] = qf[4];
+    R->hv[owned_e] = qf[5];
+    owned_e++;
+  }
+  velocities(tiny_h, op->config.h_anuga_regular, L);
+  velocities(tiny_h, op->config.h_anuga_regular, R);
+  roe_batch(L, R, E, E->flux);
+
+  double *rhs = op->rhs_local;
+  memset(rhs, 0, sizeof(double) * 3 * (size_t)m->num_cells);
+  owned_e = 0;
+  for (int ie = 0; ie < m->num_internal_edges; ++ie) {
+    int edge = m->internal_edge_ids[ie];
+    if (!edge_owned(m, edge)) continue;
+    int    cl = m->cell_ids[2 * edge], cr = m->cell_ids[2 * edge + 1];
+    double len = m->lengths[edge];
+    double hl = L->h[owned_e], hr = R->h[owned_e];
+    if (!(hr < tiny_h && hl < tiny_h)) {
+      double areal = m->areas[cl], arear = m->areas[cr];
+      double cnum  = E->amax[owned_e] * len / fmin(areal, arear) * dt;
+      if (cnum > op->courant.max_courant_num) {
+        op->courant.max_courant_num = cnum;
+        op->courant.global_edge_id  = m->edge_global_ids[edge];
+        op->courant.global_cell_id  = (areal < arear) ? m->cell_global_ids[cl] : m->cell_global_ids[cr];
+      }
+      for (int c = 0; c < 3; ++c) {
+        rhs[3 * cl + c] += E->flux[3 * owned_e + c] * (-len / areal);
+        rhs[3 * cr + c] += E->flux[3 * owned_e + c] * (len / arear);
+      }
+    }
+    owned_e++;
+  }
+  /* DMLocalToGlobal(ADD_VALUES): the owned rows here; the ghost rows stay in rhs_local for the harness */
+  for (int c = 0; c < m->num_cells; ++c) {
+    if (!m->is_owned[c]) continue;
+    for (int k = 0; k < 3; ++k) f[3 * m->local_to_owned[c] + k] += rhs[3 * c + k];
+  }
+}
+
+void    oracle_set_gradients_ready(OracleOperator *op, int ready) { op->gradients_ready = ready; }
+double *oracle_gradients(OracleOperator *op, int k) { return op->grad[k]; }
+double *oracle_rhs_local(OracleOperator *op) { return op->rhs_local; }
+double *oracle_ls_grad_coeffs(OracleOperator *op) { return op->ls_grad_coeffs; }
+
 /* ------------------------------------------------------------------------ */
 OracleOperator *oracle_create(const OracleMesh *mesh, const OracleConfig *config, int num_boundaries, const OracleBoundary *boundaries) {
   OracleOperator *op = calloc(1, sizeof(*op));
@@ -516,6 +705,30 @@ OracleOperator *oracle_create(const OracleMesh *mesh, const OracleConfig *config
       op->edges.cn[e] = mesh->cn[edge];
       op->edges.sn[e] = mesh->sn[edge];
     }
+  }
+
+  /* the second_order branch of CreatePetscSWEInteriorFluxOperator (357-403): owned-edge batch, LS coefficients */
+  if (config->second_order) {
+    int nown = 0;
+    for (int e = 0; e < ni; ++e) nown += edge_owned(mesh, mesh->internal_edge_ids[e]);
+    op->num_owned_internal_edges = nown;
+    side_alloc(&op->left2, nown);
+    side_alloc(&op->right2, nown);
+    batch_alloc(&op->edges2, nown);
+    int owned_e = 0;
+    for (int e = 0; e < ni; ++e) {
+      int edge = mesh->internal_edge_ids[e];
+      if (!edge_owned(mesh, edge)) continue;
+      op->edges2.cn[owned_e] = mesh->cn[edge];
+      op->edges2.sn[owned_e] = mesh->sn[edge];
+      owned_e++;
+    }
+    size_t nc          = mesh->num_cells > 0 ? mesh->num_cells : 1;
+    op->ls_grad_coeffs = calloc((size_t)(ni > 0 ? ni : 1) * 4, sizeof(double));
+    for (int k = 0; k < 3; ++k) op->grad[k] = calloc(nc * 2, sizeof(double));
+    op->q_reconstructed = calloc((size_t)(nown > 0 ? nown : 1) * 6, sizeof(double));
+    op->rhs_local       = calloc(nc * 3, sizeof(double));
+    precompute_ls_grad_coeffs(mesh, op->ls_grad_coeffs);
   }
 
   /* CreatePetscSWEBoundaryFluxOperator, src/swe/swe_petsc.c:653-687 */
@@ -559,6 +772,15 @@ void oracle_destroy(OracleOperator *op) {
     free(bo->fluxes);
     free(bo->fluxes_accum);
   }
+  if (op->config.second_order) {
+    side_free(&op->left2);
+    side_free(&op->right2);
+    batch_free(&op->edges2);
+    free(op->ls_grad_coeffs);
+    for (int k = 0; k < 3; ++k) free(op->grad[k]);
+    free(op->q_reconstructed);
+    free(op->rhs_local);
+  }
   free(op->boundaries);
   free(op->external_sources);
   free(op->material_properties);
@@ -570,10 +792,16 @@ void oracle_destroy(OracleOperator *op) {
 /* ApplyPetscOperator, src/operator.c:656-672: flux composite (interior, then
  * one sub-operator per boundary, src/operator_fluxes_petsc.c:17-53), copy of
  * f into flux_divergence, source composite. */
-int oracle_apply(OracleOperator *op, double dt, const double *u_local, double *f_global) {
+int oracle_apply_interior(OracleOperator *op, double dt, const double *u_local, double *f_global) {
   /* CreatePetscFluxOperator vs CreatePetscFluxHROperator (src/operator.c:186-200, src/operator_fluxes_petsc.c:17-95) */
+  if (op->config.second_order && op->config.well_balancing == ORACLE_WB_HR) return 1; /* rejected, src/operator.c:388-389 */
   if (op->config.well_balancing == ORACLE_WB_HR) apply_interior_flux_hr(op, dt, u_local, f_global);
+  else if (op->config.second_order) apply_interior_flux_2r(op, dt, u_local, f_global); /* src/swe/swe_petsc.c:403-404 */
   else apply_interior_flux(op, dt, u_local, f_global);
+  return 0;
+}
+
+int oracle_apply_rest(OracleOperator *op, double dt, const double *u_local, double *f_global) {
   for (int b = 0; b < op->num_boundaries; ++b) apply_boundary_flux(op, &op->boundaries[b], dt, u_local, f_global);
   memcpy(op->flux_divergence, f_global, sizeof(double) * 3 * (size_t)op->mesh.num_owned_cells);
   switch (op->config.source_method) {
@@ -582,6 +810,12 @@ int oracle_apply(OracleOperator *op, double dt, const double *u_local, double *f
     default: return 1;
   }
   return 0;
+}
+
+int oracle_apply(OracleOperator *op, double dt, const double *u_local, double *f_global) {
+  int rc = oracle_apply_interior(op, dt, u_local, f_global);
+  if (rc) return rc;
+  return oracle_apply_rest(op, dt, u_local, f_global);
 }
 
 double *oracle_boundary_values(OracleOperator *op, int b) { return op->boundaries[b].values; }

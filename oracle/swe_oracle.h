@@ -27,6 +27,7 @@ enum { ORACLE_BC_DIRICHLET = 0, ORACLE_BC_REFLECTING = 2, ORACLE_BC_CRITICAL_OUT
 /* RDyFlowSourceMethod, include/private/rdyconfigimpl.h:52-56 */
 enum { ORACLE_SOURCE_SEMI_IMPLICIT = 0, ORACLE_SOURCE_IMPLICIT_XQ2018 = 1 };
 enum { ORACLE_WB_NONE = 0, ORACLE_WB_HR = 2 };
+enum { ORACLE_LIMITER_MINMOD = 0, ORACLE_LIMITER_NONE = 1, ORACLE_LIMITER_VANLEER = 2 };
 
 /* the RDyMesh fields the operators read (include/private/rdymeshimpl.h) */
 typedef struct {
@@ -41,6 +42,12 @@ typedef struct {
   const int       *internal_edge_ids; /* edges.internal_edge_ids [num_internal_edges] */
   const long long *edge_global_ids;   /* edges.global_ids      [num_edges] */
   const double    *lengths, *cn, *sn; /* edges.lengths/cn/sn   [num_edges] */
+  /* second-order (MUSCL) reconstruction only; may be NULL otherwise */
+  int              num_vertices;
+  const double    *centroids;         /* cells.centroids[c].X  [num_cells][3] */
+  const int       *vertex_ids;        /* edges.vertex_ids      [2*num_edges] */
+  const double    *points;            /* vertices.points[v].X  [num_vertices][3] */
+  const int       *edge_is_owned;     /* edges.is_owned        [num_edges] (src/rdymesh.c:599) */
 } OracleMesh;
 
 typedef struct {
@@ -53,6 +60,8 @@ typedef struct {
   double tiny_h, h_anuga_regular, xq2018_threshold; /* RDyPhysicsFlow, rdyconfigimpl.h:74-85 */
   int    source_method;
   int    well_balancing; /* RDyWellBalanceMethod: 0 none, 2 hydrostatic reconstruction (rdyconfigimpl.h:58-62) */
+  int    second_order;   /* RDyNumericsSection.second_order (rdyconfigimpl.h:129): MUSCL reconstruction, ApplyInteriorFlux2R */
+  int    limiter;        /* RDyLimiterType (rdyconfigimpl.h:67-71): 0 minmod, 1 none, 2 van Leer */
 } OracleConfig;
 
 /* CourantNumberDiagnostics, include/private/rdyoperatorimpl.h:21-25 */
@@ -70,6 +79,11 @@ void            oracle_destroy(OracleOperator *op);
 
 /* ApplyPetscOperator (src/operator.c:656-672): f_global += flux divergence + sources. */
 int oracle_apply(OracleOperator *op, double dt, const double *u_local, double *f_global);
+/* the same in two steps: the interior-flux sub-operator, then the boundary-flux sub-operators and
+ * the source operator -- so that a multi-rank harness can add the second-order path's ghost rows
+ * (DMLocalToGlobal ADD_VALUES inside ApplyInteriorFlux2R, src/swe/swe_petsc.c:207) in between */
+int oracle_apply_interior(OracleOperator *op, double dt, const double *u_local, double *f_global);
+int oracle_apply_rest(OracleOperator *op, double dt, const double *u_local, double *f_global);
 
 /* operator-owned vectors (src/operator.c:91-129, 224-335) */
 double *oracle_boundary_values(OracleOperator *op, int b);       /* [num_edges][3] */
@@ -79,6 +93,22 @@ double *oracle_external_sources(OracleOperator *op);             /* [owned][3] *
 double *oracle_material_properties(OracleOperator *op);          /* [owned][1] Manning n */
 double *oracle_flux_divergence(OracleOperator *op);              /* [owned][3] */
 double *oracle_primitive_variables(OracleOperator *op);          /* [owned][3] */
+
+/* ---- second order (config.second_order): ApplyInteriorFlux2R, src/swe/swe_petsc.c:98-213 ----
+ * oracle_apply then runs ComputeLeastSquaresGradients -> ReconstructFaceValues -> Roe on the
+ * OWNED internal edges, accumulates into a local vector (ghost rows included) and adds its
+ * owned rows to f_global.  Across ranks the reference exchanges the gradients
+ * (CommunicateCellGradients) and adds the ghost rows onto their owners (DMLocalToGlobal
+ * ADD_VALUES); a multi-rank test harness does both by hand between these calls:
+ *   oracle_compute_gradients(op, u)   ComputeLeastSquaresGradients into oracle_gradients()
+ *   [overwrite ghost rows of oracle_gradients(op,k) with the owners' values]
+ *   oracle_set_gradients_ready(op, 1) the next oracle_apply uses the gradients as they are
+ *   oracle_apply(...)                 then add the ghost rows of oracle_rhs_local() to their owners */
+void    oracle_compute_gradients(OracleOperator *op, const double *u_local);
+void    oracle_set_gradients_ready(OracleOperator *op, int ready);
+double *oracle_gradients(OracleOperator *op, int k); /* k = 0,1,2: grad_h, grad_hu, grad_hv, each [num_cells][2] */
+double *oracle_rhs_local(OracleOperator *op);        /* [num_cells][3] interior-flux contributions of the last apply */
+double *oracle_ls_grad_coeffs(OracleOperator *op);   /* [num_internal_edges][4] (PrecomputeLSGradCoeffs) */
 
 void oracle_reset_diagnostics(OracleOperator *op); /* ResetOperatorDiagnostics, src/operator.c:772-784 */
 void oracle_get_diagnostics(OracleOperator *op, OracleCourant *out);

@@ -18,7 +18,8 @@ c_int64_p = C.POINTER(C.c_int64)
 
 class RDyHipConfig(C.Structure):
     _fields_ = [("tiny_h", C.c_double), ("h_anuga_regular", C.c_double), ("xq2018_threshold", C.c_double),
-                ("source_method", C.c_int32), ("riemann", C.c_int32), ("well_balancing", C.c_int32), ("reserved", C.c_int32)]
+                ("source_method", C.c_int32), ("riemann", C.c_int32), ("well_balancing", C.c_int32), ("second_order", C.c_int32),
+                ("limiter", C.c_int32), ("reserved", C.c_int32)]
 
 
 class RDyHipMesh(C.Structure):
@@ -28,6 +29,7 @@ class RDyHipMesh(C.Structure):
         ("cell_areas", c_double_p), ("cell_dz_dx", c_double_p), ("cell_dz_dy", c_double_p),
         ("edge_cell_ids", c_int32_p), ("edge_internal_ids", c_int32_p), ("edge_global_ids", c_int64_p),
         ("edge_lengths", c_double_p), ("edge_cn", c_double_p), ("edge_sn", c_double_p), ("cell_zc", c_double_p),
+        ("num_vertices", C.c_int32), ("cell_centroids", c_double_p), ("edge_vertex_ids", c_int32_p), ("vertex_points", c_double_p),
     ]
 
 
@@ -58,6 +60,7 @@ SYMBOLS = {
     "rdyhip_apply": (C.c_int, [_H, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rdyhip_rhs_function": (C.c_int, [_H, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rdyhip_apply_phase": (C.c_int, [_H, C.c_int32, C.c_int32, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rdyhip_compute_gradients": (C.c_int, [_H, C.c_int32, C.c_void_p, C.c_void_p]),
     "rdyhip_set_boundary_values": (C.c_int, [_H, C.c_int32, C.c_int32, C.c_int32, C.c_int32, c_double_p]),
     "rdyhip_get_boundary_fluxes": (C.c_int, [_H, C.c_int32, C.c_int32, C.c_int32, c_double_p]),
     "rdyhip_reset_boundary_fluxes_accum": (C.c_int, [_H]),
@@ -77,6 +80,8 @@ SYMBOLS = {
     "rdyhip_get_diagnostics": (C.c_int, [_H, C.POINTER(RDyHipCourant)]),
     "rdyhip_pack_cells": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "rdyhip_unpack_cells": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "rdyhip_pack_rows": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "rdyhip_unpack_rows": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "rdyhip_axpy_owned": (C.c_int, [_H, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rdyhip_layout_info": (C.c_int, [_H, C.POINTER(RDyHipLayoutInfo)]),
 }

@@ -34,6 +34,7 @@
 #include "swe_device.h"
 #include "swe_kernels.h"
 #include "forcing_kernels.h"
+#include "muscl_kernels.h"
 
 using namespace rdyhip;
 
@@ -121,6 +122,11 @@ struct RDyHipOperator_s {
   DevBuf<double>   d_e_cs;
   DevBuf<uint16_t> d_slot_ref;   // S == 4
   DevBuf<uint32_t> d_slot_ref3;  // S == 3
+  // second order (muscl_kernels.h)
+  bool           muscl = false;
+  DevBuf<double> d_grad, d_e_geo, d_gcx, d_gcy;
+  size_t         lds_muscl = 0;
+  int            pgrid_muscl = 0;
 
   // host copies needed to resolve the Courant position into ids
   std::vector<int32_t> h_internal_edge, h_edge_cells, h_bedge, h_boff;
@@ -141,6 +147,7 @@ struct RDyHipOperator_s {
     d_blk_pos.release(); d_courant.release(); d_stage_vals.release(); d_stage_ids.release();
     d_tiles.release(); d_e_lr.release(); d_hcells.release(); d_tile_bk.release(); d_halo_tiles.release();
     d_e_cs.release(); d_slot_ref.release(); d_slot_ref3.release(); d_zc_local.release();
+    d_grad.release(); d_e_geo.release(); d_gcx.release(); d_gcy.release();
   }
 };
 
@@ -160,8 +167,80 @@ TiledKernelFn tiled_kernel_fn_hr(int S, int src, bool ovw) {
 }
 TiledKernelFn tiled_kernel_fn(int S, int src, bool ovw, bool hr) { return hr ? tiled_kernel_fn_hr<true>(S, src, ovw) : tiled_kernel_fn_hr<false>(S, src, ovw); }
 
-int launch_rhs(RDyHipOperator op, int32_t phase, int32_t overwrite, int reset_diag, double dt, const double *u, double *f, hipStream_t st) {
+using MusclKernelFn = void (*)(const KernelArgs, const MusclArgs, const double, const double *, double *);
+
+template <int LIM>
+MusclKernelFn muscl_kernel_fn_lim(int S, int src, bool ovw) {
+  if (S == 3) {
+    if (src) return ovw ? swe_rhs_muscl_kernel<3, 1, true, LIM> : swe_rhs_muscl_kernel<3, 1, false, LIM>;
+    return ovw ? swe_rhs_muscl_kernel<3, 0, true, LIM> : swe_rhs_muscl_kernel<3, 0, false, LIM>;
+  }
+  if (src) return ovw ? swe_rhs_muscl_kernel<4, 1, true, LIM> : swe_rhs_muscl_kernel<4, 1, false, LIM>;
+  return ovw ? swe_rhs_muscl_kernel<4, 0, true, LIM> : swe_rhs_muscl_kernel<4, 0, false, LIM>;
+}
+MusclKernelFn muscl_kernel_fn(int S, int src, bool ovw, int limiter) {
+  switch (limiter) {
+    case RDYHIP_LIMITER_NONE: return muscl_kernel_fn_lim<LIMITER_NONE>(S, src, ovw);
+    case RDYHIP_LIMITER_VANLEER: return muscl_kernel_fn_lim<LIMITER_VANLEER>(S, src, ovw);
+    default: return muscl_kernel_fn_lim<LIMITER_MINMOD>(S, src, ovw);
+  }
+}
+
+MusclArgs muscl_args(RDyHipOperator op) {
+  MusclArgs g{};
+  g.grad  = op->d_grad.p;
+  g.e_geo = op->d_e_geo.p;
+  g.gcx   = op->d_gcx.p;
+  g.gcy   = op->d_gcy.p;
+  return g;
+}
+
+// ComputeLeastSquaresGradients for the owned cells selected by `phase`
+int launch_gradients(RDyHipOperator op, int32_t phase, const double *u, hipStream_t st) {
   if (!op) return fail(RDYHIP_ERR_USER, "null operator");
+  if (!op->muscl) return fail(RDYHIP_ERR_USER, "the operator was not created with second_order");
+  if (phase != RDYHIP_PHASE_ALL && phase != RDYHIP_PHASE_INTERIOR && phase != RDYHIP_PHASE_HALO) return fail(RDYHIP_ERR_USER, "unknown phase %d", phase);
+  if (op->n_owned == 0) return 0;
+  if (!u) return fail(RDYHIP_ERR_USER, "null u_local");
+  KernelArgs a{};
+  a.n_owned = op->n_owned;
+  a.stride  = op->stride;
+  a.o2l     = op->prefix ? nullptr : op->d_o2l.p;
+  a.nbr     = op->d_nbr.p;
+  a.phase   = phase;
+  int grid;
+  if (phase == RDYHIP_PHASE_HALO) {
+    if (op->n_halo == 0) return 0;
+    a.list       = op->d_halo_list.p;
+    a.n_work     = op->n_halo;
+    a.xcd_chunks = 0;
+    a.phase      = RDYHIP_PHASE_ALL;
+    grid         = (op->n_halo + BLOCK - 1) / BLOCK;
+  } else {
+    a.list       = nullptr;
+    a.n_work     = op->n_owned;
+    a.xcd_chunks = op->xcd_chunks;
+    grid         = op->grid;
+  }
+  const MusclArgs g = muscl_args(op);
+  if (op->S == 3) hipLaunchKernelGGL((muscl_gradient_kernel<3>), dim3(grid), dim3(BLOCK), 0, st, a, g, u);
+  else hipLaunchKernelGGL((muscl_gradient_kernel<4>), dim3(grid), dim3(BLOCK), 0, st, a, g, u);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int launch_rhs(RDyHipOperator op, int32_t phase, int32_t overwrite, int reset_diag, double dt, const double *u, double *f, hipStream_t st,
+               bool gradients_ready = false) {
+  if (!op) return fail(RDYHIP_ERR_USER, "null operator");
+  if (op->muscl && !gradients_ready && op->n_owned > 0) {
+    // the ghost cells' gradients come from their owners (CommunicateCellGradients): the caller has to run
+    // rdyhip_compute_gradients, exchange the ghost rows and pass RDYHIP_PHASE_GRADIENTS_READY
+    if (op->n_cells > op->n_owned || phase != RDYHIP_PHASE_ALL)
+      return fail(RDYHIP_ERR_USER, "second_order with ghost cells or a phased apply needs RDYHIP_PHASE_GRADIENTS_READY (see rdyhip_compute_gradients)");
+    if (!u) return fail(RDYHIP_ERR_USER, "null u_local / f_global");
+    int rc = launch_gradients(op, phase, u, st);
+    if (rc) return rc;
+  }
   if (op->n_owned == 0) return reset_diag ? rdyhip_reset_diagnostics(op, (void *)st) : 0;  // a rank may own nothing (f_global is then empty)
   if (!u || !f) return fail(RDYHIP_ERR_USER, "null u_local / f_global");
   KernelArgs a{};
@@ -204,6 +283,7 @@ int launch_rhs(RDyHipOperator op, int32_t phase, int32_t overwrite, int reset_di
   int        grid;
   const bool xq = op->config.source_method == RDYHIP_SOURCE_IMPLICIT_XQ2018;
   if (op->use_tiled) {
+    const int pgrid = op->muscl ? op->pgrid_muscl : op->pgrid;
     // persistent workgroups: at most as many as the device holds at once
     if (phase == RDYHIP_PHASE_HALO) {
       if (op->n_halo_tiles == 0) return 0;
@@ -211,13 +291,13 @@ int launch_rhs(RDyHipOperator op, int32_t phase, int32_t overwrite, int reset_di
       a.n_work     = op->n_halo_tiles;
       a.xcd_chunks = 0;
       a.phase      = RDYHIP_PHASE_ALL;  // the list already holds exactly the halo tiles
-      grid         = std::min(op->pgrid, op->n_halo_tiles);
+      grid         = std::min(pgrid, op->n_halo_tiles);
     } else {
       a.list   = nullptr;
       a.n_work = op->ntiles;
       // While the interior phase runs, the halo exchange's pack / RCCL / unpack kernels need somewhere
       // to run: the persistent grid would otherwise fill every SIMD's register file for the whole launch.
-      const int pg = (phase == RDYHIP_PHASE_INTERIOR) ? std::max(8, op->pgrid - op->pgrid / 32) : op->pgrid;
+      const int pg = (phase == RDYHIP_PHASE_INTERIOR) ? std::max(8, pgrid - pgrid / 32) : pgrid;
       if (op->tiled_xcd_chunks > 0) {
         a.xcd_chunks = op->tiled_xcd_chunks;
         grid         = std::min(pg & ~7, op->tiled_xcd_chunks * 8);
@@ -226,8 +306,13 @@ int launch_rhs(RDyHipOperator op, int32_t phase, int32_t overwrite, int reset_di
         grid         = std::min(pg, op->ntiles);
       }
     }
-    const size_t lds = op->lds_bytes;
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(tiled_kernel_fn(op->S, xq ? 1 : 0, overwrite != 0, op->hr)), dim3(grid), dim3(TILE), lds, st, a, dt, u, f);
+    if (op->muscl) {
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(muscl_kernel_fn(op->S, xq ? 1 : 0, overwrite != 0, op->config.limiter)), dim3(grid), dim3(TILE), op->lds_muscl,
+                         st, a, muscl_args(op), dt, u, f);
+    } else {
+      const size_t lds = op->lds_bytes;
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(tiled_kernel_fn(op->S, xq ? 1 : 0, overwrite != 0, op->hr)), dim3(grid), dim3(TILE), lds, st, a, dt, u, f);
+    }
   } else {
     if (phase == RDYHIP_PHASE_HALO) {
       if (op->n_halo == 0) return 0;
@@ -281,6 +366,13 @@ int rdyhip_create(const RDyHipConfig *config, const RDyHipMesh *mesh, int32_t nu
     return fail(RDYHIP_ERR_USER, "Only well_balancing = none or hydrostatic_reconstruction is supported in the PETSc version");  // operator.c:388
   if (config->well_balancing == RDYHIP_WELL_BALANCING_HR && !mesh->cell_zc)
     return fail(RDYHIP_ERR_USER, "hydrostatic reconstruction needs the per-cell bed elevation (RDyHipMesh.cell_zc)");
+  const bool muscl_on = config->second_order != 0;
+  if (muscl_on && config->well_balancing == RDYHIP_WELL_BALANCING_HR)
+    return fail(RDYHIP_ERR_USER, "-second_order cannot be used with well_balancing = HR simultaneously (not yet implemented)");  // operator.c:388-389
+  if (muscl_on && config->limiter != RDYHIP_LIMITER_MINMOD && config->limiter != RDYHIP_LIMITER_NONE && config->limiter != RDYHIP_LIMITER_VANLEER)
+    return fail(RDYHIP_ERR_USER, "unknown slope limiter %d", config->limiter);
+  if (muscl_on && mesh->num_edges > 0 && (!mesh->cell_centroids || !mesh->edge_vertex_ids || !mesh->vertex_points))
+    return fail(RDYHIP_ERR_USER, "second_order needs RDyHipMesh.cell_centroids, edge_vertex_ids and vertex_points");
   const int32_t nc = mesh->num_cells, no = mesh->num_owned_cells, ne = mesh->num_edges, ni = mesh->num_internal_edges;
   if (nc < 0 || no < 0 || no > nc || ne < 0 || ni < 0 || ni > ne) return fail(RDYHIP_ERR_ARG_SIZ, "inconsistent mesh sizes");
   if (nc >= NBR_GHOST) return fail(RDYHIP_ERR_ARG_SIZ, "too many local cells (%d) for the 30-bit neighbour encoding", nc);
@@ -345,6 +437,54 @@ int rdyhip_create(const RDyHipConfig *config, const RDyHipMesh *mesh, int32_t nu
   std::vector<int32_t> nbr((size_t)(S * stride), NBR_EMPTY), pos((size_t)(S * stride), -1);
   std::vector<double>  cn((size_t)(S * stride), 0.0), sn((size_t)(S * stride), 0.0), coef((size_t)(S * stride), 0.0);
   std::fill(cnt.begin(), cnt.end(), 0);
+  // second order: PrecomputeLSGradCoeffs (src/operator_fluxes_ceed.c:884-980), the reference's arithmetic on the host
+  std::vector<double> ls;  // [ni][4]: cx_LR, cy_LR, cx_RL, cy_RL
+  std::vector<double> gcx, gcy;
+  if (muscl_on) {
+    auto cdiff = [&](int32_t l, int32_t r, double &dx, double &dy, double &w) {
+      dx             = mesh->cell_centroids[3 * (size_t)r + 0] - mesh->cell_centroids[3 * (size_t)l + 0];
+      dy             = mesh->cell_centroids[3 * (size_t)r + 1] - mesh->cell_centroids[3 * (size_t)l + 1];
+      const double d = std::sqrt(dx * dx + dy * dy);
+      w              = (d > 0.0) ? 1.0 / d : 0.0;
+    };
+    std::vector<double> M((size_t)nc * 3, 0.0), inv((size_t)nc * 4, 0.0);
+    for (int32_t p = 0; p < ni; ++p) {
+      const int32_t e = mesh->edge_internal_ids[p];
+      const int32_t l = mesh->edge_cell_ids[2 * e], r = mesh->edge_cell_ids[2 * e + 1];
+      if (r == -1) return fail(RDYHIP_ERR_USER, "second_order: internal edge %d has no right cell", e);
+      double dx, dy, w;
+      cdiff(l, r, dx, dy, w);
+      for (int32_t c : {l, r}) {
+        M[(size_t)c * 3 + 0] += w * dx * dx;
+        M[(size_t)c * 3 + 1] += w * dx * dy;
+        M[(size_t)c * 3 + 2] += w * dy * dy;
+      }
+    }
+    for (int32_t c = 0; c < nc; ++c) {
+      const double m00 = M[(size_t)c * 3 + 0], m01 = M[(size_t)c * 3 + 1], m11 = M[(size_t)c * 3 + 2];
+      const double det = m00 * m11 - m01 * m01;
+      if (std::fabs(det) < 1e-15) continue;  // degenerate stencil: zero gradient
+      const double inv_det  = 1.0 / det;
+      inv[(size_t)c * 4 + 0] = m11 * inv_det;
+      inv[(size_t)c * 4 + 1] = -m01 * inv_det;
+      inv[(size_t)c * 4 + 2] = -m01 * inv_det;
+      inv[(size_t)c * 4 + 3] = m00 * inv_det;
+    }
+    ls.assign((size_t)ni * 4, 0.0);
+    for (int32_t p = 0; p < ni; ++p) {
+      const int32_t e = mesh->edge_internal_ids[p];
+      const int32_t l = mesh->edge_cell_ids[2 * e], r = mesh->edge_cell_ids[2 * e + 1];
+      double        dx, dy, w;
+      cdiff(l, r, dx, dy, w);
+      const double wdx = w * dx, wdy = w * dy;
+      ls[(size_t)p * 4 + 0] = inv[(size_t)l * 4 + 0] * wdx + inv[(size_t)l * 4 + 1] * wdy;
+      ls[(size_t)p * 4 + 1] = inv[(size_t)l * 4 + 2] * wdx + inv[(size_t)l * 4 + 3] * wdy;
+      ls[(size_t)p * 4 + 2] = inv[(size_t)r * 4 + 0] * wdx + inv[(size_t)r * 4 + 1] * wdy;
+      ls[(size_t)p * 4 + 3] = inv[(size_t)r * 4 + 2] * wdx + inv[(size_t)r * 4 + 3] * wdy;
+    }
+    gcx.assign((size_t)(S * stride), 0.0);
+    gcy.assign((size_t)(S * stride), 0.0);
+  }
   auto put = [&](int32_t o, int32_t id, double c, double s, double k, int32_t p) {
     const int64_t idx = (int64_t)cnt[o]++ * stride + o;
     nbr[idx]          = id;
@@ -352,6 +492,12 @@ int rdyhip_create(const RDyHipConfig *config, const RDyHipMesh *mesh, int32_t nu
     sn[idx]           = s;
     coef[idx]         = k;
     pos[idx]          = p;
+    if (muscl_on && p < ni) {
+      // the cell is the edge's left cell (k < 0): c_LR times (q_R - q_L) = c_LR (q_nbr - q_self);
+      // right cell: c_RL (q_R - q_L) = (-c_RL) (q_nbr - q_self)
+      gcx[idx] = (k < 0.0) ? ls[(size_t)p * 4 + 0] : -ls[(size_t)p * 4 + 2];
+      gcy[idx] = (k < 0.0) ? ls[(size_t)p * 4 + 1] : -ls[(size_t)p * 4 + 3];
+    }
   };
   for (int32_t p = 0; p < ni; ++p) {
     const int32_t e = mesh->edge_internal_ids[p];
@@ -393,7 +539,7 @@ int rdyhip_create(const RDyHipConfig *config, const RDyHipMesh *mesh, int32_t nu
   std::vector<TileDesc> tiles((size_t)ntiles + 1);
   std::vector<uint32_t> e_lr;
   std::vector<int32_t>  hcells, tile_bk, halo_tiles;
-  std::vector<double>   e_cs;
+  std::vector<double>   e_cs, e_geo;
   std::vector<uint16_t> slot_ref((size_t)no * 4, SLOT_EMPTY);
   int32_t               emax = 0, hmax = 0;
   {
@@ -446,7 +592,21 @@ int rdyhip_create(const RDyHipConfig *config, const RDyHipMesh *mesh, int32_t nu
           if (last < ni) {
             e  = mesh->edge_internal_ids[last];
             lr = slot_of(mesh->edge_cell_ids[2 * e]) | (slot_of(mesh->edge_cell_ids[2 * e + 1]) << EDGE_R_SHIFT);
+            if (muscl_on) {
+              // centroid -> edge midpoint displacements of ReconstructFaceValues (src/operator_fluxes_ceed.c:1169-1178)
+              const int32_t v0 = mesh->edge_vertex_ids[2 * e], v1 = mesh->edge_vertex_ids[2 * e + 1];
+              if (v0 < 0 || v1 < 0 || v0 >= mesh->num_vertices || v1 >= mesh->num_vertices)
+                return fail(RDYHIP_ERR_ARG_OUTOFRANGE, "edge %d has vertex ids (%d,%d) out of range", e, v0, v1);
+              const double  x_mid = 0.5 * (mesh->vertex_points[3 * (size_t)v0 + 0] + mesh->vertex_points[3 * (size_t)v1 + 0]);
+              const double  y_mid = 0.5 * (mesh->vertex_points[3 * (size_t)v0 + 1] + mesh->vertex_points[3 * (size_t)v1 + 1]);
+              const int32_t cl = mesh->edge_cell_ids[2 * e], cr = mesh->edge_cell_ids[2 * e + 1];
+              e_geo.push_back(x_mid - mesh->cell_centroids[3 * (size_t)cl + 0]);
+              e_geo.push_back(y_mid - mesh->cell_centroids[3 * (size_t)cl + 1]);
+              e_geo.push_back(x_mid - mesh->cell_centroids[3 * (size_t)cr + 0]);
+              e_geo.push_back(y_mid - mesh->cell_centroids[3 * (size_t)cr + 1]);
+            }
           } else {
+            if (muscl_on) e_geo.insert(e_geo.end(), 4, 0.0);
             const int32_t k = last - ni;
             e               = bedge[k];
             lr              = slot_of(bleft[k]) | ((uint32_t)nbk << EDGE_R_SHIFT) | EDGE_BOUNDARY;
@@ -479,7 +639,9 @@ int rdyhip_create(const RDyHipConfig *config, const RDyHipMesh *mesh, int32_t nu
   }
   const bool   hr_on     = config->well_balancing == RDYHIP_WELL_BALANCING_HR;
   const size_t lds_bytes = sizeof(double) * ((hr_on ? 6 : 5) * ((size_t)TILE + hmax) + 2 * (size_t)TILE + (hr_on ? 8 : 4) * (size_t)emax);
-  if (lds_bytes > 160 * 1024) return fail(RDYHIP_ERR_USER, "tile working set (%zu B of LDS) too large: the cell numbering has no locality", lds_bytes);
+  const size_t lds_muscl = muscl_on ? sizeof(double) * (9 * ((size_t)TILE + hmax) + 4 * (size_t)emax) : 0;
+  if (std::max(lds_bytes, lds_muscl) > 160 * 1024)
+    return fail(RDYHIP_ERR_USER, "tile working set (%zu B of LDS) too large: the cell numbering has no locality", std::max(lds_bytes, lds_muscl));
 
   // ---- per-owned-cell geometry --------------------------------------------
   std::vector<double> dzdx((size_t)no), dzdy((size_t)no);
@@ -519,15 +681,28 @@ int rdyhip_create(const RDyHipConfig *config, const RDyHipMesh *mesh, int32_t nu
       return fail(RDYHIP_ERR_LIB, "cannot reserve %d bytes of LDS per workgroup", nb);
     }
   }
+  op->muscl     = muscl_on;
+  op->lds_muscl = lds_muscl;
+  if (lds_muscl > 64 * 1024) {
+    const int nb = (int)lds_muscl;
+    bool      ok = true;
+    for (int ovw = 0; ovw < 2; ++ovw)
+      for (int src = 0; src < 2; ++src)
+        ok = ok && hipFuncSetAttribute((const void *)muscl_kernel_fn(S, src, ovw != 0, config->limiter), hipFuncAttributeMaxDynamicSharedMemorySize, nb) == hipSuccess;
+    if (!ok) {
+      delete op;
+      return fail(RDYHIP_ERR_LIB, "cannot reserve %d bytes of LDS per workgroup", nb);
+    }
+  }
   op->nrec         = (int64_t)e_lr.size();
   op->nhalo_entries = (int64_t)hcells.size();
   {
     const char *kenv = getenv("RDYHIP_KERNEL");
     op->use_tiled    = !(kenv && strcmp(kenv, "cell") == 0);
     op->hr           = hr_on;
-    if (hr_on && !op->use_tiled) {
+    if ((hr_on || muscl_on) && !op->use_tiled) {
       delete op;
-      return fail(RDYHIP_ERR_USER, "hydrostatic reconstruction is implemented by the tiled kernel only (unset RDYHIP_KERNEL=cell)");
+      return fail(RDYHIP_ERR_USER, "hydrostatic reconstruction and second_order are implemented by the tiled kernels only (unset RDYHIP_KERNEL=cell)");
     }
   }
   int rc         = 0;
@@ -553,9 +728,18 @@ int rdyhip_create(const RDyHipConfig *config, const RDyHipMesh *mesh, int32_t nu
       if (atoi(e2) > 0) per_cu = atoi(e2);
     }
     op->pgrid            = std::max(8, cus * per_cu);
+    if (muscl_on) {
+      int qm = 0, per_cu_m = 2;
+      const void *mfn = (const void *)muscl_kernel_fn(S, config->source_method == RDYHIP_SOURCE_IMPLICIT_XQ2018 ? 1 : 0, true, config->limiter);
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&qm, mfn, TILE, lds_muscl) == hipSuccess && qm > 0) per_cu_m = qm;
+      if (const char *e2 = getenv("RDYHIP_BLOCKS_PER_CU")) {
+        if (atoi(e2) > 0) per_cu_m = atoi(e2);
+      }
+      op->pgrid_muscl = std::max(8, cus * per_cu_m);
+    }
     op->tiled_xcd_chunks = (swz && ntiles >= 64) ? (ntiles + 7) / 8 : 0;
   }
-  const int maxgrid = std::max(std::max(op->grid, op->pgrid), 1);
+  const int maxgrid = std::max(std::max(std::max(op->grid, op->pgrid), op->pgrid_muscl), 1);
 
 #define TRY_RC(x)     \
   do {                \
@@ -607,6 +791,12 @@ int rdyhip_create(const RDyHipConfig *config, const RDyHipMesh *mesh, int32_t nu
     std::vector<double> zc(mesh->cell_zc, mesh->cell_zc + nc);
     TRY_RC(op->d_zc_local.upload(zc));
   }
+  if (muscl_on) {
+    TRY_RC(op->d_grad.zeros((size_t)6 * nc));
+    TRY_RC(op->d_e_geo.upload(e_geo));
+    TRY_RC(op->d_gcx.upload(gcx));
+    TRY_RC(op->d_gcy.upload(gcy));
+  }
   TRY_RC(op->d_mannings.zeros((size_t)no));
   TRY_RC(op->d_extsrc.zeros((size_t)3 * no));
   TRY_RC(op->d_bvalues.zeros((size_t)3 * K));
@@ -634,7 +824,8 @@ int rdyhip_create(const RDyHipConfig *config, const RDyHipMesh *mesh, int32_t nu
                      op->d_dzdx.bytes() + op->d_dzdy.bytes() + op->d_mannings.bytes() + op->d_extsrc.bytes() +
                      op->d_pv.bytes() + op->d_bvalues.bytes() + op->d_bflux.bytes() + op->d_baccum.bytes() + op->d_blk_max.bytes() +
                      op->d_blk_pos.bytes() + op->d_tiles.bytes() + op->d_e_lr.bytes() + op->d_hcells.bytes() + op->d_tile_bk.bytes() +
-                     op->d_e_cs.bytes() + op->d_slot_ref.bytes() + op->d_slot_ref3.bytes();
+                     op->d_e_cs.bytes() + op->d_slot_ref.bytes() + op->d_slot_ref3.bytes() + op->d_grad.bytes() + op->d_e_geo.bytes() +
+                     op->d_gcx.bytes() + op->d_gcy.bytes();
   *op_out = op;
   return 0;
 }
@@ -669,7 +860,8 @@ int rdyhip_apply_phase(RDyHipOperator op, int32_t phase, int32_t flags, double d
     int rc = rdyhip_reset_diagnostics(op, stream);  // nothing to launch in this phase: reset on its own
     if (rc) return rc;
   }
-  return launch_rhs(op, phase, (flags & RDYHIP_PHASE_OVERWRITE) ? 1 : 0, reset, dt, u_local, f_global, (hipStream_t)stream);
+  return launch_rhs(op, phase, (flags & RDYHIP_PHASE_OVERWRITE) ? 1 : 0, reset, dt, u_local, f_global, (hipStream_t)stream,
+                    (flags & RDYHIP_PHASE_GRADIENTS_READY) != 0);
 }
 
 int rdyhip_set_boundary_values(RDyHipOperator op, int32_t boundary, int32_t comp_offset, int32_t num_comp, int32_t num_edges, const double *values) {
@@ -838,6 +1030,11 @@ int rdyhip_field_ptr(RDyHipOperator op, RDyHipField field, double **device_ptr, 
       *device_ptr = op->d_fdiv.p;
       n           = 3 * (int64_t)op->n_owned;
       break;
+    case RDYHIP_FIELD_GRADIENTS:
+      if (!op->muscl) return fail(RDYHIP_ERR_USER, "the operator was not created with second_order");
+      *device_ptr = op->d_grad.p;
+      n           = 6 * (int64_t)op->n_cells;
+      break;
     default: return fail(RDYHIP_ERR_USER, "unknown field %d", (int)field);
   }
   if (num_values) *num_values = n;
@@ -908,6 +1105,30 @@ int rdyhip_unpack_cells(double *u_local, const int32_t *cell_ids, int32_t n, con
   hipLaunchKernelGGL(unpack_cells_kernel, dim3((3 * n + 255) / 256), dim3(256), 0, (hipStream_t)stream, n, u_local, cell_ids, buf);
   HIP_TRY(hipGetLastError());
   return 0;
+}
+
+int rdyhip_pack_rows(const double *src, int32_t ncomp, const int32_t *row_ids, int32_t n, double *buf, void *stream) {
+  if (n < 0 || ncomp < 1) return fail(RDYHIP_ERR_ARG_SIZ, "bad count");
+  if (n == 0) return 0;
+  if (!src || !row_ids || !buf) return fail(RDYHIP_ERR_USER, "null argument");
+  const int64_t tot = (int64_t)n * ncomp;
+  hipLaunchKernelGGL(pack_rows_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n, ncomp, src, row_ids, buf);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int rdyhip_unpack_rows(double *dst, int32_t ncomp, const int32_t *row_ids, int32_t n, const double *buf, void *stream) {
+  if (n < 0 || ncomp < 1) return fail(RDYHIP_ERR_ARG_SIZ, "bad count");
+  if (n == 0) return 0;
+  if (!dst || !row_ids || !buf) return fail(RDYHIP_ERR_USER, "null argument");
+  const int64_t tot = (int64_t)n * ncomp;
+  hipLaunchKernelGGL(unpack_rows_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n, ncomp, dst, row_ids, buf);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int rdyhip_compute_gradients(RDyHipOperator op, int32_t phase, const double *u_local, void *stream) {
+  return launch_gradients(op, phase, u_local, (hipStream_t)stream);
 }
 
 int rdyhip_axpy_owned(RDyHipOperator op, double dt, const double *f_global, double *u_local, void *stream) {

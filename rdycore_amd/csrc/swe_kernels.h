@@ -755,6 +755,18 @@ __global__ void unpack_cells_kernel(int n, double *__restrict__ u, const int32_t
   const int cell = i / 3, comp = i - 3 * cell;
   u[3 * (int64_t)ids[cell] + comp] = buf[i];
 }
+__global__ void pack_rows_kernel(int n, int ncomp, const double *__restrict__ src, const int32_t *__restrict__ ids, double *__restrict__ buf) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)n * ncomp) return;
+  const int row = (int)(i / ncomp), comp = (int)(i - (int64_t)row * ncomp);
+  buf[i]        = src[(int64_t)ids[row] * ncomp + comp];
+}
+__global__ void unpack_rows_kernel(int n, int ncomp, double *__restrict__ dst, const int32_t *__restrict__ ids, const double *__restrict__ buf) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)n * ncomp) return;
+  const int row = (int)(i / ncomp), comp = (int)(i - (int64_t)row * ncomp);
+  dst[(int64_t)ids[row] * ncomp + comp] = buf[i];
+}
 __global__ void axpy_owned_kernel(int n_owned, const int32_t *__restrict__ o2l, double dt, const double *__restrict__ f, double *__restrict__ u) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= 3 * n_owned) return;

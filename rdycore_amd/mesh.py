@@ -86,6 +86,18 @@ class RDyMesh:
     def owned_centroids(self) -> np.ndarray:
         return self.cell_centroids[self.cell_owned_to_local]
 
+    def edge_is_owned(self) -> np.ndarray:
+        """edges.is_owned (src/rdymesh.c:599).  The reference takes the owner from the DMPlex
+        point SF; any rule that gives every edge exactly one owning rank is equivalent for the
+        second-order flux (src/swe/swe_petsc.c:98-213).  Here: the rank owning the adjacent cell
+        with the smaller global id (a boundary edge: its only cell)."""
+        cl = self.edge_cell_ids[0::2]
+        cr = self.edge_cell_ids[1::2]
+        gl = self.cell_global_ids[cl]
+        gr = np.where(cr >= 0, self.cell_global_ids[np.maximum(cr, 0)], np.iinfo(np.int64).max)
+        first = np.where(gl <= gr, cl, cr)
+        return self.cell_is_owned[first].astype(np.int32)
+
     def boundary_by_name(self, name: str) -> int:
         for i, b in enumerate(self.boundaries):
             if b.name == name:

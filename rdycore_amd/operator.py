@@ -25,6 +25,7 @@ SOURCE_IMPLICIT_XQ2018 = 1
 RIEMANN_ROE = 0
 WELL_BALANCING_NONE = 0      # RDyWellBalanceMethod, include/private/rdyconfigimpl.h:58-62
 WELL_BALANCING_HR = 2        # hydrostatic reconstruction
+LIMITER_MINMOD, LIMITER_NONE, LIMITER_VANLEER = 0, 1, 2   # RDyLimiterType, include/private/rdyconfigimpl.h:64-71
 
 PHASE_ALL, PHASE_INTERIOR, PHASE_HALO = 0, 1, 2
 
@@ -39,6 +40,8 @@ class RDyFlowConfig:
     source_method: int = SOURCE_SEMI_IMPLICIT
     riemann: int = RIEMANN_ROE
     well_balancing: int = WELL_BALANCING_NONE
+    second_order: bool = False        # numerics.second_order: MUSCL reconstruction (src/swe/swe_petsc.c:98-213)
+    limiter: int = LIMITER_MINMOD     # numerics.limiter
 
 
 @dataclasses.dataclass
@@ -112,13 +115,19 @@ class Operator:
         m.edge_cn = arr(mesh.edge_cn, np.float64).ctypes.data_as(_lib.c_double_p)
         m.edge_sn = arr(mesh.edge_sn, np.float64).ctypes.data_as(_lib.c_double_p)
         m.cell_zc = arr(mesh.cell_zc, np.float64).ctypes.data_as(_lib.c_double_p)
+        if config.second_order:
+            m.num_vertices = mesh.num_vertices
+            m.cell_centroids = arr(mesh.cell_centroids, np.float64).ctypes.data_as(_lib.c_double_p)
+            m.edge_vertex_ids = arr(mesh.edge_vertex_ids, np.int32).ctypes.data_as(_lib.c_int32_p)
+            m.vertex_points = arr(mesh.xyz, np.float64).ctypes.data_as(_lib.c_double_p)
         barr = (_lib.RDyHipBoundary * max(nb, 1))()
         for i, b in enumerate(mesh.boundaries):
             barr[i].num_edges = b.num_edges
             barr[i].edge_ids = arr(b.edge_ids, np.int32).ctypes.data_as(_lib.c_int32_p)
             barr[i].condition_type = int(condition_types[i])
         cfg = _lib.RDyHipConfig(config.tiny_h, config.h_anuga_regular, config.xq2018_threshold,
-                                int(config.source_method), int(config.riemann), int(config.well_balancing), 0)
+                                int(config.source_method), int(config.riemann), int(config.well_balancing),
+                                1 if config.second_order else 0, int(config.limiter), 0)
         h = C.c_void_p()
         _lib.check(lib.rdyhip_create(C.byref(cfg), C.byref(m), nb, barr, C.byref(h)))
         return cls(h, mesh, config, condition_types)
@@ -155,11 +164,20 @@ class Operator:
         _lib.check(_lib.load().rdyhip_rhs_function(self._h, float(dt), _ptr(u_local), _ptr(f_global), _stream()))
 
     def apply_phase(self, phase: int, overwrite: bool, dt: float, u_local: torch.Tensor, f_global: torch.Tensor,
-                    reset_diagnostics: bool = False):
+                    reset_diagnostics: bool = False, gradients_ready: bool = False):
         self._check_vecs(u_local, f_global)
-        flags = (1 if overwrite else 0) | (2 if reset_diagnostics else 0)
+        flags = (1 if overwrite else 0) | (2 if reset_diagnostics else 0) | (4 if gradients_ready else 0)
         _lib.check(_lib.load().rdyhip_apply_phase(self._h, int(phase), flags, float(dt), _ptr(u_local),
                                                  _ptr(f_global), _stream()))
+
+    # -- second order: ComputeLeastSquaresGradients for the owned cells (src/operator_fluxes_ceed.c:998-1042)
+    def compute_gradients(self, u_local: torch.Tensor, phase: int = PHASE_ALL):
+        _lib.check(_lib.load().rdyhip_compute_gradients(self._h, int(phase), _ptr(u_local), _stream()))
+
+    @property
+    def gradients(self) -> torch.Tensor:
+        """[num_cells, 6] (dh/dx, dh/dy, dhu/dx, dhu/dy, dhv/dx, dhv/dy) by LOCAL cell; ghost rows are the caller's to fill"""
+        return self._field(4, 6)
 
     # -- SetOperatorBoundaryValues (src/operator.c:1045-1061) --------------
     def set_boundary_values(self, boundary: int, values, comp_offset: int = 0):
@@ -263,6 +281,15 @@ class Operator:
         info = _lib.RDyHipLayoutInfo()
         _lib.check(_lib.load().rdyhip_layout_info(self._h, C.byref(info)))
         return {k: getattr(info, k) for k, _ in info._fields_}
+
+
+def pack_rows(src: torch.Tensor, row_ids: torch.Tensor, buf: torch.Tensor):
+    """buf[i, :] = src[row_ids[i], :] for a [rows, ncomp] device array (the gradient field)"""
+    _lib.check(_lib.load().rdyhip_pack_rows(_ptr(src), int(src.shape[1]), _ptr(row_ids), int(row_ids.numel()), _ptr(buf), _stream()))
+
+
+def unpack_rows(dst: torch.Tensor, row_ids: torch.Tensor, buf: torch.Tensor):
+    _lib.check(_lib.load().rdyhip_unpack_rows(_ptr(dst), int(dst.shape[1]), _ptr(row_ids), int(row_ids.numel()), _ptr(buf), _stream()))
 
 
 def pack_cells(u_local: torch.Tensor, cell_ids: torch.Tensor, buf: torch.Tensor):

@@ -51,7 +51,7 @@ int main(int argc, char **argv) {
   if (fread(scal, sizeof(double), 4, f) != 4) return 4;
   const int32_t nc = hdr[0], no = hdr[1], ne = hdr[2], ni = hdr[3], nb = hdr[4];
 
-  RDyHipMesh m;
+  RDyHipMesh m = {0};
   m.num_cells = nc; m.num_owned_cells = no; m.num_edges = ne; m.num_internal_edges = ni;
   m.cell_is_owned       = rd(f, nc, 4);
   m.cell_local_to_owned = rd(f, nc, 4);

@@ -6,7 +6,8 @@ from oracle import oracle as O
 
 def oracle_from_case(case):
     cfg = case.config
-    orc = O.OracleOperator(case.mesh, case.condition_types, cfg.tiny_h, cfg.h_anuga_regular, cfg.xq2018_threshold, cfg.source_method, cfg.well_balancing)
+    orc = O.OracleOperator(case.mesh, case.condition_types, cfg.tiny_h, cfg.h_anuga_regular, cfg.xq2018_threshold, cfg.source_method, cfg.well_balancing,
+                           second_order=cfg.second_order, limiter=cfg.limiter)
     orc.mannings[:] = case.mannings
     orc.external_sources[:] = case.ext_src
     for b, vals in case.boundary_values.items():
@@ -21,3 +22,38 @@ def rel_linf(a, b):
     if a.size == 0:
         return 0.0
     return float(np.max(np.abs(a - b)) / max(1.0, float(np.max(np.abs(b)))))
+
+
+def second_order_oracle_ranks(cases):
+    """One second-order RHS on a partitioned mesh the way the reference runs it
+    (ApplyInteriorFlux2R, src/swe/swe_petsc.c:98-213), with the two exchanges done by
+    hand: CommunicateCellGradients (ghost gradients from their owners) and
+    DMLocalToGlobal(ADD_VALUES) (the ghost rows of each rank's local flux vector added
+    onto the owners) between the interior-flux and the boundary/source sub-operators.
+    `cases`: one Case per rank, local meshes carrying global cell ids.
+    Returns ([F_rank], [oracle_rank])."""
+    orcs = [oracle_from_case(c) for c in cases]
+    owner = {}
+    for r, c in enumerate(cases):
+        m = c.mesh
+        for lc in m.cell_owned_to_local:
+            owner[int(m.cell_global_ids[lc])] = (r, int(lc))
+    for o, c in zip(orcs, cases):
+        o.compute_gradients(c.u_local)
+    own_grads = [[g.copy() for g in o.gradients] for o in orcs]
+    for r, (o, c) in enumerate(zip(orcs, cases)):
+        m = c.mesh
+        for lc in np.nonzero(m.cell_is_owned == 0)[0]:
+            pr, plc = owner[int(m.cell_global_ids[lc])]
+            for k in range(3):
+                o.gradients[k][lc] = own_grads[pr][k][plc]
+        o.set_gradients_ready(True)
+    fs = [o.apply_interior(c.dt, c.u_local) for o, c in zip(orcs, cases)]
+    for r, (o, c) in enumerate(zip(orcs, cases)):
+        m = c.mesh
+        for lc in np.nonzero(m.cell_is_owned == 0)[0]:
+            pr, plc = owner[int(m.cell_global_ids[lc])]
+            fs[pr][cases[pr].mesh.cell_local_to_owned[plc]] += o.rhs_local[lc]
+    for o, c, f in zip(orcs, cases, fs):
+        o.apply_rest(c.dt, c.u_local, f)
+    return fs, orcs

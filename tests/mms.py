@@ -29,17 +29,23 @@ K = 0.6283185307179586
 # mms_conv_study.yaml:51-63
 EXPECTED = {"h": (0.94, 0.95, 0.94), "hu": (0.91, 0.93, 0.77), "hv": (0.91, 0.93, 0.77)}
 
+# mms_conv_study_second_order.yaml:54-69 (3 levels: base_refinement 1, num_refinements 2)
+EXPECTED_SECOND_ORDER = {"h": (1.40, 1.20, 0.80), "hu": (1.30, 1.30, 0.85), "hv": (1.30, 1.30, 0.85)}
+
 s, c, e = np.sin, np.cos, np.exp
+
+# mean water depth in units of H: 1 in mms_conv_study.yaml:22,25; 2 in mms_conv_study_second_order.yaml:23,26
+H0 = 1.0
 
 
 def fields(x, y, t):
     """mms_conv_study.yaml:20-46"""
     et = e(t / T)
     d = {}
-    d["h"] = H * (1 + s(K * x) * s(K * y)) * et
+    d["h"] = H * (H0 + s(K * x) * s(K * y)) * et
     d["dhdx"] = H * K * s(K * y) * c(K * x) * et
     d["dhdy"] = H * K * s(K * x) * c(K * y) * et
-    d["dhdt"] = H / T * (1 + s(K * x) * s(K * y)) * et
+    d["dhdt"] = H / T * (H0 + s(K * x) * s(K * y)) * et
     d["u"] = U * c(K * x) * s(K * y) * et
     d["dudx"] = -U * K * s(K * x) * s(K * y) * et
     d["dudy"] = U * K * c(K * x) * c(K * y) * et
@@ -134,9 +140,20 @@ def convergence_rates(make_apply, base_refinement=1, num_refinements=3, dt=0.01,
     return rates
 
 
-def oracle_make_apply(mesh, bc_types):
+def second_order_rates(make_apply):
+    """the study of mms_conv_study_second_order.yaml: same fields with a mean depth of 2H, three levels"""
+    global H0
+    H0 = 2.0
+    try:
+        return convergence_rates(make_apply, base_refinement=1, num_refinements=2)
+    finally:
+        H0 = 1.0
+
+
+def oracle_make_apply(mesh, bc_types, second_order=False, limiter=0):
     from oracle import oracle as O
-    orc = O.OracleOperator(mesh, bc_types, source_method=0)   # semi_implicit: the default, src/yaml_input.c:859
+    # semi_implicit: the default, src/yaml_input.c:859
+    orc = O.OracleOperator(mesh, bc_types, source_method=0, second_order=second_order, limiter=limiter)
 
     def apply(dt, u, src, bvals):
         orc.external_sources[:] = src
@@ -147,3 +164,7 @@ def oracle_make_apply(mesh, bc_types):
         orc.mannings[:] = n
 
     return apply, set_mannings
+
+
+def oracle_make_apply_second_order(mesh, bc_types):
+    return oracle_make_apply(mesh, bc_types, second_order=True, limiter=0)   # minmod: the default limiter

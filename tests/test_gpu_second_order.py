@@ -1,0 +1,198 @@
+"""GPU parity of the second-order (MUSCL) path -- rdyhip_compute_gradients and
+swe_rhs_muscl_kernel through the C ABI -- against the oracle's restatement of
+ApplyInteriorFlux2R (src/swe/swe_petsc.c:98-213).  Tolerance: RHS L-inf <= 1e-10
+relative to max(1, |F|_inf), as for the first-order path."""
+import numpy as np
+import pytest
+
+import mms
+from rdycore_amd import cases as CS
+from rdycore_amd import mesh as M
+from rdycore_amd.operator import (LIMITER_MINMOD, LIMITER_NONE, LIMITER_VANLEER, SOURCE_IMPLICIT_XQ2018, SOURCE_SEMI_IMPLICIT,
+                                  Operator, RDyFlowConfig, RDyHipError)
+
+from helpers import oracle_from_case, rel_linf
+from test_gpu_parity import check_all, run_both, tri_mms_case
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-10
+
+
+@pytest.fixture(autouse=True)
+def _tiled_only(rdyhip_kernel):
+    if rdyhip_kernel == "cell":
+        pytest.skip("second order is implemented by the tiled kernels")
+
+
+def _torch():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+def second_order(case, limiter=LIMITER_MINMOD):
+    case.config.second_order, case.config.limiter = True, limiter
+    return case
+
+
+@pytest.mark.parametrize("limiter", [LIMITER_MINMOD, LIMITER_NONE, LIMITER_VANLEER])
+@pytest.mark.parametrize("source_method", [SOURCE_SEMI_IMPLICIT, SOURCE_IMPLICIT_XQ2018])
+def test_tri_all_bcs_sources_limiters(limiter, source_method):
+    case = second_order(tri_mms_case(40, 28, source_method, order="tiled"), limiter)
+    f, fr, op, orc = run_both(case)
+    check_all(case, f, fr, op, orc)
+    # the gradients themselves
+    g = op.gradients.cpu().numpy()
+    assert rel_linf(g, orc.gradients6()) <= TOL
+    # and the scheme differs from first order on this state
+    case.config.second_order = False
+    assert np.abs(oracle_from_case(case).apply(case.dt, case.u_local) - fr).max() > 1e-8
+
+
+def test_dam_break_with_dry_cells_and_clamped_depths():
+    mesh = M.structured_tri_mesh(48, 20)
+    case = second_order(CS.dam_break_case(mesh, 24.0), LIMITER_NONE)   # unlimited extrapolation over the front: negative depths get clamped
+    case.u_local[mesh.cell_centroids[:, 0] > 30.0, 0] = 0.0            # dry bed downstream
+    f, fr, op, orc = run_both(case)
+    check_all(case, f, fr, op, orc)
+
+
+@pytest.mark.parametrize("limiter", [LIMITER_MINMOD, LIMITER_VANLEER])
+def test_quad_mesh(limiter):
+    K = 2 * np.pi / 17
+    mesh = M.structured_quad_mesh(30, 22, 1.0, 1.0, zfunc=CS.mms_bathymetry(K=K))
+    case = second_order(CS.friction_slope_case(mesh, 30, 22, dt=1e-2, K=K), limiter)
+    f, fr, op, orc = run_both(case)
+    check_all(case, f, fr, op, orc)
+    assert op.layout_info()["slots_per_cell"] == 4
+
+
+def test_accumulate_semantics():
+    case = second_order(tri_mms_case(24, 16, SOURCE_SEMI_IMPLICIT))
+    rng = np.random.default_rng(3)
+    f0 = rng.normal(size=(case.mesh.num_owned_cells, 3)) * 0.1
+    f, fr, op, orc = run_both(case, accumulate_from=f0)
+    assert rel_linf(f, fr) <= TOL
+
+
+def test_random_cell_numbering():
+    rng = np.random.default_rng(5)
+    nx, ny = 30, 20
+    K = 2 * np.pi / 13
+    xyz, conn, _, _ = M.structured_tri_connectivity(nx, ny)
+    xyz[:, 2] = CS.mms_bathymetry(K=K)(xyz[:, 0], xyz[:, 1])
+    perm = rng.permutation(conn.shape[0])
+    mesh = M.build_mesh(xyz, conn[perm], boundary_classifier=M.box_side_boundaries(0, nx, 0, ny))
+    case = second_order(CS.friction_slope_case(mesh, nx, ny, dt=1e-2, K=K))
+    f, fr, op, orc = run_both(case)
+    check_all(case, f, fr, op, orc)
+
+
+@pytest.mark.parametrize("ghosts", ["tail", "interleaved"])
+def test_one_rank_of_a_partition(ghosts):
+    """A rank's local mesh with ghost cells: owned gradients from the kernel, ghost gradients as their owners
+    would send them (here: taken from the global oracle), then the flux kernel over ALL edges of the owned
+    cells -- equals the reference's owner-computes + reverse-add result, i.e. the global RHS."""
+    torch = _torch()
+    nxg, ny = 24, 10
+    K = 2 * np.pi / 15
+    z = CS.mms_bathymetry(K=K)
+    g = M.structured_tri_mesh(nxg, ny, 1.0, zfunc=z)
+    gc = second_order(CS.friction_slope_case(g, nxg, ny, dt=1e-2, K=K))
+    og = oracle_from_case(gc)
+    fg = og.apply(gc.dt, gc.u_local)
+    gg = og.gradients6()
+    xyz, conn, cqi, _ = M.structured_tri_connectivity(nxg, ny)
+    xyz[:, 2] = z(xyz[:, 0], xyz[:, 1])
+    owned = (cqi >= 8) & (cqi < 16)
+    mesh = M.extract_local_mesh(xyz, conn, owned, boundary_classifier=M.box_side_boundaries(0, nxg, 0, ny), ghosts=ghosts)
+    case = second_order(CS.friction_slope_case(mesh, nxg, ny, dt=1e-2, K=K))
+    op = CS.create_operator(case)
+    u = torch.tensor(case.u_local, dtype=torch.float64, device="cuda")
+    f = torch.full((mesh.num_owned_cells, 3), 7.0, dtype=torch.float64, device="cuda")
+    # without the exchange the call is refused (the ghost gradients would be stale)
+    with pytest.raises(RDyHipError):
+        op.rhs_function(case.dt, u, f)
+    op.compute_gradients(u)
+    grads = op.gradients
+    ghost = np.nonzero(mesh.cell_is_owned == 0)[0]
+    own = mesh.cell_owned_to_local
+    torch.cuda.synchronize()
+    assert rel_linf(grads.cpu().numpy()[own], gg[mesh.cell_global_ids[own]]) <= TOL
+    grads[torch.as_tensor(ghost, device="cuda")] = torch.as_tensor(gg[mesh.cell_global_ids[ghost]], device="cuda")
+    op.apply_phase(0, True, case.dt, u, f, reset_diagnostics=True, gradients_ready=True)
+    torch.cuda.synchronize()
+    assert rel_linf(f.cpu().numpy(), fg[mesh.cell_global_ids[own]]) <= TOL
+    # phased: gradients interior + halo, fluxes interior + halo, bitwise the same
+    g_all = grads.clone()
+    grads[torch.as_tensor(own, device="cuda")] = 0.0
+    op.compute_gradients(u, phase=1)
+    op.compute_gradients(u, phase=2)
+    torch.cuda.synchronize()
+    assert torch.equal(grads, g_all)
+    f2 = torch.zeros_like(f)
+    op.reset_boundary_fluxes_accum()
+    op.apply_phase(1, True, case.dt, u, f2, reset_diagnostics=True, gradients_ready=True)
+    op.apply_phase(2, True, case.dt, u, f2, gradients_ready=True)
+    torch.cuda.synchronize()
+    assert torch.equal(f2, f)
+    with pytest.raises(RDyHipError):
+        op.apply_phase(1, True, case.dt, u, f2)          # a phased apply needs the gradients to be ready
+
+
+def test_second_order_mms_convergence_on_the_gpu():
+    """mms_conv_study_second_order.yaml with the HIP operator in the loop: the reference's thresholds are
+    exceeded and the rates equal the oracle's."""
+    torch = _torch()
+
+    def make_apply(mesh, bc_types):
+        op = Operator.create(RDyFlowConfig(second_order=True), mesh, bc_types)
+        f = torch.empty((mesh.num_owned_cells, 3), dtype=torch.float64, device="cuda")
+
+        def apply(dt, u, src, bvals):
+            for c in range(3):
+                op.set_domain_external_source(c, src[:, c])
+            op.set_boundary_values(0, bvals)
+            ud = torch.tensor(u, dtype=torch.float64, device="cuda")
+            op.rhs_function(dt, ud, f)
+            return f.cpu().numpy()
+
+        return apply, op.set_domain_mannings_n
+
+    rates = mms.second_order_rates(make_apply)
+    ref = mms.second_order_rates(mms.oracle_make_apply_second_order)
+    for comp, expected in mms.EXPECTED_SECOND_ORDER.items():
+        assert np.allclose(rates[comp], ref[comp], atol=1e-8), (rates[comp], ref[comp])
+        assert all(r > t for r, t in zip(rates[comp], expected))
+
+
+def test_unsupported_combinations_are_rejected():
+    _torch()
+    mesh = M.structured_tri_mesh(6, 4, project_2d=True)
+    with pytest.raises(RDyHipError) as e:
+        Operator.create(RDyFlowConfig(second_order=True, well_balancing=2), mesh, None)      # src/operator.c:388-389
+    assert e.value.code == 83
+    with pytest.raises(RDyHipError):
+        Operator.create(RDyFlowConfig(second_order=True, limiter=7), mesh, None)
+    op = Operator.create(RDyFlowConfig(), mesh, None)
+    with pytest.raises(RDyHipError):
+        op.gradients                                                                          # first-order operator: no gradient field
+
+
+@pytest.mark.parametrize("nx,ny", [(1000, 500)])
+def test_full_size_parity_and_mass_balance(nx, ny):
+    """C2 size (1 M cells): whole RHS against the oracle, and water-mass balance."""
+    torch = _torch()
+    K = 2 * np.pi / 200.0
+    mesh = M.structured_tri_mesh(nx, ny, 1.0, zfunc=CS.mms_bathymetry(K=K), order="tiled")
+    case = second_order(CS.friction_slope_case(mesh, nx, ny, K=K))
+    f, fr, op, orc = run_both(case)
+    assert rel_linf(f, fr) <= TOL
+    flux_out = 0.0
+    for b, bnd in enumerate(mesh.boundaries):
+        bf = op.boundary_fluxes(b)
+        wet = ~np.isnan(bf[:, 0])
+        flux_out += (bf[wet, 0] * mesh.edge_lengths[bnd.edge_ids][wet]).sum()
+    lhs = (f[:, 0] * mesh.cell_areas).sum()
+    rhs = -flux_out + (case.ext_src[:, 0] * mesh.cell_areas).sum()
+    assert abs(lhs - rhs) <= 1e-9 * max(1.0, abs(rhs))
