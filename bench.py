@@ -47,6 +47,9 @@ def parse():
                    help="c3: friction + bed slope + all BC types (default; use --nx 2500 --ny 2000); "
                         "c2: flat-bed dam break, all reflecting (BASELINE configs[1]: --nx 1000 --ny 500)")
     p.add_argument("--hr", action="store_true", help="hydrostatic-reconstruction variant of the operator (SURVEY 8.f row 2)")
+    p.add_argument("--second-order", action="store_true",
+                   help="MUSCL second-order variant (SURVEY 8.f row 4): gradient kernel + reconstructing flux kernel per RHS")
+    p.add_argument("--limiter", default="minmod", choices=["minmod", "none", "van_leer"])
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-cpu-all-cores", action="store_true", help="skip the all-host-cores CPU figure (the 1-core cpu_baseline stays)")
     p.add_argument("--kernel", default=None, choices=["tiled", "cell"], help="kernel variant (default: library default = tiled)")
@@ -54,7 +57,13 @@ def parse():
     return p.parse_args()
 
 
-def build_case(nx, ny, rank, world, order, source, workload="c3", hr=False):
+LIMITERS = {"minmod": 0, "none": 1, "van_leer": 2}
+# second order: 176 B + gradients written once and read once (2 x 48) + the state read again by the gradient kernel (24)
+# + least-squares coefficients (3 slots x 16) + centroid->midpoint displacements (1.5 edges x 32)
+ALG_BYTES_PER_CELL_SECOND_ORDER = 176.0 + 96.0 + 24.0 + 48.0 + 48.0
+
+
+def build_case(nx, ny, rank, world, order, source, workload="c3", hr=False, second_order=False, limiter="minmod"):
     from rdycore_amd import cases as CS
     from rdycore_amd import mesh as M
     from rdycore_amd.operator import SOURCE_IMPLICIT_XQ2018, SOURCE_SEMI_IMPLICIT
@@ -72,17 +81,19 @@ def build_case(nx, ny, rank, world, order, source, workload="c3", hr=False):
     if hr:
         from rdycore_amd.operator import WELL_BALANCING_HR
         case.config.well_balancing = WELL_BALANCING_HR
+    case.config.second_order = bool(second_order)
+    case.config.limiter = LIMITERS[limiter]
     return case
 
 
-def cpu_baseline(sample: str, source: str, workload: str = "c3", hr: bool = False):
+def cpu_baseline(sample: str, source: str, workload: str = "c3", hr: bool = False, second_order: bool = False, limiter: str = "minmod"):
     """The CPU oracle (a plain-C restatement of the reference's PETSc path, one
     core) timed on a bounded sample of the same workload."""
     from oracle import oracle as O  # test infrastructure; used here only as the timed CPU baseline
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from helpers import oracle_from_case
     nx, ny = map(int, sample.split("x"))
-    case = build_case(nx, ny, 0, 1, "rowmajor", source, workload, hr)
+    case = build_case(nx, ny, 0, 1, "rowmajor", source, workload, hr, second_order, limiter)
     orc = oracle_from_case(case)
     f = np.zeros((case.mesh.num_owned_cells, 3))
     orc.apply(case.dt, case.u_local, f)  # warm
@@ -102,10 +113,10 @@ def cpu_baseline(sample: str, source: str, workload: str = "c3", hr: bool = Fals
 
 def _cpu_strip_worker(args):
     """One host core: the oracle on one strip (with its ghost cells) of the sample mesh."""
-    nx, ny, rank, world, source, workload, hr, reps = args
+    nx, ny, rank, world, source, workload, hr, reps, second_order, limiter = args
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from helpers import oracle_from_case
-    case = build_case(nx, ny, rank, world, "rowmajor", source, workload, hr)
+    case = build_case(nx, ny, rank, world, "rowmajor", source, workload, hr, second_order, limiter)
     orc = oracle_from_case(case)
     f = np.zeros((case.mesh.num_owned_cells, 3))
     orc.apply(case.dt, case.u_local, f)
@@ -118,7 +129,7 @@ def _cpu_strip_worker(args):
     return case.mesh.num_owned_cells, float(np.median(ts))
 
 
-def cpu_baseline_all_cores(sample: str, source: str, workload: str, hr: bool):
+def cpu_baseline_all_cores(sample: str, source: str, workload: str, hr: bool, second_order: bool = False, limiter: str = "minmod"):
     """no MPI launcher exists here, so P independent oracle processes run on P strip
     partitions of the sample mesh (ghost cells present, not exchanged) -- an upper bound on what the
     MPI-parallel reference could do on these host cores."""
@@ -129,7 +140,7 @@ def cpu_baseline_all_cores(sample: str, source: str, workload: str, hr: bool):
     while nx % p:
         p -= 1
     with mp.get_context("spawn").Pool(p) as pool:
-        res = pool.map(_cpu_strip_worker, [(nx // p, ny, r, p, source, workload, hr, 5) for r in range(p)])
+        res = pool.map(_cpu_strip_worker, [(nx // p, ny, r, p, source, workload, hr, 5, second_order, limiter) for r in range(p)])
     cells = sum(r[0] for r in res)
     tmax = max(r[1] for r in res)
     return {"value": round(cells / tmax / 1e6, 2), "unit": "M cell-updates/s", "cores": p, "kind": "port",
@@ -176,7 +187,7 @@ def main():
     from rdycore_amd.halo import HaloExchange
 
     t0 = time.time()
-    case = build_case(args.nx, args.ny, rank, world, args.order, args.source, args.workload, args.hr)
+    case = build_case(args.nx, args.ny, rank, world, args.order, args.source, args.workload, args.hr, args.second_order, args.limiter)
     mesh = case.mesh
     op = CS.create_operator(case)
     halo = HaloExchange(mesh, dev) if world > 1 else None
@@ -261,23 +272,33 @@ def main():
             "config": {"workload": workload, "cells_per_gpu": n_owned, "cell_order": args.order,
                        "partition": "single" if world == 1 else f"strips_x{world}",
                        "well_balancing": "hydrostatic_reconstruction" if args.hr else "none",
+                       "spatial_order": ("second (MUSCL, %s limiter)" % args.limiter) if args.second_order else "first",
                        "halo_bytes_per_rank": halo.bytes_sent_per_exchange if halo else 0,
                        "setup_seconds": round(setup_s, 1), "max_courant": courant, "finite": finite},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4),
                          "traffic": load_traffic(f"{args.nx}x{args.ny}_{args.order}_{args.source}") if args.workload == "c3" else None,
-                         "kernel": "%s<3,%d>" % ("swe_rhs_tiled_kernel" if info["tiled_kernel"] else "swe_rhs_kernel",
-                                                 0 if args.source == "semi_implicit" else 1),
+                         "kernel": ("muscl_gradient_kernel<3> + swe_rhs_muscl_kernel<3,%d>" % (0 if args.source == "semi_implicit" else 1))
+                         if args.second_order else
+                         "%s<3,%d>" % ("swe_rhs_tiled_kernel" if info["tiled_kernel"] else "swe_rhs_kernel",
+                                       0 if args.source == "semi_implicit" else 1),
                          "tile_edge_records_per_cell": round(info["num_edge_records"] / max(n_owned, 1), 4),
                          "kernel_avg_ms": round(kern_ms, 5),
                          "algorithmic_bytes_per_launch": int(n_owned * ALG_BYTES_PER_CELL),
                          "layout_bytes_per_launch": int(info["bytes_per_apply"])},
         }
+        if args.second_order:
+            # the 176-B figure above keeps variants comparable; the second-order path's own model:
+            a2 = n_owned * ALG_BYTES_PER_CELL_SECOND_ORDER / (kern_ms * 1e-3) / 1e9
+            out["roofline"]["second_order_model"] = {"bytes_per_cell_update": ALG_BYTES_PER_CELL_SECOND_ORDER, "achieved": round(a2, 1),
+                                                     "frac": round(a2 / HBM_PEAK_GBPS, 4)}
+            out["roofline"]["traffic"] = None
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.source, args.workload, args.hr)
+            out["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.source, args.workload, args.hr, args.second_order, args.limiter)
             if not args.no_cpu_all_cores:
                 try:
-                    out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(args.cpu_sample, args.source, args.workload, args.hr)
+                    out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(args.cpu_sample, args.source, args.workload, args.hr, args.second_order,
+                                                                           args.limiter)
                 except Exception as exc:  # a reported extra, never a reason to lose the bench line
                     out["cpu_baseline_all_cores"] = {"error": repr(exc)}
         print(json.dumps(out), flush=True)

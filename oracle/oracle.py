@@ -107,7 +107,11 @@ class OracleOperator:
     """CPU oracle for ApplyOperator on one rank's mesh (mesh: rdycore_amd.mesh.RDyMesh)."""
 
     def __init__(self, mesh, bc_types: Sequence[int], tiny_h=1e-7, h_anuga_regular=0.0, xq2018_threshold=1e-10,
-                 source_method=0, well_balancing=0, second_order=False, limiter=0):
+                 source_method=0, well_balancing=0, second_order=False, limiter=0,
+                 all_edges_local=False):
+        """all_edges_local (second order only): treat every local internal edge as owned by this rank, i.e. solve the
+        cut edges redundantly on both ranks instead of the reference's owner-computes + reverse-add -- the scheme
+        of the HIP path; the owned rows of F are then complete without the reverse exchange."""
         L = lib()
         self.mesh = mesh
         self._keep = []
@@ -138,7 +142,7 @@ class OracleOperator:
             m.centroids = _dp(keep(mesh.cell_centroids, np.float64))
             m.vertex_ids = _ip(keep(mesh.edge_vertex_ids, np.int32))
             m.points = _dp(keep(mesh.xyz, np.float64))
-            m.edge_is_owned = _ip(keep(mesh.edge_is_owned(), np.int32))
+            m.edge_is_owned = _ip(keep(np.ones(mesh.num_edges) if all_edges_local else mesh.edge_is_owned(), np.int32))
         nb = len(mesh.boundaries)
         assert len(bc_types) == nb
         barr = (OracleBoundary * max(nb, 1))()

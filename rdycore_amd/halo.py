@@ -4,7 +4,10 @@ Stands in for DMGlobalToLocalBegin/End in OperatorRHSFunction
 (src/rdysetup.c:1133-1134): before an RHS evaluation every ghost cell of
 `u_local` receives the state of the rank that owns it (3 doubles per cell,
 1-cell overlap, src/rdydm.c:145-157).  First-order fluxes need no reverse
-exchange (src/swe/swe_petsc.c:272-274).
+exchange (src/swe/swe_petsc.c:272-274).  The second-order path also exchanges
+the cell gradients (6 doubles per cell, CommunicateCellGradients,
+src/operator_fluxes_ceed.c:1058-1107); its reverse ADD exchange is avoided by
+evaluating cut edges on both ranks (csrc/muscl_kernels.h).
 
 One process per GPU; the transport is torch.distributed point-to-point
 (backend "nccl" = RCCL over xGMI on the GPUs, "gloo" in the CPU tests).  The
@@ -85,26 +88,35 @@ class HaloExchange:
                 covered += got.size
         if covered != ghost_local.size:
             raise RuntimeError(f"rank {self.rank}: {ghost_local.size - covered} ghost cells have no owner")
-        # one contiguous send and one contiguous receive buffer (a slice per peer), so that a ghost
-        # update costs one pack and one unpack launch whatever the number of neighbours
         peers_s, peers_r = sorted(self.send_ids), sorted(self.recv_ids)
-        ns = sum(int(self.send_ids[p].numel()) for p in peers_s)
-        nr = sum(int(self.recv_ids[p].numel()) for p in peers_r)
-        self.send_all = torch.empty((ns, 3), dtype=torch.float64, device=self.device)
-        self.recv_all = torch.empty((nr, 3), dtype=torch.float64, device=self.device)
         self.send_ids_all = torch.cat([self.send_ids[p] for p in peers_s]) if peers_s else torch.zeros(0, dtype=torch.int32, device=self.device)
         self.recv_ids_all = torch.cat([self.recv_ids[p] for p in peers_r]) if peers_r else torch.zeros(0, dtype=torch.int32, device=self.device)
-        o = 0
-        for p in peers_s:
-            n = int(self.send_ids[p].numel())
-            self.send_buf[p] = self.send_all[o:o + n]
-            o += n
-        o = 0
-        for p in peers_r:
-            n = int(self.recv_ids[p].numel())
-            self.recv_buf[p] = self.recv_all[o:o + n]
-            o += n
-        self._p2p_ops = None
+        self._bufs = {}
+        self._buffers(3)
+        self.send_all, self.recv_all, self.send_buf, self.recv_buf = self._bufs[3][:4]
+
+    def _buffers(self, ncomp: int):
+        """one contiguous send and one contiguous receive buffer per row width (a slice per peer), so that a
+        ghost update costs one pack and one unpack launch whatever the number of neighbours"""
+        if ncomp not in self._bufs:
+            peers_s, peers_r = sorted(self.send_ids), sorted(self.recv_ids)
+            ns = sum(int(self.send_ids[p].numel()) for p in peers_s)
+            nr = sum(int(self.recv_ids[p].numel()) for p in peers_r)
+            send_all = torch.empty((ns, ncomp), dtype=torch.float64, device=self.device)
+            recv_all = torch.empty((nr, ncomp), dtype=torch.float64, device=self.device)
+            send_buf, recv_buf = {}, {}
+            o = 0
+            for p in peers_s:
+                n = int(self.send_ids[p].numel())
+                send_buf[p] = send_all[o:o + n]
+                o += n
+            o = 0
+            for p in peers_r:
+                n = int(self.recv_ids[p].numel())
+                recv_buf[p] = recv_all[o:o + n]
+                o += n
+            self._bufs[ncomp] = [send_all, recv_all, send_buf, recv_buf, None]   # last: the cached P2P op list
+        return self._bufs[ncomp]
 
     @property
     def bytes_sent_per_exchange(self) -> int:
@@ -112,36 +124,43 @@ class HaloExchange:
 
     # -- one ghost update on the current stream ----------------------------
     def exchange(self, u_local: torch.Tensor):
+        """ghost rows of a [num_cells, ncomp] array (the solution: ncomp = 3; the second-order
+        gradients: ncomp = 6, CommunicateCellGradients) <- the owners' rows"""
         if self.world == 1 or (not self.send_ids and not self.recv_ids):
             return
         cuda = u_local.is_cuda
+        ncomp = int(u_local.shape[-1]) if u_local.dim() == 2 else 3
+        rows = u_local.view(-1, ncomp)
+        bufs = self._buffers(ncomp)
+        send_all, recv_all, send_buf, recv_buf = bufs[:4]
         # device buffers go straight to RCCL; under gloo (single-GPU rehearsal of
         # several ranks, CPU tests) device buffers are staged through the host
         via_host = cuda and dist.get_backend(self.group) == "gloo"
         if cuda:
-            from .operator import pack_cells, unpack_cells
+            from .operator import pack_rows
             if self.send_ids_all.numel():
-                pack_cells(u_local, self.send_ids_all, self.send_all)
+                pack_rows(rows, self.send_ids_all, send_all)
         elif self.send_ids_all.numel():
-            self.send_all.copy_(u_local.view(-1, 3)[self.send_ids_all.long()])
+            send_all.copy_(rows[self.send_ids_all.long()])
         if via_host:
-            wire_send = {p: self.send_buf[p].cpu() for p in self.send_ids}
-            wire_recv = {p: torch.empty_like(self.recv_buf[p], device="cpu") for p in self.recv_ids}
+            wire_send = {p: send_buf[p].cpu() for p in self.send_ids}
+            wire_recv = {p: torch.empty_like(recv_buf[p], device="cpu") for p in self.recv_ids}
             ops = self._make_ops(wire_send, wire_recv)
         else:
-            if self._p2p_ops is None:           # the buffers are persistent: build the op list once
-                self._p2p_ops = self._make_ops(self.send_buf, self.recv_buf)
-            ops = self._p2p_ops
+            if bufs[4] is None:           # the buffers are persistent: build the op list once
+                bufs[4] = self._make_ops(send_buf, recv_buf)
+            ops = bufs[4]
         for w in dist.batch_isend_irecv(ops):
             w.wait()
         if via_host:
             for p in self.recv_ids:
-                self.recv_buf[p].copy_(wire_recv[p])
+                recv_buf[p].copy_(wire_recv[p])
         if cuda:
+            from .operator import unpack_rows
             if self.recv_ids_all.numel():
-                unpack_cells(u_local, self.recv_ids_all, self.recv_all)
+                unpack_rows(rows, self.recv_ids_all, recv_all)
         elif self.recv_ids_all.numel():
-            u_local.view(-1, 3)[self.recv_ids_all.long()] = self.recv_all
+            rows[self.recv_ids_all.long()] = recv_all
 
     def _make_ops(self, send, recv):
         ops = []
@@ -164,6 +183,22 @@ class HaloExchange:
         self.comm_stream.wait_stream(main)           # u_local's owned part is final
         with torch.cuda.stream(self.comm_stream):
             self.exchange(u_local)
+        if op.config.second_order:
+            # ApplyInteriorFlux2R (src/swe/swe_petsc.c:98-213) needs two exchanges: the state, then the
+            # gradients (CommunicateCellGradients).  Hidden behind them: the gradients of the cells without
+            # ghost neighbours, then the fluxes of the tiles without ghost-adjacent cells (which read owned
+            # gradient rows only).  There is no reverse exchange: every rank evaluates all edges of its cells.
+            op.compute_gradients(u_local, phase=1)
+            main.wait_stream(self.comm_stream)
+            op.compute_gradients(u_local, phase=2)
+            grads = op.gradients
+            self.comm_stream.wait_stream(main)
+            with torch.cuda.stream(self.comm_stream):
+                self.exchange(grads)
+            op.apply_phase(1, True, dt, u_local, f_global, reset_diagnostics=True, gradients_ready=True)
+            main.wait_stream(self.comm_stream)
+            op.apply_phase(2, True, dt, u_local, f_global, gradients_ready=True)
+            return
         op.apply_phase(1, True, dt, u_local, f_global, reset_diagnostics=True)   # RDYHIP_PHASE_INTERIOR (+ diagnostics reset)
         main.wait_stream(self.comm_stream)
         op.apply_phase(2, True, dt, u_local, f_global)                           # RDYHIP_PHASE_HALO

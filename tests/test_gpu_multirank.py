@@ -22,7 +22,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, kernel, q):
+def _worker(rank, world, port, kernel, q, second_order=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -44,6 +44,7 @@ def _worker(rank, world, port, kernel, q):
         z = CS.mms_bathymetry(K=K)
         mesh = M.strip_partition_tri_mesh(nxp, ny, rank, world, 1.0, zfunc=z, order="tiled", tile=8)
         case = CS.friction_slope_case(mesh, nxg, ny, dt=1e-2, K=K)
+        case.config.second_order = second_order
         op = CS.create_operator(case)
         halo = HaloExchange(mesh, dev)
         u_np = case.u_local.copy()
@@ -57,6 +58,7 @@ def _worker(rank, world, port, kernel, q):
         # single-rank truth from the oracle on the undivided mesh
         g = M.structured_tri_mesh(nxg, ny, 1.0, zfunc=z)
         gc = CS.friction_slope_case(g, nxg, ny, dt=1e-2, K=K)
+        gc.config.second_order = second_order
         og = oracle_from_case(gc)
         fg = og.apply(gc.dt, gc.u_local)
         gid = mesh.cell_global_ids[mesh.cell_owned_to_local]
@@ -88,3 +90,25 @@ def test_three_ranks_one_gpu_overlapped_rhs(rdyhip_kernel):
         assert err <= 1e-10, (rank, err)
         assert cerr <= 1e-12
         assert 0 < nhalo_tiles < ntiles
+
+
+@pytest.mark.timeout(300)
+def test_three_ranks_one_gpu_second_order(rdyhip_kernel):
+    """the second-order path across ranks: state exchange, gradients, gradient exchange (6 values per cell),
+    fluxes of interior tiles overlapped, halo tiles afterwards; no reverse exchange"""
+    if rdyhip_kernel == "cell":
+        pytest.skip("second order is implemented by the tiled kernels")
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, rdyhip_kernel, q, True)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(240)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    res = sorted(q.get(timeout=5) for _ in range(world))
+    for rank, err, cerr, nhalo_tiles, ntiles in res:
+        assert err <= 1e-10, (rank, err)
+        assert cerr <= 1e-12

@@ -19,7 +19,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, ghosts_mode, q):
+def _worker(rank, world, port, ghosts_mode, q, second_order=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -42,6 +42,7 @@ def _worker(rank, world, port, ghosts_mode, q):
             mesh = M.extract_local_mesh(xyz, conn, own, boundary_classifier=M.box_side_boundaries(0, nxg, 0, ny),
                                         ghosts="interleaved")
         case = CS.friction_slope_case(mesh, nxg, ny, dt=1e-2, K=K)
+        case.config.second_order = second_order
         truth = case.u_local.copy()
         u = torch.tensor(case.u_local)
         ghost = torch.tensor(mesh.cell_is_owned == 0)
@@ -49,10 +50,31 @@ def _worker(rank, world, port, ghosts_mode, q):
         halo = HaloExchange(mesh, torch.device("cpu"))
         halo.exchange(u)
         assert torch.equal(u, torch.tensor(truth)), "ghost cells differ from their owners' values"
-        f = oracle_from_case(case).apply(case.dt, u.numpy())
+        if second_order:
+            # the HIP path's scheme on the oracle: gradients of the owned cells, ghost gradients through the same
+            # HaloExchange (6 values per cell), then every local edge solved here -- no reverse exchange
+            from oracle import oracle as O
+            cfg = case.config
+            orc = O.OracleOperator(mesh, case.condition_types, cfg.tiny_h, cfg.h_anuga_regular, cfg.xq2018_threshold, cfg.source_method,
+                                   second_order=True, limiter=cfg.limiter, all_edges_local=True)
+            orc.mannings[:] = case.mannings
+            orc.external_sources[:] = case.ext_src
+            for b, vals in case.boundary_values.items():
+                orc.boundary_values[b][:] = vals
+            orc.compute_gradients(u.numpy())
+            g6 = torch.tensor(orc.gradients6())
+            g6[ghost] = float("nan")
+            halo.exchange(g6)
+            for k in range(3):
+                orc.gradients[k][:] = g6[:, 2 * k:2 * k + 2].numpy()
+            orc.set_gradients_ready(True)
+            f = orc.apply(case.dt, u.numpy())
+        else:
+            f = oracle_from_case(case).apply(case.dt, u.numpy())
         # single-rank answer
         g = M.structured_tri_mesh(nxg, ny, 1.0, zfunc=z)
         gc = CS.friction_slope_case(g, nxg, ny, dt=1e-2, K=K)
+        gc.config.second_order = second_order
         fg = oracle_from_case(gc).apply(gc.dt, gc.u_local)
         gid = mesh.cell_global_ids[mesh.cell_owned_to_local]
         err = rel_linf(f, fg[gid])
@@ -61,14 +83,14 @@ def _worker(rank, world, port, ghosts_mode, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("ghosts_mode", ["tail", "interleaved"])
+@pytest.mark.parametrize("ghosts_mode,second_order", [("tail", False), ("interleaved", False), ("tail", True)])
 @pytest.mark.timeout(180)
-def test_two_rank_halo_exchange_and_partitioned_rhs(ghosts_mode):
+def test_two_rank_halo_exchange_and_partitioned_rhs(ghosts_mode, second_order):
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, ghosts_mode, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, ghosts_mode, q, second_order)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
