@@ -58,9 +58,10 @@ def parse():
 
 
 LIMITERS = {"minmod": 0, "none": 1, "van_leer": 2}
-# second order: 176 B + gradients written once and read once (2 x 48) + the state read again by the gradient kernel (24)
-# + least-squares coefficients (3 slots x 16) + centroid->midpoint displacements (1.5 edges x 32)
-ALG_BYTES_PER_CELL_SECOND_ORDER = 176.0 + 96.0 + 24.0 + 48.0 + 48.0
+# second order: 176 B + least-squares coefficients (3 slots x 16) + centroid->midpoint displacements (1.5 edges x 32);
+# the split form (RDYHIP_MUSCL=split) also writes and reads the gradient array (2 x 48) and reads the state twice (24)
+ALG_BYTES_PER_CELL_SECOND_ORDER = 176.0 + 48.0 + 48.0
+ALG_BYTES_PER_CELL_SECOND_ORDER_SPLIT = ALG_BYTES_PER_CELL_SECOND_ORDER + 96.0 + 24.0
 
 
 def build_case(nx, ny, rank, world, order, source, workload="c3", hr=False, second_order=False, limiter="minmod"):
@@ -278,7 +279,8 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4),
                          "traffic": load_traffic(f"{args.nx}x{args.ny}_{args.order}_{args.source}") if args.workload == "c3" else None,
-                         "kernel": ("muscl_gradient_kernel<3> + swe_rhs_muscl_kernel<3,%d>" % (0 if args.source == "semi_implicit" else 1))
+                         "kernel": (("swe_rhs_muscl_fused_kernel<3,%d>" if info["second_order_fused"] else
+                                     "muscl_gradient_kernel<3> + swe_rhs_muscl_kernel<3,%d>") % (0 if args.source == "semi_implicit" else 1))
                          if args.second_order else
                          "%s<3,%d>" % ("swe_rhs_tiled_kernel" if info["tiled_kernel"] else "swe_rhs_kernel",
                                        0 if args.source == "semi_implicit" else 1),
@@ -289,8 +291,9 @@ def main():
         }
         if args.second_order:
             # the 176-B figure above keeps variants comparable; the second-order path's own model:
-            a2 = n_owned * ALG_BYTES_PER_CELL_SECOND_ORDER / (kern_ms * 1e-3) / 1e9
-            out["roofline"]["second_order_model"] = {"bytes_per_cell_update": ALG_BYTES_PER_CELL_SECOND_ORDER, "achieved": round(a2, 1),
+            b2 = ALG_BYTES_PER_CELL_SECOND_ORDER if info["second_order_fused"] else ALG_BYTES_PER_CELL_SECOND_ORDER_SPLIT
+            a2 = n_owned * b2 / (kern_ms * 1e-3) / 1e9
+            out["roofline"]["second_order_model"] = {"bytes_per_cell_update": b2, "achieved": round(a2, 1),
                                                      "frac": round(a2 / HBM_PEAK_GBPS, 4)}
             out["roofline"]["traffic"] = None
         if not args.no_cpu_baseline and world == 1:

@@ -34,7 +34,28 @@ struct MusclArgs {
   const double *e_geo;  // [nrec][4]: edge midpoint minus left centroid (x, y), minus right centroid (x, y)
   const double *gcx;    // [S][stride] least-squares coefficient of each slot's neighbour difference (q_nbr - q_self)
   const double *gcy;
+  // fused kernel only: the second ring of each tile and the stencils of its first-ring cells
+  const int32_t  *hcells2;  // second-ring cells of each tile (local cell ids): neighbours of first-ring cells outside the tile
+  const int32_t  *c_off;    // [ntiles+1] first hcells2 entry of each tile
+  const uint16_t *bn_idx;   // [halo entries][4] LDS slot of each first-ring cell's s-th neighbour; BN_NONE: no neighbour in that
+                            //                   slot; BN_GLOBAL: a ghost cell, its gradient comes from `grad` (exchanged)
+  const double   *bn_c;     // [halo entries][S][2] the first-ring cell's least-squares coefficients (copies of gcx, gcy)
+  int32_t         hmax2;    // largest first + second ring of a tile (LDS sizing)
 };
+constexpr uint16_t BN_NONE = 0xFFFF, BN_GLOBAL = 0xFFFE;
+
+// One neighbour's contribution to a cell's gradient.  Explicit fma, shared by every kernel that forms a
+// gradient: a cell's gradient is computed by its own tile, by every tile that has it in its first ring and (for
+// the exchange between ranks) by muscl_gradient_kernel, and a cut edge is conservative only if all of them get
+// the same bits.
+__device__ __forceinline__ void grad_add(double (&g)[6], double cx, double cy, double d0, double d1, double d2) {
+  g[0] = fma(cx, d0, g[0]);
+  g[1] = fma(cy, d0, g[1]);
+  g[2] = fma(cx, d1, g[2]);
+  g[3] = fma(cy, d1, g[3]);
+  g[4] = fma(cx, d2, g[4]);
+  g[5] = fma(cy, d2, g[5]);
+}
 
 // RDyLimiterType, include/private/rdyconfigimpl.h:67-71
 constexpr int LIMITER_MINMOD = 0, LIMITER_NONE = 1, LIMITER_VANLEER = 2;
@@ -76,13 +97,7 @@ __global__ __launch_bounds__(BLOCK) void muscl_gradient_kernel(const KernelArgs 
     if (id[s] < 0) continue;  // boundary edge or unused slot: not part of the stencil
     const int    n  = id[s] & NBR_MASK;
     const double cx = g.gcx[s * a.stride + o], cy = g.gcy[s * a.stride + o];
-    const double d0 = u[3 * (int64_t)n + 0] - q0, d1 = u[3 * (int64_t)n + 1] - q1, d2 = u[3 * (int64_t)n + 2] - q2;
-    gr[0] += cx * d0;
-    gr[1] += cy * d0;
-    gr[2] += cx * d1;
-    gr[3] += cy * d1;
-    gr[4] += cx * d2;
-    gr[5] += cy * d2;
+    grad_add(gr, cx, cy, u[3 * (int64_t)n + 0] - q0, u[3 * (int64_t)n + 1] - q1, u[3 * (int64_t)n + 2] - q2);
   }
   double2 *dst = reinterpret_cast<double2 *>(g.grad + 6 * (int64_t)c);
   dst[0]       = make_double2(gr[0], gr[1]);
@@ -237,6 +252,303 @@ __global__ __launch_bounds__(TILE) void swe_rhs_muscl_kernel(const KernelArgs a,
       const RiemannSide self = riemann_side(h, hu, hv, a.tiny_h, a.h_anuga_sq);
       cell_epilogue<SRC>(a, o, dt, h, hu, hv, self.u, self.v, acc0, acc1, acc2, a.dzdx[o], a.dzdy[o], a.mannings[o], a.extsrc[3 * (int64_t)o + 0],
                          a.extsrc[3 * (int64_t)o + 1], a.extsrc[3 * (int64_t)o + 2], f);
+    }
+    __syncthreads();  // the LDS planes are rewritten by the next tile
+  }
+  block_courant_reduce<TILE>(a, best, best_slot, best_o);
+}
+
+
+// ---------------------------------------------------------------------------
+// Fused form (default): the gradients never leave the chip.  A tile stages the
+// state of its own cells, of its first ring (cells sharing an edge with a tile
+// cell) and of its second ring (the remaining neighbours of first-ring cells),
+// computes the gradients of own + first-ring cells in LDS, and goes on as above.
+// Saves the gradient array's write + read and the second read of the state
+// (120 B per cell-update) for ~20 B of second-ring state and first-ring stencils.
+// First-ring cells that are ghosts take their gradient from `grad`, filled by the
+// caller's exchange (their stencil is not local).
+// ---------------------------------------------------------------------------
+template <int S, int SRC, bool OVW, int LIM>
+__global__ __launch_bounds__(TILE) void swe_rhs_muscl_fused_kernel(const KernelArgs a, const MusclArgs g, const double dt, const double *__restrict__ u,
+                                                                    double *__restrict__ f) {
+  extern __shared__ double lds[];
+  const int nq = TILE + g.hmax2;  // state planes: own, first ring, second ring
+  const int ng = TILE + a.hmax;   // gradient planes: own, first ring
+  double   *sq = lds;
+  double   *sg = lds + 3 * nq;
+  double   *ef0 = sg + 6 * ng, *ef1 = ef0 + a.emax, *ef2 = ef1 + a.emax, *eam = ef2 + a.emax;
+  uint32_t *slr = reinterpret_cast<uint32_t *>(eam + a.emax);  // the tile's edge records
+  const int tid = threadIdx.x;
+
+  int idx, step, hi;
+  if (a.xcd_chunks > 0) {
+    const int x = blockIdx.x & 7;
+    step        = gridDim.x >> 3;
+    idx         = x * a.xcd_chunks + (blockIdx.x >> 3);
+    hi          = min((x + 1) * a.xcd_chunks, a.n_work);
+  } else {
+    idx  = blockIdx.x;
+    step = gridDim.x;
+    hi   = a.n_work;
+  }
+  auto tile_at = [&](int i) -> int { return __builtin_amdgcn_readfirstlane(a.list ? load_uniform(a.list, i) : i); };
+  auto tile_desc = [&](int t) -> TileDesc {
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    const v4i v = load_uniform(reinterpret_cast<const v4i *>(a.tiles), t);
+    TileDesc  d;
+    d.e_off = v.x; d.h_off = v.y; d.b_off = v.z; d.halo = v.w;
+    return d;
+  };
+  // id of the ring cell (first or second ring) this thread stages for a tile
+  auto ring_id = [&](const TileDesc &td_, int nh_, int c0_, int nc2_) -> int {
+    int id = -1;
+    if (tid < nh_) id = a.hcells[td_.h_off + tid];
+    else if (tid < nh_ + nc2_) id = g.hcells2[c0_ + tid - nh_];
+    return id;
+  };
+
+  double best      = 0.0;
+  int    best_slot = -1, best_o = 0;
+  int    pre_tile = -1, pre_hid = -1;  // ring-cell id fetched one tile ahead (breaks the id -> state load chain)
+
+  for (; idx < hi; idx += step) {
+    const int      tile = tile_at(idx);
+    const TileDesc td = tile_desc(tile), tn = tile_desc(tile + 1);
+    if (a.phase == RDYHIP_PHASE_INTERIOR && td.halo) continue;  // wave-uniform
+    const int  ne = tn.e_off - td.e_off, nh = tn.h_off - td.h_off;
+    const int  c0 = load_uniform(g.c_off, tile), nc2 = load_uniform(g.c_off, tile + 1) - c0;
+    const int  o      = tile * TILE + tid;
+    const bool active = o < a.n_owned;
+
+    // ---- the tile's load batch: everything the four phases read from global memory that does not depend on LDS.
+    // hipcc waits with vmcnt(0) at the first use, so one batch = one exposed latency per tile.
+    const int hid = (pre_tile == tile) ? pre_hid : ring_id(td, nh, c0, nc2);
+    double    q[3] = {0.0, 0.0, 0.0}, hq[3] = {0.0, 0.0, 0.0};
+    uint32_t  r0 = 0xFFFFFFFFu, r1 = 0xFFFFFFFFu;
+    double    gx[S], gy[S], kf[S];
+    double    dzx = 0.0, dzy = 0.0, nman = 0.0, s0 = 0.0, s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int s = 0; s < S; ++s) gx[s] = gy[s] = kf[s] = 0.0;
+    if (active) {
+      const int c = a.o2l ? a.o2l[o] : o;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) q[k] = u[3 * (int64_t)c + k];
+      if (S == 3) {
+        r0 = reinterpret_cast<const uint32_t *>(a.slot_ref)[o];
+      } else {
+        const uint2 w = reinterpret_cast<const uint2 *>(a.slot_ref)[o];
+        r0            = w.x;
+        r1            = w.y;
+      }
+#pragma unroll
+      for (int s = 0; s < S; ++s) {
+        gx[s] = g.gcx[s * a.stride + o];
+        gy[s] = g.gcy[s * a.stride + o];
+        kf[s] = a.coef[s * a.stride + o];
+      }
+      dzx  = a.dzdx[o];
+      dzy  = a.dzdy[o];
+      nman = a.mannings[o];
+      s0   = a.extsrc[3 * (int64_t)o + 0];
+      s1   = a.extsrc[3 * (int64_t)o + 1];
+      s2   = a.extsrc[3 * (int64_t)o + 2];
+    }
+    if (hid >= 0) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) hq[k] = u[3 * (int64_t)hid + k];
+    }
+    uint2  bw = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);  // first-ring stencil of ring cell j = tid
+    double bc[2 * S];
+#pragma unroll
+    for (int s = 0; s < 2 * S; ++s) bc[s] = 0.0;
+    if (tid < nh) {
+      const int64_t entry = (int64_t)td.h_off + tid;
+      bw                  = reinterpret_cast<const uint2 *>(g.bn_idx)[entry];
+#pragma unroll
+      for (int s = 0; s < 2 * S; ++s) bc[s] = g.bn_c[entry * (2 * S) + s];
+    }
+    uint32_t lr0 = 0, lr1 = 0;
+    double   cs0 = 0.0, cs1 = 0.0;
+    double2  gl0 = make_double2(0.0, 0.0), gr0 = gl0, gl1 = gl0, gr1 = gl0;
+    if (tid < ne) {
+      lr0 = a.e_lr[td.e_off + tid];
+      cs0 = a.e_cs[td.e_off + tid];
+      const double2 *geo = reinterpret_cast<const double2 *>(g.e_geo + 4 * ((int64_t)td.e_off + tid));
+      gl0 = geo[0];
+      gr0 = geo[1];
+    }
+    if (tid + TILE < ne) {
+      lr1 = a.e_lr[td.e_off + TILE + tid];
+      cs1 = a.e_cs[td.e_off + TILE + tid];
+      const double2 *geo = reinterpret_cast<const double2 *>(g.e_geo + 4 * ((int64_t)td.e_off + TILE + tid));
+      gl1 = geo[0];
+      gr1 = geo[1];
+    }
+    // the ring-cell id of the tile this workgroup takes next
+    pre_tile = -1;
+    if (idx + step < hi) {
+      pre_tile            = tile_at(idx + step);
+      const TileDesc pd = tile_desc(pre_tile), pn = tile_desc(pre_tile + 1);
+      const int      pc0 = load_uniform(g.c_off, pre_tile);
+      pre_hid            = ring_id(pd, pn.h_off - pd.h_off, pc0, load_uniform(g.c_off, pre_tile + 1) - pc0);
+    }
+
+    // ---- phase 0: state of own cells, first ring, second ring; the tile's edge records -> LDS
+#pragma unroll
+    for (int k = 0; k < 3; ++k) sq[k * nq + tid] = q[k];
+    if (hid >= 0) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) sq[k * nq + TILE + tid] = hq[k];
+    }
+    for (int j = tid + TILE; j < nh + nc2; j += TILE) {  // only numberings with poor locality get here
+      const int hc = (j < nh) ? a.hcells[td.h_off + j] : g.hcells2[c0 + j - nh];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) sq[k * nq + TILE + j] = u[3 * (int64_t)hc + k];
+    }
+    if (tid < ne) slr[tid] = lr0;
+    if (tid + TILE < ne) slr[tid + TILE] = lr1;
+    for (int e = tid + 2 * TILE; e < ne; e += TILE) slr[e] = a.e_lr[td.e_off + e];
+    __syncthreads();
+
+    // ---- phase G: least-squares gradients of own and first-ring cells -> LDS
+    {
+      double gr[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+      if (active) {
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+          uint32_t ref;
+          if (S == 3) {
+            ref = (r0 >> (10 * s)) & 0x3FF;
+            if (ref == REF3_EMPTY) continue;
+          } else {
+            const uint32_t w = (s < 2) ? r0 : r1;
+            ref              = (s & 1) ? (w >> 16) : (w & 0xFFFFu);
+            if (ref == SLOT_EMPTY) continue;
+          }
+          const uint32_t lr = slr[ref];
+          if (lr & EDGE_BOUNDARY) continue;
+          const int jl = lr & EDGE_SLOT_MASK, jr = (lr >> EDGE_R_SHIFT) & EDGE_SLOT_MASK;
+          const int nb = (jl == tid) ? jr : jl;
+          grad_add(gr, gx[s], gy[s], sq[nb] - q[0], sq[nq + nb] - q[1], sq[2 * nq + nb] - q[2]);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 6; ++k) sg[k * ng + tid] = gr[k];
+      auto ring_gradient = [&](int j, uint2 w, const double *c, double h0, double h1, double h2) {
+        const uint32_t ix[4] = {w.x & 0xFFFFu, w.x >> 16, w.y & 0xFFFFu, w.y >> 16};
+        double         hg[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        if (ix[0] == BN_GLOBAL) {  // a ghost cell: its gradient was computed by its owner
+          const int hc = a.hcells[td.h_off + j];
+#pragma unroll
+          for (int k = 0; k < 6; ++k) hg[k] = g.grad[6 * (int64_t)hc + k];
+        } else {
+#pragma unroll
+          for (int s = 0; s < S; ++s) {
+            if (ix[s] == BN_NONE) continue;
+            const int nb = (int)ix[s];
+            grad_add(hg, c[2 * s], c[2 * s + 1], sq[nb] - h0, sq[nq + nb] - h1, sq[2 * nq + nb] - h2);
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) sg[k * ng + TILE + j] = hg[k];
+      };
+      if (tid < nh) ring_gradient(tid, bw, bc, hq[0], hq[1], hq[2]);
+      for (int j = tid + TILE; j < nh; j += TILE) {  // poor locality only
+        const int64_t entry = (int64_t)td.h_off + j;
+        double        c[2 * S];
+#pragma unroll
+        for (int s = 0; s < 2 * S; ++s) c[s] = g.bn_c[entry * (2 * S) + s];
+        ring_gradient(j, reinterpret_cast<const uint2 *>(g.bn_idx)[entry], c, sq[TILE + j], sq[nq + TILE + j], sq[2 * nq + TILE + j]);
+      }
+    }
+    __syncthreads();
+
+    // ---- phase 1: every edge of the tile once
+    auto do_edge = [&](int e, uint32_t lr, double cs, double2 dl, double2 dr) {
+      double cn, sn;
+      edge_normal(lr, cs, cn, sn);
+      const int jl = lr & EDGE_SLOT_MASK;
+      RoeFlux   fl;
+      bool      wet;
+      if (!(lr & EDGE_BOUNDARY)) {
+        const int jr = (lr >> EDGE_R_SHIFT) & EDGE_SLOT_MASK;
+        double    ql[3], qr[3];
+        // ReconstructFaceValues, src/operator_fluxes_ceed.c:1180-1200
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const double cl_ = sq[k * nq + jl], cr_ = sq[k * nq + jr];
+          const double extrap_l = sg[(2 * k) * ng + jl] * dl.x + sg[(2 * k + 1) * ng + jl] * dl.y;
+          const double extrap_r = sg[(2 * k) * ng + jr] * dr.x + sg[(2 * k + 1) * ng + jr] * dr.y;
+          const double dq       = cr_ - cl_;
+          ql[k]                 = cl_ + limit_slope<LIM>(extrap_l, 0.5 * dq);
+          qr[k]                 = cr_ + limit_slope<LIM>(extrap_r, -0.5 * dq);
+        }
+        ql[0] = fmax(0.0, ql[0]);
+        qr[0] = fmax(0.0, qr[0]);
+        const RiemannSide L = riemann_side(ql[0], ql[1], ql[2], a.tiny_h, a.h_anuga_sq);
+        const RiemannSide R = riemann_side(qr[0], qr[1], qr[2], a.tiny_h, a.h_anuga_sq);
+        fl                  = roe_flux(L, R, sn, cn);
+        wet                 = !(R.h < a.tiny_h && L.h < a.tiny_h);
+      } else {
+        const RiemannSide L  = riemann_side(sq[jl], sq[nq + jl], sq[2 * nq + jl], a.tiny_h, a.h_anuga_sq);
+        const int         k  = a.tile_bk[td.b_off + ((lr >> EDGE_R_SHIFT) & EDGE_SLOT_MASK)];
+        BoundaryFlux      bf = boundary_flux(a.btype[k], true, L, a.bvalues + 3 * (int64_t)k, sn, cn, a.tiny_h, a.h_anuga_sq);
+        fl                   = bf.flux;
+        wet                  = bf.wet;
+        store_boundary_flux(a, k, fl, dt);
+      }
+      ef0[e] = fl.f0;
+      ef1[e] = fl.f1;
+      ef2[e] = fl.f2;
+      eam[e] = wet ? fl.amax : -1.0;
+    };
+#pragma unroll 1
+    for (int r = 0; r < 2; ++r) {
+      const int e = tid + r * TILE;
+      if (e < ne) do_edge(e, r == 0 ? lr0 : lr1, r == 0 ? cs0 : cs1, r == 0 ? gl0 : gl1, r == 0 ? gr0 : gr1);
+    }
+    for (int e = tid + 2 * TILE; e < ne; e += TILE) {
+      const double2 *geo = reinterpret_cast<const double2 *>(g.e_geo + 4 * ((int64_t)td.e_off + e));
+      do_edge(e, slr[e], a.e_cs[td.e_off + e], geo[0], geo[1]);
+    }
+    __syncthreads();
+
+    // ---- phase 2: per-cell sum in the reference's edge order, source terms, stores
+    if (active) {
+      double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
+      if (!OVW) {
+        acc0 = f[3 * (int64_t)o + 0];
+        acc1 = f[3 * (int64_t)o + 1];
+        acc2 = f[3 * (int64_t)o + 2];
+      }
+#pragma unroll
+      for (int s = 0; s < S; ++s) {
+        uint32_t ref;
+        if (S == 3) {
+          ref = (r0 >> (10 * s)) & 0x3FF;
+          if (ref == REF3_EMPTY) continue;
+        } else {
+          const uint32_t w = (s < 2) ? r0 : r1;
+          ref              = (s & 1) ? (w >> 16) : (w & 0xFFFFu);
+          if (ref == SLOT_EMPTY) continue;
+        }
+        const double am = eam[ref];
+        if (am != -1.0) {
+          const double k = kf[s];
+          acc0 += ef0[ref] * k;
+          acc1 += ef1[ref] * k;
+          acc2 += ef2[ref] * k;
+          const double cnum = am * fabs(k) * dt;
+          if (cnum > best) {
+            best      = cnum;
+            best_slot = s;
+            best_o    = o;
+          }
+        }
+      }
+      const RiemannSide self = riemann_side(q[0], q[1], q[2], a.tiny_h, a.h_anuga_sq);
+      cell_epilogue<SRC>(a, o, dt, q[0], q[1], q[2], self.u, self.v, acc0, acc1, acc2, dzx, dzy, nman, s0, s1, s2, f);
     }
     __syncthreads();  // the LDS planes are rewritten by the next tile
   }

@@ -123,10 +123,14 @@ struct RDyHipOperator_s {
   DevBuf<uint16_t> d_slot_ref;   // S == 4
   DevBuf<uint32_t> d_slot_ref3;  // S == 3
   // second order (muscl_kernels.h)
-  bool           muscl = false;
-  DevBuf<double> d_grad, d_e_geo, d_gcx, d_gcy;
-  size_t         lds_muscl = 0;
-  int            pgrid_muscl = 0;
+  bool             muscl = false;
+  bool             muscl_fused = true;  // gradients formed in LDS by the flux kernel (RDYHIP_MUSCL=split: separate gradient launch)
+  DevBuf<double>   d_grad, d_e_geo, d_gcx, d_gcy, d_bn_c;
+  DevBuf<int32_t>  d_hcells2, d_c_off;
+  DevBuf<uint16_t> d_bn_idx;
+  int32_t          hmax2 = 0;
+  size_t           lds_muscl = 0;
+  int              pgrid_muscl = 0;
 
   // host copies needed to resolve the Courant position into ids
   std::vector<int32_t> h_internal_edge, h_edge_cells, h_bedge, h_boff;
@@ -147,7 +151,8 @@ struct RDyHipOperator_s {
     d_blk_pos.release(); d_courant.release(); d_stage_vals.release(); d_stage_ids.release();
     d_tiles.release(); d_e_lr.release(); d_hcells.release(); d_tile_bk.release(); d_halo_tiles.release();
     d_e_cs.release(); d_slot_ref.release(); d_slot_ref3.release(); d_zc_local.release();
-    d_grad.release(); d_e_geo.release(); d_gcx.release(); d_gcy.release();
+    d_grad.release(); d_e_geo.release(); d_gcx.release(); d_gcy.release(); d_bn_c.release(); d_hcells2.release(); d_c_off.release();
+    d_bn_idx.release();
   }
 };
 
@@ -178,11 +183,20 @@ MusclKernelFn muscl_kernel_fn_lim(int S, int src, bool ovw) {
   if (src) return ovw ? swe_rhs_muscl_kernel<4, 1, true, LIM> : swe_rhs_muscl_kernel<4, 1, false, LIM>;
   return ovw ? swe_rhs_muscl_kernel<4, 0, true, LIM> : swe_rhs_muscl_kernel<4, 0, false, LIM>;
 }
-MusclKernelFn muscl_kernel_fn(int S, int src, bool ovw, int limiter) {
+template <int LIM>
+MusclKernelFn muscl_fused_fn_lim(int S, int src, bool ovw) {
+  if (S == 3) {
+    if (src) return ovw ? swe_rhs_muscl_fused_kernel<3, 1, true, LIM> : swe_rhs_muscl_fused_kernel<3, 1, false, LIM>;
+    return ovw ? swe_rhs_muscl_fused_kernel<3, 0, true, LIM> : swe_rhs_muscl_fused_kernel<3, 0, false, LIM>;
+  }
+  if (src) return ovw ? swe_rhs_muscl_fused_kernel<4, 1, true, LIM> : swe_rhs_muscl_fused_kernel<4, 1, false, LIM>;
+  return ovw ? swe_rhs_muscl_fused_kernel<4, 0, true, LIM> : swe_rhs_muscl_fused_kernel<4, 0, false, LIM>;
+}
+MusclKernelFn muscl_kernel_fn(int S, int src, bool ovw, int limiter, bool fused) {
   switch (limiter) {
-    case RDYHIP_LIMITER_NONE: return muscl_kernel_fn_lim<LIMITER_NONE>(S, src, ovw);
-    case RDYHIP_LIMITER_VANLEER: return muscl_kernel_fn_lim<LIMITER_VANLEER>(S, src, ovw);
-    default: return muscl_kernel_fn_lim<LIMITER_MINMOD>(S, src, ovw);
+    case RDYHIP_LIMITER_NONE: return fused ? muscl_fused_fn_lim<LIMITER_NONE>(S, src, ovw) : muscl_kernel_fn_lim<LIMITER_NONE>(S, src, ovw);
+    case RDYHIP_LIMITER_VANLEER: return fused ? muscl_fused_fn_lim<LIMITER_VANLEER>(S, src, ovw) : muscl_kernel_fn_lim<LIMITER_VANLEER>(S, src, ovw);
+    default: return fused ? muscl_fused_fn_lim<LIMITER_MINMOD>(S, src, ovw) : muscl_kernel_fn_lim<LIMITER_MINMOD>(S, src, ovw);
   }
 }
 
@@ -192,6 +206,11 @@ MusclArgs muscl_args(RDyHipOperator op) {
   g.e_geo = op->d_e_geo.p;
   g.gcx   = op->d_gcx.p;
   g.gcy   = op->d_gcy.p;
+  g.hcells2 = op->d_hcells2.p;
+  g.c_off   = op->d_c_off.p;
+  g.bn_idx  = op->d_bn_idx.p;
+  g.bn_c    = op->d_bn_c.p;
+  g.hmax2   = op->hmax2;
   return g;
 }
 
@@ -232,7 +251,11 @@ int launch_gradients(RDyHipOperator op, int32_t phase, const double *u, hipStrea
 int launch_rhs(RDyHipOperator op, int32_t phase, int32_t overwrite, int reset_diag, double dt, const double *u, double *f, hipStream_t st,
                bool gradients_ready = false) {
   if (!op) return fail(RDYHIP_ERR_USER, "null operator");
-  if (op->muscl && !gradients_ready && op->n_owned > 0) {
+  if (op->muscl && !gradients_ready && op->n_owned > 0 && op->muscl_fused) {
+    // fused kernel: only ghost cells' gradients are read from memory, and they have to come from the exchange
+    if (op->n_cells > op->n_owned || phase != RDYHIP_PHASE_ALL)
+      return fail(RDYHIP_ERR_USER, "second_order with ghost cells or a phased apply needs RDYHIP_PHASE_GRADIENTS_READY (see rdyhip_compute_gradients)");
+  } else if (op->muscl && !gradients_ready && op->n_owned > 0) {
     // the ghost cells' gradients come from their owners (CommunicateCellGradients): the caller has to run
     // rdyhip_compute_gradients, exchange the ghost rows and pass RDYHIP_PHASE_GRADIENTS_READY
     if (op->n_cells > op->n_owned || phase != RDYHIP_PHASE_ALL)
@@ -307,8 +330,8 @@ int launch_rhs(RDyHipOperator op, int32_t phase, int32_t overwrite, int reset_di
       }
     }
     if (op->muscl) {
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(muscl_kernel_fn(op->S, xq ? 1 : 0, overwrite != 0, op->config.limiter)), dim3(grid), dim3(TILE), op->lds_muscl,
-                         st, a, muscl_args(op), dt, u, f);
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(muscl_kernel_fn(op->S, xq ? 1 : 0, overwrite != 0, op->config.limiter, op->muscl_fused)), dim3(grid),
+                         dim3(TILE), op->lds_muscl, st, a, muscl_args(op), dt, u, f);
     } else {
       const size_t lds = op->lds_bytes;
       hipLaunchKernelGGL(HIP_KERNEL_NAME(tiled_kernel_fn(op->S, xq ? 1 : 0, overwrite != 0, op->hr)), dim3(grid), dim3(TILE), lds, st, a, dt, u, f);
@@ -539,7 +562,10 @@ int rdyhip_create(const RDyHipConfig *config, const RDyHipMesh *mesh, int32_t nu
   std::vector<TileDesc> tiles((size_t)ntiles + 1);
   std::vector<uint32_t> e_lr;
   std::vector<int32_t>  hcells, tile_bk, halo_tiles;
-  std::vector<double>   e_cs, e_geo;
+  std::vector<double>   e_cs, e_geo, bn_c;
+  std::vector<int32_t>  hslot2, touched2, hcells2, c_off;
+  std::vector<uint16_t> bn_idx;
+  int32_t               hmax2 = 0;
   std::vector<uint16_t> slot_ref((size_t)no * 4, SLOT_EMPTY);
   int32_t               emax = 0, hmax = 0;
   {
@@ -549,6 +575,10 @@ int rdyhip_create(const RDyHipConfig *config, const RDyHipMesh *mesh, int32_t nu
     items.reserve(4 * TILE);
     std::vector<int32_t> hslot((size_t)nc, -1);      // local cell -> halo slot in the current tile
     std::vector<int32_t> touched;
+    if (muscl_on) {
+      hslot2.assign((size_t)nc, -1);
+      c_off.assign((size_t)ntiles + 1, 0);
+    }
     for (int32_t t = 0; t < ntiles; ++t) {
       const int32_t base = t * TILE, cntc = std::min<int32_t>(TILE, no - base);
       items.clear();
@@ -626,6 +656,52 @@ int rdyhip_create(const RDyHipConfig *config, const RDyHipMesh *mesh, int32_t nu
         }
         slot_ref[(size_t)(it.second >> 2) * 4 + (it.second & 3)] = (uint16_t)local;
       }
+      if (muscl_on) {
+        // fused second-order kernel: the stencil of every first-ring cell (LDS slots of its neighbours, its
+        // least-squares coefficients) and the tile's second ring (neighbours of first-ring cells outside tile + ring 1)
+        c_off[t]    = (int32_t)hcells2.size();
+        int32_t nc2 = 0;
+        touched2.clear();
+        for (int32_t b = 0; b < nh; ++b) {
+          const int32_t cell  = hcells[(size_t)tiles[t].h_off + b];
+          uint16_t      ix[4] = {BN_NONE, BN_NONE, BN_NONE, BN_NONE};
+          double        cc[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+          if (!mesh->cell_is_owned[cell]) {
+            ix[0] = ix[1] = ix[2] = ix[3] = BN_GLOBAL;  // a ghost: its stencil is on another rank
+          } else {
+            const int32_t ob = mesh->cell_local_to_owned[cell];
+            for (int32_t sl = 0; sl < S; ++sl) {
+              const int64_t idx = (int64_t)sl * stride + ob;
+              const int32_t id  = nbr[idx];
+              if (id < 0) continue;
+              const int32_t n = id & NBR_MASK;
+              if (id & NBR_GHOST) halo_tile = true;  // the tile needs a ghost's state
+              int32_t slot;
+              const int32_t on = mesh->cell_is_owned[n] ? mesh->cell_local_to_owned[n] : -1;
+              if (on >= base && on < base + cntc) slot = on - base;
+              else if (hslot[n] >= 0) slot = TILE + hslot[n];
+              else {
+                if (hslot2[n] < 0) {
+                  hslot2[n] = nc2++;
+                  hcells2.push_back(n);
+                  touched2.push_back(n);
+                }
+                slot = TILE + nh + hslot2[n];
+              }
+              ix[sl]         = (uint16_t)slot;
+              cc[2 * sl]     = gcx[idx];
+              cc[2 * sl + 1] = gcy[idx];
+            }
+          }
+          bn_idx.insert(bn_idx.end(), ix, ix + 4);
+          bn_c.insert(bn_c.end(), cc, cc + 2 * S);
+        }
+        for (int32_t cell : touched2) hslot2[cell] = -1;
+        hmax2 = std::max(hmax2, nh + nc2);
+        if (TILE + nh + nc2 >= (int32_t)BN_GLOBAL) return fail(RDYHIP_ERR_USER, "tile working set too large: the cell numbering has no locality");
+        tiles[t].halo = halo_tile ? 1 : 0;
+        if (halo_tile && (halo_tiles.empty() || halo_tiles.back() != t)) halo_tiles.push_back(t);
+      }
       for (int32_t cell : touched) hslot[cell] = -1;
       emax = std::max(emax, local + 1);
       hmax = std::max(hmax, nh);
@@ -635,11 +711,17 @@ int rdyhip_create(const RDyHipConfig *config, const RDyHipMesh *mesh, int32_t nu
     tiles[ntiles].h_off = (int32_t)hcells.size();
     tiles[ntiles].b_off = (int32_t)tile_bk.size();
     tiles[ntiles].halo  = 0;
+    if (muscl_on) c_off[ntiles] = (int32_t)hcells2.size();
     // a tile has at most 4*256 edges, so 256 + hmax <= 1280 slots < 2^11 and <= 1024 boundary edges
   }
   const bool   hr_on     = config->well_balancing == RDYHIP_WELL_BALANCING_HR;
   const size_t lds_bytes = sizeof(double) * ((hr_on ? 6 : 5) * ((size_t)TILE + hmax) + 2 * (size_t)TILE + (hr_on ? 8 : 4) * (size_t)emax);
-  const size_t lds_muscl = muscl_on ? sizeof(double) * (9 * ((size_t)TILE + hmax) + 4 * (size_t)emax) : 0;
+  const char  *menv        = getenv("RDYHIP_MUSCL");
+  const bool   muscl_fused = !(menv && strcmp(menv, "split") == 0);
+  const size_t lds_muscl   = !muscl_on ? 0
+                             : muscl_fused
+                                 ? sizeof(double) * (3 * ((size_t)TILE + hmax2) + 6 * ((size_t)TILE + hmax) + 4 * (size_t)emax + ((size_t)emax + 1) / 2)
+                                 : sizeof(double) * (9 * ((size_t)TILE + hmax) + 4 * (size_t)emax);
   if (std::max(lds_bytes, lds_muscl) > 160 * 1024)
     return fail(RDYHIP_ERR_USER, "tile working set (%zu B of LDS) too large: the cell numbering has no locality", std::max(lds_bytes, lds_muscl));
 
@@ -681,14 +763,17 @@ int rdyhip_create(const RDyHipConfig *config, const RDyHipMesh *mesh, int32_t nu
       return fail(RDYHIP_ERR_LIB, "cannot reserve %d bytes of LDS per workgroup", nb);
     }
   }
-  op->muscl     = muscl_on;
-  op->lds_muscl = lds_muscl;
+  op->muscl       = muscl_on;
+  op->muscl_fused = muscl_fused;
+  op->hmax2       = hmax2;
+  op->lds_muscl   = lds_muscl;
   if (lds_muscl > 64 * 1024) {
     const int nb = (int)lds_muscl;
     bool      ok = true;
     for (int ovw = 0; ovw < 2; ++ovw)
       for (int src = 0; src < 2; ++src)
-        ok = ok && hipFuncSetAttribute((const void *)muscl_kernel_fn(S, src, ovw != 0, config->limiter), hipFuncAttributeMaxDynamicSharedMemorySize, nb) == hipSuccess;
+        ok = ok && hipFuncSetAttribute((const void *)muscl_kernel_fn(S, src, ovw != 0, config->limiter, muscl_fused),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, nb) == hipSuccess;
     if (!ok) {
       delete op;
       return fail(RDYHIP_ERR_LIB, "cannot reserve %d bytes of LDS per workgroup", nb);
@@ -730,7 +815,8 @@ int rdyhip_create(const RDyHipConfig *config, const RDyHipMesh *mesh, int32_t nu
     op->pgrid            = std::max(8, cus * per_cu);
     if (muscl_on) {
       int qm = 0, per_cu_m = 2;
-      const void *mfn = (const void *)muscl_kernel_fn(S, config->source_method == RDYHIP_SOURCE_IMPLICIT_XQ2018 ? 1 : 0, true, config->limiter);
+      const void *mfn =
+          (const void *)muscl_kernel_fn(S, config->source_method == RDYHIP_SOURCE_IMPLICIT_XQ2018 ? 1 : 0, true, config->limiter, muscl_fused);
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&qm, mfn, TILE, lds_muscl) == hipSuccess && qm > 0) per_cu_m = qm;
       if (const char *e2 = getenv("RDYHIP_BLOCKS_PER_CU")) {
         if (atoi(e2) > 0) per_cu_m = atoi(e2);
@@ -796,6 +882,10 @@ int rdyhip_create(const RDyHipConfig *config, const RDyHipMesh *mesh, int32_t nu
     TRY_RC(op->d_e_geo.upload(e_geo));
     TRY_RC(op->d_gcx.upload(gcx));
     TRY_RC(op->d_gcy.upload(gcy));
+    TRY_RC(op->d_hcells2.upload(hcells2));
+    TRY_RC(op->d_c_off.upload(c_off));
+    TRY_RC(op->d_bn_idx.upload(bn_idx));
+    TRY_RC(op->d_bn_c.upload(bn_c));
   }
   TRY_RC(op->d_mannings.zeros((size_t)no));
   TRY_RC(op->d_extsrc.zeros((size_t)3 * no));
@@ -825,7 +915,7 @@ int rdyhip_create(const RDyHipConfig *config, const RDyHipMesh *mesh, int32_t nu
                      op->d_pv.bytes() + op->d_bvalues.bytes() + op->d_bflux.bytes() + op->d_baccum.bytes() + op->d_blk_max.bytes() +
                      op->d_blk_pos.bytes() + op->d_tiles.bytes() + op->d_e_lr.bytes() + op->d_hcells.bytes() + op->d_tile_bk.bytes() +
                      op->d_e_cs.bytes() + op->d_slot_ref.bytes() + op->d_slot_ref3.bytes() + op->d_grad.bytes() + op->d_e_geo.bytes() +
-                     op->d_gcx.bytes() + op->d_gcy.bytes();
+                     op->d_gcx.bytes() + op->d_gcy.bytes() + op->d_hcells2.bytes() + op->d_c_off.bytes() + op->d_bn_idx.bytes() + op->d_bn_c.bytes();
   *op_out = op;
   return 0;
 }
@@ -1157,6 +1247,10 @@ int rdyhip_layout_info(RDyHipOperator op, RDyHipLayoutInfo *info) {
   info->num_edge_records   = op->nrec;
   info->owned_is_prefix    = op->prefix ? 1 : 0;
   info->device_bytes       = op->device_bytes;
+  info->second_order_fused   = (op->muscl && op->muscl_fused) ? 1 : 0;
+  info->max_tile_ring2_cells = op->hmax2;
+  info->persistent_grid      = op->muscl ? op->pgrid_muscl : op->pgrid;
+  info->lds_bytes            = (int32_t)(op->muscl ? op->lds_muscl : op->lds_bytes);
   // u (own cell) 24 + slots S*(4+8+8+8) + dz 16 + n 8 + ext src 24 + F 24 + pv 24 (+4 for o2l)
   if (op->use_tiled) {
     // u 24 + slot refs 4 (8 for quads) + coef S*8 + dz 16 + n 8 + ext src 24 + F 24 + pv 24 (+4 for o2l) per cell;
@@ -1165,6 +1259,13 @@ int rdyhip_layout_info(RDyHipOperator op, RDyHipLayoutInfo *info) {
                             op->nrec * 12 + op->nhalo_entries * 4 + (int64_t)op->ntiles * 16;
   } else {
     info->bytes_per_apply = (int64_t)op->n_owned * (24 + op->S * 28 + 16 + 8 + 24 + 24 + 24 + (op->prefix ? 0 : 4));
+  }
+  if (op->muscl) {
+    // + least-squares coefficients S*16 per cell and 32 B of displacements per edge record; fused: second-ring ids and the
+    // first-ring stencils (8 B + S*16 B per halo entry); split: the gradient array written and read (96) + the state read twice (24)
+    info->bytes_per_apply += (int64_t)op->n_owned * (op->S * 16) + op->nrec * 32;
+    if (op->muscl_fused) info->bytes_per_apply += (int64_t)op->d_hcells2.n * 4 + op->nhalo_entries * (8 + op->S * 16);
+    else info->bytes_per_apply += (int64_t)op->n_owned * (96 + 24 + op->S * 4);
   }
   return 0;
 }

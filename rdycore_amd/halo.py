@@ -162,6 +162,11 @@ class HaloExchange:
         elif self.recv_ids_all.numel():
             rows[self.recv_ids_all.long()] = recv_all
 
+    def _fused(self, op) -> bool:
+        if not hasattr(op, "_second_order_fused"):
+            op._second_order_fused = bool(op.layout_info()["second_order_fused"])
+        return op._second_order_fused
+
     def _make_ops(self, send, recv):
         ops = []
         for peer in sorted(set(self.send_ids) | set(self.recv_ids)):
@@ -185,9 +190,19 @@ class HaloExchange:
             self.exchange(u_local)
         if op.config.second_order:
             # ApplyInteriorFlux2R (src/swe/swe_petsc.c:98-213) needs two exchanges: the state, then the
-            # gradients (CommunicateCellGradients).  Hidden behind them: the gradients of the cells without
-            # ghost neighbours, then the fluxes of the tiles without ghost-adjacent cells (which read owned
-            # gradient rows only).  There is no reverse exchange: every rank evaluates all edges of its cells.
+            # gradients (CommunicateCellGradients).  There is no reverse exchange: every rank evaluates all
+            # edges of its cells.
+            if self._fused(op):
+                # fused kernel: tiles whose cells and first ring touch no ghost need nothing from other ranks and
+                # hide the state exchange; only the ghost-adjacent cells' gradients go through memory
+                op.apply_phase(1, True, dt, u_local, f_global, reset_diagnostics=True, gradients_ready=True)
+                main.wait_stream(self.comm_stream)
+                op.compute_gradients(u_local, phase=2)
+                self.exchange(op.gradients)
+                op.apply_phase(2, True, dt, u_local, f_global, gradients_ready=True)
+                return
+            # split kernels.  Hidden behind the exchanges: the gradients of the cells without ghost neighbours,
+            # then the fluxes of the tiles without ghost-adjacent cells (which read owned gradient rows only).
             op.compute_gradients(u_local, phase=1)
             main.wait_stream(self.comm_stream)
             op.compute_gradients(u_local, phase=2)

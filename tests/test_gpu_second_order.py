@@ -18,10 +18,20 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-10
 
 
-@pytest.fixture(autouse=True)
-def _tiled_only(rdyhip_kernel):
+@pytest.fixture(autouse=True, params=["fused", "split"])
+def muscl_mode(request, rdyhip_kernel):
+    """both forms of the second-order path behind the C ABI: gradients formed in LDS by the flux kernel
+    (default) and the separate gradient launch (RDYHIP_MUSCL=split)"""
+    import os
     if rdyhip_kernel == "cell":
         pytest.skip("second order is implemented by the tiled kernels")
+    old = os.environ.get("RDYHIP_MUSCL")
+    os.environ["RDYHIP_MUSCL"] = request.param
+    yield request.param
+    if old is None:
+        os.environ.pop("RDYHIP_MUSCL", None)
+    else:
+        os.environ["RDYHIP_MUSCL"] = old
 
 
 def _torch():
@@ -37,13 +47,16 @@ def second_order(case, limiter=LIMITER_MINMOD):
 
 @pytest.mark.parametrize("limiter", [LIMITER_MINMOD, LIMITER_NONE, LIMITER_VANLEER])
 @pytest.mark.parametrize("source_method", [SOURCE_SEMI_IMPLICIT, SOURCE_IMPLICIT_XQ2018])
-def test_tri_all_bcs_sources_limiters(limiter, source_method):
+def test_tri_all_bcs_sources_limiters(limiter, source_method, muscl_mode):
     case = second_order(tri_mms_case(40, 28, source_method, order="tiled"), limiter)
     f, fr, op, orc = run_both(case)
     check_all(case, f, fr, op, orc)
-    # the gradients themselves
+    # the gradients themselves (the fused kernel keeps them on chip: ask for them)
+    torch = _torch()
+    op.compute_gradients(torch.tensor(case.u_local, dtype=torch.float64, device="cuda"))
     g = op.gradients.cpu().numpy()
     assert rel_linf(g, orc.gradients6()) <= TOL
+    assert op.layout_info()["second_order_fused"] == (1 if muscl_mode == "fused" else 0)
     # and the scheme differs from first order on this state
     case.config.second_order = False
     assert np.abs(oracle_from_case(case).apply(case.dt, case.u_local) - fr).max() > 1e-8
