@@ -238,7 +238,20 @@ def main():
         op.rhs_function(case.dt, u, f)
         ends[i].record()
     torch.cuda.synchronize()
-    kern_ms = float(np.mean([s.elapsed_time(e) for s, e in zip(starts, ends)]))
+    kern_all = [s.elapsed_time(e) for s, e in zip(starts, ends)]
+    kern_ms = float(np.mean(kern_all))
+
+    # multi-GPU: the ghost update on its own (pack, P2P over RCCL, unpack), not overlapped
+    halo_ms = None
+    if halo is not None:
+        torch.cuda.synchronize()
+        h0, h1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        h0.record()
+        for _ in range(k_iters):
+            halo.exchange(u)
+        h1.record()
+        torch.cuda.synchronize()
+        halo_ms = h0.elapsed_time(h1) / k_iters
 
     # sanity: the result is finite and the Courant diagnostic is alive
     op.update_diagnostics()
@@ -275,6 +288,7 @@ def main():
                        "well_balancing": "hydrostatic_reconstruction" if args.hr else "none",
                        "spatial_order": ("second (MUSCL, %s limiter)" % args.limiter) if args.second_order else "first",
                        "halo_bytes_per_rank": halo.bytes_sent_per_exchange if halo else 0,
+                       "halo_exchange_alone_ms": round(halo_ms, 5) if halo_ms is not None else None,
                        "setup_seconds": round(setup_s, 1), "max_courant": courant, "finite": finite},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4),
@@ -285,7 +299,8 @@ def main():
                          "%s<3,%d>" % ("swe_rhs_tiled_kernel" if info["tiled_kernel"] else "swe_rhs_kernel",
                                        0 if args.source == "semi_implicit" else 1),
                          "tile_edge_records_per_cell": round(info["num_edge_records"] / max(n_owned, 1), 4),
-                         "kernel_avg_ms": round(kern_ms, 5),
+                         "kernel_avg_ms": round(kern_ms, 5), "kernel_median_ms": round(float(np.median(kern_all)), 5),
+                         "kernel_min_ms": round(float(np.min(kern_all)), 5),
                          "algorithmic_bytes_per_launch": int(n_owned * ALG_BYTES_PER_CELL),
                          "layout_bytes_per_launch": int(info["bytes_per_apply"])},
         }
