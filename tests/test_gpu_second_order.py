@@ -209,3 +209,63 @@ def test_full_size_parity_and_mass_balance(nx, ny):
     lhs = (f[:, 0] * mesh.cell_areas).sum()
     rhs = -flux_out + (case.ext_src[:, 0] * mesh.cell_areas).sum()
     assert abs(lhs - rhs) <= 1e-9 * max(1.0, abs(rhs))
+
+
+# ---------------------------------------------------------------------------
+# edge cases: empty and ragged inputs
+# ---------------------------------------------------------------------------
+def test_rank_with_no_owned_cells():
+    torch = _torch()
+    xyz, conn, _, _ = M.structured_tri_connectivity(3, 2)
+    mesh = M.build_mesh(xyz, conn, is_owned=np.zeros(conn.shape[0], dtype=np.int32), boundary_classifier=M.box_side_boundaries(0, 3, 0, 2))
+    op = Operator.create(RDyFlowConfig(second_order=True), mesh)
+    u = torch.ones((mesh.num_cells, 3), dtype=torch.float64, device="cuda")
+    f = torch.zeros((0, 3), dtype=torch.float64, device="cuda")
+    op.compute_gradients(u)
+    op.apply_phase(0, True, 0.1, u, f, reset_diagnostics=True, gradients_ready=True)
+    op.rhs_function(0.1, u, f)          # nothing to do on this rank: not refused
+    op.update_diagnostics()
+    assert op.get_diagnostics().max_courant_num == 0.0
+    assert op.gradients.shape == (mesh.num_cells, 6)
+    op.destroy()
+
+
+def test_single_cell_and_two_cells_have_degenerate_stencils():
+    # one triangle (no internal edge) and two triangles (one internal edge): the 2x2 least-squares matrix is
+    # singular, the reference zeroes the gradient (operator_fluxes_ceed.c:926-933) and the scheme is first order
+    for conn in (np.array([[0, 1, 2]], dtype=np.int32), np.array([[0, 1, 2], [1, 3, 2]], dtype=np.int32)):
+        xyz = np.array([[0.0, 0.0, 0.0], [2.0, 0.0, 0.1], [0.0, 1.0, 0.3], [2.0, 1.5, 0.2]])[: conn.max() + 1]
+        mesh = M.build_mesh(xyz, conn, boundary_classifier=M.single_boundary())
+        nc = mesh.num_cells
+        case = CS.Case("tiny", mesh, RDyFlowConfig(second_order=True), [M.CONDITION_REFLECTING],
+                       np.array([[1.3, 0.4, -0.2], [0.7, -0.1, 0.3]])[:nc], np.full(nc, 0.03), np.zeros((nc, 3)), {}, 0.01)
+        f, fr, op, orc = run_both(case)
+        check_all(case, f, fr, op, orc)
+        case.config.second_order = False
+        assert np.array_equal(oracle_from_case(case).apply(case.dt, case.u_local), fr)
+
+
+def test_mixed_tri_quad_mesh_second_order():
+    # quads and triangles in one mesh: 4 slots per cell with empty slots on the triangles
+    rng = np.random.default_rng(2)
+    nx, ny = 12, 9
+    ii, jj = np.meshgrid(np.arange(nx + 1), np.arange(ny + 1), indexing="xy")
+    xyz = np.stack([ii.ravel() * 1.0, jj.ravel() * 1.0, 0.05 * np.sin(ii.ravel() * 0.7) * np.cos(jj.ravel() * 0.5)], axis=1)
+    cells = []
+    for j in range(ny):
+        for i in range(nx):
+            v00, v10, v11, v01 = j * (nx + 1) + i, j * (nx + 1) + i + 1, (j + 1) * (nx + 1) + i + 1, (j + 1) * (nx + 1) + i
+            if (i + j) % 3 == 0:
+                cells += [[v00, v10, v11, -1], [v00, v11, v01, -1]]
+            else:
+                cells.append([v00, v10, v11, v01])
+    conn = np.array(cells, dtype=np.int32)
+    mesh = M.build_mesh(xyz, conn, boundary_classifier=M.box_side_boundaries(0, nx, 0, ny))
+    xc, yc = mesh.cell_centroids[:, 0], mesh.cell_centroids[:, 1]
+    h = 1.0 + 0.2 * np.sin(0.5 * xc) * np.cos(0.4 * yc)
+    u = np.stack([h, h * 0.3 * np.cos(0.3 * yc), -h * 0.2 * np.sin(0.6 * xc)], axis=1) + rng.normal(size=(mesh.num_cells, 3)) * 1e-3
+    case = CS.Case("mixed", mesh, RDyFlowConfig(second_order=True, limiter=LIMITER_VANLEER),
+                   [M.CONDITION_REFLECTING] * len(mesh.boundaries), u, np.full(mesh.num_cells, 0.02), np.zeros((mesh.num_cells, 3)), {}, 5e-3)
+    f, fr, op, orc = run_both(case)
+    check_all(case, f, fr, op, orc)
+    assert op.layout_info()["slots_per_cell"] == 4
