@@ -39,8 +39,10 @@ def gpu_rhs(case, op=None):
 
 
 @pytest.mark.parametrize("name", sorted(make_golden.golden_cases()))
-def test_golden_vectors(name):
+def test_golden_vectors(name, rdyhip_kernel):
     case = make_golden.golden_cases()[name]
+    if rdyhip_kernel == "cell" and (case.config.second_order or case.config.well_balancing):
+        pytest.skip("second order and hydrostatic reconstruction are implemented by the tiled kernels")
     g = np.load(os.path.join(ROOT, "tests", "golden", f"rhs_{name}.npz"))
     f, op = gpu_rhs(case)
     assert rel_linf(f, g["f"]) <= TOL

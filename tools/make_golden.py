@@ -28,6 +28,19 @@ def golden_cases():
     mesh = M.structured_quad_mesh(9, 6, 1.0, 1.5, zfunc=CS.mms_bathymetry(K=K))
     out["quad_semi_implicit"] = CS.friction_slope_case(mesh, 9, 9, dt=5e-3, source_method=0, K=K)
     out["ex2b"] = CS.ex2b_case(os.path.join(ROOT, "tests", "golden", "planar_dam_10x5.msh"))
+    # second order (MUSCL): minmod on triangles, van Leer on quads; hydrostatic reconstruction
+    mesh = M.structured_tri_mesh(14, 9, 1.0, zfunc=CS.mms_bathymetry(K=K))
+    c = CS.friction_slope_case(mesh, 14, 9, dt=1e-2, source_method=0, K=K)
+    c.config.second_order = True
+    out["tri_second_order_minmod"] = c
+    mesh = M.structured_quad_mesh(9, 6, 1.0, 1.5, zfunc=CS.mms_bathymetry(K=K))
+    c = CS.friction_slope_case(mesh, 9, 9, dt=5e-3, source_method=1, K=K)
+    c.config.second_order, c.config.limiter = True, 2
+    out["quad_second_order_vanleer"] = c
+    mesh = M.structured_tri_mesh(14, 9, 1.0, zfunc=CS.mms_bathymetry(K=K), project_2d=True)
+    c = CS.friction_slope_case(mesh, 14, 9, dt=1e-2, source_method=0, K=K)
+    c.config.well_balancing = 2
+    out["tri_hydrostatic_reconstruction"] = c
     return out
 
 
