@@ -69,6 +69,89 @@ __device__ __forceinline__ double limit_slope(double extrap, double half_dq) {
   return fabs(extrap) < fabs(half_dq) ? extrap : half_dq;
 }
 
+// One tile edge of the second-order path: ReconstructFaceValues (src/operator_fluxes_ceed.c:1180-1203) for an
+// interior edge -- limited extrapolation of both cells' states to the edge midpoint, depth clamped from below --
+// then ComputeRiemannVelocities + the Roe flux on the reconstructed states (src/swe/swe_petsc.c:139-161); a boundary
+// edge stays first order.  `sq` / `sg`: LDS planes of the state (stride nq) and the gradient (stride ng);
+// dl / dr: edge midpoint minus the left / right centroid.  The flux is parked in LDS for phase 2.
+template <int LIM>
+__device__ __forceinline__ void muscl_edge(const KernelArgs &a, const TileDesc &td, double dt, int e, uint32_t lr, double cs, double2 dl, double2 dr,
+                                           const double *sq, int nq, const double *sg, int ng, double *ef0, double *ef1, double *ef2, double *eam) {
+  double cn, sn;
+  edge_normal(lr, cs, cn, sn);
+  const int jl = lr & EDGE_SLOT_MASK;
+  RoeFlux   fl;
+  bool      wet;
+  if (!(lr & EDGE_BOUNDARY)) {
+    const int jr = (lr >> EDGE_R_SHIFT) & EDGE_SLOT_MASK;
+    double    ql[3], qr[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const double cl_ = sq[k * nq + jl], cr_ = sq[k * nq + jr];
+      const double extrap_l = sg[(2 * k) * ng + jl] * dl.x + sg[(2 * k + 1) * ng + jl] * dl.y;
+      const double extrap_r = sg[(2 * k) * ng + jr] * dr.x + sg[(2 * k + 1) * ng + jr] * dr.y;
+      const double dq       = cr_ - cl_;
+      ql[k]                 = cl_ + limit_slope<LIM>(extrap_l, 0.5 * dq);
+      qr[k]                 = cr_ + limit_slope<LIM>(extrap_r, -0.5 * dq);
+    }
+    ql[0] = fmax(0.0, ql[0]);  // 1201-1203, swe_petsc.c:143-146
+    qr[0] = fmax(0.0, qr[0]);
+    const RiemannSide L = riemann_side(ql[0], ql[1], ql[2], a.tiny_h, a.h_anuga_sq);
+    const RiemannSide R = riemann_side(qr[0], qr[1], qr[2], a.tiny_h, a.h_anuga_sq);
+    fl                  = roe_flux(L, R, sn, cn);
+    wet                 = !(R.h < a.tiny_h && L.h < a.tiny_h);  // swe_petsc.c:184
+  } else {
+    const RiemannSide L  = riemann_side(sq[jl], sq[nq + jl], sq[2 * nq + jl], a.tiny_h, a.h_anuga_sq);
+    const int         k  = a.tile_bk[td.b_off + ((lr >> EDGE_R_SHIFT) & EDGE_SLOT_MASK)];
+    BoundaryFlux      bf = boundary_flux(a.btype[k], true, L, a.bvalues + 3 * (int64_t)k, sn, cn, a.tiny_h, a.h_anuga_sq);
+    fl                   = bf.flux;
+    wet                  = bf.wet;
+    store_boundary_flux(a, k, fl, dt);
+  }
+  ef0[e] = fl.f0;
+  ef1[e] = fl.f1;
+  ef2[e] = fl.f2;
+  eam[e] = wet ? fl.amax : -1.0;  // -1 marks a dry-dry edge (skipped, swe_petsc.c:184)
+}
+
+// index of slot s's edge in the tile's edge list, or -1 for an unused slot
+template <int S>
+__device__ __forceinline__ int slot_edge(uint32_t r0, uint32_t r1, int s) {
+  if (S == 3) {
+    const uint32_t ref = (r0 >> (10 * s)) & 0x3FF;
+    return ref == REF3_EMPTY ? -1 : (int)ref;
+  }
+  const uint32_t w   = (s < 2) ? r0 : r1;
+  const uint32_t ref = (s & 1) ? (w >> 16) : (w & 0xFFFFu);
+  return ref == SLOT_EMPTY ? -1 : (int)ref;
+}
+
+// Phase 2 of both second-order kernels: a cell's flux sum in the reference's edge order + the Courant number
+// (src/swe/swe_petsc.c:184-201); kf[s] = -+len/area of slot s.
+template <int S>
+__device__ __forceinline__ void muscl_cell_sum(uint32_t r0, uint32_t r1, const double (&kf)[S], const double *ef0, const double *ef1, const double *ef2,
+                                               const double *eam, double dt, int o, double &acc0, double &acc1, double &acc2, double &best,
+                                               int &best_slot, int &best_o) {
+#pragma unroll
+  for (int s = 0; s < S; ++s) {
+    const int ref = slot_edge<S>(r0, r1, s);
+    if (ref < 0) continue;
+    const double am = eam[ref];
+    if (am != -1.0) {
+      const double k = kf[s];
+      acc0 += ef0[ref] * k;
+      acc1 += ef1[ref] * k;
+      acc2 += ef2[ref] * k;
+      const double cnum = am * fabs(k) * dt;  // len/area_self: the max over the two cells is len / min(area_l, area_r)
+      if (cnum > best) {
+        best      = cnum;
+        best_slot = s;
+        best_o    = o;
+      }
+    }
+  }
+}
+
 // ComputeLeastSquaresGradients, src/operator_fluxes_ceed.c:998-1042, gathered per cell:
 // grad(cell) = sum over its internal edges of c_edge * (q_nbr - q_cell), where c_edge is
 // (cx_LR, cy_LR) if the cell is the edge's left cell and -(cx_RL, cy_RL) if it is the right
@@ -165,45 +248,8 @@ __global__ __launch_bounds__(TILE) void swe_rhs_muscl_kernel(const KernelArgs a,
 
     // ---- phase 1: every edge of the tile once
     for (int e = tid; e < ne; e += TILE) {
-      const uint32_t lr = a.e_lr[td.e_off + e];
-      double         cn, sn;
-      edge_normal(lr, a.e_cs[td.e_off + e], cn, sn);
-      const int jl = lr & EDGE_SLOT_MASK;
-      RoeFlux   fl;
-      bool      wet;
-      if (!(lr & EDGE_BOUNDARY)) {
-        const int      jr  = (lr >> EDGE_R_SHIFT) & EDGE_SLOT_MASK;
-        const double2 *geo = reinterpret_cast<const double2 *>(g.e_geo + 4 * ((int64_t)td.e_off + e));
-        const double2  dl = geo[0], dr = geo[1];
-        double         ql[3], qr[3];
-        // ReconstructFaceValues, src/operator_fluxes_ceed.c:1180-1200
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          const double cl_ = sq[k * nside + jl], cr_ = sq[k * nside + jr];
-          const double extrap_l = sg[(2 * k) * nside + jl] * dl.x + sg[(2 * k + 1) * nside + jl] * dl.y;
-          const double extrap_r = sg[(2 * k) * nside + jr] * dr.x + sg[(2 * k + 1) * nside + jr] * dr.y;
-          const double dq       = cr_ - cl_;
-          ql[k]                 = cl_ + limit_slope<LIM>(extrap_l, 0.5 * dq);
-          qr[k]                 = cr_ + limit_slope<LIM>(extrap_r, -0.5 * dq);
-        }
-        ql[0] = fmax(0.0, ql[0]);  // depth clamped from below (1201-1203, swe_petsc.c:143-146)
-        qr[0] = fmax(0.0, qr[0]);
-        const RiemannSide L = riemann_side(ql[0], ql[1], ql[2], a.tiny_h, a.h_anuga_sq);
-        const RiemannSide R = riemann_side(qr[0], qr[1], qr[2], a.tiny_h, a.h_anuga_sq);
-        fl                  = roe_flux(L, R, sn, cn);
-        wet                 = !(R.h < a.tiny_h && L.h < a.tiny_h);  // swe_petsc.c:184
-      } else {
-        const RiemannSide L  = riemann_side(sq[jl], sq[nside + jl], sq[2 * nside + jl], a.tiny_h, a.h_anuga_sq);
-        const int         k  = a.tile_bk[td.b_off + ((lr >> EDGE_R_SHIFT) & EDGE_SLOT_MASK)];
-        BoundaryFlux      bf = boundary_flux(a.btype[k], true, L, a.bvalues + 3 * (int64_t)k, sn, cn, a.tiny_h, a.h_anuga_sq);
-        fl                   = bf.flux;
-        wet                  = bf.wet;
-        store_boundary_flux(a, k, fl, dt);
-      }
-      ef0[e] = fl.f0;
-      ef1[e] = fl.f1;
-      ef2[e] = fl.f2;
-      eam[e] = wet ? fl.amax : -1.0;
+      const double2 *geo = reinterpret_cast<const double2 *>(g.e_geo + 4 * ((int64_t)td.e_off + e));
+      muscl_edge<LIM>(a, td, dt, e, a.e_lr[td.e_off + e], a.e_cs[td.e_off + e], geo[0], geo[1], sq, nside, sg, nside, ef0, ef1, ef2, eam);
     }
     __syncthreads();
 
@@ -223,31 +269,10 @@ __global__ __launch_bounds__(TILE) void swe_rhs_muscl_kernel(const KernelArgs a,
         acc1 = f[3 * (int64_t)o + 1];
         acc2 = f[3 * (int64_t)o + 2];
       }
+      double kf[S];
 #pragma unroll
-      for (int s = 0; s < S; ++s) {
-        uint32_t ref;
-        if (S == 3) {
-          ref = (r0 >> (10 * s)) & 0x3FF;
-          if (ref == REF3_EMPTY) continue;
-        } else {
-          const uint32_t w = (s < 2) ? r0 : r1;
-          ref              = (s & 1) ? (w >> 16) : (w & 0xFFFFu);
-          if (ref == SLOT_EMPTY) continue;
-        }
-        const double am = eam[ref];
-        if (am != -1.0) {
-          const double k = a.coef[s * a.stride + o];
-          acc0 += ef0[ref] * k;
-          acc1 += ef1[ref] * k;
-          acc2 += ef2[ref] * k;
-          const double cnum = am * fabs(k) * dt;
-          if (cnum > best) {
-            best      = cnum;
-            best_slot = s;
-            best_o    = o;
-          }
-        }
-      }
+      for (int s = 0; s < S; ++s) kf[s] = a.coef[s * a.stride + o];
+      muscl_cell_sum<S>(r0, r1, kf, ef0, ef1, ef2, eam, dt, o, acc0, acc1, acc2, best, best_slot, best_o);
       const double      h = sq[tid], hu = sq[nside + tid], hv = sq[2 * nside + tid];
       const RiemannSide self = riemann_side(h, hu, hv, a.tiny_h, a.h_anuga_sq);
       cell_epilogue<SRC>(a, o, dt, h, hu, hv, self.u, self.v, acc0, acc1, acc2, a.dzdx[o], a.dzdy[o], a.mannings[o], a.extsrc[3 * (int64_t)o + 0],
@@ -417,15 +442,8 @@ __global__ __launch_bounds__(TILE) void swe_rhs_muscl_fused_kernel(const KernelA
       if (active) {
 #pragma unroll
         for (int s = 0; s < S; ++s) {
-          uint32_t ref;
-          if (S == 3) {
-            ref = (r0 >> (10 * s)) & 0x3FF;
-            if (ref == REF3_EMPTY) continue;
-          } else {
-            const uint32_t w = (s < 2) ? r0 : r1;
-            ref              = (s & 1) ? (w >> 16) : (w & 0xFFFFu);
-            if (ref == SLOT_EMPTY) continue;
-          }
+          const int ref = slot_edge<S>(r0, r1, s);
+          if (ref < 0) continue;
           const uint32_t lr = slr[ref];
           if (lr & EDGE_BOUNDARY) continue;
           const int jl = lr & EDGE_SLOT_MASK, jr = (lr >> EDGE_R_SHIFT) & EDGE_SLOT_MASK;
@@ -466,42 +484,7 @@ __global__ __launch_bounds__(TILE) void swe_rhs_muscl_fused_kernel(const KernelA
 
     // ---- phase 1: every edge of the tile once
     auto do_edge = [&](int e, uint32_t lr, double cs, double2 dl, double2 dr) {
-      double cn, sn;
-      edge_normal(lr, cs, cn, sn);
-      const int jl = lr & EDGE_SLOT_MASK;
-      RoeFlux   fl;
-      bool      wet;
-      if (!(lr & EDGE_BOUNDARY)) {
-        const int jr = (lr >> EDGE_R_SHIFT) & EDGE_SLOT_MASK;
-        double    ql[3], qr[3];
-        // ReconstructFaceValues, src/operator_fluxes_ceed.c:1180-1200
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          const double cl_ = sq[k * nq + jl], cr_ = sq[k * nq + jr];
-          const double extrap_l = sg[(2 * k) * ng + jl] * dl.x + sg[(2 * k + 1) * ng + jl] * dl.y;
-          const double extrap_r = sg[(2 * k) * ng + jr] * dr.x + sg[(2 * k + 1) * ng + jr] * dr.y;
-          const double dq       = cr_ - cl_;
-          ql[k]                 = cl_ + limit_slope<LIM>(extrap_l, 0.5 * dq);
-          qr[k]                 = cr_ + limit_slope<LIM>(extrap_r, -0.5 * dq);
-        }
-        ql[0] = fmax(0.0, ql[0]);
-        qr[0] = fmax(0.0, qr[0]);
-        const RiemannSide L = riemann_side(ql[0], ql[1], ql[2], a.tiny_h, a.h_anuga_sq);
-        const RiemannSide R = riemann_side(qr[0], qr[1], qr[2], a.tiny_h, a.h_anuga_sq);
-        fl                  = roe_flux(L, R, sn, cn);
-        wet                 = !(R.h < a.tiny_h && L.h < a.tiny_h);
-      } else {
-        const RiemannSide L  = riemann_side(sq[jl], sq[nq + jl], sq[2 * nq + jl], a.tiny_h, a.h_anuga_sq);
-        const int         k  = a.tile_bk[td.b_off + ((lr >> EDGE_R_SHIFT) & EDGE_SLOT_MASK)];
-        BoundaryFlux      bf = boundary_flux(a.btype[k], true, L, a.bvalues + 3 * (int64_t)k, sn, cn, a.tiny_h, a.h_anuga_sq);
-        fl                   = bf.flux;
-        wet                  = bf.wet;
-        store_boundary_flux(a, k, fl, dt);
-      }
-      ef0[e] = fl.f0;
-      ef1[e] = fl.f1;
-      ef2[e] = fl.f2;
-      eam[e] = wet ? fl.amax : -1.0;
+      muscl_edge<LIM>(a, td, dt, e, lr, cs, dl, dr, sq, nq, sg, ng, ef0, ef1, ef2, eam);
     };
 #pragma unroll 1
     for (int r = 0; r < 2; ++r) {
@@ -522,31 +505,7 @@ __global__ __launch_bounds__(TILE) void swe_rhs_muscl_fused_kernel(const KernelA
         acc1 = f[3 * (int64_t)o + 1];
         acc2 = f[3 * (int64_t)o + 2];
       }
-#pragma unroll
-      for (int s = 0; s < S; ++s) {
-        uint32_t ref;
-        if (S == 3) {
-          ref = (r0 >> (10 * s)) & 0x3FF;
-          if (ref == REF3_EMPTY) continue;
-        } else {
-          const uint32_t w = (s < 2) ? r0 : r1;
-          ref              = (s & 1) ? (w >> 16) : (w & 0xFFFFu);
-          if (ref == SLOT_EMPTY) continue;
-        }
-        const double am = eam[ref];
-        if (am != -1.0) {
-          const double k = kf[s];
-          acc0 += ef0[ref] * k;
-          acc1 += ef1[ref] * k;
-          acc2 += ef2[ref] * k;
-          const double cnum = am * fabs(k) * dt;
-          if (cnum > best) {
-            best      = cnum;
-            best_slot = s;
-            best_o    = o;
-          }
-        }
-      }
+      muscl_cell_sum<S>(r0, r1, kf, ef0, ef1, ef2, eam, dt, o, acc0, acc1, acc2, best, best_slot, best_o);
       const RiemannSide self = riemann_side(q[0], q[1], q[2], a.tiny_h, a.h_anuga_sq);
       cell_epilogue<SRC>(a, o, dt, q[0], q[1], q[2], self.u, self.v, acc0, acc1, acc2, dzx, dzy, nman, s0, s1, s2, f);
     }
