@@ -297,6 +297,16 @@ int rdyhip_unpack_rows(double *dst, int32_t ncomp, const int32_t *row_ids, int32
  * scatter from the global to the local vector is folded in). */
 int rdyhip_axpy_owned(RDyHipOperator op, double dt, const double *f_global, double *u_local, void *stream);
 
+/* The whole forward-Euler step in one pass (TSStep_Euler: F = RHS(U); U += dt F, with OperatorRHSFunction's zeroing
+ * of F, src/rdysetup.c:1120-1172): u_local_out[owned cell] = u_local[owned cell] + dt * F, where F is what
+ * rdyhip_rhs_function would produce.  Not in place: the caller ping-pongs two local state arrays (the ghost rows of
+ * u_local_out are left for the next halo update).  f_global may be NULL -- the first-order and HR tiled kernels then
+ * never write F (one 24 B/cell stream less and no separate axpy pass); primitive_variables, boundary fluxes and the
+ * Courant diagnostic are produced as by any RHS evaluation.  `phase` / `flags` as in rdyhip_apply_phase
+ * (RDYHIP_PHASE_OVERWRITE is implied). */
+int rdyhip_euler_step(RDyHipOperator op, int32_t phase, int32_t flags, double dt, const double *u_local, double *u_local_out, double *f_global,
+                      void *stream);
+
 /* ---- introspection ----------------------------------------------------------
  * numbers describing the device layout, for DESIGN.md / bench.py */
 typedef struct {

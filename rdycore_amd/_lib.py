@@ -85,6 +85,7 @@ SYMBOLS = {
     "rdyhip_pack_rows": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "rdyhip_unpack_rows": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "rdyhip_axpy_owned": (C.c_int, [_H, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rdyhip_euler_step": (C.c_int, [_H, C.c_int32, C.c_int32, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rdyhip_layout_info": (C.c_int, [_H, C.POINTER(RDyHipLayoutInfo)]),
 }
 

@@ -138,6 +138,7 @@ struct RDyHipOperator_s {
   std::vector<double>  h_area;
   RDyHipCourant        courant{0.0, -1, -1};
   // staging buffers for the setters
+  DevBuf<double>  d_scratch_f;   // F of rdyhip_euler_step when the caller wants none and the kernel cannot skip it
   DevBuf<double>  d_stage_vals;
   DevBuf<int32_t> d_stage_ids;
 
@@ -148,7 +149,7 @@ struct RDyHipOperator_s {
     d_bghost_list.release(); d_cn.release(); d_sn.release(); d_coef.release(); d_dzdx.release(); d_dzdy.release();
     d_mannings.release(); d_extsrc.release(); d_bvalues.release(); d_bflux.release();
     d_baccum.release(); d_bcn.release(); d_bsn.release(); d_pv.release(); d_fdiv.release(); d_blk_max.release();
-    d_blk_pos.release(); d_courant.release(); d_stage_vals.release(); d_stage_ids.release();
+    d_blk_pos.release(); d_courant.release(); d_stage_vals.release(); d_stage_ids.release(); d_scratch_f.release();
     d_tiles.release(); d_e_lr.release(); d_hcells.release(); d_tile_bk.release(); d_halo_tiles.release();
     d_e_cs.release(); d_slot_ref.release(); d_slot_ref3.release(); d_zc_local.release();
     d_grad.release(); d_e_geo.release(); d_gcx.release(); d_gcy.release(); d_bn_c.release(); d_hcells2.release(); d_c_off.release();
@@ -171,6 +172,13 @@ TiledKernelFn tiled_kernel_fn_hr(int S, int src, bool ovw) {
   return ovw ? swe_rhs_tiled_kernel<4, 0, true, HR> : swe_rhs_tiled_kernel<4, 0, false, HR>;
 }
 TiledKernelFn tiled_kernel_fn(int S, int src, bool ovw, bool hr) { return hr ? tiled_kernel_fn_hr<true>(S, src, ovw) : tiled_kernel_fn_hr<false>(S, src, ovw); }
+// the instantiation with the forward-Euler update fused into the stores (rdyhip_euler_step)
+template <bool HR>
+TiledKernelFn tiled_euler_fn_hr(int S, int src) {
+  if (S == 3) return src ? swe_rhs_tiled_kernel<3, 1, true, HR, true> : swe_rhs_tiled_kernel<3, 0, true, HR, true>;
+  return src ? swe_rhs_tiled_kernel<4, 1, true, HR, true> : swe_rhs_tiled_kernel<4, 0, true, HR, true>;
+}
+TiledKernelFn tiled_euler_fn(int S, int src, bool hr) { return hr ? tiled_euler_fn_hr<true>(S, src) : tiled_euler_fn_hr<false>(S, src); }
 
 using MusclKernelFn = void (*)(const KernelArgs, const MusclArgs, const double, const double *, double *);
 
@@ -249,8 +257,18 @@ int launch_gradients(RDyHipOperator op, int32_t phase, const double *u, hipStrea
 }
 
 int launch_rhs(RDyHipOperator op, int32_t phase, int32_t overwrite, int reset_diag, double dt, const double *u, double *f, hipStream_t st,
-               bool gradients_ready = false) {
+               bool gradients_ready = false, double *u_out = nullptr) {
   if (!op) return fail(RDYHIP_ERR_USER, "null operator");
+  // rdyhip_euler_step: the first-order / HR tiled kernel has the update fused into its stores (F optional); the
+  // other kernels evaluate F (into a scratch vector if the caller wants none) and a separate update follows
+  const bool euler_fused = u_out && op->use_tiled && !op->muscl;
+  if (u_out && !euler_fused && !f && op->n_owned > 0) {
+    if (!op->d_scratch_f.p) {
+      int rc = op->d_scratch_f.alloc((size_t)3 * op->n_owned);
+      if (rc) return rc;
+    }
+    f = op->d_scratch_f.p;
+  }
   if (op->muscl && !gradients_ready && op->n_owned > 0 && op->muscl_fused) {
     // fused kernel: only ghost cells' gradients are read from memory, and they have to come from the exchange
     if (op->n_cells > op->n_owned || phase != RDYHIP_PHASE_ALL)
@@ -265,8 +283,9 @@ int launch_rhs(RDyHipOperator op, int32_t phase, int32_t overwrite, int reset_di
     if (rc) return rc;
   }
   if (op->n_owned == 0) return reset_diag ? rdyhip_reset_diagnostics(op, (void *)st) : 0;  // a rank may own nothing (f_global is then empty)
-  if (!u || !f) return fail(RDYHIP_ERR_USER, "null u_local / f_global");
+  if (!u || (!f && !euler_fused)) return fail(RDYHIP_ERR_USER, "null u_local / f_global");
   KernelArgs a{};
+  a.u_out      = u_out;
   a.n_owned    = op->n_owned;
   a.stride     = op->stride;
   a.o2l        = op->prefix ? nullptr : op->d_o2l.p;
@@ -332,6 +351,8 @@ int launch_rhs(RDyHipOperator op, int32_t phase, int32_t overwrite, int reset_di
     if (op->muscl) {
       hipLaunchKernelGGL(HIP_KERNEL_NAME(muscl_kernel_fn(op->S, xq ? 1 : 0, overwrite != 0, op->config.limiter, op->muscl_fused)), dim3(grid),
                          dim3(TILE), op->lds_muscl, st, a, muscl_args(op), dt, u, f);
+    } else if (euler_fused) {
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(tiled_euler_fn(op->S, xq ? 1 : 0, op->hr)), dim3(grid), dim3(TILE), op->lds_bytes, st, a, dt, u, f);
     } else {
       const size_t lds = op->lds_bytes;
       hipLaunchKernelGGL(HIP_KERNEL_NAME(tiled_kernel_fn(op->S, xq ? 1 : 0, overwrite != 0, op->hr)), dim3(grid), dim3(TILE), lds, st, a, dt, u, f);
@@ -365,6 +386,12 @@ int launch_rhs(RDyHipOperator op, int32_t phase, int32_t overwrite, int reset_di
   if (op->n_bghost > 0 && phase != RDYHIP_PHASE_INTERIOR) {
     hipLaunchKernelGGL(boundary_ghost_kernel, dim3((op->n_bghost + 63) / 64), dim3(64), 0, st, op->n_bghost, op->d_bghost_list.p, op->d_bleft.p,
                        op->d_btype.p, op->d_bcn.p, op->d_bsn.p, op->d_bvalues.p, op->d_bflux.p, op->d_baccum.p, u, dt, a.tiny_h, a.h_anuga_sq);
+    HIP_TRY(hipGetLastError());
+  }
+  if (u_out && !euler_fused && phase != RDYHIP_PHASE_INTERIOR) {
+    // F is complete once the halo (or the only) phase has run
+    const int n3 = 3 * op->n_owned;
+    hipLaunchKernelGGL(euler_out_kernel, dim3((n3 + 255) / 256), dim3(256), 0, st, op->n_owned, op->prefix ? nullptr : op->d_o2l.p, dt, f, u, u_out);
     HIP_TRY(hipGetLastError());
   }
   return 0;
@@ -757,7 +784,8 @@ int rdyhip_create(const RDyHipConfig *config, const RDyHipMesh *mesh, int32_t nu
     for (int ovw = 0; ovw < 2; ++ovw)
       for (int src = 0; src < 2; ++src)
         for (int sl = 3; sl <= 4; ++sl)
-          ok = ok && hipFuncSetAttribute((const void *)tiled_kernel_fn(sl, src, ovw != 0, hr_on), hipFuncAttributeMaxDynamicSharedMemorySize, nb) == hipSuccess;
+          ok = ok && hipFuncSetAttribute((const void *)tiled_kernel_fn(sl, src, ovw != 0, hr_on), hipFuncAttributeMaxDynamicSharedMemorySize, nb) == hipSuccess &&
+               hipFuncSetAttribute((const void *)tiled_euler_fn(sl, src, hr_on), hipFuncAttributeMaxDynamicSharedMemorySize, nb) == hipSuccess;
     if (!ok) {
       delete op;
       return fail(RDYHIP_ERR_LIB, "cannot reserve %d bytes of LDS per workgroup", nb);
@@ -952,6 +980,20 @@ int rdyhip_apply_phase(RDyHipOperator op, int32_t phase, int32_t flags, double d
   }
   return launch_rhs(op, phase, (flags & RDYHIP_PHASE_OVERWRITE) ? 1 : 0, reset, dt, u_local, f_global, (hipStream_t)stream,
                     (flags & RDYHIP_PHASE_GRADIENTS_READY) != 0);
+}
+
+int rdyhip_euler_step(RDyHipOperator op, int32_t phase, int32_t flags, double dt, const double *u_local, double *u_local_out, double *f_global,
+                      void *stream) {
+  if (phase != RDYHIP_PHASE_ALL && phase != RDYHIP_PHASE_INTERIOR && phase != RDYHIP_PHASE_HALO) return fail(RDYHIP_ERR_USER, "bad phase %d", phase);
+  if (!op) return fail(RDYHIP_ERR_USER, "null operator");
+  if (op->n_owned > 0 && (!u_local_out || u_local_out == u_local)) return fail(RDYHIP_ERR_USER, "rdyhip_euler_step needs a second state array (not in place)");
+  const int reset = (flags & RDYHIP_PHASE_RESET_DIAGNOSTICS) ? 1 : 0;
+  if (reset) op->courant = RDyHipCourant{0.0, -1, -1};
+  if (reset && phase == RDYHIP_PHASE_HALO && (op->use_tiled ? op->n_halo_tiles == 0 : op->n_halo == 0)) {
+    int rc = rdyhip_reset_diagnostics(op, stream);
+    if (rc) return rc;
+  }
+  return launch_rhs(op, phase, 1, reset, dt, u_local, f_global, (hipStream_t)stream, (flags & RDYHIP_PHASE_GRADIENTS_READY) != 0, u_local_out);
 }
 
 int rdyhip_set_boundary_values(RDyHipOperator op, int32_t boundary, int32_t comp_offset, int32_t num_comp, int32_t num_edges, const double *values) {

@@ -67,6 +67,7 @@ struct KernelArgs {
   double        *baccum;     // [K][3]
   double        *pv;         // [n_owned][3]
   double        *fdiv;       // [n_owned][3] or nullptr
+  double        *u_out;      // EULER kernels: [num_cells][3] state after the step, owned rows written (u_out = u + dt F)
   double        *blk_max;    // [grid]
   int32_t       *blk_pos;    // [grid]
   double         tiny_h, h_anuga_sq, xq_thresh;
@@ -160,6 +161,23 @@ __device__ __forceinline__ void cell_store(const KernelArgs &a, int o, const dou
   f[3 * (int64_t)o + 0]    = out[0];
   f[3 * (int64_t)o + 1]    = out[1];
   f[3 * (int64_t)o + 2]    = out[2];
+  a.pv[3 * (int64_t)o + 0] = out[3];
+  a.pv[3 * (int64_t)o + 1] = out[4];
+  a.pv[3 * (int64_t)o + 2] = out[5];
+}
+
+// the same with F optional (EULER kernels: the caller may not want F at all)
+__device__ __forceinline__ void cell_store_opt_f(const KernelArgs &a, int o, const double *fdiv, const double *out, double *__restrict__ f) {
+  if (a.fdiv) {
+    a.fdiv[3 * (int64_t)o + 0] = fdiv[0];
+    a.fdiv[3 * (int64_t)o + 1] = fdiv[1];
+    a.fdiv[3 * (int64_t)o + 2] = fdiv[2];
+  }
+  if (f) {
+    f[3 * (int64_t)o + 0] = out[0];
+    f[3 * (int64_t)o + 1] = out[1];
+    f[3 * (int64_t)o + 2] = out[2];
+  }
   a.pv[3 * (int64_t)o + 0] = out[3];
   a.pv[3 * (int64_t)o + 1] = out[4];
   a.pv[3 * (int64_t)o + 2] = out[5];
@@ -284,7 +302,10 @@ __device__ __forceinline__ void load_streams(const KernelArgs &a, int o, bool ac
 // each interior edge's two depths are reconstructed against max(zc_l, zc_r) before
 // the Roe solver, a pressure correction 0.5 g (h^2 - h_rec^2) (cn, sn) is added per
 // side, and the source term drops the bed slope (CreatePetscSWESourceHROperator, 1229-1263).
-template <int S, int SRC, bool OVW, bool HR>
+//
+// EULER = the forward-Euler update fused into the store phase (what TSEULER's VecAXPY does after the RHS,
+// rdyhip_euler_step): the owned rows of a second state array receive u + dt F, F itself is stored only if f != nullptr.
+template <int S, int SRC, bool OVW, bool HR, bool EULER = false>
 __global__ __launch_bounds__(TILE) void swe_rhs_tiled_kernel(const KernelArgs a, const double dt, const double *__restrict__ u,
                                                               double *__restrict__ f) {
   extern __shared__ double lds[];
@@ -506,6 +527,7 @@ __global__ __launch_bounds__(TILE) void swe_rhs_tiled_kernel(const KernelArgs a,
       // ---- phase 2: per-cell sum in the reference's edge order, source terms; the stores come last
       double out[6]      = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};  // F[3], then the primitive variables (h, u, v)
       double acc_fdiv[3] = {0.0, 0.0, 0.0};
+      double own_hu = 0.0, own_hv = 0.0;  // EULER only
       if (active) {
         double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
         if (!OVW) {  // ApplyOperator semantics: add into f (and let the friction term see it)
@@ -552,6 +574,10 @@ __global__ __launch_bounds__(TILE) void swe_rhs_tiled_kernel(const KernelArgs a,
         out[3] = sd_h[tid];
         out[4] = sd_u[tid];
         out[5] = sd_v[tid];
+        if (EULER) {
+          own_hu = sd_hu[tid];
+          own_hv = sd_hv[tid];
+        }
       }
       const bool last = idx1 >= hi;
       // The tile's single wait on global loads: the youngest load of the prefetch batch is "used" here, before
@@ -567,7 +593,17 @@ __global__ __launch_bounds__(TILE) void swe_rhs_tiled_kernel(const KernelArgs a,
       lr0 = nlr0; lr1 = nlr1; cs0 = ncs0; cs1 = ncs1;
       cur = nxt;
       __builtin_amdgcn_sched_barrier(0);
-      if (active) cell_store(a, o, acc_fdiv, out, f);
+      if (active) {
+        if (!EULER) {
+          cell_store(a, o, acc_fdiv, out, f);
+        } else {
+          const int64_t c = a.o2l ? a.o2l[o] : o;
+          a.u_out[3 * c + 0] = out[3] + dt * out[0];
+          a.u_out[3 * c + 1] = own_hu + dt * out[1];
+          a.u_out[3 * c + 2] = own_hv + dt * out[2];
+          cell_store_opt_f(a, o, acc_fdiv, out, f);
+        }
+      }
       if (last) break;
     }
   }
@@ -776,6 +812,18 @@ __global__ void axpy_owned_kernel(int n_owned, const int32_t *__restrict__ o2l, 
   } else {
     u[i] += dt * f[i];
   }
+}
+// u_out[owned cell o] = u_in[o] + dt * f[o]  (fallback of rdyhip_euler_step for the kernels without the fused update)
+__global__ void euler_out_kernel(int n_owned, const int32_t *__restrict__ o2l, double dt, const double *__restrict__ f, const double *__restrict__ u_in,
+                                 double *__restrict__ u_out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 3 * n_owned) return;
+  int64_t j = i;
+  if (o2l) {
+    const int o = i / 3, comp = i - 3 * o;
+    j           = 3 * (int64_t)o2l[o] + comp;
+  }
+  u_out[j] = u_in[j] + dt * f[i];
 }
 __global__ void scatter_component_kernel(int n, const int32_t *__restrict__ ids, const double *__restrict__ vals, double *__restrict__ dst, int ncomp,
                                          int comp) {

@@ -162,6 +162,23 @@ class HaloExchange:
         elif self.recv_ids_all.numel():
             rows[self.recv_ids_all.long()] = recv_all
 
+    # -- one forward-Euler step with the exchange hidden the same way -------
+    def step_overlapped(self, op, dt: float, u_local: torch.Tensor, u_out: torch.Tensor):
+        """u_out[owned] = u_local[owned] + dt RHS(u_local) (Operator.euler_step) with the ghost update of u_local
+        overlapped; the ghost rows of u_out are filled by the next call's exchange."""
+        if self.world == 1:
+            op.euler_step(dt, u_local, u_out)
+            return
+        if op.config.second_order:
+            raise NotImplementedError("second order: use rhs_overlapped + axpy_owned")
+        main = torch.cuda.current_stream(self.device)
+        self.comm_stream.wait_stream(main)
+        with torch.cuda.stream(self.comm_stream):
+            self.exchange(u_local)
+        op.euler_step(dt, u_local, u_out, phase=1, reset_diagnostics=True)
+        main.wait_stream(self.comm_stream)
+        op.euler_step(dt, u_local, u_out, phase=2, reset_diagnostics=False)
+
     def _fused(self, op) -> bool:
         if not hasattr(op, "_second_order_fused"):
             op._second_order_fused = bool(op.layout_info()["second_order_fused"])

@@ -170,6 +170,21 @@ class Operator:
         _lib.check(_lib.load().rdyhip_apply_phase(self._h, int(phase), flags, float(dt), _ptr(u_local),
                                                  _ptr(f_global), _stream()))
 
+    # -- TSStep_Euler fused with the RHS: u_out[owned] = u_local[owned] + dt * RHS(u_local) ----------------
+    def euler_step(self, dt: float, u_local: torch.Tensor, u_out: torch.Tensor, f_global: Optional[torch.Tensor] = None,
+                   phase: int = PHASE_ALL, reset_diagnostics: bool = True, gradients_ready: bool = False):
+        """One forward-Euler step without a separate axpy pass (rdyhip_euler_step).  Not in place; the ghost rows
+        of u_out are the next halo update's.  f_global=None: F is not stored at all where the kernel allows it."""
+        n = self.mesh.num_cells
+        for name, t in (("u_local", u_local), ("u_out", u_out)):
+            if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float64 and t.is_contiguous() and t.numel() == 3 * n):
+                raise RDyHipError(83, f"{name} must be a contiguous float64 device tensor of {n} cells x 3")
+        if f_global is not None:
+            self._check_vecs(u_local, f_global)
+        flags = (2 if reset_diagnostics else 0) | (4 if gradients_ready else 0)
+        _lib.check(_lib.load().rdyhip_euler_step(self._h, int(phase), flags, float(dt), _ptr(u_local), _ptr(u_out),
+                                                 _ptr(f_global) if f_global is not None else None, _stream()))
+
     # -- second order: ComputeLeastSquaresGradients for the owned cells (src/operator_fluxes_ceed.c:998-1042)
     def compute_gradients(self, u_local: torch.Tensor, phase: int = PHASE_ALL):
         _lib.check(_lib.load().rdyhip_compute_gradients(self._h, int(phase), _ptr(u_local), _stream()))

@@ -3,7 +3,10 @@ section 8.f row 1): what PETSc's TSEULER and RDyAdvance do between RHS
 evaluations, with the state kept on the GPU.
 
   * forward Euler: F = RHS(t, U); U += dt F   (TSStep_Euler's VecAXPY; the RHS is
-    OperatorRHSFunction, src/rdysetup.c:1120-1172)
+    OperatorRHSFunction, src/rdysetup.c:1120-1172).  `fused=True` (default) does both in
+    one pass over the mesh (rdyhip_euler_step: the update rides on the RHS kernel's
+    stores, F is never written, two state arrays ping-pong); `fused=False` keeps the
+    RHS + axpy pair.
   * RDyAdvance (src/rdyadvance.c:261-383): advance to the next coupling time
     with the last step shortened to land on it (TS_EXACTFINALTIME_MATCHSTEP),
     and, when adaptive time stepping is on, rescale dt from the previous
@@ -27,8 +30,10 @@ class AdaptiveTime:
 
 
 class EulerStepper:
-    def __init__(self, op, halo=None, adaptive: Optional[AdaptiveTime] = None):
+    def __init__(self, op, halo=None, adaptive: Optional[AdaptiveTime] = None, fused: bool = True):
         self.op = op
+        self.fused = fused and not op.config.second_order   # the second-order path steps with RHS + axpy
+        self._u2 = None
         self.halo = halo
         self.adaptive = adaptive
         self.time = 0.0
@@ -57,12 +62,25 @@ class EulerStepper:
                 dt *= a.target_courant_number / self.max_courant
         t_end = self.time + interval
         self.op.reset_diagnostics()
+        cur = u_local
+        if self.fused and (self._u2 is None or self._u2.shape != u_local.shape):
+            self._u2 = torch.empty_like(u_local)
         while self.time < t_end * (1.0 - 1e-14):
             h = min(dt, t_end - self.time)       # TS_EXACTFINALTIME_MATCHSTEP
-            self.rhs(h, u_local, self._f)
-            self.op.axpy_owned(h, self._f, u_local)
+            if self.fused:
+                nxt = self._u2 if cur is u_local else u_local
+                if self.halo is not None and self.halo.world > 1:
+                    self.halo.step_overlapped(self.op, h, cur, nxt)
+                else:
+                    self.op.euler_step(h, cur, nxt)   # resets the Courant diagnostic like every RHS (src/rdysetup.c:1136)
+                cur = nxt
+            else:
+                self.rhs(h, u_local, self._f)
+                self.op.axpy_owned(h, self._f, u_local)
             self.time += h
             self.step += 1
+        if cur is not u_local:
+            u_local.copy_(cur)                   # an odd number of steps ended in the second buffer
         if a is not None:
             # UpdateOperatorDiagnostics: local 16-byte copy + the MPI_Allreduce(max) of src/operator.c:879
             self.op.update_diagnostics()

@@ -162,7 +162,8 @@ def test_full_size_properties(nx, ny):
     assert np.array_equal(f.cpu().numpy(), f1)
 
 
-def test_adaptive_euler_advance_matches_oracle_loop():
+@pytest.mark.parametrize("fused", [True, False])
+def test_adaptive_euler_advance_matches_oracle_loop(fused):
     """RDyAdvance with adaptive dt (src/rdyadvance.c:303-343) on ex2b: the
     device-resident stepper against the same rules driven by the oracle."""
     torch = _torch()
@@ -171,7 +172,7 @@ def test_adaptive_euler_advance_matches_oracle_loop():
     op = CS.create_operator(case)
     orc = oracle_from_case(case)
     ad = AdaptiveTime(target_courant_number=0.4, max_increase_factor=1.5)
-    st = EulerStepper(op, adaptive=ad)
+    st = EulerStepper(op, adaptive=ad, fused=fused)
     u = torch.tensor(case.u_local, dtype=torch.float64, device="cuda")
     uc = case.u_local.copy()
     dt_g = dt_c = 0.002
@@ -196,3 +197,54 @@ def test_adaptive_euler_advance_matches_oracle_loop():
     torch.cuda.synchronize()
     assert st.step > 100 and abs(st.time - 12 * interval) < 1e-9
     assert rel_linf(u.cpu().numpy(), uc) <= 1e-9
+
+
+@pytest.mark.parametrize("variant", ["first", "hr", "second"])
+def test_fused_euler_step_equals_rhs_plus_axpy(variant, rdyhip_kernel):
+    """rdyhip_euler_step (update fused into the RHS kernel's stores, or the fallback pair) against
+    rdyhip_rhs_function + rdyhip_axpy_owned, on one rank of a partition (ghost cells, phased) and with F
+    requested or not."""
+    if rdyhip_kernel == "cell" and variant != "first":
+        pytest.skip("tiled kernels only")
+    torch = _torch()
+    nxg, ny = 24, 10
+    K = 2 * np.pi / 15
+    xyz, conn, cqi, _ = M.structured_tri_connectivity(nxg, ny)
+    xyz[:, 2] = CS.mms_bathymetry(K=K)(xyz[:, 0], xyz[:, 1])
+    owned = (cqi >= 8) & (cqi < 16) if variant != "second" else np.ones(conn.shape[0], dtype=bool)
+    mesh = M.extract_local_mesh(xyz, conn, owned, boundary_classifier=M.box_side_boundaries(0, nxg, 0, ny), ghosts="interleaved",
+                                project_2d=(variant == "hr"))
+    case = CS.friction_slope_case(mesh, nxg, ny, dt=1e-2, K=K)
+    case.config.well_balancing = 2 if variant == "hr" else 0
+    case.config.second_order = variant == "second"
+    op = CS.create_operator(case)
+    u = torch.tensor(case.u_local, dtype=torch.float64, device="cuda")
+    f = torch.empty((mesh.num_owned_cells, 3), dtype=torch.float64, device="cuda")
+    op.rhs_function(case.dt, u, f)
+    ref = u.clone()
+    op.axpy_owned(case.dt, f, ref)
+    op.update_diagnostics()
+    c_ref = op.get_diagnostics().max_courant_num
+    pv_ref = op.primitive_variables.clone()
+    ghost = torch.as_tensor(mesh.cell_is_owned == 0, device="cuda")
+    for with_f in (False, True):
+        out = torch.full_like(u, -7.0)
+        f2 = torch.full_like(f, 3.0) if with_f else None
+        op.primitive_variables.zero_()
+        if variant == "second":
+            op.euler_step(case.dt, u, out, f2)
+        else:
+            op.reset_boundary_fluxes_accum()
+            op.euler_step(case.dt, u, out, f2, phase=1)
+            op.euler_step(case.dt, u, out, f2, phase=2, reset_diagnostics=False)
+        torch.cuda.synchronize()
+        assert torch.all(out[ghost] == -7.0)                               # ghost rows are the next exchange's
+        assert torch.allclose(out[~ghost], ref[~ghost], rtol=0, atol=1e-14)
+        assert torch.equal(op.primitive_variables, pv_ref)
+        if with_f:
+            assert torch.equal(f2, f)
+        op.update_diagnostics()
+        assert op.get_diagnostics().max_courant_num == c_ref
+    from rdycore_amd.operator import RDyHipError
+    with pytest.raises(RDyHipError):
+        op.euler_step(case.dt, u, u)                                       # not in place
