@@ -30,8 +30,10 @@ class AdaptiveTime:
 
 
 class EulerStepper:
-    def __init__(self, op, halo=None, adaptive: Optional[AdaptiveTime] = None, fused: bool = True):
+    def __init__(self, op, halo=None, adaptive: Optional[AdaptiveTime] = None, fused: bool = True, forcing=None):
         self.op = op
+        self.forcing = forcing   # rdycore_amd.forcing.Forcing: applied at the start of every interval, as the
+                                 # driver calls RDyApplyForcing before each RDyAdvance (driver/main.c time loop)
         self.fused = fused and not op.config.second_order   # the second-order path steps with RHS + axpy
         self._u2 = None
         self.halo = halo
@@ -61,6 +63,8 @@ class EulerStepper:
             else:
                 dt *= a.target_courant_number / self.max_courant
         t_end = self.time + interval
+        if self.forcing is not None:
+            self.forcing.apply(self.time)
         self.op.reset_diagnostics()
         cur = u_local
         if self.fused and (self._u2 is None or self._u2.shape != u_local.shape):

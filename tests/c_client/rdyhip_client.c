@@ -124,9 +124,42 @@ int main(int argc, char **argv) {
     sp = fmax(sp, fabs(pv_exp[i]));
   }
   printf("cells %d  rhs_linf %.3e  pv_linf %.3e  courant %.15g (expected %.15g)\n", no, ef / sf, ep / sp, cd.max_courant_num, courant_exp);
+
+  /* the whole forward-Euler step in one call: u2[owned] = u[owned] + dt F, F not requested */
+  double ee = 0.0;
+  if (hdr[6]) {
+    double *d_u2 = NULL, *u2 = malloc(sizeof(double) * 3 * (size_t)nc);
+    HIPCHECK(hipMalloc((void **)&d_u2, sizeof(double) * 3 * (size_t)nc));
+    HIPCHECK(hipMemset(d_u2, 0, sizeof(double) * 3 * (size_t)nc));
+    CHECK(rdyhip_euler_step(op, RDYHIP_PHASE_ALL, RDYHIP_PHASE_RESET_DIAGNOSTICS, scal[3], d_u, d_u2, NULL, st));
+    HIPCHECK(hipStreamSynchronize(st));
+    HIPCHECK(hipMemcpy(u2, d_u2, sizeof(double) * 3 * (size_t)nc, hipMemcpyDeviceToHost));
+    for (int32_t c = 0; c < nc; ++c) {
+      if (!((const int32_t *)m.cell_is_owned)[c]) continue;
+      const int32_t o = ((const int32_t *)m.cell_local_to_owned)[c];
+      for (int k = 0; k < 3; ++k) ee = fmax(ee, fabs(u2[3 * c + k] - (u[3 * c + k] + scal[3] * f_exp[3 * o + k])));
+    }
+    printf("euler_step linf %.3e\n", ee / sf);
+    ee /= sf;
+    HIPCHECK(hipFree(d_u2));
+    free(u2);
+  }
+  /* forcing ingestion on the device: a constant water source over the whole domain */
+  CHECK(rdyhip_forcing_fill_source(op, 0, no, NULL, 2.5e-6, st));
+  HIPCHECK(hipStreamSynchronize(st));
+  double *d_src = NULL, *src_out = malloc(sizeof(double) * 3 * (size_t)no);
+  int64_t nsrc  = 0;
+  CHECK(rdyhip_field_ptr(op, RDYHIP_FIELD_EXTERNAL_SOURCES, &d_src, &nsrc));
+  HIPCHECK(hipMemcpy(src_out, d_src, sizeof(double) * (size_t)nsrc, hipMemcpyDeviceToHost));
+  int src_ok = nsrc == 3 * (int64_t)no;
+  for (int32_t o = 0; o < no && src_ok; ++o)
+    src_ok = src_out[3 * o] == 2.5e-6 && src_out[3 * o + 1] == extsrc[(size_t)no + o] && src_out[3 * o + 2] == extsrc[2 * (size_t)no + o];
+  printf("forcing_fill_source %s\n", src_ok ? "ok" : "MISMATCH");
+  free(src_out);
   CHECK(rdyhip_destroy(&op));
   HIPCHECK(hipFree(d_u));
   HIPCHECK(hipFree(d_f));
-  const int ok = ef / sf <= 1e-10 && ep / sp <= 1e-10 && fabs(cd.max_courant_num - courant_exp) <= 1e-12 * fmax(1.0, courant_exp);
+  const int ok = ef / sf <= 1e-10 && ep / sp <= 1e-10 && ee <= 1e-10 && src_ok &&
+                 fabs(cd.max_courant_num - courant_exp) <= 1e-12 * fmax(1.0, courant_exp);
   return ok ? 0 : 5;
 }

@@ -168,3 +168,37 @@ def test_forcing_argument_errors():
     assert L.rdyhip_forcing_fill_boundary(op._h, 99, 1, 1.0, None) == 83
     assert L.rdyhip_forcing_fill_boundary(op._h, 0, mesh.boundaries[0].num_edges + 1, 1.0, None) == 83
     assert L.rdyhip_forcing_gather_source(op._h, 0, 4, None, None, None, 1, 0, 1.0, None) == 83
+
+
+def test_time_stepping_with_forcing_matches_the_oracle_loop():
+    """the driver's loop -- RDyApplyForcing, then RDyAdvance over one coupling interval -- on the device
+    (EulerStepper with a Forcing, fused Euler steps) against the same loop on the oracle"""
+    torch = _torch()
+    from rdycore_amd.timestep import EulerStepper
+    nx, ny = 16, 10
+    mesh = M.structured_tri_mesh(nx, ny, 1.0, zfunc=CS.mms_bathymetry(K=2 * np.pi / 20))
+    case = CS.friction_slope_case(mesh, nx, ny, dt=5e-3, K=2 * np.pi / 20, dry_disc=False)
+    op = CS.create_operator(case)
+    orc = oracle_from_case(case)
+    rain = np.array([[0.0, 0.0], [0.05, 4e-3], [0.1, 1e-3], [0.2, 0.0]])
+    stage = np.array([[0.0, 1.0], [0.1, 1.3]])
+    dirichlet = [b for b, t in enumerate(case.condition_types) if t == CONDITION_DIRICHLET][0]
+    frc = F.Forcing(op)
+    frc.add_homogeneous_source(None, F.HomogeneousDataset(rain, temporally_interpolate=True))
+    frc.add_homogeneous_boundary(dirichlet, F.HomogeneousDataset(stage, temporally_interpolate=False))
+    st = EulerStepper(op, forcing=frc)
+    u = torch.tensor(case.u_local, dtype=torch.float64, device="cuda")
+    uc = case.u_local.copy()
+    t, interval = 0.0, 0.025
+    for _ in range(9):
+        st.advance(u, case.dt, interval)
+        orc.external_sources[:, 0] = O.forcing_current_data(rain, t, True)[1]
+        orc.boundary_values[dirichlet][:] = [O.forcing_current_data(stage, t, False)[1], 0.0, 0.0]
+        t_end = t + interval
+        while t < t_end * (1.0 - 1e-14):
+            h = min(case.dt, t_end - t)
+            uc = uc + h * orc.apply(h, uc)
+            t += h
+    torch.cuda.synchronize()
+    assert st.step == 45
+    assert rel_linf(u.cpu().numpy(), uc) <= 1e-10
