@@ -29,6 +29,26 @@
 
 namespace rdyhip {
 
+// non-temporal hints for the fused kernel's streamed-once data (see swe_kernels.h); -DRDYHIP_MUSCL_NO_NT: off
+#ifndef RDYHIP_MUSCL_NO_NT
+#define RDY_MLD(ptr) __builtin_nontemporal_load(ptr)
+#define RDY_MST(ptr, val) __builtin_nontemporal_store((val), (ptr))
+#else
+#define RDY_MLD(ptr) (*(ptr))
+#define RDY_MST(ptr, val) (*(ptr) = (val))
+#endif
+
+typedef double   rdy_d2v __attribute__((ext_vector_type(2)));
+typedef uint32_t rdy_u2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double2 load_d2(const double *p) {  // 16-byte aligned pair
+  const rdy_d2v v = RDY_MLD(reinterpret_cast<const rdy_d2v *>(p));
+  return make_double2(v.x, v.y);
+}
+__device__ __forceinline__ uint2 load_u2(const void *p) {
+  const rdy_u2v v = RDY_MLD(reinterpret_cast<const rdy_u2v *>(p));
+  return make_uint2(v.x, v.y);
+}
+
 struct MusclArgs {
   double       *grad;   // [num_cells][6]: dh/dx, dh/dy, dhu/dx, dhu/dy, dhv/dx, dhv/dy (local cell index)
   const double *e_geo;  // [nrec][4]: edge midpoint minus left centroid (x, y), minus right centroid (x, y)
@@ -360,7 +380,7 @@ __global__ __launch_bounds__(TILE) void swe_rhs_muscl_fused_kernel(const KernelA
 #pragma unroll
       for (int k = 0; k < 3; ++k) q[k] = u[3 * (int64_t)c + k];
       if (S == 3) {
-        r0 = reinterpret_cast<const uint32_t *>(a.slot_ref)[o];
+        r0 = RDY_MLD(&reinterpret_cast<const uint32_t *>(a.slot_ref)[o]);
       } else {
         const uint2 w = reinterpret_cast<const uint2 *>(a.slot_ref)[o];
         r0            = w.x;
@@ -368,16 +388,16 @@ __global__ __launch_bounds__(TILE) void swe_rhs_muscl_fused_kernel(const KernelA
       }
 #pragma unroll
       for (int s = 0; s < S; ++s) {
-        gx[s] = g.gcx[s * a.stride + o];
-        gy[s] = g.gcy[s * a.stride + o];
-        kf[s] = a.coef[s * a.stride + o];
+        gx[s] = RDY_MLD(&g.gcx[s * a.stride + o]);
+        gy[s] = RDY_MLD(&g.gcy[s * a.stride + o]);
+        kf[s] = RDY_MLD(&a.coef[s * a.stride + o]);
       }
-      dzx  = a.dzdx[o];
-      dzy  = a.dzdy[o];
-      nman = a.mannings[o];
-      s0   = a.extsrc[3 * (int64_t)o + 0];
-      s1   = a.extsrc[3 * (int64_t)o + 1];
-      s2   = a.extsrc[3 * (int64_t)o + 2];
+      dzx  = RDY_MLD(&a.dzdx[o]);
+      dzy  = RDY_MLD(&a.dzdy[o]);
+      nman = RDY_MLD(&a.mannings[o]);
+      s0   = RDY_MLD(&a.extsrc[3 * (int64_t)o + 0]);
+      s1   = RDY_MLD(&a.extsrc[3 * (int64_t)o + 1]);
+      s2   = RDY_MLD(&a.extsrc[3 * (int64_t)o + 2]);
     }
     if (hid >= 0) {
 #pragma unroll
@@ -389,26 +409,26 @@ __global__ __launch_bounds__(TILE) void swe_rhs_muscl_fused_kernel(const KernelA
     for (int s = 0; s < 2 * S; ++s) bc[s] = 0.0;
     if (tid < nh) {
       const int64_t entry = (int64_t)td.h_off + tid;
-      bw                  = reinterpret_cast<const uint2 *>(g.bn_idx)[entry];
+      bw                  = load_u2(g.bn_idx + 4 * entry);
 #pragma unroll
-      for (int s = 0; s < 2 * S; ++s) bc[s] = g.bn_c[entry * (2 * S) + s];
+      for (int s = 0; s < 2 * S; ++s) bc[s] = RDY_MLD(&g.bn_c[entry * (2 * S) + s]);
     }
     uint32_t lr0 = 0, lr1 = 0;
     double   cs0 = 0.0, cs1 = 0.0;
     double2  gl0 = make_double2(0.0, 0.0), gr0 = gl0, gl1 = gl0, gr1 = gl0;
     if (tid < ne) {
-      lr0 = a.e_lr[td.e_off + tid];
-      cs0 = a.e_cs[td.e_off + tid];
-      const double2 *geo = reinterpret_cast<const double2 *>(g.e_geo + 4 * ((int64_t)td.e_off + tid));
-      gl0 = geo[0];
-      gr0 = geo[1];
+      lr0 = RDY_MLD(&a.e_lr[td.e_off + tid]);
+      cs0 = RDY_MLD(&a.e_cs[td.e_off + tid]);
+      const double *geo = g.e_geo + 4 * ((int64_t)td.e_off + tid);
+      gl0 = load_d2(geo);
+      gr0 = load_d2(geo + 2);
     }
     if (tid + TILE < ne) {
-      lr1 = a.e_lr[td.e_off + TILE + tid];
-      cs1 = a.e_cs[td.e_off + TILE + tid];
-      const double2 *geo = reinterpret_cast<const double2 *>(g.e_geo + 4 * ((int64_t)td.e_off + TILE + tid));
-      gl1 = geo[0];
-      gr1 = geo[1];
+      lr1 = RDY_MLD(&a.e_lr[td.e_off + TILE + tid]);
+      cs1 = RDY_MLD(&a.e_cs[td.e_off + TILE + tid]);
+      const double *geo = g.e_geo + 4 * ((int64_t)td.e_off + TILE + tid);
+      gl1 = load_d2(geo);
+      gr1 = load_d2(geo + 2);
     }
     // the ring-cell id of the tile this workgroup takes next
     pre_tile = -1;
@@ -507,7 +527,19 @@ __global__ __launch_bounds__(TILE) void swe_rhs_muscl_fused_kernel(const KernelA
       }
       muscl_cell_sum<S>(r0, r1, kf, ef0, ef1, ef2, eam, dt, o, acc0, acc1, acc2, best, best_slot, best_o);
       const RiemannSide self = riemann_side(q[0], q[1], q[2], a.tiny_h, a.h_anuga_sq);
-      cell_epilogue<SRC>(a, o, dt, q[0], q[1], q[2], self.u, self.v, acc0, acc1, acc2, dzx, dzy, nman, s0, s1, s2, f);
+      double            res[3];
+      cell_results<SRC>(a, dt, q[0], q[1], q[2], acc0, acc1, acc2, dzx, dzy, nman, s0, s1, s2, res);
+      if (a.fdiv) {
+        RDY_MST(&a.fdiv[3 * (int64_t)o + 0], acc0);
+        RDY_MST(&a.fdiv[3 * (int64_t)o + 1], acc1);
+        RDY_MST(&a.fdiv[3 * (int64_t)o + 2], acc2);
+      }
+      RDY_MST(&f[3 * (int64_t)o + 0], res[0]);
+      RDY_MST(&f[3 * (int64_t)o + 1], res[1]);
+      RDY_MST(&f[3 * (int64_t)o + 2], res[2]);
+      RDY_MST(&a.pv[3 * (int64_t)o + 0], q[0]);
+      RDY_MST(&a.pv[3 * (int64_t)o + 1], self.u);
+      RDY_MST(&a.pv[3 * (int64_t)o + 2], self.v);
     }
     __syncthreads();  // the LDS planes are rewritten by the next tile
   }
