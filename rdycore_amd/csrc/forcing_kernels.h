@@ -33,14 +33,14 @@ __global__ void forcing_gather_kernel(int n, const int32_t *__restrict__ ids, co
 
 // RDyForcingSetHomogeneousBoundary (rdyforcing_dataset.c:380-406): bvalues[e] = [h, 0, 0]
 __global__ void forcing_fill_boundary_kernel(int n, double h, double *__restrict__ bvalues) {
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 3 * n; i += gridDim.x * blockDim.x) bvalues[i] = (i % 3 == 0) ? h : 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < 3 * (int64_t)n; i += (int64_t)gridDim.x * blockDim.x) bvalues[i] = (i % 3 == 0) ? h : 0.0;
 }
 
 // RDyForcingSetUnstructuredData on a boundary dataset (stride 3): bvalues[e][c] = data[map[e] * stride + c + offset]
 __global__ void forcing_gather_boundary_kernel(int n, const double *__restrict__ data, const int32_t *__restrict__ map, int64_t stride,
                                                int64_t offset, double *__restrict__ bvalues) {
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 3 * n; i += gridDim.x * blockDim.x) {
-    const int e = i / 3, c = i - 3 * e;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < 3 * (int64_t)n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int e = (int)(i / 3), c = (int)(i - 3 * (int64_t)e);
     bvalues[i]  = data[(int64_t)map[e] * stride + c + offset];
   }
 }

@@ -390,8 +390,8 @@ int launch_rhs(RDyHipOperator op, int32_t phase, int32_t overwrite, int reset_di
   }
   if (u_out && !euler_fused && phase != RDYHIP_PHASE_INTERIOR) {
     // F is complete once the halo (or the only) phase has run
-    const int n3 = 3 * op->n_owned;
-    hipLaunchKernelGGL(euler_out_kernel, dim3((n3 + 255) / 256), dim3(256), 0, st, op->n_owned, op->prefix ? nullptr : op->d_o2l.p, dt, f, u, u_out);
+    const int64_t n3 = 3 * (int64_t)op->n_owned;
+    hipLaunchKernelGGL(euler_out_kernel, dim3((unsigned)((n3 + 255) / 256)), dim3(256), 0, st, op->n_owned, op->prefix ? nullptr : op->d_o2l.p, dt, f, u, u_out);
     HIP_TRY(hipGetLastError());
   }
   return 0;
@@ -1225,7 +1225,7 @@ int rdyhip_pack_cells(const double *u_local, const int32_t *cell_ids, int32_t n,
   if (n < 0) return fail(RDYHIP_ERR_ARG_SIZ, "negative count");
   if (n == 0) return 0;
   if (!u_local || !cell_ids || !buf) return fail(RDYHIP_ERR_USER, "null argument");
-  hipLaunchKernelGGL(pack_cells_kernel, dim3((3 * n + 255) / 256), dim3(256), 0, (hipStream_t)stream, n, u_local, cell_ids, buf);
+  hipLaunchKernelGGL(pack_cells_kernel, dim3((unsigned)((3 * (int64_t)n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n, u_local, cell_ids, buf);
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -1234,7 +1234,7 @@ int rdyhip_unpack_cells(double *u_local, const int32_t *cell_ids, int32_t n, con
   if (n < 0) return fail(RDYHIP_ERR_ARG_SIZ, "negative count");
   if (n == 0) return 0;
   if (!u_local || !cell_ids || !buf) return fail(RDYHIP_ERR_USER, "null argument");
-  hipLaunchKernelGGL(unpack_cells_kernel, dim3((3 * n + 255) / 256), dim3(256), 0, (hipStream_t)stream, n, u_local, cell_ids, buf);
+  hipLaunchKernelGGL(unpack_cells_kernel, dim3((unsigned)((3 * (int64_t)n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n, u_local, cell_ids, buf);
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -1266,8 +1266,8 @@ int rdyhip_compute_gradients(RDyHipOperator op, int32_t phase, const double *u_l
 int rdyhip_axpy_owned(RDyHipOperator op, double dt, const double *f_global, double *u_local, void *stream) {
   if (!op || !f_global || !u_local) return fail(RDYHIP_ERR_USER, "null argument");
   if (op->n_owned == 0) return 0;
-  const int n3 = 3 * op->n_owned;
-  hipLaunchKernelGGL(axpy_owned_kernel, dim3((n3 + 255) / 256), dim3(256), 0, (hipStream_t)stream, op->n_owned, op->prefix ? nullptr : op->d_o2l.p, dt,
+  const int64_t n3 = 3 * (int64_t)op->n_owned;
+  hipLaunchKernelGGL(axpy_owned_kernel, dim3((unsigned)((n3 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, op->n_owned, op->prefix ? nullptr : op->d_o2l.p, dt,
                      f_global, u_local);
   HIP_TRY(hipGetLastError());
   return 0;

@@ -793,15 +793,15 @@ __global__ void boundary_ghost_kernel(int n, const int32_t *__restrict__ klist, 
 }
 
 __global__ void pack_cells_kernel(int n, const double *__restrict__ u, const int32_t *__restrict__ ids, double *__restrict__ buf) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= 3 * n) return;
-  const int cell = i / 3, comp = i - 3 * cell;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 3 * (int64_t)n) return;
+  const int cell = (int)(i / 3), comp = (int)(i - 3 * (int64_t)cell);
   buf[i]         = u[3 * (int64_t)ids[cell] + comp];
 }
 __global__ void unpack_cells_kernel(int n, double *__restrict__ u, const int32_t *__restrict__ ids, const double *__restrict__ buf) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= 3 * n) return;
-  const int cell = i / 3, comp = i - 3 * cell;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 3 * (int64_t)n) return;
+  const int cell = (int)(i / 3), comp = (int)(i - 3 * (int64_t)cell);
   u[3 * (int64_t)ids[cell] + comp] = buf[i];
 }
 __global__ void pack_rows_kernel(int n, int ncomp, const double *__restrict__ src, const int32_t *__restrict__ ids, double *__restrict__ buf) {
@@ -817,10 +817,10 @@ __global__ void unpack_rows_kernel(int n, int ncomp, double *__restrict__ dst, c
   dst[(int64_t)ids[row] * ncomp + comp] = buf[i];
 }
 __global__ void axpy_owned_kernel(int n_owned, const int32_t *__restrict__ o2l, double dt, const double *__restrict__ f, double *__restrict__ u) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= 3 * n_owned) return;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 3 * (int64_t)n_owned) return;
   if (o2l) {
-    const int o = i / 3, comp = i - 3 * o;
+    const int o = (int)(i / 3), comp = (int)(i - 3 * (int64_t)o);
     u[3 * (int64_t)o2l[o] + comp] += dt * f[i];
   } else {
     u[i] += dt * f[i];
@@ -829,11 +829,11 @@ __global__ void axpy_owned_kernel(int n_owned, const int32_t *__restrict__ o2l, 
 // u_out[owned cell o] = u_in[o] + dt * f[o]  (fallback of rdyhip_euler_step for the kernels without the fused update)
 __global__ void euler_out_kernel(int n_owned, const int32_t *__restrict__ o2l, double dt, const double *__restrict__ f, const double *__restrict__ u_in,
                                  double *__restrict__ u_out) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= 3 * n_owned) return;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 3 * (int64_t)n_owned) return;
   int64_t j = i;
   if (o2l) {
-    const int o = i / 3, comp = i - 3 * o;
+    const int o = (int)(i / 3), comp = (int)(i - 3 * (int64_t)o);
     j           = 3 * (int64_t)o2l[o] + comp;
   }
   u_out[j] = u_in[j] + dt * f[i];
