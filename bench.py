@@ -41,7 +41,8 @@ def parse():
     p.add_argument("--warmup", type=int, default=20)
     p.add_argument("--nx", type=int, default=2500, help="squares per rank along x")
     p.add_argument("--ny", type=int, default=2000, help="squares along y")
-    p.add_argument("--order", default="tiled", choices=["rowmajor", "tiled"], help="cell numbering of the synthetic mesh")
+    p.add_argument("--order", default="tiled", choices=["rowmajor", "tiled", "hilbert"],
+                   help="cell numbering of the synthetic mesh: generator order, 16x16-square blocks, or squares along a Hilbert curve")
     p.add_argument("--source", default="semi_implicit", choices=["semi_implicit", "implicit_xq2018"])
     p.add_argument("--workload", default="c3", choices=["c3", "c2"],
                    help="c3: friction + bed slope + all BC types (default; use --nx 2500 --ny 2000); "

@@ -384,6 +384,10 @@ def structured_tri_connectivity(nx: int, ny: int, d: float = 1.0, i0: int = 0,
         perm = np.argsort(key, kind="stable")
         qi = qi[perm]
         qj = qj[perm]
+    elif order == "hilbert":   # squares along a Hilbert curve (the two triangles of a square stay together)
+        perm = hilbert_cell_order(np.stack([qi + 0.5, qj + 0.5], axis=1))
+        qi = qi[perm]
+        qj = qj[perm]
     elif order != "rowmajor":
         raise ValueError(order)
     v00 = vid(qi, qj)
@@ -429,6 +433,35 @@ def structured_quad_mesh(nx: int, ny: int, dx: float = 1.0, dy: float = 1.0,
     conn = np.stack([v(qi, qj), v(qi + 1, qj), v(qi + 1, qj + 1), v(qi, qj + 1)], 1).astype(np.int32)
     cls = box_side_boundaries(0.0, nx * dx, 0.0, ny * dy) if boundaries == "sides" else single_boundary()
     return build_mesh(xyz, conn, boundary_classifier=cls, project_2d=project_2d)
+
+
+def hilbert_cell_order(centroids: np.ndarray) -> np.ndarray:
+    """Permutation that sorts cells along a Hilbert curve through their centroids (x, y).
+
+    The operator tiles the owned cells in runs of 256 consecutive cells of the CALLER's numbering
+    (rdycore_amd/csrc/rdyhip_api.hip), so that numbering decides how many edges are cut by tile
+    boundaries.  A mesh in generator / row-major / partitioner order is best renumbered once by its
+    owner before the operator is created (all of its arrays then move together; DESIGN.md section 7
+    has the measurements): `conn = conn[hilbert_cell_order(centroids)]`.
+    """
+    c = np.asarray(centroids, dtype=np.float64)
+    lo = c[:, :2].min(axis=0)
+    ext = max(float((c[:, :2].max(axis=0) - lo).max()), 1e-300)
+    x = np.minimum(65535, ((c[:, 0] - lo[0]) / ext * 65535.0)).astype(np.int64)
+    y = np.minimum(65535, ((c[:, 1] - lo[1]) / ext * 65535.0)).astype(np.int64)
+    d = np.zeros(c.shape[0], dtype=np.int64)
+    s = 32768
+    while s > 0:
+        rx = ((x & s) > 0).astype(np.int64)
+        ry = ((y & s) > 0).astype(np.int64)
+        d += s * s * ((3 * rx) ^ ry)
+        flip = (ry == 0) & (rx == 1)
+        x = np.where(flip, 65535 - x, x)
+        y = np.where(flip, 65535 - y, y)
+        swap = ry == 0
+        x, y = np.where(swap, y, x), np.where(swap, x, y)
+        s >>= 1
+    return np.argsort(d, kind="stable")
 
 
 def refine_triangles(xyz: np.ndarray, conn: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:

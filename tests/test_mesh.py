@@ -106,3 +106,17 @@ def test_interleaved_ghost_numbering():
     m = M.extract_local_mesh(xyz, conn, (cqi >= 4) & (cqi < 8), ghosts="interleaved")
     assert not (m.cell_owned_to_local == np.arange(m.num_owned_cells)).all()
     assert sorted(m.cell_local_to_owned.tolist()) == list(range(m.num_cells))
+
+
+def test_hilbert_cell_order_is_a_local_permutation():
+    xyz, conn, _, _ = M.structured_tri_connectivity(64, 48)
+    cent = xyz[conn].mean(axis=1)
+    p = M.hilbert_cell_order(cent)
+    assert sorted(p.tolist()) == list(range(conn.shape[0]))
+    # consecutive cells along the curve are neighbours or nearly so (row-major order jumps a whole row at each row end)
+    step = np.linalg.norm(np.diff(cent[p][:, :2], axis=0), axis=1)
+    assert step.mean() < 1.0 and np.percentile(step, 99) < 3.0
+    # and the generator's "hilbert" order is that permutation applied to the squares
+    m = M.structured_tri_mesh(20, 12, order="hilbert")
+    r = M.structured_tri_mesh(20, 12, order="rowmajor")
+    assert m.num_cells == r.num_cells and np.isclose(m.cell_areas.sum(), r.cell_areas.sum())
