@@ -209,7 +209,10 @@ int rdyhip_apply_phase(RDyHipOperator op, int32_t phase, int32_t flags, double d
  *   rdyhip_apply_phase(op, RDYHIP_PHASE_ALL, flags | RDYHIP_PHASE_GRADIENTS_READY, ...)
  * Every rank then evaluates all edges of its owned cells itself (a cut edge on both ranks, from
  * identical operands), so the reference's reverse DMLocalToGlobal(ADD_VALUES) has no counterpart.
- * PHASE_INTERIOR / PHASE_HALO select owned cells without / with a ghost neighbour, for overlap. */
+ * PHASE_INTERIOR / PHASE_HALO select owned cells without / with a ghost neighbour, for overlap.  With the default
+ * fused kernel (RDyHipLayoutInfo.second_order_fused) the gradients of interior cells never leave the chip: only
+ * rdyhip_compute_gradients(RDYHIP_PHASE_HALO) is needed to feed the exchange, and the INTERIOR tiles of
+ * rdyhip_apply_phase need no data from other ranks at all. */
 int rdyhip_compute_gradients(RDyHipOperator op, int32_t phase, const double *u_local, void *stream);
 
 /* ---- operator data (host-side setters, as in the reference) -----------------
@@ -314,7 +317,7 @@ typedef struct {
   int32_t num_halo_cells;     /* owned cells with a ghost neighbour */
   int32_t tiled_kernel;       /* 1: tiled LDS kernel (default), 0: cell-centric kernel (RDYHIP_KERNEL=cell) */
   int32_t num_tiles;          /* tiles of 256 owned cells */
-  int32_t num_halo_tiles;     /* tiles with a ghost-adjacent cell */
+  int32_t num_halo_tiles;     /* tiles with a ghost-adjacent cell (second order: or a ghost-adjacent first-ring cell) */
   int32_t max_tile_edges;     /* largest edge list of a tile */
   int32_t max_tile_halo_cells; /* largest number of out-of-tile neighbour cells of a tile */
   int64_t num_halo_entries;   /* sum of the tiles' halo-cell lists */
