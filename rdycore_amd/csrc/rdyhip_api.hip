@@ -306,6 +306,8 @@ int launch_rhs(RDyHipOperator op, int32_t phase, int32_t overwrite, int reset_di
   a.fdiv       = op->keep_fdiv ? op->d_fdiv.p : nullptr;
   a.blk_max    = op->d_blk_max.p;
   a.blk_pos    = op->d_blk_pos.p;
+  a.n_buckets  = (int32_t)op->d_blk_max.n;
+  a.reset_diag = reset_diag ? 1 : 0;
   a.tiny_h     = op->config.tiny_h;
   a.h_anuga_sq = op->config.h_anuga_regular * op->config.h_anuga_regular;
   a.xq_thresh  = op->config.xq2018_threshold;
@@ -379,8 +381,6 @@ int launch_rhs(RDyHipOperator op, int32_t phase, int32_t overwrite, int reset_di
       else hipLaunchKernelGGL((swe_rhs_kernel<4, 0>), dim3(grid), dim3(BLOCK), 0, st, a, dt, u, f);
     }
   }
-  HIP_TRY(hipGetLastError());
-  hipLaunchKernelGGL(courant_finalize_kernel, dim3(1), dim3(1024), 0, st, grid, op->d_blk_max.p, op->d_blk_pos.p, op->d_courant.p, reset_diag);
   HIP_TRY(hipGetLastError());
   // boundary edges hanging off ghost cells (diagnostic vectors only); once per full apply
   if (op->n_bghost > 0 && phase != RDYHIP_PHASE_INTERIOR) {
@@ -925,7 +925,7 @@ int rdyhip_create(const RDyHipConfig *config, const RDyHipMesh *mesh, int32_t nu
   TRY_RC(op->d_blk_pos.zeros((size_t)maxgrid));
   TRY_RC(op->d_courant.zeros(1));
 #undef TRY_RC
-  hipLaunchKernelGGL(courant_reset_kernel, dim3(1), dim3(1), 0, 0, op->d_courant.p);
+  hipLaunchKernelGGL(courant_reset_kernel, dim3(4), dim3(1024), 0, 0, (int)op->d_blk_max.n, op->d_blk_max.p, op->d_blk_pos.p);
   if (hipDeviceSynchronize() != hipSuccess) {
     delete op;
     return fail(RDYHIP_ERR_LIB, "device synchronisation failed after create");
@@ -1185,7 +1185,7 @@ int rdyhip_enable_flux_divergence(RDyHipOperator op, int32_t enable) {
 
 int rdyhip_reset_diagnostics(RDyHipOperator op, void *stream) {
   if (!op) return fail(RDYHIP_ERR_USER, "null operator");
-  hipLaunchKernelGGL(courant_reset_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, op->d_courant.p);
+  hipLaunchKernelGGL(courant_reset_kernel, dim3(4), dim3(1024), 0, (hipStream_t)stream, (int)op->d_blk_max.n, op->d_blk_max.p, op->d_blk_pos.p);
   HIP_TRY(hipGetLastError());
   op->courant = RDyHipCourant{0.0, -1, -1};
   return 0;
@@ -1193,6 +1193,10 @@ int rdyhip_reset_diagnostics(RDyHipOperator op, void *stream) {
 
 int rdyhip_update_diagnostics(RDyHipOperator op, void *stream) {
   if (!op) return fail(RDYHIP_ERR_USER, "null operator");
+  // the RHS launches keep one running (max, first position) bucket per workgroup slot; they are merged only here
+  hipLaunchKernelGGL(courant_finalize_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (int)op->d_blk_max.n, op->d_blk_max.p, op->d_blk_pos.p,
+                     op->d_courant.p);
+  HIP_TRY(hipGetLastError());
   DeviceCourant dc;
   HIP_TRY(hipMemcpyAsync(&dc, op->d_courant.p, sizeof(dc), hipMemcpyDeviceToHost, (hipStream_t)stream));
   HIP_TRY(hipStreamSynchronize((hipStream_t)stream));

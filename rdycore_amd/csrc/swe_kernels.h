@@ -81,8 +81,10 @@ struct KernelArgs {
   double        *pv;         // [n_owned][3]
   double        *fdiv;       // [n_owned][3] or nullptr
   double        *u_out;      // EULER kernels: [num_cells][3] state after the step, owned rows written (u_out = u + dt F)
-  double        *blk_max;    // [grid]
-  int32_t       *blk_pos;    // [grid]
+  double        *blk_max;    // [n_buckets] the Courant diagnostic, one running (max, first position) bucket per workgroup slot;
+  int32_t       *blk_pos;    //             merged by courant_finalize_kernel only when the host asks (rdyhip_update_diagnostics)
+  int32_t        n_buckets;
+  int32_t        reset_diag; // 1: this launch starts a new diagnostic (ResetOperatorDiagnostics): buckets are overwritten
   double         tiny_h, h_anuga_sq, xq_thresh;
   int32_t        phase;      // RDYHIP_PHASE_*
   int32_t        overwrite;  // 1: f = rhs, 0: f += rhs
@@ -219,8 +221,25 @@ __device__ __forceinline__ void block_courant_reduce(const KernelArgs &a, double
     int bp = s_pos[0];
 #pragma unroll
     for (int w = 1; w < NT / 64; ++w) bp = min(bp, s_pos[w]);
-    a.blk_max[blockIdx.x] = bmax;
-    a.blk_pos[blockIdx.x] = (bmax > 0.0) ? bp : -1;
+    double m = bmax;
+    int    q = (bmax > 0.0) ? bp : -1;
+    const int b = blockIdx.x;
+    if (!a.reset_diag) {  // merge into the bucket: larger value, then the earlier edge (swe_petsc.c:291 keeps the first)
+      const double pm = a.blk_max[b];
+      const int    pq = a.blk_pos[b];
+      if (pm > m || (pm == m && pm > 0.0 && pq < q)) {
+        m = pm;
+        q = pq;
+      }
+    }
+    a.blk_max[b] = m;
+    a.blk_pos[b] = q;
+    if (a.reset_diag) {  // buckets no workgroup of this launch owns
+      for (int k = b + gridDim.x; k < a.n_buckets; k += gridDim.x) {
+        a.blk_max[k] = 0.0;
+        a.blk_pos[k] = -1;
+      }
+    }
   }
 }
 
@@ -711,10 +730,9 @@ __global__ __launch_bounds__(BLOCK) void swe_rhs_kernel(const KernelArgs a, cons
   block_courant_reduce<BLOCK>(a, best, best_slot, o);
 }
 
-// merges the per-block partials into the persistent diagnostic (reset != 0:
-// the diagnostic is first reset, ResetOperatorDiagnostics src/operator.c:772-784)
+// merges the per-workgroup buckets into the 16-byte diagnostic the host reads (rdyhip_update_diagnostics)
 __global__ __launch_bounds__(1024) void courant_finalize_kernel(int nblk, const double *__restrict__ blk_max, const int32_t *__restrict__ blk_pos,
-                                                               DeviceCourant *diag, int reset) {
+                                                               DeviceCourant *diag) {
   double m = 0.0;
   int    p = INT32_MAX;
   constexpr int U = 8;  // independent loads in flight per thread
@@ -755,20 +773,17 @@ __global__ __launch_bounds__(1024) void courant_finalize_kernel(int nblk, const 
         bp = s_pos[w];
       }
     }
-    double cur_max = reset ? 0.0 : diag->max_courant;
-    int    cur_pos = reset ? -1 : diag->pos;
-    if (bm > cur_max || (bm == cur_max && bm > 0.0 && bp < cur_pos)) {
-      cur_max = bm;
-      cur_pos = bp;
-    }
-    diag->max_courant = cur_max;
-    diag->pos         = cur_pos;
+    diag->max_courant = bm;
+    diag->pos         = bm > 0.0 ? bp : -1;
   }
 }
 
-__global__ void courant_reset_kernel(DeviceCourant *diag) {
-  diag->max_courant = 0.0;
-  diag->pos         = -1;
+// ResetOperatorDiagnostics (src/operator.c:772-784) on its own: clears every bucket
+__global__ void courant_reset_kernel(int nblk, double *__restrict__ blk_max, int32_t *__restrict__ blk_pos) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nblk; i += gridDim.x * blockDim.x) {
+    blk_max[i] = 0.0;
+    blk_pos[i] = -1;
+  }
 }
 
 // boundary edges whose left cell is a ghost: the reference still evaluates
