@@ -314,7 +314,7 @@ __global__ __launch_bounds__(TILE) void swe_rhs_muscl_kernel(const KernelArgs a,
 // First-ring cells that are ghosts take their gradient from `grad`, filled by the
 // caller's exchange (their stencil is not local).
 // ---------------------------------------------------------------------------
-template <int S, int SRC, bool OVW, int LIM>
+template <int S, int SRC, bool OVW, int LIM, bool EULER = false>
 __global__ __launch_bounds__(TILE) void swe_rhs_muscl_fused_kernel(const KernelArgs a, const MusclArgs g, const double dt, const double *__restrict__ u,
                                                                     double *__restrict__ f) {
   extern __shared__ double lds[];
@@ -534,9 +534,17 @@ __global__ __launch_bounds__(TILE) void swe_rhs_muscl_fused_kernel(const KernelA
         RDY_MST(&a.fdiv[3 * (int64_t)o + 1], acc1);
         RDY_MST(&a.fdiv[3 * (int64_t)o + 2], acc2);
       }
-      RDY_MST(&f[3 * (int64_t)o + 0], res[0]);
-      RDY_MST(&f[3 * (int64_t)o + 1], res[1]);
-      RDY_MST(&f[3 * (int64_t)o + 2], res[2]);
+      if (EULER) {  // rdyhip_euler_step: the forward-Euler update rides on the stores, F only if asked for
+        const int64_t c = a.o2l ? a.o2l[o] : o;
+        RDY_MST(&a.u_out[3 * c + 0], q[0] + dt * res[0]);
+        RDY_MST(&a.u_out[3 * c + 1], q[1] + dt * res[1]);
+        RDY_MST(&a.u_out[3 * c + 2], q[2] + dt * res[2]);
+      }
+      if (!EULER || f) {
+        RDY_MST(&f[3 * (int64_t)o + 0], res[0]);
+        RDY_MST(&f[3 * (int64_t)o + 1], res[1]);
+        RDY_MST(&f[3 * (int64_t)o + 2], res[2]);
+      }
       RDY_MST(&a.pv[3 * (int64_t)o + 0], q[0]);
       RDY_MST(&a.pv[3 * (int64_t)o + 1], self.u);
       RDY_MST(&a.pv[3 * (int64_t)o + 2], self.v);

@@ -200,6 +200,18 @@ MusclKernelFn muscl_fused_fn_lim(int S, int src, bool ovw) {
   if (src) return ovw ? swe_rhs_muscl_fused_kernel<4, 1, true, LIM> : swe_rhs_muscl_fused_kernel<4, 1, false, LIM>;
   return ovw ? swe_rhs_muscl_fused_kernel<4, 0, true, LIM> : swe_rhs_muscl_fused_kernel<4, 0, false, LIM>;
 }
+template <int LIM>
+MusclKernelFn muscl_fused_euler_fn_lim(int S, int src) {
+  if (S == 3) return src ? swe_rhs_muscl_fused_kernel<3, 1, true, LIM, true> : swe_rhs_muscl_fused_kernel<3, 0, true, LIM, true>;
+  return src ? swe_rhs_muscl_fused_kernel<4, 1, true, LIM, true> : swe_rhs_muscl_fused_kernel<4, 0, true, LIM, true>;
+}
+MusclKernelFn muscl_fused_euler_fn(int S, int src, int limiter) {
+  switch (limiter) {
+    case RDYHIP_LIMITER_NONE: return muscl_fused_euler_fn_lim<LIMITER_NONE>(S, src);
+    case RDYHIP_LIMITER_VANLEER: return muscl_fused_euler_fn_lim<LIMITER_VANLEER>(S, src);
+    default: return muscl_fused_euler_fn_lim<LIMITER_MINMOD>(S, src);
+  }
+}
 MusclKernelFn muscl_kernel_fn(int S, int src, bool ovw, int limiter, bool fused) {
   switch (limiter) {
     case RDYHIP_LIMITER_NONE: return fused ? muscl_fused_fn_lim<LIMITER_NONE>(S, src, ovw) : muscl_kernel_fn_lim<LIMITER_NONE>(S, src, ovw);
@@ -261,7 +273,7 @@ int launch_rhs(RDyHipOperator op, int32_t phase, int32_t overwrite, int reset_di
   if (!op) return fail(RDYHIP_ERR_USER, "null operator");
   // rdyhip_euler_step: the first-order / HR tiled kernel has the update fused into its stores (F optional); the
   // other kernels evaluate F (into a scratch vector if the caller wants none) and a separate update follows
-  const bool euler_fused = u_out && op->use_tiled && !op->muscl;
+  const bool euler_fused = u_out && op->use_tiled && (!op->muscl || op->muscl_fused);
   if (u_out && !euler_fused && !f && op->n_owned > 0) {
     if (!op->d_scratch_f.p) {
       int rc = op->d_scratch_f.alloc((size_t)3 * op->n_owned);
@@ -351,8 +363,9 @@ int launch_rhs(RDyHipOperator op, int32_t phase, int32_t overwrite, int reset_di
       }
     }
     if (op->muscl) {
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(muscl_kernel_fn(op->S, xq ? 1 : 0, overwrite != 0, op->config.limiter, op->muscl_fused)), dim3(grid),
-                         dim3(TILE), op->lds_muscl, st, a, muscl_args(op), dt, u, f);
+      MusclKernelFn kfn = euler_fused ? muscl_fused_euler_fn(op->S, xq ? 1 : 0, op->config.limiter)
+                                      : muscl_kernel_fn(op->S, xq ? 1 : 0, overwrite != 0, op->config.limiter, op->muscl_fused);
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(kfn), dim3(grid), dim3(TILE), op->lds_muscl, st, a, muscl_args(op), dt, u, f);
     } else if (euler_fused) {
       hipLaunchKernelGGL(HIP_KERNEL_NAME(tiled_euler_fn(op->S, xq ? 1 : 0, op->hr)), dim3(grid), dim3(TILE), op->lds_bytes, st, a, dt, u, f);
     } else {
@@ -801,7 +814,9 @@ int rdyhip_create(const RDyHipConfig *config, const RDyHipMesh *mesh, int32_t nu
     for (int ovw = 0; ovw < 2; ++ovw)
       for (int src = 0; src < 2; ++src)
         ok = ok && hipFuncSetAttribute((const void *)muscl_kernel_fn(S, src, ovw != 0, config->limiter, muscl_fused),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, nb) == hipSuccess;
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, nb) == hipSuccess &&
+             (!muscl_fused || hipFuncSetAttribute((const void *)muscl_fused_euler_fn(S, src, config->limiter),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, nb) == hipSuccess);
     if (!ok) {
       delete op;
       return fail(RDYHIP_ERR_LIB, "cannot reserve %d bytes of LDS per workgroup", nb);

@@ -162,23 +162,6 @@ class HaloExchange:
         elif self.recv_ids_all.numel():
             rows[self.recv_ids_all.long()] = recv_all
 
-    # -- one forward-Euler step with the exchange hidden the same way -------
-    def step_overlapped(self, op, dt: float, u_local: torch.Tensor, u_out: torch.Tensor):
-        """u_out[owned] = u_local[owned] + dt RHS(u_local) (Operator.euler_step) with the ghost update of u_local
-        overlapped; the ghost rows of u_out are filled by the next call's exchange."""
-        if self.world == 1:
-            op.euler_step(dt, u_local, u_out)
-            return
-        if op.config.second_order:
-            raise NotImplementedError("second order: use rhs_overlapped + axpy_owned")
-        main = torch.cuda.current_stream(self.device)
-        self.comm_stream.wait_stream(main)
-        with torch.cuda.stream(self.comm_stream):
-            self.exchange(u_local)
-        op.euler_step(dt, u_local, u_out, phase=1, reset_diagnostics=True)
-        main.wait_stream(self.comm_stream)
-        op.euler_step(dt, u_local, u_out, phase=2, reset_diagnostics=False)
-
     def _fused(self, op) -> bool:
         if not hasattr(op, "_second_order_fused"):
             op._second_order_fused = bool(op.layout_info()["second_order_fused"])
@@ -193,13 +176,27 @@ class HaloExchange:
                 ops.append(dist.P2POp(dist.irecv, recv[peer], peer, group=self.group))
         return ops
 
-    # -- RHS with the exchange hidden behind the interior cells -----------
+    # -- RHS (or a whole Euler step) with the exchange hidden behind the interior cells
     def rhs_overlapped(self, op, dt: float, u_local: torch.Tensor, f_global: torch.Tensor):
         """OperatorRHSFunction (src/rdysetup.c:1120-1172) on one rank: ghost
         update on a side stream while the cells without ghost neighbours are
         evaluated, then the remaining (halo-adjacent) cells."""
+        self._overlapped(op, dt, u_local, f_global, None)
+
+    def step_overlapped(self, op, dt: float, u_local: torch.Tensor, u_out: torch.Tensor):
+        """u_out[owned] = u_local[owned] + dt RHS(u_local) (Operator.euler_step) with the ghost update of u_local
+        overlapped the same way; the ghost rows of u_out are filled by the next call's exchange."""
+        self._overlapped(op, dt, u_local, None, u_out)
+
+    def _overlapped(self, op, dt, u_local, f_global, u_out):
+        def part(phase, reset=False, ready=False):
+            if u_out is not None:
+                op.euler_step(dt, u_local, u_out, None, phase=phase, reset_diagnostics=reset, gradients_ready=ready)
+            else:
+                op.apply_phase(phase, True, dt, u_local, f_global, reset_diagnostics=reset, gradients_ready=ready)
+
         if self.world == 1:
-            op.rhs_function(dt, u_local, f_global)
+            part(0, reset=True)
             return
         main = torch.cuda.current_stream(self.device)
         self.comm_stream.wait_stream(main)           # u_local's owned part is final
@@ -212,11 +209,11 @@ class HaloExchange:
             if self._fused(op):
                 # fused kernel: tiles whose cells and first ring touch no ghost need nothing from other ranks and
                 # hide the state exchange; only the ghost-adjacent cells' gradients go through memory
-                op.apply_phase(1, True, dt, u_local, f_global, reset_diagnostics=True, gradients_ready=True)
+                part(1, reset=True, ready=True)
                 main.wait_stream(self.comm_stream)
                 op.compute_gradients(u_local, phase=2)
                 self.exchange(op.gradients)
-                op.apply_phase(2, True, dt, u_local, f_global, gradients_ready=True)
+                part(2, ready=True)
                 return
             # split kernels.  Hidden behind the exchanges: the gradients of the cells without ghost neighbours,
             # then the fluxes of the tiles without ghost-adjacent cells (which read owned gradient rows only).
@@ -227,10 +224,10 @@ class HaloExchange:
             self.comm_stream.wait_stream(main)
             with torch.cuda.stream(self.comm_stream):
                 self.exchange(grads)
-            op.apply_phase(1, True, dt, u_local, f_global, reset_diagnostics=True, gradients_ready=True)
+            part(1, reset=True, ready=True)
             main.wait_stream(self.comm_stream)
-            op.apply_phase(2, True, dt, u_local, f_global, gradients_ready=True)
+            part(2, ready=True)
             return
-        op.apply_phase(1, True, dt, u_local, f_global, reset_diagnostics=True)   # RDYHIP_PHASE_INTERIOR (+ diagnostics reset)
+        part(1, reset=True)                          # RDYHIP_PHASE_INTERIOR (+ diagnostics reset)
         main.wait_stream(self.comm_stream)
-        op.apply_phase(2, True, dt, u_local, f_global)                           # RDYHIP_PHASE_HALO
+        part(2)                                      # RDYHIP_PHASE_HALO

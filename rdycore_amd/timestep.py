@@ -34,7 +34,7 @@ class EulerStepper:
         self.op = op
         self.forcing = forcing   # rdycore_amd.forcing.Forcing: applied at the start of every interval, as the
                                  # driver calls RDyApplyForcing before each RDyAdvance (driver/main.c time loop)
-        self.fused = fused and not op.config.second_order   # the second-order path steps with RHS + axpy
+        self.fused = fused
         self._u2 = None
         self.halo = halo
         self.adaptive = adaptive

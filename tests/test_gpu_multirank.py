@@ -55,6 +55,13 @@ def _worker(rank, world, port, kernel, q, second_order=False):
             halo.rhs_overlapped(op, case.dt, u, f)
         torch.cuda.synchronize()
         assert torch.equal(u, torch.tensor(case.u_local, device=dev)), "ghost update wrong"
+        # the whole forward-Euler step with the same overlap (update fused into the kernels' stores)
+        u2 = torch.full_like(u, float("nan"))
+        halo.step_overlapped(op, case.dt, u, u2)
+        torch.cuda.synchronize()
+        own = torch.as_tensor(mesh.cell_owned_to_local, device=dev).long()
+        assert torch.allclose(u2[own], u[own] + case.dt * f, rtol=0, atol=1e-13), "fused Euler step differs from RHS + axpy"
+        halo.rhs_overlapped(op, case.dt, u, f)           # leave the diagnostics of a plain RHS behind
         # single-rank truth from the oracle on the undivided mesh
         g = M.structured_tri_mesh(nxg, ny, 1.0, zfunc=z)
         gc = CS.friction_slope_case(g, nxg, ny, dt=1e-2, K=K)
