@@ -271,7 +271,7 @@ def main():
     # ---- extra (not the metric): one whole forward-Euler step, the update fused into the RHS kernel's stores
     # (rdyhip_euler_step, F never written) against the RHS + axpy pair -- SURVEY.md 8.f row 1
     euler = None
-    if not args.second_order:
+    if True:
         u2 = torch.empty_like(u)
         u3 = u.clone()
 
