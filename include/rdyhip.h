@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RDYHIP_VERSION 103
+#define RDYHIP_VERSION 104
 
 /* error codes = PETSc's values */
 #define RDYHIP_SUCCESS 0
@@ -333,6 +333,11 @@ typedef struct {
   int32_t lds_bytes;          /* dynamic LDS per workgroup of that kernel */
 } RDyHipLayoutInfo;
 int rdyhip_layout_info(RDyHipOperator op, RDyHipLayoutInfo *info);
+/* the same numbers from the host-side layout pass alone (validation of the mesh, slot tables, tiles): no device is
+ * touched, so a mesh and its numbering can be checked -- and every rdyhip_create argument error reproduced -- on a
+ * machine without a GPU; device_bytes and persistent_grid are 0 */
+int rdyhip_probe_layout(const RDyHipConfig *config, const RDyHipMesh *mesh, int32_t num_boundaries, const RDyHipBoundary *boundaries,
+                        RDyHipLayoutInfo *info);
 
 #ifdef __cplusplus
 }

@@ -86,6 +86,8 @@ SYMBOLS = {
     "rdyhip_unpack_rows": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "rdyhip_axpy_owned": (C.c_int, [_H, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rdyhip_euler_step": (C.c_int, [_H, C.c_int32, C.c_int32, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rdyhip_probe_layout": (C.c_int, [C.POINTER(RDyHipConfig), C.POINTER(RDyHipMesh), C.c_int32, C.POINTER(RDyHipBoundary),
+                                      C.POINTER(RDyHipLayoutInfo)]),
     "rdyhip_layout_info": (C.c_int, [_H, C.POINTER(RDyHipLayoutInfo)]),
 }
 

@@ -412,15 +412,23 @@ int launch_rhs(RDyHipOperator op, int32_t phase, int32_t overwrite, int reset_di
 
 }  // namespace
 
-extern "C" {
+// Everything rdyhip_create derives from the mesh on the host, before any device call: validation, the slot tables in the
+// reference's loop order, the tiles with their edge records / halo lists / boundary lists, the second-order stencils.
+struct HostLayout {
+  int32_t nc = 0, no = 0, ne = 0, ni = 0, K = 0, S = 3, ntiles = 0, emax = 0, hmax = 0, hmax2 = 0;
+  int64_t stride = 0;
+  bool    prefix = true, hr_on = false, muscl_on = false, muscl_fused = true;
+  size_t  lds_bytes = 0, lds_muscl = 0;
+  std::vector<int32_t>  o2l, boff, nbr, pos, btype, bleft, bedge, bghost, halo, hcells, tile_bk, halo_tiles, hcells2, c_off;
+  std::vector<double>   cn, sn, coef, gcx, gcy, bcn, bsn, e_cs, e_geo, bn_c, dzdx, dzdy;
+  std::vector<TileDesc> tiles;
+  std::vector<uint32_t> e_lr;
+  std::vector<uint16_t> slot_ref, bn_idx;
+};
 
-const char *rdyhip_last_error(void) { return g_err.c_str(); }
-int32_t     rdyhip_version(void) { return RDYHIP_VERSION; }
-
-int rdyhip_create(const RDyHipConfig *config, const RDyHipMesh *mesh, int32_t num_boundaries, const RDyHipBoundary *boundaries,
-                  RDyHipOperator *op_out) {
-  if (!config || !mesh || !op_out) return fail(RDYHIP_ERR_USER, "null argument to rdyhip_create");
-  *op_out = nullptr;
+static int build_host_layout(const RDyHipConfig *config, const RDyHipMesh *mesh, int32_t num_boundaries, const RDyHipBoundary *boundaries,
+                             HostLayout &L) {
+  if (!config || !mesh) return fail(RDYHIP_ERR_USER, "null argument to rdyhip_create");
   if (num_boundaries < 0 || (num_boundaries > 0 && !boundaries)) return fail(RDYHIP_ERR_USER, "bad boundary list");
   if (config->riemann != RDYHIP_RIEMANN_ROE) return fail(RDYHIP_ERR_USER, "Unsupported Riemann solver");  // swe_petsc.c:269
   if (config->source_method != RDYHIP_SOURCE_SEMI_IMPLICIT && config->source_method != RDYHIP_SOURCE_IMPLICIT_XQ2018)
@@ -771,6 +779,44 @@ int rdyhip_create(const RDyHipConfig *config, const RDyHipMesh *mesh, int32_t nu
     dzdx[o] = mesh->cell_dz_dx[o2l[o]];
     dzdy[o] = mesh->cell_dz_dy[o2l[o]];
   }
+
+  L.nc = nc; L.no = no; L.ne = ne; L.ni = ni; L.K = K; L.S = S; L.ntiles = ntiles; L.emax = emax; L.hmax = hmax; L.hmax2 = hmax2;
+  L.stride = stride; L.prefix = prefix; L.hr_on = hr_on; L.muscl_on = muscl_on; L.muscl_fused = muscl_fused;
+  L.lds_bytes = lds_bytes; L.lds_muscl = lds_muscl;
+  L.o2l = std::move(o2l); L.boff = std::move(boff); L.nbr = std::move(nbr); L.pos = std::move(pos); L.btype = std::move(btype);
+  L.bleft = std::move(bleft); L.bedge = std::move(bedge); L.bghost = std::move(bghost); L.halo = std::move(halo);
+  L.hcells = std::move(hcells); L.tile_bk = std::move(tile_bk); L.halo_tiles = std::move(halo_tiles); L.hcells2 = std::move(hcells2);
+  L.c_off = std::move(c_off); L.cn = std::move(cn); L.sn = std::move(sn); L.coef = std::move(coef); L.gcx = std::move(gcx);
+  L.gcy = std::move(gcy); L.bcn = std::move(bcn); L.bsn = std::move(bsn); L.e_cs = std::move(e_cs); L.e_geo = std::move(e_geo);
+  L.bn_c = std::move(bn_c); L.dzdx = std::move(dzdx); L.dzdy = std::move(dzdy); L.tiles = std::move(tiles); L.e_lr = std::move(e_lr);
+  L.slot_ref = std::move(slot_ref); L.bn_idx = std::move(bn_idx);
+  return 0;
+}
+
+extern "C" {
+
+const char *rdyhip_last_error(void) { return g_err.c_str(); }
+int32_t     rdyhip_version(void) { return RDYHIP_VERSION; }
+
+int rdyhip_create(const RDyHipConfig *config, const RDyHipMesh *mesh, int32_t num_boundaries, const RDyHipBoundary *boundaries,
+                  RDyHipOperator *op_out) {
+  if (!config || !mesh || !op_out) return fail(RDYHIP_ERR_USER, "null argument to rdyhip_create");
+  *op_out = nullptr;
+  HostLayout L;
+  {
+    const int rc0 = build_host_layout(config, mesh, num_boundaries, boundaries, L);
+    if (rc0) return rc0;
+  }
+  const int32_t nc = L.nc, no = L.no, ne = L.ne, ni = L.ni, K = L.K, S = L.S, ntiles = L.ntiles, emax = L.emax, hmax = L.hmax, hmax2 = L.hmax2;
+  const int64_t stride = L.stride;
+  const bool    prefix = L.prefix, hr_on = L.hr_on, muscl_on = L.muscl_on, muscl_fused = L.muscl_fused;
+  const size_t  lds_bytes = L.lds_bytes, lds_muscl = L.lds_muscl;
+  auto &o2l = L.o2l; auto &boff = L.boff; auto &nbr = L.nbr; auto &pos = L.pos; auto &btype = L.btype; auto &bleft = L.bleft; auto &bedge = L.bedge;
+  auto &bghost = L.bghost; auto &halo = L.halo; auto &hcells = L.hcells; auto &tile_bk = L.tile_bk; auto &halo_tiles = L.halo_tiles;
+  auto &hcells2 = L.hcells2; auto &c_off = L.c_off; auto &cn = L.cn; auto &sn = L.sn; auto &coef = L.coef; auto &gcx = L.gcx; auto &gcy = L.gcy;
+  auto &bcn = L.bcn; auto &bsn = L.bsn; auto &e_cs = L.e_cs; auto &e_geo = L.e_geo; auto &bn_c = L.bn_c; auto &dzdx = L.dzdx; auto &dzdy = L.dzdy;
+  auto &tiles = L.tiles; auto &e_lr = L.e_lr; auto &slot_ref = L.slot_ref; auto &bn_idx = L.bn_idx;
+  (void)ne;
 
   // ---- build the operator --------------------------------------------------
   RDyHipOperator op = new (std::nothrow) RDyHipOperator_s;
@@ -1290,6 +1336,22 @@ int rdyhip_axpy_owned(RDyHipOperator op, double dt, const double *f_global, doub
                      f_global, u_local);
   HIP_TRY(hipGetLastError());
   return 0;
+}
+
+int rdyhip_probe_layout(const RDyHipConfig *config, const RDyHipMesh *mesh, int32_t num_boundaries, const RDyHipBoundary *boundaries,
+                        RDyHipLayoutInfo *info) {
+  if (!info) return fail(RDYHIP_ERR_USER, "null argument");
+  HostLayout L;
+  const int  rc = build_host_layout(config, mesh, num_boundaries, boundaries, L);
+  if (rc) return rc;
+  RDyHipOperator_s tmp;  // scalars only: nothing is allocated on a device
+  tmp.n_cells = L.nc; tmp.n_owned = L.no; tmp.S = L.S; tmp.K = L.K; tmp.n_halo = (int32_t)L.halo.size(); tmp.use_tiled = true;
+  tmp.ntiles = L.ntiles; tmp.n_halo_tiles = (int32_t)L.halo_tiles.size(); tmp.emax = L.emax; tmp.hmax = L.hmax;
+  tmp.nhalo_entries = (int64_t)L.hcells.size(); tmp.nrec = (int64_t)L.e_lr.size(); tmp.prefix = L.prefix; tmp.muscl = L.muscl_on;
+  tmp.muscl_fused = L.muscl_fused; tmp.hmax2 = L.hmax2; tmp.d_hcells2.n = L.hcells2.size(); tmp.lds_bytes = L.lds_bytes; tmp.lds_muscl = L.lds_muscl;
+  const int rc2 = rdyhip_layout_info(&tmp, info);
+  tmp.d_hcells2.n = 0;
+  return rc2;
 }
 
 int rdyhip_layout_info(RDyHipOperator op, RDyHipLayoutInfo *info) {

@@ -68,6 +68,61 @@ def _stream() -> int:
     return int(torch.cuda.current_stream().cuda_stream)
 
 
+def _abi_arguments(config: "RDyFlowConfig", mesh: RDyMesh, condition_types: Optional[Sequence[int]]):
+    """RDyHipConfig / RDyHipMesh / RDyHipBoundary[] for a mesh (the arrays are borrowed: keep `keep` alive during the call)"""
+    nb = len(mesh.boundaries)
+    if condition_types is None:
+        condition_types = [CONDITION_REFLECTING] * nb
+    if len(condition_types) != nb:
+        raise RDyHipError(83, f"{len(condition_types)} boundary conditions for {nb} boundaries")
+    keep = []
+
+    def arr(a, dt):
+        a = np.ascontiguousarray(a, dtype=dt)
+        keep.append(a)
+        return a
+
+    m = _lib.RDyHipMesh()
+    m.num_cells, m.num_owned_cells = mesh.num_cells, mesh.num_owned_cells
+    m.num_edges, m.num_internal_edges = mesh.num_edges, mesh.num_internal_edges
+    m.cell_is_owned = arr(mesh.cell_is_owned, np.int32).ctypes.data_as(_lib.c_int32_p)
+    m.cell_local_to_owned = arr(mesh.cell_local_to_owned, np.int32).ctypes.data_as(_lib.c_int32_p)
+    m.cell_global_ids = arr(mesh.cell_global_ids, np.int64).ctypes.data_as(_lib.c_int64_p)
+    m.cell_areas = arr(mesh.cell_areas, np.float64).ctypes.data_as(_lib.c_double_p)
+    m.cell_dz_dx = arr(mesh.cell_dz_dx, np.float64).ctypes.data_as(_lib.c_double_p)
+    m.cell_dz_dy = arr(mesh.cell_dz_dy, np.float64).ctypes.data_as(_lib.c_double_p)
+    m.edge_cell_ids = arr(mesh.edge_cell_ids, np.int32).ctypes.data_as(_lib.c_int32_p)
+    m.edge_internal_ids = arr(mesh.edge_internal_ids, np.int32).ctypes.data_as(_lib.c_int32_p)
+    m.edge_global_ids = arr(mesh.edge_global_ids, np.int64).ctypes.data_as(_lib.c_int64_p)
+    m.edge_lengths = arr(mesh.edge_lengths, np.float64).ctypes.data_as(_lib.c_double_p)
+    m.edge_cn = arr(mesh.edge_cn, np.float64).ctypes.data_as(_lib.c_double_p)
+    m.edge_sn = arr(mesh.edge_sn, np.float64).ctypes.data_as(_lib.c_double_p)
+    m.cell_zc = arr(mesh.cell_zc, np.float64).ctypes.data_as(_lib.c_double_p)
+    if config.second_order:
+        m.num_vertices = mesh.num_vertices
+        m.cell_centroids = arr(mesh.cell_centroids, np.float64).ctypes.data_as(_lib.c_double_p)
+        m.edge_vertex_ids = arr(mesh.edge_vertex_ids, np.int32).ctypes.data_as(_lib.c_int32_p)
+        m.vertex_points = arr(mesh.xyz, np.float64).ctypes.data_as(_lib.c_double_p)
+    barr = (_lib.RDyHipBoundary * max(nb, 1))()
+    for i, b in enumerate(mesh.boundaries):
+        barr[i].num_edges = b.num_edges
+        barr[i].edge_ids = arr(b.edge_ids, np.int32).ctypes.data_as(_lib.c_int32_p)
+        barr[i].condition_type = int(condition_types[i])
+    cfg = _lib.RDyHipConfig(config.tiny_h, config.h_anuga_regular, config.xq2018_threshold,
+                            int(config.source_method), int(config.riemann), int(config.well_balancing),
+                            1 if config.second_order else 0, int(config.limiter), 0)
+    return cfg, m, nb, barr, list(condition_types), keep
+
+
+def probe_layout(config: "RDyFlowConfig", mesh: RDyMesh, condition_types: Optional[Sequence[int]] = None) -> dict:
+    """rdyhip_probe_layout: the host-side layout pass of rdyhip_create alone (no GPU needed) -- validates the mesh
+    exactly as create does and returns the layout numbers (tiles, edge records, halo lists, LDS per workgroup)."""
+    cfg, m, nb, barr, _, _keep = _abi_arguments(config, mesh, condition_types)
+    info = _lib.RDyHipLayoutInfo()
+    _lib.check(_lib.load().rdyhip_probe_layout(C.byref(cfg), C.byref(m), nb, barr, C.byref(info)))
+    return {k: getattr(info, k) for k, _ in info._fields_}
+
+
 class Operator:
     """Operator (include/private/rdyoperatorimpl.h:103-201), native MI355X backend."""
 
@@ -86,48 +141,8 @@ class Operator:
         lib = _lib.load()
         if not torch.cuda.is_available():
             raise RuntimeError("rdycore_amd.Operator needs a HIP device (no CPU fallback)")
-        nb = len(mesh.boundaries)
-        if condition_types is None:
-            condition_types = [CONDITION_REFLECTING] * nb
-        if len(condition_types) != nb:
-            raise RDyHipError(83, f"{len(condition_types)} boundary conditions for {nb} boundaries")
         torch.cuda.current_device()  # make sure the HIP context exists on the chosen device
-        keep = []
-
-        def arr(a, dt):
-            a = np.ascontiguousarray(a, dtype=dt)
-            keep.append(a)
-            return a
-
-        m = _lib.RDyHipMesh()
-        m.num_cells, m.num_owned_cells = mesh.num_cells, mesh.num_owned_cells
-        m.num_edges, m.num_internal_edges = mesh.num_edges, mesh.num_internal_edges
-        m.cell_is_owned = arr(mesh.cell_is_owned, np.int32).ctypes.data_as(_lib.c_int32_p)
-        m.cell_local_to_owned = arr(mesh.cell_local_to_owned, np.int32).ctypes.data_as(_lib.c_int32_p)
-        m.cell_global_ids = arr(mesh.cell_global_ids, np.int64).ctypes.data_as(_lib.c_int64_p)
-        m.cell_areas = arr(mesh.cell_areas, np.float64).ctypes.data_as(_lib.c_double_p)
-        m.cell_dz_dx = arr(mesh.cell_dz_dx, np.float64).ctypes.data_as(_lib.c_double_p)
-        m.cell_dz_dy = arr(mesh.cell_dz_dy, np.float64).ctypes.data_as(_lib.c_double_p)
-        m.edge_cell_ids = arr(mesh.edge_cell_ids, np.int32).ctypes.data_as(_lib.c_int32_p)
-        m.edge_internal_ids = arr(mesh.edge_internal_ids, np.int32).ctypes.data_as(_lib.c_int32_p)
-        m.edge_global_ids = arr(mesh.edge_global_ids, np.int64).ctypes.data_as(_lib.c_int64_p)
-        m.edge_lengths = arr(mesh.edge_lengths, np.float64).ctypes.data_as(_lib.c_double_p)
-        m.edge_cn = arr(mesh.edge_cn, np.float64).ctypes.data_as(_lib.c_double_p)
-        m.edge_sn = arr(mesh.edge_sn, np.float64).ctypes.data_as(_lib.c_double_p)
-        m.cell_zc = arr(mesh.cell_zc, np.float64).ctypes.data_as(_lib.c_double_p)
-        if config.second_order:
-            m.num_vertices = mesh.num_vertices
-            m.cell_centroids = arr(mesh.cell_centroids, np.float64).ctypes.data_as(_lib.c_double_p)
-            m.edge_vertex_ids = arr(mesh.edge_vertex_ids, np.int32).ctypes.data_as(_lib.c_int32_p)
-            m.vertex_points = arr(mesh.xyz, np.float64).ctypes.data_as(_lib.c_double_p)
-        barr = (_lib.RDyHipBoundary * max(nb, 1))()
-        for i, b in enumerate(mesh.boundaries):
-            barr[i].num_edges = b.num_edges
-            barr[i].edge_ids = arr(b.edge_ids, np.int32).ctypes.data_as(_lib.c_int32_p)
-            barr[i].condition_type = int(condition_types[i])
-        cfg = _lib.RDyHipConfig(config.tiny_h, config.h_anuga_regular, config.xq2018_threshold,
-                                int(config.source_method), int(config.riemann), int(config.well_balancing),
-                                1 if config.second_order else 0, int(config.limiter), 0)
+        cfg, m, nb, barr, condition_types, _keep = _abi_arguments(config, mesh, condition_types)
         h = C.c_void_p()
         _lib.check(lib.rdyhip_create(C.byref(cfg), C.byref(m), nb, barr, C.byref(h)))
         return cls(h, mesh, config, condition_types)
