@@ -270,42 +270,40 @@ def main():
 
     # ---- extra (not the metric): one whole forward-Euler step, the update fused into the RHS kernel's stores
     # (rdyhip_euler_step, F never written) against the RHS + axpy pair -- SURVEY.md 8.f row 1
-    euler = None
-    if True:
-        u2 = torch.empty_like(u)
-        u3 = u.clone()
+    u2 = torch.empty_like(u)
+    u3 = u.clone()
 
-        def timed(fn, n):
+    def timed(fn, n):
+        fn()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
             fn()
-            torch.cuda.synchronize()
-            if world > 1:
-                dist.barrier()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(n):
-                fn()
-            e1.record()
-            torch.cuda.synchronize()
-            return e0.elapsed_time(e1) / n
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n
 
-        def fused_step():
-            if halo is not None:
-                halo.step_overlapped(op, case.dt, u, u2)
-            else:
-                op.euler_step(case.dt, u, u2)
+    def fused_step():
+        if halo is not None:
+            halo.step_overlapped(op, case.dt, u, u2)
+        else:
+            op.euler_step(case.dt, u, u2)
 
-        def pair_step():
-            if halo is not None:
-                halo.rhs_overlapped(op, case.dt, u, f)
-            else:
-                op.rhs_function(case.dt, u, f)
-            op.axpy_owned(0.0, f, u3)      # dt = 0: same traffic, the scratch state stays put
+    def pair_step():
+        if halo is not None:
+            halo.rhs_overlapped(op, case.dt, u, f)
+        else:
+            op.rhs_function(case.dt, u, f)
+        op.axpy_owned(0.0, f, u3)      # dt = 0: same traffic, the scratch state stays put
 
-        ef, ep = timed(fused_step, k_iters), timed(pair_step, k_iters)
-        euler = {"fused_ms_per_step": round(ef, 5), "rhs_plus_axpy_ms_per_step": round(ep, 5),
-                 "fused_steps_per_s": round(1e3 / ef, 1)}
-        del u2, u3
-        op.rhs_function(case.dt, u, f) if halo is None else halo.rhs_overlapped(op, case.dt, u, f)
+    ef, ep = timed(fused_step, k_iters), timed(pair_step, k_iters)
+    euler = {"fused_ms_per_step": round(ef, 5), "rhs_plus_axpy_ms_per_step": round(ep, 5),
+             "fused_steps_per_s": round(1e3 / ef, 1)}
+    del u2, u3
+    op.rhs_function(case.dt, u, f) if halo is None else halo.rhs_overlapped(op, case.dt, u, f)
 
     # sanity: the result is finite and the Courant diagnostic is alive
     op.update_diagnostics()
@@ -359,8 +357,7 @@ def main():
                          "algorithmic_bytes_per_launch": int(n_owned * ALG_BYTES_PER_CELL),
                          "layout_bytes_per_launch": int(info["bytes_per_apply"])},
         }
-        if euler is not None:
-            out["euler_step"] = euler
+        out["euler_step"] = euler
         if args.second_order:
             # the 176-B figure above keeps variants comparable; the second-order path's own model:
             b2 = ALG_BYTES_PER_CELL_SECOND_ORDER if info["second_order_fused"] else ALG_BYTES_PER_CELL_SECOND_ORDER_SPLIT
