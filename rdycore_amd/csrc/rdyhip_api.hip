@@ -426,8 +426,8 @@ struct HostLayout {
   std::vector<uint16_t> slot_ref, bn_idx;
 };
 
-static int build_host_layout(const RDyHipConfig *config, const RDyHipMesh *mesh, int32_t num_boundaries, const RDyHipBoundary *boundaries,
-                             HostLayout &L) {
+// argument checks of rdyhip_create (the reference's PetscCheck messages where it has them)
+static int layout_check_arguments(const RDyHipConfig *config, const RDyHipMesh *mesh, int32_t num_boundaries, const RDyHipBoundary *boundaries) {
   if (!config || !mesh) return fail(RDYHIP_ERR_USER, "null argument to rdyhip_create");
   if (num_boundaries < 0 || (num_boundaries > 0 && !boundaries)) return fail(RDYHIP_ERR_USER, "bad boundary list");
   if (config->riemann != RDYHIP_RIEMANN_ROE) return fail(RDYHIP_ERR_USER, "Unsupported Riemann solver");  // swe_petsc.c:269
@@ -452,6 +452,15 @@ static int build_host_layout(const RDyHipConfig *config, const RDyHipMesh *mesh,
   if (ne > 0 && (!mesh->edge_cell_ids || !mesh->edge_lengths || !mesh->edge_cn || !mesh->edge_sn)) return fail(RDYHIP_ERR_USER, "null edge array");
   if (ni > 0 && !mesh->edge_internal_ids) return fail(RDYHIP_ERR_USER, "null internal edge list");
 
+  return 0;
+}
+
+// owned <-> local maps, the boundary-edge table and the per-cell slot tables in the reference's loop order
+// (with the least-squares gradient coefficients of the second-order path)
+static int layout_build_slots(const RDyHipConfig *config, const RDyHipMesh *mesh, int32_t num_boundaries, const RDyHipBoundary *boundaries,
+                              HostLayout &L) {
+  const bool    muscl_on = config->second_order != 0;
+  const int32_t nc = mesh->num_cells, no = mesh->num_owned_cells, ne = mesh->num_edges, ni = mesh->num_internal_edges;
   // ---- owned <-> local maps ---------------------------------------------
   std::vector<int32_t> o2l((size_t)no, -1);
   int32_t              owned_seen = 0;
@@ -605,6 +614,22 @@ static int build_host_layout(const RDyHipConfig *config, const RDyHipMesh *mesh,
     if (g) halo.push_back(o);
   }
 
+  L.nc = nc; L.no = no; L.ne = ne; L.ni = ni; L.K = K; L.S = S; L.stride = stride; L.prefix = prefix; L.muscl_on = muscl_on;
+  L.o2l = std::move(o2l); L.boff = std::move(boff); L.nbr = std::move(nbr); L.pos = std::move(pos); L.btype = std::move(btype);
+  L.bleft = std::move(bleft); L.bedge = std::move(bedge); L.bghost = std::move(bghost); L.halo = std::move(halo);
+  L.cn = std::move(cn); L.sn = std::move(sn); L.coef = std::move(coef); L.gcx = std::move(gcx); L.gcy = std::move(gcy);
+  L.bcn = std::move(bcn); L.bsn = std::move(bsn);
+  return 0;
+}
+
+// the tiles of 256 consecutive owned cells: edge records, halo-cell lists, boundary lists, slot references, and for the
+// second-order kernel the first-ring stencils and the second ring
+static int layout_build_tiles(const RDyHipMesh *mesh, HostLayout &L) {
+  const int32_t nc = L.nc, no = L.no, ni = L.ni, S = L.S;
+  const int64_t stride   = L.stride;
+  const bool    muscl_on = L.muscl_on;
+  const auto &nbr = L.nbr; const auto &pos = L.pos; const auto &bedge = L.bedge; const auto &bleft = L.bleft;
+  const auto &gcx = L.gcx; const auto &gcy = L.gcy;
   // ---- tiles of 256 consecutive owned cells: edge list, halo cells, boundary edges (tiled kernel) ----
   const int32_t         ntiles = (no + TILE - 1) / TILE;
   std::vector<TileDesc> tiles((size_t)ntiles + 1);
@@ -762,6 +787,22 @@ static int build_host_layout(const RDyHipConfig *config, const RDyHipMesh *mesh,
     if (muscl_on) c_off[ntiles] = (int32_t)hcells2.size();
     // a tile has at most 4*256 edges, so 256 + hmax <= 1280 slots < 2^11 and <= 1024 boundary edges
   }
+  L.ntiles = ntiles; L.emax = emax; L.hmax = hmax; L.hmax2 = hmax2;
+  L.hcells = std::move(hcells); L.tile_bk = std::move(tile_bk); L.halo_tiles = std::move(halo_tiles); L.hcells2 = std::move(hcells2);
+  L.c_off = std::move(c_off); L.e_cs = std::move(e_cs); L.e_geo = std::move(e_geo); L.bn_c = std::move(bn_c); L.tiles = std::move(tiles);
+  L.e_lr = std::move(e_lr); L.slot_ref = std::move(slot_ref); L.bn_idx = std::move(bn_idx);
+  return 0;
+}
+
+static int build_host_layout(const RDyHipConfig *config, const RDyHipMesh *mesh, int32_t num_boundaries, const RDyHipBoundary *boundaries,
+                             HostLayout &L) {
+  int rc = layout_check_arguments(config, mesh, num_boundaries, boundaries);
+  if (!rc) rc = layout_build_slots(config, mesh, num_boundaries, boundaries, L);
+  if (!rc) rc = layout_build_tiles(mesh, L);
+  if (rc) return rc;
+  const int32_t no = L.no, emax = L.emax, hmax = L.hmax, hmax2 = L.hmax2;
+  const bool    muscl_on = L.muscl_on;
+  const auto   &o2l      = L.o2l;
   const bool   hr_on     = config->well_balancing == RDYHIP_WELL_BALANCING_HR;
   const size_t lds_bytes = sizeof(double) * ((hr_on ? 6 : 5) * ((size_t)TILE + hmax) + 2 * (size_t)TILE + (hr_on ? 8 : 4) * (size_t)emax);
   const char  *menv        = getenv("RDYHIP_MUSCL");
@@ -780,16 +821,8 @@ static int build_host_layout(const RDyHipConfig *config, const RDyHipMesh *mesh,
     dzdy[o] = mesh->cell_dz_dy[o2l[o]];
   }
 
-  L.nc = nc; L.no = no; L.ne = ne; L.ni = ni; L.K = K; L.S = S; L.ntiles = ntiles; L.emax = emax; L.hmax = hmax; L.hmax2 = hmax2;
-  L.stride = stride; L.prefix = prefix; L.hr_on = hr_on; L.muscl_on = muscl_on; L.muscl_fused = muscl_fused;
-  L.lds_bytes = lds_bytes; L.lds_muscl = lds_muscl;
-  L.o2l = std::move(o2l); L.boff = std::move(boff); L.nbr = std::move(nbr); L.pos = std::move(pos); L.btype = std::move(btype);
-  L.bleft = std::move(bleft); L.bedge = std::move(bedge); L.bghost = std::move(bghost); L.halo = std::move(halo);
-  L.hcells = std::move(hcells); L.tile_bk = std::move(tile_bk); L.halo_tiles = std::move(halo_tiles); L.hcells2 = std::move(hcells2);
-  L.c_off = std::move(c_off); L.cn = std::move(cn); L.sn = std::move(sn); L.coef = std::move(coef); L.gcx = std::move(gcx);
-  L.gcy = std::move(gcy); L.bcn = std::move(bcn); L.bsn = std::move(bsn); L.e_cs = std::move(e_cs); L.e_geo = std::move(e_geo);
-  L.bn_c = std::move(bn_c); L.dzdx = std::move(dzdx); L.dzdy = std::move(dzdy); L.tiles = std::move(tiles); L.e_lr = std::move(e_lr);
-  L.slot_ref = std::move(slot_ref); L.bn_idx = std::move(bn_idx);
+  L.hr_on = hr_on; L.muscl_fused = muscl_fused; L.lds_bytes = lds_bytes; L.lds_muscl = lds_muscl;
+  L.dzdx = std::move(dzdx); L.dzdy = std::move(dzdy);
   return 0;
 }
 
