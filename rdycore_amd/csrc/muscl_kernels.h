@@ -460,6 +460,7 @@ __global__ __launch_bounds__(TILE) void swe_rhs_muscl_fused_kernel(const KernelA
     {
       double gr[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
       if (active) {
+        const double own0 = sq[tid], own1 = sq[nq + tid], own2 = sq[2 * nq + tid];  // the own state again, from LDS (registers are scarce)
 #pragma unroll
         for (int s = 0; s < S; ++s) {
           const int ref = slot_edge<S>(r0, r1, s);
@@ -468,7 +469,7 @@ __global__ __launch_bounds__(TILE) void swe_rhs_muscl_fused_kernel(const KernelA
           if (lr & EDGE_BOUNDARY) continue;
           const int jl = lr & EDGE_SLOT_MASK, jr = (lr >> EDGE_R_SHIFT) & EDGE_SLOT_MASK;
           const int nb = (jl == tid) ? jr : jl;
-          grad_add(gr, gx[s], gy[s], sq[nb] - q[0], sq[nq + nb] - q[1], sq[2 * nq + nb] - q[2]);
+          grad_add(gr, gx[s], gy[s], sq[nb] - own0, sq[nq + nb] - own1, sq[2 * nq + nb] - own2);
         }
       }
 #pragma unroll
@@ -518,36 +519,38 @@ __global__ __launch_bounds__(TILE) void swe_rhs_muscl_fused_kernel(const KernelA
     __syncthreads();
 
     // ---- phase 2: per-cell sum in the reference's edge order, source terms, stores
+    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, res[3] = {0.0, 0.0, 0.0}, pu = 0.0, pv_ = 0.0;
+    const double h = sq[tid], hu = sq[nq + tid], hv = sq[2 * nq + tid];
     if (active) {
-      double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
       if (!OVW) {
         acc0 = f[3 * (int64_t)o + 0];
         acc1 = f[3 * (int64_t)o + 1];
         acc2 = f[3 * (int64_t)o + 2];
       }
       muscl_cell_sum<S>(r0, r1, kf, ef0, ef1, ef2, eam, dt, o, acc0, acc1, acc2, best, best_slot, best_o);
-      const RiemannSide self = riemann_side(q[0], q[1], q[2], a.tiny_h, a.h_anuga_sq);
-      double            res[3];
-      cell_results<SRC>(a, dt, q[0], q[1], q[2], acc0, acc1, acc2, dzx, dzy, nman, s0, s1, s2, res);
-      if (a.fdiv) {
-        RDY_MST(&a.fdiv[3 * (int64_t)o + 0], acc0);
-        RDY_MST(&a.fdiv[3 * (int64_t)o + 1], acc1);
-        RDY_MST(&a.fdiv[3 * (int64_t)o + 2], acc2);
-      }
+      const RiemannSide self = riemann_side(h, hu, hv, a.tiny_h, a.h_anuga_sq);
+      pu                     = self.u;
+      pv_                    = self.v;
+      cell_results<SRC>(a, dt, h, hu, hv, acc0, acc1, acc2, dzx, dzy, nman, s0, s1, s2, res);
+    }
+    {  // whole-line stores of the [cell][3] rows (wave_store_rows3, swe_kernels.h); all 64 lanes take part
+      const int     lane  = tid & 63;
+      const int64_t base  = 3 * ((int64_t)o - lane);
+      const int     ncell = a.n_owned - (o - lane);
+      if (a.fdiv) wave_store_rows3(a.fdiv, base, lane, ncell, acc0, acc1, acc2);
+      if (!EULER || f) wave_store_rows3(f, base, lane, ncell, res[0], res[1], res[2]);
+      wave_store_rows3(a.pv, base, lane, ncell, h, pu, pv_);
       if (EULER) {  // rdyhip_euler_step: the forward-Euler update rides on the stores, F only if asked for
-        const int64_t c = a.o2l ? a.o2l[o] : o;
-        RDY_MST(&a.u_out[3 * c + 0], q[0] + dt * res[0]);
-        RDY_MST(&a.u_out[3 * c + 1], q[1] + dt * res[1]);
-        RDY_MST(&a.u_out[3 * c + 2], q[2] + dt * res[2]);
+        const double n0 = h + dt * res[0], n1 = hu + dt * res[1], n2 = hv + dt * res[2];
+        if (!a.o2l) {
+          wave_store_rows3(a.u_out, base, lane, ncell, n0, n1, n2);
+        } else if (active) {
+          const int64_t c = a.o2l[o];
+          RDY_MST(&a.u_out[3 * c + 0], n0);
+          RDY_MST(&a.u_out[3 * c + 1], n1);
+          RDY_MST(&a.u_out[3 * c + 2], n2);
+        }
       }
-      if (!EULER || f) {
-        RDY_MST(&f[3 * (int64_t)o + 0], res[0]);
-        RDY_MST(&f[3 * (int64_t)o + 1], res[1]);
-        RDY_MST(&f[3 * (int64_t)o + 2], res[2]);
-      }
-      RDY_MST(&a.pv[3 * (int64_t)o + 0], q[0]);
-      RDY_MST(&a.pv[3 * (int64_t)o + 1], self.u);
-      RDY_MST(&a.pv[3 * (int64_t)o + 2], self.v);
     }
     __syncthreads();  // the LDS planes are rewritten by the next tile
   }
