@@ -436,6 +436,7 @@ __global__ __launch_bounds__(TILE) void swe_rhs_tiled_kernel(const KernelArgs a,
       // loads completed a tile ago, and the first use of this batch is the register rotation at the
       // very end (one wait per tile, a whole flux phase after the loads were issued).
       // (a) which tile comes after the next, and the ids it needs (the only dependent loads: first)
+      __builtin_amdgcn_s_setprio(3);  // waves that reach their load batch issue it ahead of waves that are computing (+0.7..1 %)
       int      idx2 = hi, tile2 = 0, hid2 = 0, c2 = 0;
       TileDesc td2 = td1, tn2 = tn1;
       if (idx1 < hi) {
@@ -467,6 +468,7 @@ __global__ __launch_bounds__(TILE) void swe_rhs_tiled_kernel(const KernelArgs a,
         if (tid + TILE < ne1) { nlr1 = RDY_LD(&a.e_lr[td1.e_off + TILE + tid]); ncs1 = RDY_LD(&a.e_cs[td1.e_off + TILE + tid]); }
       }
       load_streams<S, HR>(a, tile1 * TILE + tid, idx1 < hi && tile1 * TILE + tid < a.n_owned, nxt);
+      __builtin_amdgcn_s_setprio(0);
 
       // ---- phase 1: every edge of the tile once, operands from LDS only
       // (ApplyInteriorFlux / ApplyBoundaryFlux, swe_petsc.c:215-316, 506-630)
