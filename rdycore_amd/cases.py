@@ -93,6 +93,22 @@ def friction_slope_case(mesh: RDyMesh, lx: float, ly: float, dt: float = 1e-3,
     return Case("friction_slope", mesh, RDyFlowConfig(source_method=source_method), ctypes, u, n, src, bvals, dt)
 
 
+def houston_case(data_dir: str) -> Case:
+    """driver/tests/swe_roe/Houston1km.DirichletBC.yaml on share/meshes/Houston1km_with_z.exo: 2746 triangles
+    over a real DEM, initial state from Houston1km.ic.*.bin (natural cell order, [cell][h, hu, hv]), Manning
+    0.015, side set 1 = Dirichlet boundary (height 0 unless a bc series drives it), every other boundary
+    edge reflecting (src/rdysetup.c:342-431), dt = 30 s, coupling interval 60 s, stop 4200 s."""
+    import os
+    from . import mesh as M
+    xyz, conn, side_sets = M.read_exodus(os.path.join(data_dir, "Houston1km_with_z.exo"))
+    mesh = M.build_mesh(xyz, conn, boundary_classifier=M.boundaries_from_side_sets(side_sets, conn, {1: "bottom_wall"}))
+    u = M.read_petsc_vec(os.path.join(data_dir, "Houston1km.ic.int32.bin")).reshape(mesh.num_cells, 3)
+    ctypes = [CONDITION_DIRICHLET if b.name == "bottom_wall" else CONDITION_REFLECTING for b in mesh.boundaries]
+    bvals = {i: np.zeros((b.num_edges, 3)) for i, b in enumerate(mesh.boundaries) if b.name == "bottom_wall"}
+    no = mesh.num_owned_cells
+    return Case("houston1km", mesh, RDyFlowConfig(), ctypes, u, np.full(no, 0.015), np.zeros((no, 3)), bvals, 30.0)
+
+
 def create_operator(case: Case):
     """CreateOperator + the data setters the reference's setup calls
     (InitMaterialProperties / InitSourceConditions / InitDirichletBoundaryConditions,

@@ -683,3 +683,72 @@ def read_exodus_tri(path: str) -> Tuple[np.ndarray, np.ndarray]:
     conn = np.array(f.variables["connect1"][:], dtype=np.int32) - 1
     f.close()
     return np.stack([x, y, z], axis=1), conn
+
+
+def read_exodus(path: str):
+    """Exodus II (NetCDF-3) mesh with any number of TRI3 / SHELL4 element blocks and side sets (e.g.
+    share/meshes/Houston1km_with_z.exo, DamBreak_grid5x10_mixed_elements.exo): returns xyz, conn
+    ([cells,4], -1 padded, 0-based, blocks in file order = the natural cell order the reference's binary
+    condition files use) and {side set id: [(cell, local edge)]} with 0-based cells and 0-based local
+    edges (edge k joins nodes k and k+1 of the element, cyclic).  In a 3-D file TRI3 / SHELL4 are shell
+    elements whose sides 1 and 2 are the two faces, so their edges are sides 3, 4, ...; in a 2-D file the
+    edges are sides 1, 2, ..."""
+    from scipy.io import netcdf_file
+    f = netcdf_file(path, "r", mmap=False)
+    x = np.array(f.variables["coordx"][:], dtype=np.float64)
+    y = np.array(f.variables["coordy"][:], dtype=np.float64)
+    z = np.array(f.variables["coordz"][:], dtype=np.float64) if "coordz" in f.variables else np.zeros_like(x)
+    blocks = []
+    for b in range(1, int(f.dimensions.get("num_el_blk", 1)) + 1):
+        c = np.array(f.variables[f"connect{b}"][:], dtype=np.int32) - 1
+        if c.shape[1] == 3:
+            c = np.concatenate([c, -np.ones((c.shape[0], 1), np.int32)], axis=1)
+        blocks.append(c)
+    conn = np.concatenate(blocks, axis=0)
+    side_sets = {}
+    nss = int(f.dimensions.get("num_side_sets", 0) or 0)
+    ids = np.array(f.variables["ss_prop1"][:], dtype=np.int64) if nss else []
+    for k in range(1, nss + 1):
+        el = np.array(f.variables[f"elem_ss{k}"][:], dtype=np.int64) - 1
+        sd = np.array(f.variables[f"side_ss{k}"][:], dtype=np.int64) - (3 if int(f.dimensions["num_dim"]) == 3 else 1)
+        side_sets[int(ids[k - 1])] = list(zip(el.tolist(), sd.tolist()))
+    f.close()
+    return np.stack([x, y, z], axis=1), conn, side_sets
+
+
+def boundaries_from_side_sets(side_sets, conn: np.ndarray, names: Optional[Dict[int, str]] = None):
+    """Boundary classifier from Exodus side sets.  Boundary edges that belong to no side set are collected in
+    one extra boundary, to which the caller applies a reflecting condition, as the reference does
+    (src/rdysetup.c:342-431); its id is the first id no side set uses, counted from 0."""
+    names = names or {}
+
+    def f(mesh: RDyMesh) -> List[RDyBoundary]:
+        tag: Dict[Tuple[int, int], int] = {}
+        for sid, sides in side_sets.items():
+            for cell, side in sides:
+                nv = int((conn[cell] >= 0).sum())
+                a, b = int(conn[cell][side % nv]), int(conn[cell][(side + 1) % nv])
+                tag[(min(a, b), max(a, b))] = sid
+        be = mesh.edge_boundary_ids
+        v = mesh.edge_vertex_ids[be]
+        tags = np.array([tag.get((int(min(a, b)), int(max(a, b))), -1) for a, b in v])
+        out = [RDyBoundary(t, names.get(t, f"boundary_{t}"), be[tags == t].astype(np.int32)) for t in sorted(side_sets) if (tags == t).any()]
+        if (tags == -1).any():
+            free = 0
+            while free in side_sets:
+                free += 1
+            out.append(RDyBoundary(free, "unassigned", be[tags == -1].astype(np.int32)))
+        return out
+    return f
+
+
+def read_petsc_vec(path: str) -> np.ndarray:
+    """PETSc binary Vec as the reference's share/conditions files hold them: big-endian
+    {int32 classid = 1211214, int32 n} followed by n float64."""
+    import struct
+    with open(path, "rb") as fh:
+        raw = fh.read()
+    classid, n = struct.unpack(">ii", raw[:8])
+    if classid != 1211214:
+        raise ValueError(f"{path}: not a PETSc Vec file (classid {classid})")
+    return np.frombuffer(raw[8:8 + 8 * n], dtype=">f8").astype(np.float64)
