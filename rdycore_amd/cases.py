@@ -109,6 +109,24 @@ def houston_case(data_dir: str) -> Case:
     return Case("houston1km", mesh, RDyFlowConfig(), ctypes, u, np.full(no, 0.015), np.zeros((no, 3)), bvals, 30.0)
 
 
+def levee_hr_case(data_dir: str) -> Case:
+    """driver/tests/swe_roe/levee.hr.yaml (the reference's hydrostatic-reconstruction test) on share/meshes/levee.exo:
+    506 triangles, per-cell bed elevation from levee_elevation.*.bin (grid.cell_elevation: it replaces the centroid z
+    and thereby the HR operator's zc, src/rdysetup.c:1078-1100, src/swe/swe_petsc.c:1213-1215), initial state from
+    levee_ic.*.bin (dry cells on the levee), Manning 0.033, no side sets: every boundary edge reflecting; x-y projected
+    lengths and areas as HR requires (src/rdymesh.c:1478-1509); 600 steps of 0.1 s."""
+    import os
+    from . import mesh as M
+    from .operator import WELL_BALANCING_HR
+    xyz, conn, side_sets = M.read_exodus(os.path.join(data_dir, "levee.exo"))
+    mesh = M.build_mesh(xyz, conn, boundary_classifier=M.boundaries_from_side_sets(side_sets, conn), project_2d=True)
+    mesh.cell_zc = M.read_petsc_vec(os.path.join(data_dir, "levee_elevation.int32.bin"))[: mesh.num_cells].copy()
+    u = M.read_petsc_vec(os.path.join(data_dir, "levee_ic.int32.bin")).reshape(mesh.num_cells, 3)
+    no = mesh.num_owned_cells
+    return Case("levee_hr", mesh, RDyFlowConfig(well_balancing=WELL_BALANCING_HR), [CONDITION_REFLECTING] * len(mesh.boundaries), u,
+                np.full(no, 0.033), np.zeros((no, 3)), {}, 60.0 / 600.0)
+
+
 def create_operator(case: Case):
     """CreateOperator + the data setters the reference's setup calls
     (InitMaterialProperties / InitSourceConditions / InitDirichletBoundaryConditions,

@@ -50,3 +50,29 @@ def test_houston_second_order(rdyhip_kernel):
     _, u, op, st = H.device_run("homogeneous", t_stop=240.0, second_order=True)
     assert st.step == 8 and np.isfinite(u_ref).all() and np.abs(u_ref).max() < 1e3
     assert rel_linf(u, u_ref) <= 1e-10
+
+
+def test_levee_lake_at_rest_with_hydrostatic_reconstruction(rdyhip_kernel):
+    """the reference's HR test (driver/tests/swe_roe/levee.hr.yaml) on its own fixtures: 600 fused Euler steps of the HR
+    kernel leave the lake behind the dry levee at rest, as the oracle does"""
+    if rdyhip_kernel == "cell":
+        pytest.skip("tiled kernels only")
+    import os
+    import torch
+    from rdycore_amd import cases as CS
+    from rdycore_amd.timestep import EulerStepper
+    from helpers import oracle_from_case
+    case = CS.levee_hr_case(os.path.join(os.path.dirname(houston.DATA), "levee"))
+    op = CS.create_operator(case)
+    st = EulerStepper(op)
+    u = torch.tensor(case.u_local, dtype=torch.float64, device="cuda")
+    st.advance(u, case.dt, 60.0)
+    torch.cuda.synchronize()
+    assert st.step == 600
+    orc = oracle_from_case(case)
+    u_ref = case.u_local.copy()
+    for _ in range(600):
+        u_ref = u_ref + case.dt * orc.apply(case.dt, u_ref)
+    got = u.cpu().numpy()
+    assert np.abs(got - case.u_local).max() < 1e-12          # at rest
+    assert rel_linf(got, u_ref) <= 1e-10

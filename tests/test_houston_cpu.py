@@ -33,3 +33,25 @@ def test_oracle_runs_the_houston_case(mode):
         for k in range(20):
             src += O.forcing_current_data(rain, 60.0 * k, False)[1] * 60.0 * mesh.cell_areas.sum()
         assert abs(added - (src - out)) <= 1e-9 * abs(src)
+
+
+def test_oracle_keeps_the_levee_lake_at_rest():
+    """driver/tests/swe_roe/levee.hr.yaml, the reference's hydrostatic-reconstruction test, on its own fixtures
+    (tests/golden/levee/): a lake at eta = 15 m behind a dry levee.  With HR 600 steps leave it untouched; without
+    HR the first-order scheme sets it in motion."""
+    import os
+    from rdycore_amd import cases as CS
+    from helpers import oracle_from_case
+    case = CS.levee_hr_case(os.path.join(os.path.dirname(houston.DATA), "levee"))
+    mesh = case.mesh
+    assert mesh.num_cells == 506 and [b.name for b in mesh.boundaries] == ["unassigned"]
+    wet = case.u_local[:, 0] > 0
+    assert 200 < wet.sum() < 300 and np.allclose(case.u_local[wet, 0] + mesh.cell_zc[wet], 15.0, atol=1e-12)
+    orc = oracle_from_case(case)
+    u = case.u_local.copy()
+    for _ in range(600):
+        u = u + case.dt * orc.apply(case.dt, u)
+    assert np.abs(u - case.u_local).max() < 1e-12
+    case.config.well_balancing = 0
+    f = oracle_from_case(case).apply(case.dt, case.u_local)
+    assert np.abs(f).max() > 1e-2
