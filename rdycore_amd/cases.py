@@ -127,6 +127,21 @@ def levee_hr_case(data_dir: str) -> Case:
                 np.full(no, 0.033), np.zeros((no, 3)), {}, 60.0 / 600.0)
 
 
+def mixed_elements_case(data_dir: str) -> Case:
+    """driver/tests/swe_roe/mixed_elements_ic_file.yaml on share/meshes/DamBreak_grid5x10_mixed_elements.exo: 20 quads +
+    96 triangles (two element blocks), initial state and Manning n from binary files in natural cell order, no side sets
+    (every boundary edge reflecting), 1000 steps of 0.018 s."""
+    import os
+    from . import mesh as M
+    xyz, conn, side_sets = M.read_exodus(os.path.join(data_dir, "DamBreak_grid5x10_mixed_elements.exo"))
+    mesh = M.build_mesh(xyz, conn, boundary_classifier=M.boundaries_from_side_sets(side_sets, conn))
+    u = M.read_petsc_vec(os.path.join(data_dir, "DamBreak_grid5x10_mixed_elements_wetdownstream.ic.int32.bin")).reshape(mesh.num_cells, 3)
+    n = M.read_petsc_vec(os.path.join(data_dir, "manning_grid5x10_mixed_elements.int32.bin"))[: mesh.num_cells]
+    no = mesh.num_owned_cells
+    return Case("mixed_elements", mesh, RDyFlowConfig(), [CONDITION_REFLECTING] * len(mesh.boundaries), u, n.copy(), np.zeros((no, 3)), {},
+                0.005 * 3600.0 / 1000.0)
+
+
 def create_operator(case: Case):
     """CreateOperator + the data setters the reference's setup calls
     (InitMaterialProperties / InitSourceConditions / InitDirichletBoundaryConditions,

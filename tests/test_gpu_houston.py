@@ -76,3 +76,30 @@ def test_levee_lake_at_rest_with_hydrostatic_reconstruction(rdyhip_kernel):
     got = u.cpu().numpy()
     assert np.abs(got - case.u_local).max() < 1e-12          # at rest
     assert rel_linf(got, u_ref) <= 1e-10
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_mixed_elements_dam_break_trajectory(fused, rdyhip_kernel):
+    """driver/tests/swe_roe/mixed_elements_ic_file.yaml on its own fixtures (tests/golden/mixed/): 20 quads + 96 triangles,
+    initial state and Manning n from the reference's binary files, 1000 Euler steps of 0.018 s, device against oracle"""
+    import os
+    import torch
+    from rdycore_amd import cases as CS
+    from rdycore_amd.timestep import EulerStepper
+    from helpers import oracle_from_case
+    case = CS.mixed_elements_case(os.path.join(os.path.dirname(houston.DATA), "mixed"))
+    op = CS.create_operator(case)
+    assert op.layout_info()["slots_per_cell"] == 4
+    st = EulerStepper(op, fused=fused)
+    u = torch.tensor(case.u_local, dtype=torch.float64, device="cuda")
+    st.advance(u, case.dt, 1000 * case.dt)
+    torch.cuda.synchronize()
+    assert st.step == 1000
+    orc = oracle_from_case(case)
+    u_ref = case.u_local.copy()
+    for _ in range(1000):
+        u_ref = u_ref + case.dt * orc.apply(case.dt, u_ref)
+    assert rel_linf(u.cpu().numpy(), u_ref) <= 1e-10
+    # reflecting walls all around: the water volume is the initial one
+    a = case.mesh.cell_areas
+    assert abs(u.cpu().numpy()[:, 0] @ a - case.u_local[:, 0] @ a) <= 1e-10 * (case.u_local[:, 0] @ a)

@@ -55,3 +55,12 @@ def test_oracle_keeps_the_levee_lake_at_rest():
     case.config.well_balancing = 0
     f = oracle_from_case(case).apply(case.dt, case.u_local)
     assert np.abs(f).max() > 1e-2
+
+
+def test_mixed_elements_fixture():
+    import os
+    from rdycore_amd import cases as CS
+    case = CS.mixed_elements_case(os.path.join(os.path.dirname(houston.DATA), "mixed"))
+    m = case.mesh
+    assert m.num_cells == 116 and int((m.cell_nverts == 4).sum()) == 20 and m.boundaries[0].num_edges == m.num_boundary_edges == 36
+    assert sorted(np.unique(case.u_local[:, 0]).tolist()) == [5.0, 10.0] and case.mannings.shape == (116,)
