@@ -142,6 +142,35 @@ def mixed_elements_case(data_dir: str) -> Case:
                 0.005 * 3600.0 / 1000.0)
 
 
+def quad_tri_case(data_dir: str):
+    """driver/tests/swe_roe/quad_tri_mesh.yaml on share/meshes/quad_tri_mesh.exo: 4 quads + 8 triangles in three element
+    blocks (= regions quad, tri_1, tri_2), h = 3 everywhere, Manning 0.015, boundaries right / left / bottom Dirichlet
+    (h = 5), top critical outflow, a runoff source of 2e-4 m/s on tri_1 only, 10 steps of 5e-4 s.  Returns the Case and
+    the cells' region ids (the multi-homogeneous forcing of the reference's test addresses regions 1 and 3 and
+    boundaries 1, 2 and 4)."""
+    import os
+    from . import mesh as M
+    xyz, conn, side_sets, region = M.read_exodus(os.path.join(data_dir, "quad_tri_mesh.exo"), return_regions=True)
+    names = {1: "right", 2: "left", 3: "top", 4: "bottom"}
+    side_sets = {k: v for k, v in side_sets.items() if k in names}     # side set 5 is not a boundary of the yaml
+    mesh = M.build_mesh(xyz, conn, boundary_classifier=M.boundaries_from_side_sets(side_sets, conn, names))
+    u = np.zeros((mesh.num_cells, 3))
+    u[:, 0] = 3.0
+    ctypes, bvals = [], {}
+    for i, b in enumerate(mesh.boundaries):
+        if b.name == "top":
+            ctypes.append(CONDITION_CRITICAL_OUTFLOW)
+        elif b.name in ("right", "left", "bottom"):
+            ctypes.append(CONDITION_DIRICHLET)
+            bvals[i] = np.tile([5.0, 0.0, 0.0], (b.num_edges, 1))
+        else:
+            ctypes.append(CONDITION_REFLECTING)
+    src = np.zeros((mesh.num_owned_cells, 3))
+    src[region == 2, 0] = 0.0002
+    case = Case("quad_tri", mesh, RDyFlowConfig(), ctypes, u, np.full(mesh.num_owned_cells, 0.015), src, bvals, 0.005 / 10)
+    return case, region
+
+
 def create_operator(case: Case):
     """CreateOperator + the data setters the reference's setup calls
     (InitMaterialProperties / InitSourceConditions / InitDirichletBoundaryConditions,

@@ -685,7 +685,7 @@ def read_exodus_tri(path: str) -> Tuple[np.ndarray, np.ndarray]:
     return np.stack([x, y, z], axis=1), conn
 
 
-def read_exodus(path: str):
+def read_exodus(path: str, return_regions: bool = False):
     """Exodus II (NetCDF-3) mesh with any number of TRI3 / SHELL4 element blocks and side sets (e.g.
     share/meshes/Houston1km_with_z.exo, DamBreak_grid5x10_mixed_elements.exo): returns xyz, conn
     ([cells,4], -1 padded, 0-based, blocks in file order = the natural cell order the reference's binary
@@ -698,12 +698,15 @@ def read_exodus(path: str):
     x = np.array(f.variables["coordx"][:], dtype=np.float64)
     y = np.array(f.variables["coordy"][:], dtype=np.float64)
     z = np.array(f.variables["coordz"][:], dtype=np.float64) if "coordz" in f.variables else np.zeros_like(x)
-    blocks = []
-    for b in range(1, int(f.dimensions.get("num_el_blk", 1)) + 1):
+    blocks, regions = [], []
+    nblk = int(f.dimensions.get("num_el_blk", 1))
+    blk_ids = np.array(f.variables["eb_prop1"][:], dtype=np.int64) if "eb_prop1" in f.variables else np.arange(1, nblk + 1)
+    for b in range(1, nblk + 1):
         c = np.array(f.variables[f"connect{b}"][:], dtype=np.int32) - 1
         if c.shape[1] == 3:
             c = np.concatenate([c, -np.ones((c.shape[0], 1), np.int32)], axis=1)
         blocks.append(c)
+        regions.append(np.full(c.shape[0], int(blk_ids[b - 1]), dtype=np.int32))   # grid_region_id = element block id
     conn = np.concatenate(blocks, axis=0)
     side_sets = {}
     nss = int(f.dimensions.get("num_side_sets", 0) or 0)
@@ -713,6 +716,8 @@ def read_exodus(path: str):
         sd = np.array(f.variables[f"side_ss{k}"][:], dtype=np.int64) - (3 if int(f.dimensions["num_dim"]) == 3 else 1)
         side_sets[int(ids[k - 1])] = list(zip(el.tolist(), sd.tolist()))
     f.close()
+    if return_regions:
+        return np.stack([x, y, z], axis=1), conn, side_sets, np.concatenate(regions)
     return np.stack([x, y, z], axis=1), conn, side_sets
 
 

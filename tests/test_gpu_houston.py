@@ -103,3 +103,46 @@ def test_mixed_elements_dam_break_trajectory(fused, rdyhip_kernel):
     # reflecting walls all around: the water volume is the initial one
     a = case.mesh.cell_areas
     assert abs(u.cpu().numpy()[:, 0] @ a - case.u_local[:, 0] @ a) <= 1e-10 * (case.u_local[:, 0] @ a)
+
+
+def test_quad_tri_mesh_with_multi_homogeneous_forcing(rdyhip_kernel):
+    """driver/tests/swe_roe/quad_tri_mesh.yaml with the flags of its add_test line (CMakeLists.txt:233): the rain series on
+    regions 1 and 3, the stage series on boundaries 1, 2 and 4 (FORCING_DATASET_MULTI_HOMOGENEOUS, src/forcing/rdyforcing.c:
+    728-735, 757-769), a runoff source on region 2, a critical-outflow boundary -- all three boundary kinds, regional
+    sources and mixed elements in twelve cells; 10 steps, device (Forcing + fused Euler) against oracle"""
+    import os
+    import torch
+    from oracle import oracle as O
+    from rdycore_amd import cases as CS
+    from rdycore_amd import forcing as F
+    from rdycore_amd.timestep import EulerStepper
+    from helpers import oracle_from_case
+    case, region = CS.quad_tri_case(os.path.join(os.path.dirname(houston.DATA), "quad_tri"))
+    mesh = case.mesh
+    rain, bc, _ = houston.datasets()
+    rain_regions = [np.nonzero(region == r)[0].astype(np.int32) for r in (1, 3)]
+    bc_boundaries = [mesh.boundary_by_name(n) for n in ("right", "left", "bottom")]
+    op = CS.create_operator(case)
+    frc = F.Forcing(op)
+    for ids in rain_regions:
+        frc.add_homogeneous_source(ids, F.HomogeneousDataset(rain, temporally_interpolate=False))
+    for b in bc_boundaries:
+        frc.add_homogeneous_boundary(b, F.HomogeneousDataset(bc, temporally_interpolate=False))
+    st = EulerStepper(op, forcing=frc)
+    u = torch.tensor(case.u_local, dtype=torch.float64, device="cuda")
+    st.advance(u, case.dt, 0.005)
+    torch.cuda.synchronize()
+    assert st.step == 10
+    orc = oracle_from_case(case)
+    for ids in rain_regions:
+        orc.external_sources[ids, 0] = O.forcing_current_data(rain, 0.0, False)[1]
+    for b in bc_boundaries:
+        orc.boundary_values[b][:] = [O.forcing_current_data(bc, 0.0, False)[1], 0.0, 0.0]
+    assert np.array_equal(op.external_sources.cpu().numpy(), orc.external_sources)
+    assert orc.external_sources[region == 2, 0].tolist() == [0.0002] * 4            # the yaml's runoff stays on tri_1
+    u_ref = case.u_local.copy()
+    for _ in range(10):
+        u_ref = u_ref + case.dt * orc.apply(case.dt, u_ref)
+    assert rel_linf(u.cpu().numpy(), u_ref) <= 1e-10
+    for b in range(len(mesh.boundaries)):
+        assert rel_linf(np.nan_to_num(op.boundary_fluxes(b, accumulated=True)), np.nan_to_num(orc.boundary_fluxes_accum[b])) <= 1e-10
