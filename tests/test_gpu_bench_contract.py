@@ -1,0 +1,35 @@
+"""GPU: bench.py prints ONE JSON line with the keys the driver's contract names (small mesh, a few steps)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("extra", [[], ["--second-order"], ["--hr"]])
+def test_bench_line_has_the_contract_keys(extra, rdyhip_kernel):
+    if rdyhip_kernel == "cell":
+        pytest.skip("one kernel variant is enough")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2", "--nx", "120", "--ny", "90",
+           "--cpu-sample", "60x40", "--no-cpu-all-cores"] + extra
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["metric"].startswith("M cell-updates/s") and d["unit"] == "M cell-updates/s" and d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 2
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f64" and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "model" not in d["config"] and d["config"]["finite"] is True
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert "traffic" in r and r["achieved"] > 0
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and c["unit"] == "M cell-updates/s" and "sample" in c
+    assert d["value"] > 0 and abs(d["value"] - d["config"]["cells_per_gpu"] / d["ms_per_step"] / 1e3) <= 1e-3 * d["value"] + 0.11
