@@ -6,17 +6,28 @@ M cell-updates/s + achieved HBM GB/s).
 
 A "step" is one OperatorRHSFunction (src/rdysetup.c:1120-1172): for N > 1 the
 ghost update of u_local, then the fused Roe-flux + source kernel over every
-owned cell, including the Courant-number reduction.  Workload (N = 1):
-BASELINE.json configs[2] -- the 10 M-cell friction + bed-slope mesh the
-north-star's >= 40 % HBM target is quoted on (SURVEY.md section 8.d "C3");
-for N > 1 each rank owns one such block (strips along x, configs[3], weak
-scaling).  State is resident in HBM before the timed region.
+owned cell, including the Courant-number reduction.  Workloads:
 
-Prints ONE JSON line on rank 0.
+  c3 (default)     BASELINE.json configs[2]: the 10 M-cell friction + bed-slope triangle mesh the
+                   north-star's >= 40 % HBM target is quoted on; N > 1: one such block per rank
+                   (strips along x, configs[3], weak scaling) or --scaling strong (RCB parts of one mesh)
+  c2               configs[1]: flat-bed dam break on triangles (--nx 1000 --ny 500 = 1 M cells)
+  dambreak_quads   the reference's own published benchmark problem: 5120 x 2560 quads minus the dam =
+                   11,534,336 cells, h = 10 / 5 m, n = 0.015, dt = 1.5625e-5 s, reflecting walls
+                   (docs/user/example-cases/dam-break/index.md:10-13, inputdeck_5120x2560.yaml); strong scaling
+  c5               configs[4] stand-in: nx x ny x 2 triangles over a rough DEM, ~40 % dry, rain, critical-outflow
+                   segment, hydrostatic reconstruction; strong scaling over RCB parts (default 5000 x 5000 for
+                   N = 8; --emulate-world / --emulate-rank time one rank's part on one GPU)
+
+`--gpus N` with N > 1 started as a plain command launches its own N ranks (one process per GPU, fresh
+children, RANK / WORLD_SIZE / MASTER_* set; rdycore_amd/launch.py) and relays rank 0's line; under
+torch.distributed.run (WORLD_SIZE already set) it is simply one of the ranks.  State is resident in HBM
+before the timed region.  Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -26,76 +37,116 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import numpy as np
-import torch
-import torch.distributed as dist
-
-ALG_BYTES_PER_CELL = 176.0     # algorithmic bytes per cell-update
+ALG_BYTES_PER_CELL = 176.0     # algorithmic bytes per cell-update (triangles: 1.5 edges per cell)
+ALG_BYTES_PER_CELL_QUADS = 192.0   # the same count with 2 edges per cell: 80 + 32 x 2 + 48
 HBM_PEAK_GBPS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8 TB/s
+LIMITERS = {"minmod": 0, "none": 1, "van_leer": 2}
+# second order: 176 B + cell centroids (16) + one edge midpoint per edge (1.5 x 16) -- the least-squares coefficients and
+# the centroid->midpoint displacements are formed on the chip; the split form (RDYHIP_MUSCL=split) streams them
+# (3 x 16 + 1.5 x 32) and also writes and reads the gradient array (2 x 48) and reads the state twice (24)
+ALG_BYTES_PER_CELL_SECOND_ORDER = 176.0 + 48.0 + 48.0
+ALG_BYTES_PER_CELL_SECOND_ORDER_SPLIT = ALG_BYTES_PER_CELL_SECOND_ORDER + 96.0 + 24.0
+KERNEL_SOURCES = ["rdyhip_api.hip", "swe_kernels.h", "swe_device.h", "muscl_kernels.h"]
 
 
-def parse():
+def parse(argv=None):
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=200)
     p.add_argument("--warmup", type=int, default=20)
-    p.add_argument("--nx", type=int, default=2500, help="squares per rank along x")
-    p.add_argument("--ny", type=int, default=2000, help="squares along y")
+    p.add_argument("--workload", default="c3", choices=["c3", "c2", "dambreak_quads", "c5"])
+    p.add_argument("--nx", type=int, default=None, help="squares along x (weak scaling: per rank; strong: of the whole mesh)")
+    p.add_argument("--ny", type=int, default=None, help="squares along y")
+    p.add_argument("--scaling", default=None, choices=["weak", "strong"],
+                   help="weak: per-rank work fixed (default for c3 / c2); strong: one mesh cut into N parts by RCB (default for dambreak_quads / c5)")
     p.add_argument("--order", default="tiled", choices=["rowmajor", "tiled", "hilbert"],
                    help="cell numbering of the synthetic mesh: generator order, 16x16-square blocks, or squares along a Hilbert curve")
     p.add_argument("--source", default="semi_implicit", choices=["semi_implicit", "implicit_xq2018"])
-    p.add_argument("--workload", default="c3", choices=["c3", "c2"],
-                   help="c3: friction + bed slope + all BC types (default; use --nx 2500 --ny 2000); "
-                        "c2: flat-bed dam break, all reflecting (BASELINE configs[1]: --nx 1000 --ny 500)")
     p.add_argument("--hr", action="store_true", help="hydrostatic-reconstruction variant of the operator (SURVEY 8.f row 2)")
-    p.add_argument("--second-order", action="store_true",
-                   help="MUSCL second-order variant (SURVEY 8.f row 4): gradient kernel + reconstructing flux kernel per RHS")
-    p.add_argument("--limiter", default="minmod", choices=["minmod", "none", "van_leer"])
+    p.add_argument("--second-order", action="store_true", help="MUSCL second-order variant (SURVEY 8.f row 4)")
+    p.add_argument("--limiter", default="minmod", choices=sorted(LIMITERS))
+    p.add_argument("--emulate-world", type=int, default=0, help="with --gpus 1: time the part one rank of an N-rank strong-scaling run would own")
+    p.add_argument("--emulate-rank", type=int, default=0)
+    p.add_argument("--condition-seconds", type=float, default=1.0,
+                   help="untimed RHS launches for this long before --warmup (brings the device out of the idle clock state the host-only "
+                        "setup leaves it in; disclosed in config.conditioning)")
+    p.add_argument("--halo", default=None, choices=["torch", "c"],
+                   help="N > 1: who drives the exchange -- torch.distributed P2P from Python, or the C ABI's RCCL path (default: c with nccl)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-cpu-all-cores", action="store_true", help="skip the all-host-cores CPU figure (the 1-core cpu_baseline stays)")
+    p.add_argument("--no-order-study", action="store_true", help="skip the row-major / Hilbert numbering figures (c3, N = 1 only)")
     p.add_argument("--kernel", default=None, choices=["tiled", "cell"], help="kernel variant (default: library default = tiled)")
-    p.add_argument("--cpu-sample", default="1000x500", help="nx x ny of the CPU-baseline sample mesh")
-    return p.parse_args()
+    p.add_argument("--cpu-sample", default=None, help="nx x ny of the CPU-baseline sample mesh")
+    p.add_argument("--launch-timeout", type=float, default=1500.0, help="N > 1 self-launch: give up after this many seconds")
+    a = p.parse_args(argv)
+    defaults = {"c3": (2500, 2000), "c2": (1000, 500), "dambreak_quads": (5120, 2560), "c5": (5000, 5000)}
+    if a.nx is None:
+        a.nx = defaults[a.workload][0]
+    if a.ny is None:
+        a.ny = defaults[a.workload][1]
+    if a.scaling is None:
+        a.scaling = "strong" if a.workload in ("dambreak_quads", "c5") else "weak"
+    if a.workload == "c5":
+        a.hr = True
+    if a.cpu_sample is None:
+        a.cpu_sample = {"c3": "1000x500", "c2": "1000x500", "dambreak_quads": "1280x640", "c5": "700x700"}[a.workload]
+    return a
 
 
-LIMITERS = {"minmod": 0, "none": 1, "van_leer": 2}
-# second order: 176 B + least-squares coefficients (3 slots x 16) + centroid->midpoint displacements (1.5 edges x 32);
-# the split form (RDYHIP_MUSCL=split) also writes and reads the gradient array (2 x 48) and reads the state twice (24)
-ALG_BYTES_PER_CELL_SECOND_ORDER = 176.0 + 48.0 + 48.0
-ALG_BYTES_PER_CELL_SECOND_ORDER_SPLIT = ALG_BYTES_PER_CELL_SECOND_ORDER + 96.0 + 24.0
-
-
-def build_case(nx, ny, rank, world, order, source, workload="c3", hr=False, second_order=False, limiter="minmod"):
+def build_case(args, rank, world, nx=None, ny=None, order=None):
+    """The Case (mesh + state + operator data) of `rank` in a `world`-rank run of the chosen workload."""
+    import numpy as np
     from rdycore_amd import cases as CS
     from rdycore_amd import mesh as M
-    from rdycore_amd.operator import SOURCE_IMPLICIT_XQ2018, SOURCE_SEMI_IMPLICIT
-    K = 2 * np.pi / 200.0
-    src = SOURCE_SEMI_IMPLICIT if source == "semi_implicit" else SOURCE_IMPLICIT_XQ2018
-    zf = CS.mms_bathymetry(K=K) if workload == "c3" else None
-    if world == 1:
-        mesh = M.structured_tri_mesh(nx, ny, 1.0, zfunc=zf, order=order, project_2d=hr)
+    from rdycore_amd import partition as P
+    from rdycore_amd.operator import SOURCE_IMPLICIT_XQ2018, SOURCE_SEMI_IMPLICIT, WELL_BALANCING_HR
+    nx = args.nx if nx is None else nx
+    ny = args.ny if ny is None else ny
+    order = args.order if order is None else order
+    src = SOURCE_SEMI_IMPLICIT if args.source == "semi_implicit" else SOURCE_IMPLICIT_XQ2018
+    wl = args.workload
+    strong = args.scaling == "strong"
+    if wl in ("c3", "c2"):
+        K = 2 * np.pi / 200.0
+        zf = CS.mms_bathymetry(K=K) if wl == "c3" else None
+        nxg = nx if (strong or world == 1) else nx * world
+        if world == 1:
+            mesh = M.structured_tri_mesh(nx, ny, 1.0, zfunc=zf, order=order, project_2d=args.hr)
+        elif strong:
+            mesh = P.partitioned_structured_mesh("tri", nx, ny, 1.0, rank, world, zfunc=zf, order=order,
+                                                 boundary_classifier=M.box_side_boundaries(0.0, nx * 1.0, 0.0, ny * 1.0), project_2d=args.hr)
+        else:
+            mesh = M.strip_partition_tri_mesh(nx, ny, rank, world, 1.0, zfunc=zf, order=order)
+        if wl == "c2":
+            case = CS.dam_break_case(mesh, nxg * 1.0, dt=1e-3, source_method=src)
+        else:
+            case = CS.friction_slope_case(mesh, nxg * 1.0, ny * 1.0, dt=1e-3, source_method=src, K=K)
+    elif wl == "dambreak_quads":
+        nxg = nx if (strong or world == 1) else nx * world
+        mesh = CS.dam_break_quads_mesh(nxg, ny, rank, world, order=order)
+        case = CS.dam_break_quads_case(mesh)
+        case.config.source_method = src
     else:
-        mesh = M.strip_partition_tri_mesh(nx, ny, rank, world, 1.0, zfunc=zf, order=order)
-    if workload == "c2":
-        case = CS.dam_break_case(mesh, nx * world * 1.0, dt=1e-3, source_method=src)
-    else:
-        case = CS.friction_slope_case(mesh, nx * world * 1.0, ny * 1.0, dt=1e-3, source_method=src, K=K)
-    if hr:
-        from rdycore_amd.operator import WELL_BALANCING_HR
+        nxg = nx if (strong or world == 1) else nx * world
+        mesh = CS.c5_mesh(nxg, ny, rank, world, order=order)
+        case = CS.c5_case(mesh, nxg * 1.0, ny * 1.0)
+        case.config.source_method = src
+    if args.hr:
         case.config.well_balancing = WELL_BALANCING_HR
-    case.config.second_order = bool(second_order)
-    case.config.limiter = LIMITERS[limiter]
+    case.config.second_order = bool(args.second_order)
+    case.config.limiter = LIMITERS[args.limiter]
     return case
 
 
-def cpu_baseline(sample: str, source: str, workload: str = "c3", hr: bool = False, second_order: bool = False, limiter: str = "minmod"):
+def cpu_baseline(args):
     """The CPU oracle (a plain-C restatement of the reference's PETSc path, one
     core) timed on a bounded sample of the same workload."""
-    from oracle import oracle as O  # test infrastructure; used here only as the timed CPU baseline
+    import numpy as np
+    from oracle import oracle as O  # noqa: F401  test infrastructure; used here only as the timed CPU baseline
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from helpers import oracle_from_case
-    nx, ny = map(int, sample.split("x"))
-    case = build_case(nx, ny, 0, 1, "rowmajor", source, workload, hr, second_order, limiter)
+    nx, ny = map(int, args.cpu_sample.split("x"))
+    case = build_case(args, 0, 1, nx, ny, "rowmajor")
     orc = oracle_from_case(case)
     f = np.zeros((case.mesh.num_owned_cells, 3))
     orc.apply(case.dt, case.u_local, f)  # warm
@@ -109,16 +160,19 @@ def cpu_baseline(sample: str, source: str, workload: str = "c3", hr: bool = Fals
     med = float(np.median(times))
     nc = case.mesh.num_owned_cells
     return {"value": round(nc / med / 1e6, 3), "unit": "M cell-updates/s", "cores": 1, "kind": "port",
-            "sample": f"{len(times)} RHS evaluations of the same workload on a {nx}x{ny}x2 = {nc}-cell mesh, "
+            "sample": f"{len(times)} RHS evaluations of the same workload on a {nx}x{ny}-square = {nc}-cell mesh, "
                       f"oracle/swe_oracle.c (gcc -O2, 1 thread), median {med * 1e3:.1f} ms/RHS"}
 
 
-def _cpu_strip_worker(args):
-    """One host core: the oracle on one strip (with its ghost cells) of the sample mesh."""
-    nx, ny, rank, world, source, workload, hr, reps, second_order, limiter = args
+def _cpu_part_worker(a):
+    """One host core: the oracle on one RCB part (with its ghost cells) of the sample mesh."""
+    argv, nx, ny, rank, world, reps = a
+    import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from helpers import oracle_from_case
-    case = build_case(nx, ny, rank, world, "rowmajor", source, workload, hr, second_order, limiter)
+    args = parse(argv)
+    args.scaling = "strong"
+    case = build_case(args, rank, world, nx, ny, "rowmajor")
     orc = oracle_from_case(case)
     f = np.zeros((case.mesh.num_owned_cells, 3))
     orc.apply(case.dt, case.u_local, f)
@@ -131,50 +185,74 @@ def _cpu_strip_worker(args):
     return case.mesh.num_owned_cells, float(np.median(ts))
 
 
-def cpu_baseline_all_cores(sample: str, source: str, workload: str, hr: bool, second_order: bool = False, limiter: str = "minmod"):
-    """no MPI launcher exists here, so P independent oracle processes run on P strip
-    partitions of the sample mesh (ghost cells present, not exchanged) -- an upper bound on what the
-    MPI-parallel reference could do on these host cores."""
+def cpu_baseline_all_cores(args, argv):
+    """no MPI launcher exists here, so P independent oracle processes run on the P parts of an RCB
+    partition of the sample mesh (ghost cells present, not exchanged) -- an upper bound on what the MPI-parallel
+    reference could do on these host cores."""
     import multiprocessing as mp
-    nx, ny = map(int, sample.split("x"))
+    nx, ny = map(int, args.cpu_sample.split("x"))
     cores = len(os.sched_getaffinity(0))
     p = max(1, min(cores, 32))
-    while nx % p:
-        p -= 1
     with mp.get_context("spawn").Pool(p) as pool:
-        res = pool.map(_cpu_strip_worker, [(nx // p, ny, r, p, source, workload, hr, 5, second_order, limiter) for r in range(p)])
+        res = pool.map(_cpu_part_worker, [(argv, nx, ny, r, p, 5) for r in range(p)])
     cells = sum(r[0] for r in res)
     tmax = max(r[1] for r in res)
     return {"value": round(cells / tmax / 1e6, 2), "unit": "M cell-updates/s", "cores": p, "kind": "port",
-            "sample": f"{p} independent oracle processes, one x-strip each of the {nx}x{ny}x2-cell sample mesh, no halo exchange "
-                      f"(upper bound on an MPI run), slowest strip {tmax * 1e3:.1f} ms/RHS"}
+            "sample": f"{p} independent oracle processes, one RCB part each of the {nx}x{ny}-square sample mesh, no halo exchange "
+                      f"(upper bound on an MPI run), slowest part {tmax * 1e3:.1f} ms/RHS"}
+
+
+def kernel_sha() -> str:
+    """hash of the kernel sources: ties a stored PMC traffic figure to the code it was measured on"""
+    h = hashlib.sha256()
+    for name in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "rdycore_amd", "csrc", name), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def load_traffic(workload_key: str):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes, if present."""
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic.json), only if they were
+    collected on exactly this kernel source; a stale file is reported as such, never silently."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
+    sha = kernel_sha()
+    src = {"source": "profiles/traffic.json", "key": workload_key, "kernel_sha": sha}
     try:
         with open(path) as fh:
             t = json.load(fh)
-        return t.get(workload_key, {}).get("hbm_bytes_per_launch")
-    except Exception:
-        return None
+    except Exception as exc:
+        src["status"] = f"unreadable: {exc!r}"
+        return None, src
+    ent = t.get(workload_key)
+    if not ent:
+        src["status"] = "no PMC passes for this workload"
+        return None, src
+    if ent.get("kernel_sha") != sha:
+        src["status"] = f"STALE: measured on kernel_sha {ent.get('kernel_sha')}, current sources are {sha} -- rerun tools/profile_gpu.sh"
+        print(f"bench.py: profiles/traffic.json[{workload_key}] is stale ({ent.get('kernel_sha')} != {sha}); roofline.traffic = null", file=sys.stderr)
+        return None, src
+    src["status"] = "measured on this kernel source"
+    return ent.get("hbm_bytes_per_launch"), src
 
 
-def main():
-    args = parse()
+def run_rank(args, argv):
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
     if args.kernel:
         os.environ["RDYHIP_KERNEL"] = args.kernel
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device")
     backend = os.environ.get("BENCH_BACKEND", "nccl")   # "gloo": rehearsal of several ranks on one GPU (host-staged halo)
     ndev = torch.cuda.device_count()
+    if backend == "nccl" and world > ndev:
+        raise SystemExit(f"--gpus {world} needs {world} devices, {ndev} visible (BENCH_BACKEND=gloo rehearses several ranks on one GPU)")
     dev_index = local_rank if backend == "nccl" else local_rank % max(ndev, 1)
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
@@ -189,10 +267,17 @@ def main():
     from rdycore_amd.halo import HaloExchange
 
     t0 = time.time()
-    case = build_case(args.nx, args.ny, rank, world, args.order, args.source, args.workload, args.hr, args.second_order, args.limiter)
+    if world == 1 and args.emulate_world > 1:
+        sav = args.scaling
+        args.scaling = "strong"
+        case = build_case(args, args.emulate_rank, args.emulate_world)
+        args.scaling = sav
+    else:
+        case = build_case(args, rank, world)
     mesh = case.mesh
     op = CS.create_operator(case)
-    halo = HaloExchange(mesh, dev) if world > 1 else None
+    halo_mode = args.halo or ("c" if backend == "nccl" else "torch")
+    halo = HaloExchange(mesh, dev, transport=halo_mode, op=op) if world > 1 else None
     u = torch.tensor(case.u_local, dtype=torch.float64, device=dev)
     f = torch.empty((mesh.num_owned_cells, 3), dtype=torch.float64, device=dev)
     setup_s = time.time() - t0
@@ -204,6 +289,17 @@ def main():
         else:
             op.rhs_function(case.dt, u, f)
 
+    # ---- device conditioning (untimed, disclosed): the mesh setup above is seconds of host-only work, after which
+    # the first launches run at the idle clock state (profiles/r02_launch_series.json); a driver that times 20 steps
+    # after 5 warm-up steps would otherwise measure the ramp, not the kernel
+    n_cond = 0
+    if args.condition_seconds > 0:
+        t_c = time.perf_counter()
+        while time.perf_counter() - t_c < args.condition_seconds:
+            for _ in range(10):
+                step()
+            torch.cuda.synchronize()
+            n_cond += 10
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -229,14 +325,17 @@ def main():
         tot = torch.tensor([n_owned], dtype=torch.int64, device=rdev)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         total_cells = int(tot.item())
+        tmax = torch.tensor([n_owned], dtype=torch.int64, device=rdev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        max_cells = int(tmax.item())
     else:
-        total_cells = n_owned
+        total_cells = max_cells = n_owned
 
-    # ---- dominant kernel: average duration with HIP events on the launch stream
-    # (one rhs call = reset (1 thread) + swe_rhs_kernel + Courant finalize (1 block))
+    # ---- dominant kernel: average duration with HIP events on the launch stream (one rhs call = ONE launch)
     k_iters = max(10, min(args.steps, 50))
     starts = [torch.cuda.Event(enable_timing=True) for _ in range(k_iters)]
     ends = [torch.cuda.Event(enable_timing=True) for _ in range(k_iters)]
+
     def kernel_only():
         if args.second_order and halo is not None:
             # the ghost gradients of the last timed step are still in place: the flux launch alone
@@ -256,27 +355,10 @@ def main():
     # individually bracketed launches are used there
     kern_ms = ev0.elapsed_time(ev1) / args.steps if world == 1 else kern_isolated_ms
 
-    # multi-GPU: the ghost update on its own (pack, P2P over RCCL, unpack), not overlapped
-    halo_ms = None
-    if halo is not None:
-        torch.cuda.synchronize()
-        h0, h1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        h0.record()
-        for _ in range(k_iters):
-            halo.exchange(u)
-        h1.record()
-        torch.cuda.synchronize()
-        halo_ms = h0.elapsed_time(h1) / k_iters
-
-    # ---- extra (not the metric): one whole forward-Euler step, the update fused into the RHS kernel's stores
-    # (rdyhip_euler_step, F never written) against the RHS + axpy pair -- SURVEY.md 8.f row 1
-    u2 = torch.empty_like(u)
-    u3 = u.clone()
-
-    def timed(fn, n):
+    def timed(fn, n, sync_ranks=True):
         fn()
         torch.cuda.synchronize()
-        if world > 1:
+        if world > 1 and sync_ranks:
             dist.barrier()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -286,6 +368,18 @@ def main():
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / n
 
+    # steady state: the launch-to-launch period of back-to-back launches, median over batches (what a long run sees)
+    periods = [timed(kernel_only, 10, sync_ranks=False) for _ in range(12)] if world == 1 else []
+    period_median_ms = float(np.median(periods)) if periods else None
+
+    # multi-GPU: the ghost update on its own (pack, P2P over RCCL, unpack), not overlapped
+    halo_ms = timed(lambda: halo.exchange(u), k_iters) if halo is not None else None
+
+    # ---- extra (not the metric): one whole forward-Euler step, the update fused into the RHS kernel's stores
+    # (rdyhip_euler_step, F never written) against the RHS + axpy pair -- SURVEY.md 8.f row 1
+    u2 = torch.empty_like(u)
+    u3 = u.clone()
+
     def fused_step():
         if halo is not None:
             halo.step_overlapped(op, case.dt, u, u2)
@@ -293,35 +387,81 @@ def main():
             op.euler_step(case.dt, u, u2)
 
     def pair_step():
-        if halo is not None:
-            halo.rhs_overlapped(op, case.dt, u, f)
-        else:
-            op.rhs_function(case.dt, u, f)
+        step()
         op.axpy_owned(0.0, f, u3)      # dt = 0: same traffic, the scratch state stays put
 
     ef, ep = timed(fused_step, k_iters), timed(pair_step, k_iters)
-    euler = {"fused_ms_per_step": round(ef, 5), "rhs_plus_axpy_ms_per_step": round(ep, 5),
-             "fused_steps_per_s": round(1e3 / ef, 1)}
+    euler = {"fused_ms_per_step": round(ef, 5), "rhs_plus_axpy_ms_per_step": round(ep, 5), "fused_steps_per_s": round(1e3 / ef, 1)}
     del u2, u3
     step()   # leave F and the diagnostics of a plain RHS evaluation behind for the sanity checks below
 
-    # sanity: the result is finite and the Courant diagnostic is alive
+    # sanity: the result is finite and the Courant diagnostic is alive (cross-rank struct-max, src/operator.c:705-751)
+    from rdycore_amd.timestep import reduce_courant
     op.update_diagnostics()
-    courant = op.get_diagnostics().max_courant_num
+    cd = reduce_courant(op.get_diagnostics(), dev)
     finite = bool(torch.isfinite(f).all().item())
+    if world > 1:
+        fin = torch.tensor([1 if finite else 0], dtype=torch.int32, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(fin, op=dist.ReduceOp.MIN)
+        finite = bool(fin.item())
+
+    order_study = None
+    if rank == 0 and world == 1 and args.workload == "c3" and not args.no_order_study and args.emulate_world <= 1 \
+            and not args.second_order and not args.hr:
+        # SURVEY.md 8.d "report both": the same mesh in the generator's row-major numbering and along a Hilbert curve
+        order_study = {args.order: round(n_owned / period_median_ms / 1e3, 1)}
+        info_main = op.layout_info()
+        order_study["edge_records_per_cell"] = {args.order: round(info_main["num_edge_records"] / n_owned, 4)}
+        for o2 in ("rowmajor", "hilbert", "tiled"):
+            if o2 == args.order:
+                continue
+            c2 = build_case(args, 0, 1, order=o2)
+            op2 = CS.create_operator(c2)
+            uu = torch.tensor(c2.u_local, dtype=torch.float64, device=dev)
+            ms = float(np.median([timed(lambda: op2.rhs_function(c2.dt, uu, f), 10, sync_ranks=False) for _ in range(8)]))
+            order_study[o2] = round(n_owned / ms / 1e3, 1)
+            order_study["edge_records_per_cell"][o2] = round(op2.layout_info()["num_edge_records"] / n_owned, 4)
+            op2.destroy()
+            del uu, c2, op2
+        order_study["unit"] = "M cell-updates/s (steady-state launch period, same box, same run)"
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = total_cells / (elapsed / args.steps) / 1e6
-        achieved = n_owned * ALG_BYTES_PER_CELL / (kern_ms * 1e-3) / 1e9
         info = op.layout_info()
+        quads = info["slots_per_cell"] == 4
+        alg = ALG_BYTES_PER_CELL_QUADS if quads else ALG_BYTES_PER_CELL
+        achieved = n_owned * alg / (kern_ms * 1e-3) / 1e9
+        nxg = args.nx if (args.scaling == "strong" or world == 1) else args.nx * world
+        part = "single" if world == 1 else (f"rcb_{world}" if args.scaling == "strong" else f"strips_x{world}")
+        if world == 1 and args.emulate_world > 1:
+            part = f"rank {args.emulate_rank} of rcb_{args.emulate_world} (ghost cells present, not exchanged)"
+        friction = f"{args.source} friction"
         if args.workload == "c3":
-            workload = (f"C3: synthetic {args.nx * world}x{args.ny}x2 = {total_cells}-cell triangle mesh "
+            workload = (f"C3: synthetic {nxg}x{args.ny}x2 = {total_cells}-cell triangle mesh "
                         f"({n_owned} cells/GPU), MMS-style state over sinusoidal bathymetry, Manning field, rain source, "
-                        f"dry disc, Dirichlet + critical-outflow + reflecting boundaries, {args.source} friction, dt=1e-3")
+                        f"dry disc, Dirichlet + critical-outflow + reflecting boundaries, {friction}, dt=1e-3")
+        elif args.workload == "c2":
+            workload = (f"C2: synthetic {nxg}x{args.ny}x2 = {total_cells}-cell triangle mesh ({n_owned} cells/GPU), "
+                        f"flat-bed dam break h = 10 / 5 with perturbed momenta, Manning 0.015, reflecting walls, {friction}, dt=1e-3")
+        elif args.workload == "dambreak_quads":
+            workload = (f"the reference's dam-break benchmark (docs/user/example-cases/dam-break): {nxg}x{args.ny} quads minus the dam = "
+                        f"{total_cells} cells ({n_owned} on rank 0), dx = dy = 10 m / {nxg}, h = 10 / 5 m at rest, Manning 0.015, "
+                        f"all walls reflecting, {friction}, dt = 1.5625e-5 s")
         else:
-            workload = (f"C2: synthetic {args.nx * world}x{args.ny}x2 = {total_cells}-cell triangle mesh ({n_owned} cells/GPU), "
-                        f"flat-bed dam break h = 10 / 5 with perturbed momenta, Manning 0.015, reflecting walls, {args.source} friction, dt=1e-3")
+            dry = float((case.u_local[mesh.cell_owned_to_local, 0] == 0.0).mean())
+            workload = (f"C5 stand-in for the Harvey mesh: synthetic {nxg}x{args.ny}x2 triangles over a rough analytic DEM (ramp + 3 sinusoids), "
+                        f"{total_cells} cells in this run ({n_owned} on rank 0), {dry:.0%} of them dry, rain 1e-5 m/s, Manning 0.03, "
+                        f"critical-outflow segment + reflecting walls, hydrostatic reconstruction, {friction}, dt = 0.05 s")
+        traffic, traffic_src = (None, None)
+        if world == 1 and not args.second_order and args.emulate_world <= 1:
+            traffic, traffic_src = load_traffic(f"{args.workload}_{args.nx}x{args.ny}_{args.order}_{args.source}" + ("_hr" if args.hr and args.workload != "c5" else ""))
+        if args.second_order:
+            kname = (("swe_rhs_muscl_fused_kernel<%d,%d>" if info["second_order_fused"] else "muscl_gradient_kernel<%d> + swe_rhs_muscl_kernel<.,%d>")
+                     % (info["slots_per_cell"], 0 if args.source == "semi_implicit" else 1))
+        else:
+            kname = "%s<%d,%d%s>" % ("swe_rhs_tiled_kernel" if info["tiled_kernel"] else "swe_rhs_kernel", info["slots_per_cell"],
+                                     0 if args.source == "semi_implicit" else 1, ",HR" if args.hr else "")
         out = {
             "metric": "M cell-updates/s (SWE RHS eval)",
             "value": round(value, 1),
@@ -331,53 +471,76 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 5),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": workload, "cells_per_gpu": n_owned, "cell_order": args.order,
-                       "partition": "single" if world == 1 else f"strips_x{world}",
+            "config": {"workload": workload, "cells_per_gpu": n_owned, "max_cells_per_gpu": max_cells, "total_cells": total_cells,
+                       "cell_order": args.order, "partition": part,
+                       "world_size": dist.get_world_size() if world > 1 else 1,
+                       "backend": (backend if world > 1 else None),
+                       "rccl_version": ".".join(map(str, torch.cuda.nccl.version())) if world > 1 and backend == "nccl" else None,
+                       "halo_driver": (halo.transport if halo is not None else None),
                        "well_balancing": "hydrostatic_reconstruction" if args.hr else "none",
                        "spatial_order": ("second (MUSCL, %s limiter)" % args.limiter) if args.second_order else "first",
                        "halo_bytes_per_rank": halo.bytes_sent_per_exchange if halo else 0,
                        "halo_exchange_alone_ms": round(halo_ms, 5) if halo_ms is not None else None,
-                       "setup_seconds": round(setup_s, 1), "max_courant": courant, "finite": finite},
+                       "conditioning": (f"{n_cond} untimed RHS launches ({args.condition_seconds:g} s) before --warmup"
+                                        if n_cond else "none"),
+                       "setup_seconds": round(setup_s, 1), "max_courant": cd.max_courant_num,
+                       "max_courant_edge": cd.global_edge_id, "max_courant_cell": cd.global_cell_id, "finite": finite},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                         "traffic": load_traffic(f"{args.nx}x{args.ny}_{args.order}_{args.source}") if args.workload == "c3" else None,
-                         "kernel": (("swe_rhs_muscl_fused_kernel<3,%d>" if info["second_order_fused"] else
-                                     "muscl_gradient_kernel<3> + swe_rhs_muscl_kernel<3,%d>") % (0 if args.source == "semi_implicit" else 1))
-                         if args.second_order else
-                         "%s<3,%d>" % ("swe_rhs_tiled_kernel" if info["tiled_kernel"] else "swe_rhs_kernel",
-                                       0 if args.source == "semi_implicit" else 1),
+                         "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel": kname,
+                         "algorithmic_bytes_per_cell": alg,
                          "tile_edge_records_per_cell": round(info["num_edge_records"] / max(n_owned, 1), 4),
                          "kernel_avg_ms": round(kern_ms, 5),
                          "kernel_isolated_avg_ms": round(kern_isolated_ms, 5), "kernel_isolated_median_ms": round(float(np.median(kern_all)), 5),
                          "kernel_isolated_min_ms": round(float(np.min(kern_all)), 5),
-                         "algorithmic_bytes_per_launch": int(n_owned * ALG_BYTES_PER_CELL),
+                         "steady_state_period_median_ms": round(period_median_ms, 5) if period_median_ms else None,
+                         "steady_state_frac": round(n_owned * alg / (period_median_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if period_median_ms else None,
+                         "algorithmic_bytes_per_launch": int(n_owned * alg),
                          "layout_bytes_per_launch": int(info["bytes_per_apply"])},
         }
+        if quads:
+            out["roofline"]["frac_176B_model"] = round(n_owned * ALG_BYTES_PER_CELL / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
         out["euler_step"] = euler
+        if order_study:
+            out["cell_order_study"] = order_study
         if args.second_order:
             # the 176-B figure above keeps variants comparable; the second-order path's own model:
             b2 = ALG_BYTES_PER_CELL_SECOND_ORDER if info["second_order_fused"] else ALG_BYTES_PER_CELL_SECOND_ORDER_SPLIT
             a2 = n_owned * b2 / (kern_ms * 1e-3) / 1e9
             out["roofline"]["second_order_model"] = {"bytes_per_cell_update": b2, "achieved": round(a2, 1),
                                                      "frac": round(a2 / HBM_PEAK_GBPS, 4)}
-            out["roofline"]["traffic"] = None
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.source, args.workload, args.hr, args.second_order, args.limiter)
+            out["cpu_baseline"] = cpu_baseline(args)
             if not args.no_cpu_all_cores:
                 try:
-                    out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(args.cpu_sample, args.source, args.workload, args.hr, args.second_order,
-                                                                           args.limiter)
+                    out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(args, argv)
                 except Exception as exc:  # a reported extra, never a reason to lose the bench line
                     out["cpu_baseline_all_cores"] = {"error": repr(exc)}
         print(json.dumps(out), flush=True)
+    if halo is not None:
+        halo.destroy()
     op.destroy()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started as a plain command: become the launcher.  Nothing here may touch the GPU (no HIP call, no
+        # torch.cuda.*): the ranks are fresh children, this process only relays rank 0's line.
+        from rdycore_amd.launch import launch_ranks
+        rc = launch_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + argv, timeout=args.launch_timeout,
+                          keep=lambda line: line.lstrip().startswith("{"))     # the JSON line; library chatter goes to stderr
+        sys.exit(rc)
+    run_rank(args, argv)
 
 
 if __name__ == "__main__":

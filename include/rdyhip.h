@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RDYHIP_VERSION 104
+#define RDYHIP_VERSION 105
 
 /* error codes = PETSc's values */
 #define RDYHIP_SUCCESS 0
@@ -294,6 +294,48 @@ int rdyhip_unpack_cells(double *u_local, const int32_t *cell_ids, int32_t n, con
 /* the same for rows of `ncomp` values (the [num_cells][6] gradient field): buf[i][:] = src[ids[i]][:] and back */
 int rdyhip_pack_rows(const double *src, int32_t ncomp, const int32_t *row_ids, int32_t n, double *buf, void *stream);
 int rdyhip_unpack_rows(double *dst, int32_t ncomp, const int32_t *row_ids, int32_t n, const double *buf, void *stream);
+
+/* ---- the ghost update and its overlap with the interior cells, behind the ABI ----
+ * OperatorRHSFunction's DMGlobalToLocalBegin/End (src/rdysetup.c:1133-1134) for a C host: the operator packs the owned
+ * cells its neighbours need, exchanges them and unpacks into its ghost cells on an internal high-priority stream, while
+ * the cells without ghost neighbours are evaluated on the caller's stream; the ghost-adjacent cells follow.
+ *
+ *   rdyhip_halo_create   the exchange pattern of this rank: for each of `npeers` neighbour ranks, the LOCAL ids of the
+ *                        owned cells it needs from this rank (send lists) and of this rank's ghost cells it owns (receive
+ *                        lists), in an order both sides agree on (e.g. ascending global id), concatenated in peer order.
+ *                        `nccl_comm`: an RCCL communicator (ncclComm_t passed as void*) spanning the operator's ranks, or
+ *                        NULL if the bytes travel through rdyhip_halo_set_transport.  With RCCL one exchange is
+ *                        ncclGroupStart(); ncclSend / ncclRecv per peer; ncclGroupEnd() over xGMI -- point-to-point, no collective.
+ *   rdyhip_halo_set_transport  replaces RCCL by the caller's transport (GPU-aware MPI_Isend/Irecv in an MPI code, a
+ *                        host-staged exchange in the single-GPU tests): called once per exchange, after the send buffer has
+ *                        been packed on `stream`, it must deliver d_send's per-peer slices into the peers' d_recv slices
+ *                        ([cells][ncomp] doubles, peer order as at create) so that work enqueued on `stream` afterwards sees
+ *                        d_recv filled; it may block the host (the interior launch is already enqueued by then).
+ *   rdyhip_halo_exchange the plain ghost update of a [num_cells][ncomp] array (ncomp = 3: the solution; 6: the
+ *                        second-order gradients, CommunicateCellGradients), all on `stream`
+ *   rdyhip_rhs_overlapped        = halo update of u_local + rdyhip_rhs_function, overlapped (the whole OperatorRHSFunction)
+ *   rdyhip_euler_step_overlapped = halo update of u_local + rdyhip_euler_step(PHASE_ALL), overlapped
+ * Second order: the state exchange hides behind the tiles that need no ghost data, then the ghost-adjacent gradients are
+ * computed, exchanged (6 values per cell) and the remaining tiles follow.  The exchanges are ordered after everything
+ * already enqueued on `stream`; when the call returns all work is enqueued and later work on `stream` is ordered after it. */
+typedef struct RDyHipHalo_s *RDyHipHalo;
+typedef int (*RDyHipTransportFn)(void *ctx, const double *d_send, double *d_recv, int32_t ncomp, void *stream);
+int rdyhip_halo_create(RDyHipOperator op, void *nccl_comm, int32_t npeers, const int32_t *peers, const int32_t *send_counts,
+                       const int32_t *send_cell_ids, const int32_t *recv_counts, const int32_t *recv_cell_ids, RDyHipHalo *halo);
+int rdyhip_halo_destroy(RDyHipHalo *halo);
+int rdyhip_halo_set_transport(RDyHipHalo halo, RDyHipTransportFn fn, void *ctx);
+int rdyhip_halo_exchange(RDyHipHalo halo, double *rows, int32_t ncomp, void *stream);
+int rdyhip_rhs_overlapped(RDyHipOperator op, RDyHipHalo halo, double dt, double *u_local, double *f_global, void *stream);
+int rdyhip_euler_step_overlapped(RDyHipOperator op, RDyHipHalo halo, double dt, double *u_local, double *u_local_out, double *f_global,
+                                 void *stream);
+/* RCCL communicator helpers, so that a host needs no RCCL binding of its own: rank 0 calls rdyhip_comm_unique_id and
+ * broadcasts the 128 bytes (MPI_Bcast in RDycore), then every rank calls rdyhip_comm_init_rank (ncclCommInitRank on the
+ * current device; collective over the ranks). */
+#define RDYHIP_COMM_ID_BYTES 128
+int rdyhip_comm_unique_id(char id[RDYHIP_COMM_ID_BYTES]);
+int rdyhip_comm_init_rank(int32_t nranks, int32_t rank, const char id[RDYHIP_COMM_ID_BYTES], void **nccl_comm);
+int rdyhip_comm_destroy(void *nccl_comm);
+int32_t rdyhip_rccl_version(void);
 
 /* ---- explicit update kept on the device (what TSEULER does between RHS calls)
  * u_local[owned cell o] += dt * f_global[o]   (PETSc TSStep_Euler VecAXPY; the

@@ -86,10 +86,23 @@ SYMBOLS = {
     "rdyhip_unpack_rows": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "rdyhip_axpy_owned": (C.c_int, [_H, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rdyhip_euler_step": (C.c_int, [_H, C.c_int32, C.c_int32, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rdyhip_halo_create": (C.c_int, [_H, C.c_void_p, C.c_int32, c_int32_p, c_int32_p, c_int32_p, c_int32_p, c_int32_p, C.POINTER(C.c_void_p)]),
+    "rdyhip_halo_destroy": (C.c_int, [C.POINTER(C.c_void_p)]),
+    "rdyhip_halo_set_transport": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rdyhip_halo_exchange": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+    "rdyhip_rhs_overlapped": (C.c_int, [_H, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rdyhip_euler_step_overlapped": (C.c_int, [_H, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rdyhip_comm_unique_id": (C.c_int, [C.c_char_p]),
+    "rdyhip_comm_init_rank": (C.c_int, [C.c_int32, C.c_int32, C.c_char_p, C.POINTER(C.c_void_p)]),
+    "rdyhip_comm_destroy": (C.c_int, [C.c_void_p]),
+    "rdyhip_rccl_version": (C.c_int32, []),
     "rdyhip_probe_layout": (C.c_int, [C.POINTER(RDyHipConfig), C.POINTER(RDyHipMesh), C.c_int32, C.POINTER(RDyHipBoundary),
                                       C.POINTER(RDyHipLayoutInfo)]),
     "rdyhip_layout_info": (C.c_int, [_H, C.POINTER(RDyHipLayoutInfo)]),
 }
+
+# RDyHipTransportFn: int (*)(void *ctx, const double *d_send, double *d_recv, int32_t ncomp, void *stream)
+TRANSPORT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p)
 
 _LIB = None
 

@@ -14,8 +14,9 @@ CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(CSRC, "librdyhip.so")
 SOURCES = ["rdyhip_api.hip"]
-DEPS = SOURCES + ["swe_device.h", "swe_kernels.h", "forcing_kernels.h", "muscl_kernels.h"]
+DEPS = SOURCES + ["swe_device.h", "swe_kernels.h", "forcing_kernels.h", "muscl_kernels.h", "halo_exchange.h"]
 ARCH = "gfx950"
+ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 
 
 def lib_path() -> str:
@@ -40,7 +41,8 @@ def build_native(force: bool = False, verbose: bool = False) -> str:
         raise RuntimeError("hipcc not found: cannot build librdyhip.so (the HIP extension is required; there is no CPU fallback)")
     extra = os.environ.get("RDYHIP_EXTRA_HIPCC_FLAGS", "").split()   # experiments only
     cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
-           f"-I{INCLUDE}", f"-I{CSRC}"] + extra + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+           f"-I{INCLUDE}", f"-I{CSRC}", f"-I{ROCM}/include"] + extra + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES] + [
+               f"-L{ROCM}/lib", "-lrccl"]   # RCCL: the halo exchange behind the ABI (csrc/halo_exchange.h)
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

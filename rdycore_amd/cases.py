@@ -200,3 +200,91 @@ def ex2b_case(msh_path: str) -> Case:
     no = mesh.num_owned_cells
     return Case("ex2b", mesh, RDyFlowConfig(source_method=SOURCE_IMPLICIT_XQ2018), ctypes, u,
                 np.full(no, 0.015), np.zeros((no, 3)), {}, 0.005 * 3600.0 / 1000.0)
+
+
+# ---------------------------------------------------------------------------
+# the reference's own dam-break benchmark (docs/user/example-cases/dam-break)
+# ---------------------------------------------------------------------------
+
+def dam_break_keep(nxg: int, nyg: int):
+    """Squares of the 10 m x 5 m partial dam-break domain that are NOT dam (dam-break-initial-condition.png: the dam
+    occupies 4 <= x < 6 m except for the breach 2 <= y < 4 m).  On the 5120 x 2560 grid that leaves the 11,534,336
+    cells of docs/user/example-cases/dam-break/index.md:10-11."""
+    def keep(qi, qj):
+        in_dam_x = (qi * 10 >= 4 * nxg) & (qi * 10 < 6 * nxg)
+        in_breach = (qj * 5 >= 2 * nyg) & (qj * 5 < 4 * nyg)
+        return ~(in_dam_x & ~in_breach)
+    return keep
+
+
+def dam_break_quads_mesh(nxg: int = 5120, nyg: int = 2560, rank: int = 0, world: int = 1, order: str = "tiled") -> RDyMesh:
+    """The quad mesh of the reference's dam-break benchmark (DamBreak_grid5120x2560: dx = dy = 10 m / 5120), this
+    rank's part of an RCB partition; every domain-boundary edge (outer walls and the dam's faces) is one reflecting
+    boundary (index.md:11-12)."""
+    from . import partition as P
+    return P.partitioned_structured_mesh("quad", nxg, nyg, (10.0 / nxg, 5.0 / nyg), rank, world, order=order,
+                                         keep=dam_break_keep(nxg, nyg))
+
+
+def dam_break_quads_case(mesh: RDyMesh, dt: float = 1.5625e-5) -> Case:
+    """inputdeck_5120x2560.yaml:13-16, 34-56: h = 10 m upstream of the dam (x < 4 m), 5 m elsewhere, momenta zero,
+    Manning 0.015, semi-implicit friction (the default), dt = 1.5625e-5 s, 100 Euler steps."""
+    u = np.zeros((mesh.num_cells, 3))
+    u[:, 0] = np.where(mesh.cell_centroids[:, 0] < 4.0, 10.0, 5.0)
+    no = mesh.num_owned_cells
+    return Case("dam_break_quads", mesh, RDyFlowConfig(), [CONDITION_REFLECTING] * len(mesh.boundaries), u, np.full(no, 0.015),
+                np.zeros((no, 3)), {}, dt)
+
+
+# ---------------------------------------------------------------------------
+# C5: Harvey-scale stand-in (BASELINE.json configs[4]; the real Turning_30m mesh is not in the tree)
+# ---------------------------------------------------------------------------
+
+C5_ETA0 = 3.0   # initial water surface elevation [m]: leaves ~1/3 of the cells dry on the DEM below
+
+
+def c5_dem(lx: float, ly: float):
+    """Rough analytic DEM: a ramp towards the outlet side plus three sinusoids of decreasing wavelength
+    ("sum of 3 sinusoids + ramp")."""
+    def z(x, y):
+        tp = 2.0 * np.pi
+        return (5.0 * (1.0 - x / lx) + 2.0 * np.sin(tp * x / (0.2 * lx)) * np.sin(tp * y / (0.16 * ly))
+                + 1.0 * np.sin(tp * (x + y) / (0.07 * lx)) + 0.5 * np.sin(tp * x / (0.0194 * lx)) * np.cos(tp * y / (0.0226 * ly)))
+    return z
+
+
+def c5_boundaries(lx: float, ly: float, tol: float = 1e-9):
+    """critical-outflow segment on the low (right) side, 0.4 ly <= y <= 0.6 ly; every other boundary edge reflecting
+    (the Harvey case: 13 outflow edges, everything else closed; harvey-flooding.md:3-7)"""
+    from . import partition as P
+
+    def namer(a, b):
+        on_right = (np.abs(a[:, 0] - lx) < tol) & (np.abs(b[:, 0] - lx) < tol)
+        ym = 0.5 * (a[:, 1] + b[:, 1])
+        return np.where(on_right & (ym >= 0.4 * ly) & (ym <= 0.6 * ly), 1, 0)
+    return P.owned_cell_boundaries(namer, ("walls", "outlet"))
+
+
+def c5_mesh(nxg: int = 5000, nyg: int = 5000, rank: int = 0, world: int = 1, d: float = 1.0, order: str = "tiled") -> RDyMesh:
+    from . import partition as P
+    lx, ly = nxg * d, nyg * d
+    return P.partitioned_structured_mesh("tri", nxg, nyg, d, rank, world, zfunc=c5_dem(lx, ly), order=order,
+                                         boundary_classifier=c5_boundaries(lx, ly), project_2d=True)
+
+
+def c5_case(mesh: RDyMesh, lx: float, ly: float, dt: float = 0.05) -> Case:
+    """Flooded rough terrain: water surface at C5_ETA0 over the DEM (cells above it dry, about a third of them), a gentle
+    flow field where wet, uniform rain (1e-5 m/s = 36 mm/h), Manning 0.03, hydrostatic reconstruction (needed on real DEMs:
+    docs/theory/second_order_hydrostatic_reconstruction.md), outlet = critical outflow."""
+    from .operator import WELL_BALANCING_HR
+    xc, yc = mesh.cell_centroids[:, 0], mesh.cell_centroids[:, 1]
+    h = np.maximum(0.0, C5_ETA0 - mesh.cell_zc)
+    tp = 2.0 * np.pi
+    uu = 0.2 * np.sin(tp * yc / (0.12 * ly))
+    vv = 0.1 * np.cos(tp * xc / (0.14 * lx))
+    u = np.stack([h, h * uu, h * vv], axis=1)
+    no = mesh.num_owned_cells
+    src = np.zeros((no, 3))
+    src[:, 0] = 1e-5
+    ctypes = [CONDITION_CRITICAL_OUTFLOW if b.name == "outlet" else CONDITION_REFLECTING for b in mesh.boundaries]
+    return Case("c5_flood", mesh, RDyFlowConfig(well_balancing=WELL_BALANCING_HR), ctypes, u, np.full(no, 0.03), src, {}, dt)

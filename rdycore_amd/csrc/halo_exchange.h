@@ -1,0 +1,287 @@
+// Ghost-cell update of a rank's local vectors and its overlap with the interior tiles, behind the C ABI
+// (include/rdyhip.h, "the ghost update and its overlap").  Stands in for DMGlobalToLocalBegin/End in
+// OperatorRHSFunction (src/rdysetup.c:1133-1134) and, for the second-order path, for CommunicateCellGradients
+// (src/operator_fluxes_ceed.c:1058-1107).
+//
+// One exchange = one pack launch (every peer's cells into one contiguous buffer, a slice per peer), one
+// ncclGroupStart .. ncclSend/ncclRecv per peer .. ncclGroupEnd over xGMI, one unpack launch -- all on an internal
+// high-priority stream that is forked from and joined back into the caller's stream with HIP events, so the interior
+// tiles (rdyhip_apply_phase(INTERIOR)) run on the caller's stream meanwhile.  Included by rdyhip_api.hip only.
+#pragma once
+#include <rccl/rccl.h>
+
+struct RDyHipHalo_s {
+  RDyHipOperator op = nullptr;
+  ncclComm_t     comm = nullptr;
+  RDyHipTransportFn transport = nullptr;
+  void             *transport_ctx = nullptr;
+  std::vector<int32_t> peers, send_off, recv_off;  // offsets in cells, [npeers + 1]
+  DevBuf<int32_t> d_send_ids, d_recv_ids;
+  DevBuf<double>  d_send, d_recv;  // [cells][max_comp]
+  int32_t         max_comp = 3;
+  hipStream_t     cs = nullptr;  // exchange stream
+  hipEvent_t      ev_fork = nullptr, ev_join = nullptr;
+  ~RDyHipHalo_s() {
+    d_send_ids.release(); d_recv_ids.release(); d_send.release(); d_recv.release();
+    if (ev_fork) (void)hipEventDestroy(ev_fork);
+    if (ev_join) (void)hipEventDestroy(ev_join);
+    if (cs) (void)hipStreamDestroy(cs);
+  }
+};
+
+namespace {
+
+#define NCCL_TRY(expr)                                                                                 \
+  do {                                                                                                 \
+    ncclResult_t r_ = (expr);                                                                          \
+    if (r_ != ncclSuccess) return fail(RDYHIP_ERR_LIB, "%s failed: %s", #expr, ncclGetErrorString(r_)); \
+  } while (0)
+
+// the three pieces of one ghost update of `rows` ([num_cells][ncomp]) on stream `s`: pack, transfer, unpack
+int halo_check(RDyHipHalo h, const double *rows, int32_t ncomp) {
+  if (ncomp < 1 || ncomp > h->max_comp) return fail(RDYHIP_ERR_ARG_SIZ, "halo exchange of %d components per cell (the halo was sized for %d)", ncomp, h->max_comp);
+  if (!rows && (h->send_off.back() > 0 || h->recv_off.back() > 0)) return fail(RDYHIP_ERR_USER, "null array");
+  return 0;
+}
+int halo_pack(RDyHipHalo h, const double *rows, int32_t ncomp, hipStream_t s) {
+  const int32_t ns = h->send_off.back();
+  if (ns == 0) return 0;
+  const int64_t tot = (int64_t)ns * ncomp;
+  hipLaunchKernelGGL(pack_rows_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, ns, ncomp, rows, h->d_send_ids.p, h->d_send.p);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+int halo_transfer(RDyHipHalo h, int32_t ncomp, hipStream_t s) {
+  const int32_t np = (int32_t)h->peers.size();
+  if (h->send_off[np] == 0 && h->recv_off[np] == 0) return 0;
+  if (h->transport) {
+    const int rc = h->transport(h->transport_ctx, h->d_send.p, h->d_recv.p, ncomp, (void *)s);
+    if (rc) return fail(RDYHIP_ERR_LIB, "the halo transport callback returned %d", rc);
+    return 0;
+  }
+  if (!h->comm) return fail(RDYHIP_ERR_USER, "the halo has neither an RCCL communicator nor a transport callback");
+  NCCL_TRY(ncclGroupStart());
+  for (int32_t i = 0; i < np; ++i) {
+    const size_t cnt_s = (size_t)(h->send_off[i + 1] - h->send_off[i]) * ncomp, cnt_r = (size_t)(h->recv_off[i + 1] - h->recv_off[i]) * ncomp;
+    if (cnt_s) NCCL_TRY(ncclSend(h->d_send.p + (size_t)h->send_off[i] * ncomp, cnt_s, ncclDouble, h->peers[i], h->comm, s));
+    if (cnt_r) NCCL_TRY(ncclRecv(h->d_recv.p + (size_t)h->recv_off[i] * ncomp, cnt_r, ncclDouble, h->peers[i], h->comm, s));
+  }
+  NCCL_TRY(ncclGroupEnd());
+  return 0;
+}
+int halo_unpack(RDyHipHalo h, double *rows, int32_t ncomp, hipStream_t s) {
+  const int32_t nr = h->recv_off.back();
+  if (nr == 0) return 0;
+  const int64_t tot = (int64_t)nr * ncomp;
+  hipLaunchKernelGGL(unpack_rows_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, nr, ncomp, rows, h->d_recv_ids.p, h->d_recv.p);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+int halo_exchange_on(RDyHipHalo h, double *rows, int32_t ncomp, hipStream_t s) {
+  int rc = halo_check(h, rows, ncomp);
+  if (!rc) rc = halo_pack(h, rows, ncomp, s);
+  if (!rc) rc = halo_transfer(h, ncomp, s);
+  if (!rc) rc = halo_unpack(h, rows, ncomp, s);
+  return rc;
+}
+
+// OperatorRHSFunction (u_out == nullptr) or one forward-Euler step (u_out != nullptr) with the ghost update of u
+// hidden behind the tiles that need no ghost data
+int overlapped(RDyHipOperator op, RDyHipHalo h, double dt, double *u, double *f, double *u_out, hipStream_t st) {
+  if (!op || !h) return fail(RDYHIP_ERR_USER, "null argument");
+  if (h->op != op) return fail(RDYHIP_ERR_USER, "the halo belongs to another operator");
+  if (op->n_cells > 0 && !u) return fail(RDYHIP_ERR_USER, "null u_local");
+  if (u_out && u_out == u) return fail(RDYHIP_ERR_USER, "rdyhip_euler_step_overlapped needs a second state array (not in place)");
+  {
+    const int rc0 = halo_check(h, u, 3);
+    if (rc0) return rc0;
+  }
+  op->courant = RDyHipCourant{0.0, -1, -1};
+  auto part = [&](int32_t phase, int reset, bool ready) -> int {
+    if (reset && phase == RDYHIP_PHASE_HALO && (op->use_tiled ? op->n_halo_tiles == 0 : op->n_halo == 0)) {
+      const int rc = rdyhip_reset_diagnostics(op, (void *)st);
+      if (rc) return rc;
+    }
+    return launch_rhs(op, phase, 1, reset, dt, u, f, st, ready, u_out);
+  };
+  int rc;
+  // fork: the exchange starts once everything already enqueued on the caller's stream (the update that produced u) is done
+  HIP_TRY(hipEventRecord(h->ev_fork, st));
+  HIP_TRY(hipStreamWaitEvent(h->cs, h->ev_fork, 0));
+  if (!op->muscl) {
+    // the pack launch goes first, then the interior tiles are enqueued BEFORE the transfer is started: a transport that
+    // blocks the host (a callback) then blocks while the device already works on the interior
+    rc = halo_pack(h, u, 3, h->cs);
+    if (!rc) rc = part(RDYHIP_PHASE_INTERIOR, 1, false);
+    if (!rc) rc = halo_transfer(h, 3, h->cs);
+    if (!rc) rc = halo_unpack(h, u, 3, h->cs);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(h->ev_join, h->cs));
+    HIP_TRY(hipStreamWaitEvent(st, h->ev_join, 0));
+    return part(RDYHIP_PHASE_HALO, 0, false);
+  }
+  // ApplyInteriorFlux2R (src/swe/swe_petsc.c:98-213) needs two exchanges: the state, then the gradients of the ghost
+  // cells (CommunicateCellGradients).  No reverse exchange: every rank evaluates all edges of its owned cells.
+  if (op->muscl_fused) {
+    // tiles whose cells and first ring touch no ghost need nothing from other ranks and hide the state exchange; only the
+    // ghost-adjacent cells' gradients go through memory
+    rc = halo_pack(h, u, 3, h->cs);
+    if (!rc) rc = part(RDYHIP_PHASE_INTERIOR, 1, true);
+    if (!rc) rc = halo_transfer(h, 3, h->cs);
+    if (!rc) rc = halo_unpack(h, u, 3, h->cs);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(h->ev_join, h->cs));
+    HIP_TRY(hipStreamWaitEvent(st, h->ev_join, 0));
+    rc = launch_gradients(op, RDYHIP_PHASE_HALO, u, st);
+    if (rc) return rc;
+    rc = halo_exchange_on(h, op->d_grad.p, 6, st);
+    if (rc) return rc;
+    return part(RDYHIP_PHASE_HALO, 0, true);
+  }
+  // split kernels: the gradients of the cells without ghost neighbours hide the state exchange, the fluxes of the tiles
+  // without ghost-adjacent cells (which read owned gradient rows only) hide the gradient exchange
+  rc = halo_pack(h, u, 3, h->cs);
+  if (!rc) rc = launch_gradients(op, RDYHIP_PHASE_INTERIOR, u, st);
+  if (!rc) rc = halo_transfer(h, 3, h->cs);
+  if (!rc) rc = halo_unpack(h, u, 3, h->cs);
+  if (rc) return rc;
+  HIP_TRY(hipEventRecord(h->ev_join, h->cs));
+  HIP_TRY(hipStreamWaitEvent(st, h->ev_join, 0));
+  rc = launch_gradients(op, RDYHIP_PHASE_HALO, u, st);
+  if (rc) return rc;
+  HIP_TRY(hipEventRecord(h->ev_fork, st));
+  HIP_TRY(hipStreamWaitEvent(h->cs, h->ev_fork, 0));
+  rc = halo_pack(h, op->d_grad.p, 6, h->cs);
+  if (!rc) rc = part(RDYHIP_PHASE_INTERIOR, 1, true);
+  if (!rc) rc = halo_transfer(h, 6, h->cs);
+  if (!rc) rc = halo_unpack(h, op->d_grad.p, 6, h->cs);
+  if (rc) return rc;
+  HIP_TRY(hipEventRecord(h->ev_join, h->cs));
+  HIP_TRY(hipStreamWaitEvent(st, h->ev_join, 0));
+  return part(RDYHIP_PHASE_HALO, 0, true);
+}
+
+}  // namespace
+
+extern "C" {
+
+int rdyhip_halo_create(RDyHipOperator op, void *nccl_comm, int32_t npeers, const int32_t *peers, const int32_t *send_counts,
+                       const int32_t *send_cell_ids, const int32_t *recv_counts, const int32_t *recv_cell_ids, RDyHipHalo *halo) {
+  if (!op || !halo) return fail(RDYHIP_ERR_USER, "null argument to rdyhip_halo_create");
+  *halo = nullptr;
+  if (npeers < 0 || (npeers > 0 && (!peers || !send_counts || !recv_counts))) return fail(RDYHIP_ERR_USER, "bad peer list");
+  RDyHipHalo h = new (std::nothrow) RDyHipHalo_s;
+  if (!h) return fail(RDYHIP_ERR_MEM, "out of host memory");
+  h->op   = op;
+  h->comm = (ncclComm_t)nccl_comm;
+  h->peers.assign(peers, peers + npeers);
+  h->send_off.assign((size_t)npeers + 1, 0);
+  h->recv_off.assign((size_t)npeers + 1, 0);
+  for (int32_t i = 0; i < npeers; ++i) {
+    if (peers[i] < 0 || send_counts[i] < 0 || recv_counts[i] < 0) {
+      delete h;
+      return fail(RDYHIP_ERR_USER, "bad entry for peer %d", i);
+    }
+    h->send_off[i + 1] = h->send_off[i] + send_counts[i];
+    h->recv_off[i + 1] = h->recv_off[i] + recv_counts[i];
+  }
+  const int32_t ns = h->send_off[npeers], nr = h->recv_off[npeers];
+  if ((ns > 0 && !send_cell_ids) || (nr > 0 && !recv_cell_ids)) {
+    delete h;
+    return fail(RDYHIP_ERR_USER, "null cell id list");
+  }
+  // what is sent are owned cells, what is received are ghost cells (DMPlex's point SF roots and leaves)
+  for (int32_t i = 0; i < ns; ++i)
+    if (send_cell_ids[i] < 0 || send_cell_ids[i] >= op->n_cells) {
+      delete h;
+      return fail(RDYHIP_ERR_ARG_OUTOFRANGE, "send cell id %d out of range", send_cell_ids[i]);
+    }
+  for (int32_t i = 0; i < nr; ++i)
+    if (recv_cell_ids[i] < 0 || recv_cell_ids[i] >= op->n_cells) {
+      delete h;
+      return fail(RDYHIP_ERR_ARG_OUTOFRANGE, "receive cell id %d out of range", recv_cell_ids[i]);
+    }
+  h->max_comp = op->muscl ? 6 : 3;
+  int rc      = h->d_send_ids.upload(std::vector<int32_t>(send_cell_ids, send_cell_ids + ns));
+  if (!rc) rc = h->d_recv_ids.upload(std::vector<int32_t>(recv_cell_ids, recv_cell_ids + nr));
+  if (!rc) rc = h->d_send.zeros((size_t)ns * h->max_comp);
+  if (!rc) rc = h->d_recv.zeros((size_t)nr * h->max_comp);
+  if (rc) {
+    delete h;
+    return rc;
+  }
+  int lo = 0, hi = 0;  // hi = numerically lowest = highest priority
+  if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) lo = hi = 0;
+  if (hipStreamCreateWithPriority(&h->cs, hipStreamNonBlocking, hi) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) {
+    delete h;
+    return fail(RDYHIP_ERR_LIB, "cannot create the exchange stream / events");
+  }
+  *halo = h;
+  return 0;
+}
+
+int rdyhip_halo_destroy(RDyHipHalo *halo) {
+  if (!halo) return fail(RDYHIP_ERR_USER, "null argument to rdyhip_halo_destroy");
+  if (*halo) {
+    (void)hipDeviceSynchronize();
+    delete *halo;
+    *halo = nullptr;
+  }
+  return 0;
+}
+
+int rdyhip_halo_set_transport(RDyHipHalo halo, RDyHipTransportFn fn, void *ctx) {
+  if (!halo) return fail(RDYHIP_ERR_USER, "null halo");
+  halo->transport     = fn;
+  halo->transport_ctx = ctx;
+  return 0;
+}
+
+int rdyhip_halo_exchange(RDyHipHalo halo, double *rows, int32_t ncomp, void *stream) {
+  if (!halo) return fail(RDYHIP_ERR_USER, "null halo");
+  return halo_exchange_on(halo, rows, ncomp, (hipStream_t)stream);
+}
+
+int rdyhip_rhs_overlapped(RDyHipOperator op, RDyHipHalo halo, double dt, double *u_local, double *f_global, void *stream) {
+  return overlapped(op, halo, dt, u_local, f_global, nullptr, (hipStream_t)stream);
+}
+
+int rdyhip_euler_step_overlapped(RDyHipOperator op, RDyHipHalo halo, double dt, double *u_local, double *u_local_out, double *f_global,
+                                 void *stream) {
+  if (op && op->n_owned > 0 && !u_local_out) return fail(RDYHIP_ERR_USER, "rdyhip_euler_step_overlapped needs a second state array (not in place)");
+  return overlapped(op, halo, dt, u_local, f_global, u_local_out, (hipStream_t)stream);
+}
+
+int rdyhip_comm_unique_id(char id[RDYHIP_COMM_ID_BYTES]) {
+  static_assert(RDYHIP_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "ncclUniqueId size");
+  if (!id) return fail(RDYHIP_ERR_USER, "null argument");
+  ncclUniqueId uid;
+  NCCL_TRY(ncclGetUniqueId(&uid));
+  memcpy(id, uid.internal, NCCL_UNIQUE_ID_BYTES);
+  return 0;
+}
+
+int rdyhip_comm_init_rank(int32_t nranks, int32_t rank, const char id[RDYHIP_COMM_ID_BYTES], void **nccl_comm) {
+  if (!id || !nccl_comm) return fail(RDYHIP_ERR_USER, "null argument");
+  if (nranks < 1 || rank < 0 || rank >= nranks) return fail(RDYHIP_ERR_USER, "bad rank %d of %d", rank, nranks);
+  ncclUniqueId uid;
+  memcpy(uid.internal, id, NCCL_UNIQUE_ID_BYTES);
+  ncclComm_t comm = nullptr;
+  NCCL_TRY(ncclCommInitRank(&comm, nranks, uid, rank));
+  *nccl_comm = (void *)comm;
+  return 0;
+}
+
+int rdyhip_comm_destroy(void *nccl_comm) {
+  if (nccl_comm) NCCL_TRY(ncclCommDestroy((ncclComm_t)nccl_comm));
+  return 0;
+}
+
+int32_t rdyhip_rccl_version(void) {
+  int v = 0;
+  return ncclGetVersion(&v) == ncclSuccess ? (int32_t)v : -1;
+}
+
+}  // extern "C"

@@ -336,13 +336,16 @@ int launch_rhs(RDyHipOperator op, int32_t phase, int32_t overwrite, int reset_di
   a.emax     = op->emax;
   a.hmax     = op->hmax;
 
-  int        grid;
+  int        grid = 0;
   const bool xq = op->config.source_method == RDYHIP_SOURCE_IMPLICIT_XQ2018;
-  if (op->use_tiled) {
+  // a HALO phase on a rank without ghost-adjacent cells has no flux launch, but the tail below (boundary edges of
+  // ghost cells, the separate Euler update of the non-fused kernels) still belongs to it
+  const bool nothing_to_launch = phase == RDYHIP_PHASE_HALO && (op->use_tiled ? op->n_halo_tiles == 0 : op->n_halo == 0);
+  if (nothing_to_launch) {
+  } else if (op->use_tiled) {
     const int pgrid = op->muscl ? op->pgrid_muscl : op->pgrid;
     // persistent workgroups: at most as many as the device holds at once
     if (phase == RDYHIP_PHASE_HALO) {
-      if (op->n_halo_tiles == 0) return 0;
       a.list       = op->d_halo_tiles.p;
       a.n_work     = op->n_halo_tiles;
       a.xcd_chunks = 0;
@@ -374,7 +377,6 @@ int launch_rhs(RDyHipOperator op, int32_t phase, int32_t overwrite, int reset_di
     }
   } else {
     if (phase == RDYHIP_PHASE_HALO) {
-      if (op->n_halo == 0) return 0;
       a.list       = op->d_halo_list.p;
       a.n_work     = op->n_halo;
       a.xcd_chunks = 0;
@@ -1098,6 +1100,9 @@ int rdyhip_set_boundary_values(RDyHipOperator op, int32_t boundary, int32_t comp
   if (comp_offset < 0 || num_comp < 0 || comp_offset + num_comp > 3) return fail(RDYHIP_ERR_USER, "bad component range [%d,%d)", comp_offset, comp_offset + num_comp);
   if (n == 0 || num_comp == 0) return 0;
   if (!values) return fail(RDYHIP_ERR_USER, "null values");
+  // the apply calls run on the caller's streams (PETSc's and torch's are non-blocking): an RHS still in flight may be
+  // reading the values this call replaces
+  HIP_TRY(hipDeviceSynchronize());
   double *dst = op->d_bvalues.p + 3 * (size_t)op->h_boff[boundary];
   if (comp_offset == 0 && num_comp == 3) {
     HIP_TRY(hipMemcpy(dst, values, sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice));
@@ -1135,6 +1140,7 @@ static int scatter_component(RDyHipOperator op, double *dst, int ncomp, int comp
     for (int32_t i = 0; i < n; ++i)
       if (ids[i] < 0 || ids[i] >= op->n_owned) return fail(RDYHIP_ERR_ARG_OUTOFRANGE, "owned cell id %d out of range", ids[i]);
   }
+  HIP_TRY(hipDeviceSynchronize());  // an RHS in flight on a non-blocking stream may still read the array (and the staging buffers)
   if (op->d_stage_vals.n < (size_t)n) {
     op->d_stage_vals.release();
     int rc = op->d_stage_vals.alloc((size_t)n);
@@ -1427,3 +1433,5 @@ int rdyhip_layout_info(RDyHipOperator op, RDyHipLayoutInfo *info) {
 }
 
 }  // extern "C"
+
+#include "halo_exchange.h"

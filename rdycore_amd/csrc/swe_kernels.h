@@ -37,6 +37,9 @@ constexpr int BLOCK = 256;  // threads per workgroup of the cell-centric kernel
 constexpr int TILE = RDYHIP_TILE;  // cells per tile = threads per workgroup of the tiled kernel (a multiple of 64)
 
 constexpr uint16_t SLOT_EMPTY = 0xFFFF;
+#ifndef RDYHIP_QUAD_ROUNDS
+#define RDYHIP_QUAD_ROUNDS 3  // register-resident edge-record rounds of the S == 4 (quads / mixed) tiled kernel (2 or 3)
+#endif
 
 // Data that is streamed through exactly once per launch -- the per-cell streams (flux coefficients, bed slopes,
 // Manning n, external source), the tile edge records and the outputs F / primitive variables -- is loaded and
@@ -317,8 +320,12 @@ __device__ __forceinline__ void load_streams(const KernelArgs &a, int o, bool ac
 // EULER = the forward-Euler update fused into the store phase (what TSEULER's VecAXPY does after the RHS,
 // rdyhip_euler_step): the owned rows of a second state array receive u + dt F, F itself is stored only if f != nullptr.
 template <int S, int SRC, bool OVW, bool HR, bool EULER = false>
-__global__ __launch_bounds__(TILE) void swe_rhs_tiled_kernel(const KernelArgs a, const double dt, const double *__restrict__ u,
+__global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(3, 3))) void swe_rhs_tiled_kernel(const KernelArgs a, const double dt, const double *__restrict__ u,
                                                               double *__restrict__ f) {
+  // edge-record rounds held in registers: a 256-cell tile of a well-numbered triangle mesh has <= 2 x 256 edge records
+  // (1.6 per cell), a quad tile up to 3 x 256 (a 16 x 16 block: 544).  Records beyond that (poor numberings) are loaded
+  // inside the flux phase.
+  constexpr int NR = (S == 3) ? 2 : RDYHIP_QUAD_ROUNDS;
   extern __shared__ double lds[];
   const int nside = TILE + a.hmax;
   double   *sd_h = lds, *sd_u = lds + nside, *sd_v = lds + 2 * nside, *sd_sq = lds + 3 * nside, *sd_c = lds + 4 * nside;
@@ -369,8 +376,8 @@ __global__ __launch_bounds__(TILE) void swe_rhs_tiled_kernel(const KernelArgs a,
     double   pu0 = 0.0, pu1 = 0.0, pu2 = 0.0;  // own cell state of the tile being started
     double   ph0 = 0.0, ph1 = 0.0, ph2 = 0.0;  // state of this thread's halo cell
     double   pz = 0.0, phz = 0.0;              // HR: bed elevation of the own / halo cell
-    uint32_t lr0 = 0, lr1 = 0;                 // first two rounds of edge records
-    double   cs0 = 0.0, cs1 = 0.0;
+    uint32_t lr0 = 0, lr1 = 0, lr2 = 0;        // first NR rounds of edge records
+    double   cs0 = 0.0, cs1 = 0.0, cs2 = 0.0;
     CellStreams<S> cur;
     {
       const int o = tile * TILE + tid;
@@ -387,6 +394,7 @@ __global__ __launch_bounds__(TILE) void swe_rhs_tiled_kernel(const KernelArgs a,
       const int ne = tn.e_off - td.e_off;
       if (tid < ne) { lr0 = RDY_LD(&a.e_lr[td.e_off + tid]); cs0 = RDY_LD(&a.e_cs[td.e_off + tid]); }
       if (tid + TILE < ne) { lr1 = RDY_LD(&a.e_lr[td.e_off + TILE + tid]); cs1 = RDY_LD(&a.e_cs[td.e_off + TILE + tid]); }
+      if (NR > 2 && tid + 2 * TILE < ne) { lr2 = RDY_LD(&a.e_lr[td.e_off + 2 * TILE + tid]); cs2 = RDY_LD(&a.e_cs[td.e_off + 2 * TILE + tid]); }
       load_streams<S, HR>(a, o, o < a.n_owned, cur);
     }
     int      idx1 = next_valid(idx + step);
@@ -451,8 +459,8 @@ __global__ __launch_bounds__(TILE) void swe_rhs_tiled_kernel(const KernelArgs a,
         }
       }
       // (b) the next tile's cell states, edge records and per-cell streams
-      uint32_t nlr0 = 0, nlr1 = 0;
-      double   ncs0 = 0.0, ncs1 = 0.0;
+      uint32_t nlr0 = 0, nlr1 = 0, nlr2 = 0;
+      double   ncs0 = 0.0, ncs1 = 0.0, ncs2 = 0.0;
       CellStreams<S> nxt;
       if (idx1 < hi) {
         if (tile1 * TILE + tid < a.n_owned) {
@@ -466,6 +474,7 @@ __global__ __launch_bounds__(TILE) void swe_rhs_tiled_kernel(const KernelArgs a,
         const int ne1 = tn1.e_off - td1.e_off;
         if (tid < ne1) { nlr0 = RDY_LD(&a.e_lr[td1.e_off + tid]); ncs0 = RDY_LD(&a.e_cs[td1.e_off + tid]); }
         if (tid + TILE < ne1) { nlr1 = RDY_LD(&a.e_lr[td1.e_off + TILE + tid]); ncs1 = RDY_LD(&a.e_cs[td1.e_off + TILE + tid]); }
+        if (NR > 2 && tid + 2 * TILE < ne1) { nlr2 = RDY_LD(&a.e_lr[td1.e_off + 2 * TILE + tid]); ncs2 = RDY_LD(&a.e_cs[td1.e_off + 2 * TILE + tid]); }
       }
       load_streams<S, HR>(a, tile1 * TILE + tid, idx1 < hi && tile1 * TILE + tid < a.n_owned, nxt);
       __builtin_amdgcn_s_setprio(0);
@@ -525,16 +534,16 @@ __global__ __launch_bounds__(TILE) void swe_rhs_tiled_kernel(const KernelArgs a,
         ef2[e] = fl.f2;
         eam[e] = wet ? fl.amax : -1.0;  // -1 marks a dry-dry edge (skipped, swe_petsc.c:285)
       };
-      // Rounds 0 and 1 take their records from registers.  This loop must contain no global load on any
+      // The first NR rounds take their records from registers.  This loop must contain no global load on any
       // path: hipcc would put an s_waitcnt vmcnt(0) at the merge, and every round would then wait for
       // the whole prefetch batch issued above.
 #pragma unroll 1
-      for (int r = 0; r < 2; ++r) {
+      for (int r = 0; r < NR; ++r) {
         const int e = tid + r * TILE;
-        if (e < ne) do_edge(e, r == 0 ? lr0 : lr1, r == 0 ? cs0 : cs1);
+        if (e < ne) do_edge(e, r == 0 ? lr0 : (r == 1 || NR == 2 ? lr1 : lr2), r == 0 ? cs0 : (r == 1 || NR == 2 ? cs1 : cs2));
       }
-      // further rounds (quads, or numberings with poor locality) load their records here
-      for (int e = tid + 2 * TILE; e < ne; e += TILE) do_edge(e, a.e_lr[td.e_off + e], a.e_cs[td.e_off + e]);
+      // further rounds (numberings with poor locality) load their records here
+      for (int e = tid + NR * TILE; e < ne; e += TILE) do_edge(e, a.e_lr[td.e_off + e], a.e_cs[td.e_off + e]);
       __syncthreads();
 
       // ---- phase 2: per-cell sum in the reference's edge order, source terms; the stores come last
@@ -598,12 +607,14 @@ __global__ __launch_bounds__(TILE) void swe_rhs_tiled_kernel(const KernelArgs a,
       // materialised at the very end of the loop body).
       asm volatile("" ::"v"(pu0), "v"(pu1), "v"(pu2), "v"(ph0), "v"(ph1), "v"(ph2), "v"(pz), "v"(phz), "v"(nlr0), "v"(nlr1), "v"(ncs0), "v"(ncs1),
                    "v"(hid2), "v"(c2));
+      if (NR > 2) asm volatile("" ::"v"(nlr2), "v"(ncs2));
       asm volatile("" ::"v"(nxt.r0), "v"(nxt.r1), "v"(nxt.coef[0]), "v"(nxt.coef[1]), "v"(nxt.coef[2]), "v"(nxt.coef[S - 1]), "v"(nxt.dzdx),
                    "v"(nxt.dzdy), "v"(nxt.nman), "v"(nxt.s0), "v"(nxt.s1), "v"(nxt.s2));
       // rotate the pipeline registers, store
       idx = idx1; tile = tile1; td = td1; tn = tn1;
       idx1 = idx2; tile1 = tile2; td1 = td2; tn1 = tn2; hid1 = hid2; c1 = c2;
       lr0 = nlr0; lr1 = nlr1; cs0 = ncs0; cs1 = ncs1;
+      if (NR > 2) { lr2 = nlr2; cs2 = ncs2; }
       cur = nxt;
       __builtin_amdgcn_sched_barrier(0);
       // F, pv (and fdiv, u_out) are [cell][3]: a wave's 64 cells own 192 consecutive doubles of each.  The rows are

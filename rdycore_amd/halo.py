@@ -9,11 +9,17 @@ the cell gradients (6 doubles per cell, CommunicateCellGradients,
 src/operator_fluxes_ceed.c:1058-1107); its reverse ADD exchange is avoided by
 evaluating cut edges on both ranks (csrc/muscl_kernels.h).
 
-One process per GPU; the transport is torch.distributed point-to-point
-(backend "nccl" = RCCL over xGMI on the GPUs, "gloo" in the CPU tests).  The
-pack / unpack kernels are the HIP ones behind the C ABI (rdyhip_pack_cells /
-rdyhip_unpack_cells); on CPU tensors (gloo tests of the host logic) plain
-indexing is used.  The pattern is neighbour point-to-point, not a collective:
+One process per GPU.  Two drivers of the same exchange pattern:
+
+  * transport="c" (what a C host gets, and the default of bench.py on RCCL): the whole overlapped step is ONE call into
+    librdyhip.so -- rdyhip_rhs_overlapped / rdyhip_euler_step_overlapped (csrc/halo_exchange.h): pack, ncclSend / ncclRecv in
+    one group over xGMI and unpack on the library's own high-priority stream, HIP events for the fork / join, interior
+    tiles meanwhile, ghost-adjacent tiles after.  This module then only discovers the pattern (who needs which cells)
+    and owns the RCCL communicator.  Under the "gloo" backend (several ranks rehearsed on ONE GPU, where RCCL cannot
+    run) the bytes travel through the ABI's transport callback, host-staged -- the C orchestration is the same.
+  * transport="torch": torch.distributed point-to-point driven from Python (backend "nccl" = RCCL, or "gloo" in the CPU
+    tests), with the pack / unpack kernels and the phased applies called one by one; on CPU tensors (gloo tests of the
+    host logic) plain indexing is used.  The pattern is neighbour point-to-point, not a collective:
 per RHS each rank sends ~perimeter x 24 B to each neighbour, which is
 latency-bound, so it is issued on a side stream and overlapped with the
 interior cells (see `rhs_overlapped`).
@@ -30,7 +36,15 @@ from .mesh import RDyMesh
 
 
 class HaloExchange:
-    def __init__(self, mesh: RDyMesh, device: torch.device, group=None):
+    def __init__(self, mesh: RDyMesh, device: torch.device, group=None, transport: str = "torch", op=None):
+        if transport not in ("torch", "c"):
+            raise ValueError(transport)
+        if transport == "c" and op is None:
+            raise ValueError('transport="c" needs the operator the halo belongs to')
+        self.transport = transport
+        self._halo = None          # RDyHipHalo
+        self._comm = None          # ncclComm_t owned by this object
+        self._cb = None
         self.mesh = mesh
         self.device = torch.device(device)
         self.group = group
@@ -42,6 +56,80 @@ class HaloExchange:
         self.recv_buf: Dict[int, torch.Tensor] = {}
         self._setup()
         self.comm_stream = torch.cuda.Stream(device=self.device, priority=-1) if self.device.type == "cuda" else None
+        if transport == "c" and self.world > 1:
+            self._create_c_halo(op)
+
+    # -- the exchange behind the C ABI (include/rdyhip.h: rdyhip_halo_create) ------------------------------
+    def _create_c_halo(self, op):
+        import ctypes as C
+        from . import _lib
+        lib = _lib.load()
+        peers = sorted(set(self.send_ids) | set(self.recv_ids))
+        i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+        send_counts = i32([int(self.send_ids[p].numel()) if p in self.send_ids else 0 for p in peers])
+        recv_counts = i32([int(self.recv_ids[p].numel()) if p in self.recv_ids else 0 for p in peers])
+        cat = lambda d: i32(np.concatenate([d[p].cpu().numpy() for p in peers if p in d])) if any(p in d for p in peers) else i32([])
+        send_ids, recv_ids, peers_a = cat(self.send_ids), cat(self.recv_ids), i32(peers)
+        comm = C.c_void_p()
+        if dist.get_backend(self.group) == "nccl":
+            # an RCCL communicator of our own over the same ranks: rank 0 draws the id, everybody joins
+            box = [None]
+            if self.rank == 0:
+                buf = C.create_string_buffer(128)
+                _lib.check(lib.rdyhip_comm_unique_id(buf))
+                box[0] = buf.raw
+            dist.broadcast_object_list(box, src=0, group=self.group)
+            _lib.check(lib.rdyhip_comm_init_rank(self.world, self.rank, box[0], C.byref(comm)))
+            self._comm = comm
+        h = C.c_void_p()
+        p = lambda a: a.ctypes.data_as(_lib.c_int32_p)
+        _lib.check(lib.rdyhip_halo_create(op._h, comm, len(peers), p(peers_a), p(send_counts), p(send_ids), p(recv_counts), p(recv_ids),
+                                          C.byref(h)))
+        self._halo = h
+        self._c_peers, self._c_send_counts, self._c_recv_counts = peers, send_counts, recv_counts
+        if self._comm is None:
+            # no RCCL between ranks that share a device: the bytes go through the transport callback, staged on the host
+            self._cb = _lib.TRANSPORT_FN(self._host_staged_transport)
+            _lib.check(lib.rdyhip_halo_set_transport(h, C.cast(self._cb, C.c_void_p), None))
+
+    def _host_staged_transport(self, ctx, d_send, d_recv, ncomp, stream):
+        """RDyHipTransportFn: d_send's per-peer slices -> the peers' d_recv slices through the process group (gloo)"""
+        try:
+            from .operator import _DeviceArray
+            ns, nr = int(self._c_send_counts.sum()), int(self._c_recv_counts.sum())
+            st = torch.cuda.ExternalStream(stream, device=self.device) if stream else torch.cuda.default_stream(self.device)
+            st.synchronize()                                   # the pack launch has filled d_send
+            send_h = torch.as_tensor(_DeviceArray(d_send, (ns * ncomp,), self), device=self.device).cpu() if ns else torch.zeros(0, dtype=torch.float64)
+            recv_h = torch.empty(nr * ncomp, dtype=torch.float64)
+            ops, so, ro = [], 0, 0
+            for peer, cs, cr in zip(self._c_peers, self._c_send_counts, self._c_recv_counts):
+                if cs:
+                    ops.append(dist.P2POp(dist.isend, send_h[so * ncomp:(so + int(cs)) * ncomp], peer, group=self.group))
+                    so += int(cs)
+                if cr:
+                    ops.append(dist.P2POp(dist.irecv, recv_h[ro * ncomp:(ro + int(cr)) * ncomp], peer, group=self.group))
+                    ro += int(cr)
+            for w in (dist.batch_isend_irecv(ops) if ops else []):
+                w.wait()
+            if nr:
+                with torch.cuda.stream(st):
+                    torch.as_tensor(_DeviceArray(d_recv, (nr * ncomp,), self), device=self.device).copy_(recv_h)
+            return 0
+        except Exception:          # an exception must not unwind through the C frames
+            import traceback
+            traceback.print_exc()
+            return 1
+
+    def destroy(self):
+        """frees the C halo and the RCCL communicator (idempotent)"""
+        import ctypes as C
+        from . import _lib
+        if self._halo is not None:
+            _lib.check(_lib.load().rdyhip_halo_destroy(C.byref(self._halo)))
+            self._halo = None
+        if self._comm is not None:
+            _lib.check(_lib.load().rdyhip_comm_destroy(self._comm))
+            self._comm = None
 
     # -- pattern discovery (setup only) -----------------------------------
     def _setup(self):
@@ -128,6 +216,12 @@ class HaloExchange:
         gradients: ncomp = 6, CommunicateCellGradients) <- the owners' rows"""
         if self.world == 1 or (not self.send_ids and not self.recv_ids):
             return
+        if self._halo is not None and u_local.is_cuda:
+            from . import _lib
+            ncomp = int(u_local.shape[-1]) if u_local.dim() == 2 else 3
+            _lib.check(_lib.load().rdyhip_halo_exchange(self._halo, int(u_local.data_ptr()), ncomp,
+                                                        int(torch.cuda.current_stream(self.device).cuda_stream)))
+            return
         cuda = u_local.is_cuda
         ncomp = int(u_local.shape[-1]) if u_local.dim() == 2 else 3
         rows = u_local.view(-1, ncomp)
@@ -197,6 +291,15 @@ class HaloExchange:
 
         if self.world == 1:
             part(0, reset=True)
+            return
+        if self._halo is not None:
+            from . import _lib
+            lib = _lib.load()
+            st = int(torch.cuda.current_stream(self.device).cuda_stream)
+            if u_out is not None:
+                _lib.check(lib.rdyhip_euler_step_overlapped(op._h, self._halo, float(dt), int(u_local.data_ptr()), int(u_out.data_ptr()), None, st))
+            else:
+                _lib.check(lib.rdyhip_rhs_overlapped(op._h, self._halo, float(dt), int(u_local.data_ptr()), int(f_global.data_ptr()), st))
             return
         main = torch.cuda.current_stream(self.device)
         self.comm_stream.wait_stream(main)           # u_local's owned part is final

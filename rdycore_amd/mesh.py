@@ -193,12 +193,18 @@ def build_mesh(xyz: np.ndarray, conn: np.ndarray,
                num_cells_global: Optional[int] = None,
                boundary_classifier: Optional[Callable[["RDyMesh"], List[RDyBoundary]]] = None,
                project_2d: bool = False,
+               vertex_global_ids: Optional[np.ndarray] = None,
+               num_vertices_global: Optional[int] = None,
                ) -> RDyMesh:
     """Build the RDyMesh arrays from vertices + cell->vertex connectivity.
 
     `conn` is [Nc,3] or [Nc,4] (pad triangles with -1 in a mixed mesh).
     Edge e's left cell is the lower-numbered of its two cells; edges are
     numbered in order of first appearance while walking the cells.
+    `vertex_global_ids` (a rank's piece of a partitioned mesh): edges.global_ids then become
+    min(g1, g2) * num_vertices_global + max(g1, g2) of the edge's two vertices -- the same number on every
+    rank that sees the edge, which is what the cross-rank Courant diagnostic reports (the reference takes
+    DMPlex's global point numbering, src/rdymesh.c:554-599).  Without it: the local edge index.
     """
     xyz = np.ascontiguousarray(xyz, dtype=np.float64)
     conn = np.asarray(conn)
@@ -311,12 +317,31 @@ def build_mesh(xyz: np.ndarray, conn: np.ndarray,
         edge_cell_ids=cell_ids,
         edge_vertex_ids=np.stack([v1f, v2f], axis=1).astype(np.int32),
         edge_internal_ids=internal_ids, edge_boundary_ids=boundary_ids,
-        edge_global_ids=np.arange(ne, dtype=np.int64),
+        edge_global_ids=_edge_gids(ne, v1f, v2f, vertex_global_ids, num_vertices_global),
         edge_lengths=lengths, edge_cn=cn, edge_sn=sn, edge_centroids=mid,
     )
     if boundary_classifier is not None:
         mesh.boundaries = boundary_classifier(mesh)
     return mesh
+
+
+def _edge_gids(ne, v1, v2, vertex_global_ids, num_vertices_global):
+    if vertex_global_ids is None:
+        return np.arange(ne, dtype=np.int64)
+    g = np.asarray(vertex_global_ids, dtype=np.int64)
+    nvg = int(num_vertices_global) if num_vertices_global is not None else int(g.max()) + 1
+    g1, g2 = g[v1], g[v2]
+    return np.minimum(g1, g2) * nvg + np.maximum(g1, g2)
+
+
+def edge_vertex_key(mesh: "RDyMesh", edge: int, vertex_global_ids=None, num_vertices_global=None) -> int:
+    """the partition-independent id of an edge (see build_mesh) from a mesh whose vertices carry the given global ids
+    (default: the mesh's own vertex numbering is the global one)"""
+    a, b = int(mesh.edge_vertex_ids[edge, 0]), int(mesh.edge_vertex_ids[edge, 1])
+    if vertex_global_ids is not None:
+        a, b = int(vertex_global_ids[a]), int(vertex_global_ids[b])
+    nvg = int(num_vertices_global) if num_vertices_global is not None else mesh.num_vertices
+    return min(a, b) * nvg + max(a, b)
 
 
 def single_boundary(name: str = "domain_boundary", bid: int = 1):
@@ -498,7 +523,9 @@ def extract_local_mesh(xyz: np.ndarray, conn: np.ndarray, owned_mask: np.ndarray
                        cell_global_ids: Optional[np.ndarray] = None,
                        num_cells_global: Optional[int] = None,
                        boundary_classifier=None,
-                       ghosts: str = "tail", project_2d: bool = False) -> RDyMesh:
+                       ghosts: str = "tail", project_2d: bool = False,
+                       vertex_global_ids: Optional[np.ndarray] = None,
+                       num_vertices_global: Optional[int] = None) -> RDyMesh:
     """Local mesh of one rank: the cells flagged in `owned_mask` plus every
     cell sharing an edge with one of them (the 1-cell overlap of
     DMPlexDistributeOverlap(dm, 1, ...), src/rdydm.c:145-157, under edge
@@ -543,10 +570,12 @@ def extract_local_mesh(xyz: np.ndarray, conn: np.ndarray, owned_mask: np.ndarray
     remap[used] = np.arange(used.size)
     sub_conn = np.where(sub_conn >= 0, remap[np.maximum(sub_conn, 0)], -1).astype(np.int32)
     gids = np.arange(nc, dtype=np.int64) if cell_global_ids is None else np.asarray(cell_global_ids)
+    vg = used if vertex_global_ids is None else np.asarray(vertex_global_ids)[used]
     return build_mesh(xyz[used], sub_conn, is_owned=owned_mask[sel].astype(np.int32),
                       cell_global_ids=gids[sel],
                       num_cells_global=num_cells_global if num_cells_global is not None else nc,
-                      boundary_classifier=boundary_classifier, project_2d=project_2d)
+                      boundary_classifier=boundary_classifier, project_2d=project_2d,
+                      vertex_global_ids=vg, num_vertices_global=num_vertices_global if num_vertices_global is not None else nv)
 
 
 def strip_partition_tri_mesh(nx_per_rank: int, ny: int, rank: int, nranks: int, d: float = 1.0,
@@ -570,8 +599,11 @@ def strip_partition_tri_mesh(nx_per_rank: int, ny: int, rank: int, nranks: int, 
     t = np.arange(conn.shape[0]) % 2
     gids = 2 * (cqj.astype(np.int64) * nxg + gi) + t
     cls = box_side_boundaries(0.0, nxg * d, 0.0, ny * d)
+    ii, jj = np.meshgrid(np.arange(nxl + 1, dtype=np.int64), np.arange(ny + 1, dtype=np.int64), indexing="xy")
+    vgid = jj.ravel() * (nxg + 1) + ii.ravel() + i0          # vertex (i, j) of the global (nxg+1) x (ny+1) lattice
     return extract_local_mesh(xyz, conn, owned, cell_global_ids=gids,
-                              num_cells_global=2 * nxg * ny, boundary_classifier=cls)
+                              num_cells_global=2 * nxg * ny, boundary_classifier=cls,
+                              vertex_global_ids=vgid, num_vertices_global=(nxg + 1) * (ny + 1))
 
 
 # ---------------------------------------------------------------------------

@@ -21,6 +21,32 @@ import torch
 import torch.distributed as dist
 
 
+def reduce_courant(diag, device=None, group=None):
+    """UpdateOperatorDiagnostics' cross-rank step (src/operator.c:879): the MPI_Allreduce of the
+    {max_courant_num, global_edge_id, global_cell_id} struct with FindCourantNumberDiagnostics (705-715), which keeps
+    the struct holding the larger value -- so the edge and cell ids of the global maximum travel with it.  One
+    all-gather of the three 8-byte words per rank (the value's bit pattern, so nothing is rounded); ties go to the
+    lowest rank, a rank without a wet edge contributes (0, -1, -1) as ResetOperatorDiagnostics leaves it (772-784)."""
+    from .operator import CourantNumberDiagnostics
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return diag
+    import struct
+    world = dist.get_world_size(group)
+    on_gpu = dist.get_backend(group) == "nccl"
+    bits = struct.unpack("<q", struct.pack("<d", float(diag.max_courant_num)))[0]
+    mine = torch.tensor([bits, int(diag.global_edge_id), int(diag.global_cell_id)], dtype=torch.int64,
+                        device=device if on_gpu else "cpu")
+    parts = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine, group=group)
+    rows = torch.stack(parts).cpu().tolist()
+    best = CourantNumberDiagnostics(0.0, -1, -1)
+    for b, e, c in rows:                      # rank order: a later rank replaces only on a strictly larger value
+        v = struct.unpack("<d", struct.pack("<q", b))[0]
+        if v > best.max_courant_num:
+            best = CourantNumberDiagnostics(v, e, c)
+    return best
+
+
 @dataclasses.dataclass
 class AdaptiveTime:
     """RDyTimeAdaptiveSection (include/private/rdyconfigimpl.h): enable,
@@ -41,6 +67,7 @@ class EulerStepper:
         self.time = 0.0
         self.step = 0
         self.max_courant = None      # diagnostics of the last interval, all ranks (None = not updated yet)
+        self.courant = None          # the whole struct (value + global edge / cell id of the maximum)
         self._f = None
 
     def rhs(self, dt, u_local, f_global):
@@ -55,10 +82,12 @@ class EulerStepper:
         if self._f is None or self._f.shape[0] != self.op.mesh.num_owned_cells:
             self._f = torch.empty((self.op.mesh.num_owned_cells, 3), dtype=torch.float64, device=u_local.device)
         a = self.adaptive
-        if a is not None and self.max_courant is not None and self.max_courant > 0.0:
-            # src/rdyadvance.c:311-332
+        if a is not None and self.max_courant is not None:
+            # src/rdyadvance.c:308-330: rescaled whenever the diagnostics are valid; a zero Courant number (nothing
+            # wet) makes target / max infinite there, i.e. the factor is max_increase_factor
             if self.max_courant < a.target_courant_number:
-                dt *= min(a.target_courant_number / self.max_courant, a.max_increase_factor)
+                ratio = a.target_courant_number / self.max_courant if self.max_courant > 0.0 else float("inf")
+                dt *= min(ratio, a.max_increase_factor)
                 dt = min(dt, interval)
             else:
                 dt *= a.target_courant_number / self.max_courant
@@ -88,10 +117,6 @@ class EulerStepper:
         if a is not None:
             # UpdateOperatorDiagnostics: local 16-byte copy + the MPI_Allreduce(max) of src/operator.c:879
             self.op.update_diagnostics()
-            c = self.op.get_diagnostics().max_courant_num
-            if dist.is_initialized() and dist.get_world_size() > 1:
-                t = torch.tensor([c], dtype=torch.float64, device=u_local.device if dist.get_backend() == "nccl" else "cpu")
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                c = float(t.item())
-            self.max_courant = c
+            self.courant = reduce_courant(self.op.get_diagnostics(), u_local.device)
+            self.max_courant = self.courant.max_courant_num
         return dt

@@ -10,12 +10,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("extra", [[], ["--second-order"], ["--hr"]])
+@pytest.mark.parametrize("extra", [[], ["--second-order"], ["--hr"], ["--workload", "dambreak_quads", "--nx", "160", "--ny", "80", "--cpu-sample", "80x40"],
+                                   ["--workload", "c5", "--nx", "100", "--ny", "100", "--cpu-sample", "50x50", "--emulate-world", "4", "--emulate-rank", "1"]])
 def test_bench_line_has_the_contract_keys(extra, rdyhip_kernel):
     if rdyhip_kernel == "cell":
         pytest.skip("one kernel variant is enough")
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2", "--nx", "120", "--ny", "90",
-           "--cpu-sample", "60x40", "--no-cpu-all-cores"] + extra
+           "--cpu-sample", "60x40", "--no-cpu-all-cores", "--condition-seconds", "0.1"] + extra
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
@@ -25,11 +26,16 @@ def test_bench_line_has_the_contract_keys(extra, rdyhip_kernel):
               "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
     assert d["metric"].startswith("M cell-updates/s") and d["unit"] == "M cell-updates/s" and d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 2
-    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f64" and d["data"] == "synthetic"
+    strong = "dambreak_quads" in extra or "c5" in extra
+    assert d["higher_is_better"] is True and d["scaling"] == ("strong" if strong else "weak") and d["vs_baseline"] is None and d["dtype"] == "f64" and d["data"] == "synthetic"
+    assert "untimed RHS launches" in d["config"]["conditioning"] and d["config"]["world_size"] == 1
     assert "workload" in d["config"] and "model" not in d["config"] and d["config"]["finite"] is True
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
-    assert "traffic" in r and r["achieved"] > 0
+    assert "traffic" in r and r["achieved"] > 0 and r["steady_state_period_median_ms"] > 0
+    assert r["algorithmic_bytes_per_cell"] == (192.0 if "dambreak_quads" in extra else 176.0)
+    if not extra:
+        assert r["traffic_source"]["kernel_sha"] and set(d["cell_order_study"]) >= {"tiled", "rowmajor", "hilbert"}
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and c["unit"] == "M cell-updates/s" and "sample" in c
     assert d["value"] > 0 and abs(d["value"] - d["config"]["cells_per_gpu"] / d["ms_per_step"] / 1e3) <= 1e-3 * d["value"] + 0.11

@@ -1,8 +1,10 @@
-"""Several ranks on ONE GPU (gloo transport, device buffers staged through the
-host): the rank-local pieces of the N > 1 path -- strip partition, pack/unpack
-kernels, side-stream exchange overlapped with the interior tiles, halo tiles
-afterwards -- give the single-rank RHS.  RCCL itself cannot be exercised with
-several ranks on one device; everything around it is."""
+"""Several ranks on ONE GPU (gloo process group, bytes staged through the host): the rank-local pieces of the
+N > 1 path -- partition (strips or RCB), pack / unpack kernels, side-stream exchange overlapped with the interior
+tiles, halo tiles afterwards, the cross-rank Courant struct-max -- give the single-rank RHS.  Two drivers:
+transport="torch" (Python calls the ABI's pack / phase / unpack entry points one by one) and transport="c"
+(ONE call: rdyhip_rhs_overlapped / rdyhip_euler_step_overlapped, csrc/halo_exchange.h, with the bytes going through the
+ABI's transport callback because RCCL cannot connect several ranks that share a device).  RCCL itself is exercised by
+the one-rank self-exchange test at the bottom."""
 import os
 import socket
 import sys
@@ -22,7 +24,44 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, kernel, q, second_order=False):
+def _cases(kind, rank, world, second_order):
+    """(this rank's Case, the undivided Case, the undivided mesh's partition-independent edge id function)"""
+    from rdycore_amd import cases as CS
+    from rdycore_amd import mesh as M
+    from rdycore_amd import partition as P
+    if kind == "strips":
+        nxp, ny = 40, 48                      # per-rank strip: 3840 owned cells = 15 tiles
+        nxg = nxp * world
+        K = 2 * np.pi / 37
+        z = CS.mms_bathymetry(K=K)
+        mesh = M.strip_partition_tri_mesh(nxp, ny, rank, world, 1.0, zfunc=z, order="tiled", tile=8)
+        case = CS.friction_slope_case(mesh, nxg, ny, dt=1e-2, K=K)
+        g = M.structured_tri_mesh(nxg, ny, 1.0, zfunc=z)
+        gc = CS.friction_slope_case(g, nxg, ny, dt=1e-2, K=K)
+        ekey = lambda e: M.edge_vertex_key(g, e)
+    elif kind == "rcb_c5":
+        nx, ny = 200, 200                     # the C5 miniature: 80 000 triangles over the rough DEM, HR, ~40 % dry
+        case = CS.c5_case(CS.c5_mesh(nx, ny, rank, world), float(nx), float(ny))
+        g = CS.c5_mesh(nx, ny)
+        gc = CS.c5_case(g, float(nx), float(ny))
+        ekey = lambda e: e                     # the oracle reports edges.global_ids, which this mesh already carries partition-independent
+    elif kind == "rcb_quads":
+        case = CS.dam_break_quads_case(CS.dam_break_quads_mesh(320, 160, rank, world))
+        g = CS.dam_break_quads_mesh(320, 160)
+        gc = CS.dam_break_quads_case(g)
+        for c in (case, gc):                  # a moving state (the benchmark's initial state is at rest)
+            xc, yc = c.mesh.cell_centroids[:, 0], c.mesh.cell_centroids[:, 1]
+            c.u_local[:, 1] = 0.3 * c.u_local[:, 0] * np.sin(1.7 * xc + 0.9 * yc)
+            c.u_local[:, 2] = 0.2 * c.u_local[:, 0] * np.cos(1.1 * xc - 2.3 * yc)
+        ekey = lambda e: e
+    else:
+        raise ValueError(kind)
+    case.config.second_order = second_order
+    gc.config.second_order = second_order
+    return case, gc, ekey
+
+
+def _worker(rank, world, port, kernel, q, second_order=False, transport="torch", kind="strips"):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -33,20 +72,15 @@ def _worker(rank, world, port, kernel, q, second_order=False):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from rdycore_amd import cases as CS
-        from rdycore_amd import mesh as M
         from rdycore_amd.halo import HaloExchange
+        from rdycore_amd.timestep import reduce_courant
         from helpers import oracle_from_case, rel_linf
         torch.cuda.set_device(0)
         dev = torch.device("cuda", 0)
-        nxp, ny = 40, 48                      # per-rank strip: 3840 owned cells = 15 tiles
-        nxg = nxp * world
-        K = 2 * np.pi / 37
-        z = CS.mms_bathymetry(K=K)
-        mesh = M.strip_partition_tri_mesh(nxp, ny, rank, world, 1.0, zfunc=z, order="tiled", tile=8)
-        case = CS.friction_slope_case(mesh, nxg, ny, dt=1e-2, K=K)
-        case.config.second_order = second_order
+        case, gc, ekey = _cases(kind, rank, world, second_order)
+        mesh = case.mesh
         op = CS.create_operator(case)
-        halo = HaloExchange(mesh, dev)
+        halo = HaloExchange(mesh, dev, transport=transport, op=op)
         u_np = case.u_local.copy()
         u_np[mesh.cell_is_owned == 0] = np.nan          # ghosts unknown until exchanged
         u = torch.tensor(u_np, dtype=torch.float64, device=dev)
@@ -61,61 +95,150 @@ def _worker(rank, world, port, kernel, q, second_order=False):
         torch.cuda.synchronize()
         own = torch.as_tensor(mesh.cell_owned_to_local, device=dev).long()
         assert torch.allclose(u2[own], u[own] + case.dt * f, rtol=0, atol=1e-13), "fused Euler step differs from RHS + axpy"
+        # the plain (not overlapped) ghost update of a fresh array
+        u3 = torch.tensor(u_np, dtype=torch.float64, device=dev)
+        halo.exchange(u3)
+        torch.cuda.synchronize()
+        assert torch.equal(u3, u)
         halo.rhs_overlapped(op, case.dt, u, f)           # leave the diagnostics of a plain RHS behind
         # single-rank truth from the oracle on the undivided mesh
-        g = M.structured_tri_mesh(nxg, ny, 1.0, zfunc=z)
-        gc = CS.friction_slope_case(g, nxg, ny, dt=1e-2, K=K)
-        gc.config.second_order = second_order
         og = oracle_from_case(gc)
         fg = og.apply(gc.dt, gc.u_local)
-        gid = mesh.cell_global_ids[mesh.cell_owned_to_local]
-        err = rel_linf(f.cpu().numpy(), fg[gid])
+        g2row = {int(g): i for i, g in enumerate(gc.mesh.cell_global_ids)}
+        rows = np.array([g2row[int(g)] for g in mesh.cell_global_ids[mesh.cell_owned_to_local]])
+        err = rel_linf(f.cpu().numpy(), fg[rows])
+        # UpdateOperatorDiagnostics: local 16 bytes + the struct-max across ranks, ids included (src/operator.c:705-715, 879)
         op.update_diagnostics()
-        cmax = torch.tensor([op.get_diagnostics().max_courant_num], dtype=torch.float64)
-        dist.all_reduce(cmax, op=dist.ReduceOp.MAX)      # the MPI_Allreduce of src/operator.c:879
+        red = reduce_courant(op.get_diagnostics(), dev)
+        cg, eg, cellg = og.diagnostics()
+        ids_ok = red.global_cell_id == cellg and (red.global_edge_id == ekey(eg) if eg >= 0 else red.global_edge_id == -1)
         info = op.layout_info()
-        q.put((rank, err, abs(float(cmax) - og.diagnostics()[0]), info["num_halo_tiles"], info["num_tiles"]))
+        q.put((rank, err, abs(red.max_courant_num - cg), bool(ids_ok), info["num_halo_tiles"], info["num_tiles"]))
+        halo.destroy()
         op.destroy()
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.timeout(300)
-def test_three_ranks_one_gpu_overlapped_rhs(rdyhip_kernel):
-    world = 3
+def _run(world, args):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, rdyhip_kernel, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port) + args[:1] + (q,) + args[1:]) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
         p.join(240)
     assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
-    res = sorted(q.get(timeout=5) for _ in range(world))
-    for rank, err, cerr, nhalo_tiles, ntiles in res:
-        assert err <= 1e-10, (rank, err)
-        assert cerr <= 1e-12
-        assert 0 < nhalo_tiles < ntiles
+    return sorted(q.get(timeout=5) for _ in range(world))
 
 
 @pytest.mark.timeout(300)
-def test_three_ranks_one_gpu_second_order(rdyhip_kernel):
+@pytest.mark.parametrize("transport", ["torch", "c"])
+def test_three_ranks_one_gpu_overlapped_rhs(rdyhip_kernel, transport):
+    for rank, err, cerr, ids_ok, nhalo_tiles, ntiles in _run(3, (rdyhip_kernel, False, transport, "strips")):
+        assert err <= 1e-10, (rank, err)
+        assert cerr <= 1e-12 and ids_ok
+        if rdyhip_kernel != "cell":
+            assert 0 < nhalo_tiles < ntiles
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("transport", ["torch", "c"])
+def test_three_ranks_one_gpu_second_order(rdyhip_kernel, transport):
     """the second-order path across ranks: state exchange, gradients, gradient exchange (6 values per cell),
     fluxes of interior tiles overlapped, halo tiles afterwards; no reverse exchange"""
     if rdyhip_kernel == "cell":
         pytest.skip("second order is implemented by the tiled kernels")
-    world = 3
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, rdyhip_kernel, q, True)) for r in range(world)]
-    for p in procs:
-        p.start()
-    for p in procs:
-        p.join(240)
-    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
-    res = sorted(q.get(timeout=5) for _ in range(world))
-    for rank, err, cerr, nhalo_tiles, ntiles in res:
+    for rank, err, cerr, ids_ok, nhalo_tiles, ntiles in _run(3, (rdyhip_kernel, True, transport, "strips")):
         assert err <= 1e-10, (rank, err)
-        assert cerr <= 1e-12
+        assert cerr <= 1e-12 and ids_ok
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("kind", ["rcb_c5", "rcb_quads"])
+def test_three_rcb_ranks_one_gpu(rdyhip_kernel, kind):
+    """RCB parts (rdycore_amd/partition.py) instead of strips: the C5 miniature (rough DEM, hydrostatic reconstruction, dry
+    cells, outlet) and the reference's dam-break quad mesh with its hole, each on 3 ranks through the C-side overlapped
+    RHS = the oracle on the undivided mesh"""
+    if rdyhip_kernel == "cell" and kind == "rcb_c5":
+        pytest.skip("hydrostatic reconstruction is implemented by the tiled kernel")
+    for rank, err, cerr, ids_ok, nhalo_tiles, ntiles in _run(3, (rdyhip_kernel, False, "c", kind)):
+        assert err <= 1e-10, (rank, err)
+        assert cerr <= 1e-12 and ids_ok
+
+
+@pytest.mark.timeout(300)
+def test_rccl_self_exchange_one_rank(rdyhip_kernel):
+    """RCCL itself, as far as one device allows: a one-rank communicator (rdyhip_comm_init_rank) and a halo whose only
+    peer is this rank -- ncclSend / ncclRecv to self inside one group on the library's stream -- moves the packed cells
+    into the "ghost" rows; then the overlapped RHS through that halo equals the plain RHS"""
+    if rdyhip_kernel == "cell":
+        pytest.skip("one kernel variant is enough")
+    import ctypes as C
+    from rdycore_amd import _lib
+    from rdycore_amd import cases as CS
+    from rdycore_amd import mesh as M
+    lib = _lib.load()
+    torch.cuda.set_device(0)
+    assert lib.rdyhip_rccl_version() > 20000
+    K = 2 * np.pi / 37
+    mesh = M.structured_tri_mesh(48, 40, 1.0, zfunc=CS.mms_bathymetry(K=K), order="tiled", tile=8)
+    case = CS.friction_slope_case(mesh, 48.0, 40.0, dt=1e-2, K=K)
+    op = CS.create_operator(case)
+    uid = C.create_string_buffer(128)
+    _lib.check(lib.rdyhip_comm_unique_id(uid))
+    comm = C.c_void_p()
+    _lib.check(lib.rdyhip_comm_init_rank(1, 0, uid.raw, C.byref(comm)))
+    n = 500
+    i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+    send, recv = i32(np.arange(0, n)), i32(np.arange(2000, 2000 + n))      # "owned" cells 0..499 -> "ghost" rows 2000..2499
+    p = lambda a: a.ctypes.data_as(_lib.c_int32_p)
+    h = C.c_void_p()
+    _lib.check(lib.rdyhip_halo_create(op._h, comm, 1, p(i32([0])), p(i32([n])), p(send), p(i32([n])), p(recv), C.byref(h)))
+    u = torch.tensor(case.u_local, dtype=torch.float64, device="cuda:0")
+    v = u.clone()
+    st = int(torch.cuda.current_stream().cuda_stream)
+    _lib.check(lib.rdyhip_halo_exchange(h, int(v.data_ptr()), 3, st))
+    torch.cuda.synchronize()
+    expect = u.clone()
+    expect[2000:2000 + n] = u[0:n]
+    assert torch.equal(v, expect)
+    # overlapped RHS through the same halo: the exchange rewrites rows 2000.. of u before the halo phase; with no ghost
+    # cells in the mesh every tile is an interior tile, which reads u while the exchange writes it -- so feed a state whose
+    # rows 2000.. already equal rows 0.. (the exchange then rewrites identical values)
+    w = expect.clone()
+    f1 = torch.empty((mesh.num_owned_cells, 3), dtype=torch.float64, device="cuda:0")
+    f2 = torch.empty_like(f1)
+    _lib.check(lib.rdyhip_rhs_overlapped(op._h, h, case.dt, int(w.data_ptr()), int(f1.data_ptr()), st))
+    op.rhs_function(case.dt, expect, f2)
+    torch.cuda.synchronize()
+    assert torch.equal(w, expect) and torch.equal(f1, f2)
+    _lib.check(lib.rdyhip_halo_destroy(C.byref(h)))
+    _lib.check(lib.rdyhip_comm_destroy(comm))
+    op.destroy()
+
+
+@pytest.mark.timeout(600)
+def test_bench_self_launches_two_ranks(rdyhip_kernel):
+    """`python bench.py --gpus 2` started as a plain command launches its own ranks (rdycore_amd/launch.py) and prints
+    one line; BENCH_BACKEND=gloo lets both ranks share this box's one GPU"""
+    if rdyhip_kernel == "cell":
+        pytest.skip("one kernel variant is enough")
+    import json
+    import subprocess
+    env = dict(os.environ, BENCH_BACKEND="gloo")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    for extra, driver in (([], "torch"), (["--halo", "c"], "c"), (["--workload", "c5", "--nx", "160", "--ny", "160", "--halo", "c"], "c")):
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--nx", "200", "--ny", "200",
+               "--condition-seconds", "0.2"] + extra
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=500, cwd=ROOT, env=env)
+        assert out.returncode == 0, out.stderr[-3000:]
+        lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+        assert len(lines) == 1, lines
+        d = json.loads(lines[0])
+        assert d["n_gpus"] == 2 and d["config"]["world_size"] == 2 and d["config"]["backend"] == "gloo" and d["config"]["finite"] is True
+        assert d["scaling"] == ("strong" if "c5" in extra else "weak") and d["value"] > 0
+        assert d["config"]["halo_driver"] == driver and d["config"]["halo_bytes_per_rank"] > 0
+        assert d["config"]["max_courant"] > 0 and d["config"]["max_courant_cell"] >= 0

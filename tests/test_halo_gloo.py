@@ -70,14 +70,24 @@ def _worker(rank, world, port, ghosts_mode, q, second_order=False):
             orc.set_gradients_ready(True)
             f = orc.apply(case.dt, u.numpy())
         else:
-            f = oracle_from_case(case).apply(case.dt, u.numpy())
+            orc = oracle_from_case(case)
+            f = orc.apply(case.dt, u.numpy())
         # single-rank answer
         g = M.structured_tri_mesh(nxg, ny, 1.0, zfunc=z)
         gc = CS.friction_slope_case(g, nxg, ny, dt=1e-2, K=K)
         gc.config.second_order = second_order
-        fg = oracle_from_case(gc).apply(gc.dt, gc.u_local)
+        og = oracle_from_case(gc)
+        fg = og.apply(gc.dt, gc.u_local)
         gid = mesh.cell_global_ids[mesh.cell_owned_to_local]
         err = rel_linf(f, fg[gid])
+        # UpdateOperatorDiagnostics across ranks: the struct-max keeps the ids of the global maximum (src/operator.c:705-715, 879)
+        from rdycore_amd.operator import CourantNumberDiagnostics
+        from rdycore_amd.timestep import reduce_courant
+        red = reduce_courant(CourantNumberDiagnostics(*orc.diagnostics()))
+        cg, eg, cellg = og.diagnostics()
+        assert red.max_courant_num == cg and cg > 0.0
+        assert red.global_cell_id == cellg                           # global cell ids of the undivided mesh = its local ids
+        assert red.global_edge_id == M.edge_vertex_key(g, eg)        # partition-independent edge id (mesh.build_mesh)
         q.put((rank, err, halo.bytes_sent_per_exchange, int(ghost.sum())))
     finally:
         dist.destroy_process_group()

@@ -1,0 +1,53 @@
+"""profiles/traffic.json entry from the PMC passes of tools/profile_gpu.sh.
+
+usage: python tools/make_traffic.py gpurun_out/prof_<tag>/summary.json <key> [source note]
+  key = <workload>_<nx>x<ny>_<order>_<source>[_hr]   (what bench.py looks up)
+
+FETCH_SIZE is doubled (gfx950 counts 128-B requests as 64 B, MI355X_MICROARCH.md HBM section) and both counters are
+checked against the calibration kernel of the same session (rdyhip::axpy_owned_kernel on 10 M cells: 480 MB read,
+240 MB written).  The entry carries the hash of the kernel sources it was measured on; bench.py reports the figure
+only while that hash matches (a stale entry is reported as stale, never silently)."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def main():
+    summ, key = sys.argv[1], sys.argv[2]
+    note = sys.argv[3] if len(sys.argv) > 3 else os.path.relpath(summ, ROOT)
+    s = json.load(open(summ))
+    raw = s["pmc_raw_KB"]
+
+    def pick(sub, needle):
+        for k, v in raw.get(sub, {}).items():
+            if needle in k and v["mean"] is not None:
+                return k, v["mean"]
+        return None, None
+
+    kname, fetch = pick("pmc_fetch", "swe_rhs")
+    _, write = pick("pmc_write", "swe_rhs")
+    _, cal_f = pick("cal_fetch", "axpy_owned")
+    _, cal_w = pick("cal_write", "axpy_owned")
+    if fetch is None or write is None:
+        raise SystemExit("no FETCH_SIZE / WRITE_SIZE for the RHS kernel in " + summ)
+    rd, wr = fetch * 1024 * 2, write * 1024
+    ent = {"kernel": kname, "kernel_sha": bench.kernel_sha(), "FETCH_SIZE_KB_raw": fetch, "WRITE_SIZE_KB_raw": write,
+           "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr,
+           "correction": "FETCH_SIZE x2 (gfx950 counts 128-B requests as 64 B, MI355X_MICROARCH.md HBM section); WRITE_SIZE as is",
+           "source": note}
+    if cal_f is not None and cal_w is not None:
+        ent["calibration"] = {"kernel": "rdyhip::axpy_owned_kernel, 10 M cells: 480.0 MB read / 240.0 MB written by construction",
+                              "FETCH_SIZE_x2_MB": round(cal_f * 1024 * 2 / 1e6, 1), "WRITE_SIZE_MB": round(cal_w * 1024 / 1e6, 1)}
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    t = json.load(open(path)) if os.path.exists(path) else {}
+    t[key] = ent
+    json.dump(t, open(path, "w"), indent=1)
+    print(json.dumps({key: ent}, indent=1))
+
+
+if __name__ == "__main__":
+    main()
