@@ -41,11 +41,12 @@ ALG_BYTES_PER_CELL = 176.0     # algorithmic bytes per ce
 ALG_BYTES_PER_CELL_QUADS = 192.0   # the same count with 2 edges per cell: 80 + 32 x 2 + 48
 HBM_PEAK_GBPS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8 TB/s
 LIMITERS = {"minmod": 0, "none": 1, "van_leer": 2}
-# second order: 176 B + cell centroids (16) + one edge midpoint per edge (1.5 x 16) -- the least-squares coefficients and
-# the centroid->midpoint displacements are formed on the chip; the split form (RDYHIP_MUSCL=split) streams them
-# (3 x 16 + 1.5 x 32) and also writes and reads the gradient array (2 x 48) and reads the state twice (24)
-ALG_BYTES_PER_CELL_SECOND_ORDER = 176.0 + 48.0 + 48.0
-ALG_BYTES_PER_CELL_SECOND_ORDER_SPLIT = ALG_BYTES_PER_CELL_SECOND_ORDER + 96.0 + 24.0
+# second order: 176 B + cell centroids (16) + one edge midpoint per edge (1.5 x 16) -- the least-squares coefficients
+# (3 x 16 B per cell in the reference) and the centroid->midpoint displacements (1.5 x 32 B) are formed on the chip from
+# them; the split form (RDYHIP_MUSCL=split) also writes and reads the gradient array (2 x 48) and reads the state and the
+# centroids twice (24 + 16)
+ALG_BYTES_PER_CELL_SECOND_ORDER = 176.0 + 16.0 + 24.0
+ALG_BYTES_PER_CELL_SECOND_ORDER_SPLIT = ALG_BYTES_PER_CELL_SECOND_ORDER + 96.0 + 24.0 + 16.0
 KERNEL_SOURCES = ["rdyhip_api.hip", "swe_kernels.h", "swe_device.h", "muscl_kernels.h"]
 
 
@@ -355,11 +356,14 @@ def run_rank(args, argv):
     # individually bracketed launches are used there
     kern_ms = ev0.elapsed_time(ev1) / args.steps if world == 1 else kern_isolated_ms
 
-    def timed(fn, n, sync_ranks=True):
-        fn()
-        torch.cuda.synchronize()
+    def timed(fn, n, sync_ranks=True, lead=40):
+        """ms per call over n back-to-back calls.  `lead` untimed calls go first with no gap before the timed ones: after
+        ANY idle moment (a synchronize is enough) launches 5..40 run 20-30 % slow (profiles/r02_launch_series.json)."""
         if world > 1 and sync_ranks:
+            torch.cuda.synchronize()
             dist.barrier()
+        for _ in range(lead):
+            fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(n):
@@ -369,11 +373,22 @@ def run_rank(args, argv):
         return e0.elapsed_time(e1) / n
 
     # steady state: the launch-to-launch period of back-to-back launches, median over batches (what a long run sees)
-    periods = [timed(kernel_only, 10, sync_ranks=False) for _ in range(12)] if world == 1 else []
+    periods = []
+    if world == 1:
+        for _ in range(40):
+            kernel_only()
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(13)]
+        evs[0].record()
+        for b in range(12):
+            for _ in range(10):
+                kernel_only()
+            evs[b + 1].record()
+        torch.cuda.synchronize()
+        periods = [evs[b].elapsed_time(evs[b + 1]) / 10 for b in range(12)]
     period_median_ms = float(np.median(periods)) if periods else None
 
     # multi-GPU: the ghost update on its own (pack, P2P over RCCL, unpack), not overlapped
-    halo_ms = timed(lambda: halo.exchange(u), k_iters) if halo is not None else None
+    halo_ms = timed(lambda: halo.exchange(u), k_iters, lead=5) if halo is not None else None
 
     # ---- extra (not the metric): one whole forward-Euler step, the update fused into the RHS kernel's stores
     # (rdyhip_euler_step, F never written) against the RHS + axpy pair -- SURVEY.md 8.f row 1
@@ -390,7 +405,7 @@ def run_rank(args, argv):
         step()
         op.axpy_owned(0.0, f, u3)      # dt = 0: same traffic, the scratch state stays put
 
-    ef, ep = timed(fused_step, k_iters), timed(pair_step, k_iters)
+    ef, ep = timed(fused_step, 60), timed(pair_step, 60)
     euler = {"fused_ms_per_step": round(ef, 5), "rhs_plus_axpy_ms_per_step": round(ep, 5), "fused_steps_per_s": round(1e3 / ef, 1)}
     del u2, u3
     step()   # leave F and the diagnostics of a plain RHS evaluation behind for the sanity checks below
@@ -418,7 +433,7 @@ def run_rank(args, argv):
             c2 = build_case(args, 0, 1, order=o2)
             op2 = CS.create_operator(c2)
             uu = torch.tensor(c2.u_local, dtype=torch.float64, device=dev)
-            ms = float(np.median([timed(lambda: op2.rhs_function(c2.dt, uu, f), 10, sync_ranks=False) for _ in range(8)]))
+            ms = timed(lambda: op2.rhs_function(c2.dt, uu, f), 100, sync_ranks=False)
             order_study[o2] = round(n_owned / ms / 1e3, 1)
             order_study["edge_records_per_cell"][o2] = round(op2.layout_info()["num_edge_records"] / n_owned, 4)
             op2.destroy()

@@ -4,9 +4,15 @@
 // (src/operator_fluxes_ceed.c:998-1042, 1155-1206).
 //
 //  * muscl_gradient_kernel: one thread per owned cell; the weighted
-//    least-squares gradient of (h, hu, hv) from the cell's <= S neighbours with
-//    coefficients precomputed at create (PrecomputeLSGradCoeffs), summed in the
-//    reference's internal-edge order; writes grad[local cell][6].
+//    least-squares gradient of (h, hu, hv) from the cell's <= S neighbours,
+//    accumulated in the reference's internal-edge order; writes grad[local cell][6].
+//    The least-squares coefficients are NOT streamed from memory: the reference
+//    precomputes c_edge = M^-1 w d per (cell, edge) (PrecomputeLSGradCoeffs, 48 B per
+//    triangle) -- here every gradient is formed from the cell centroids (16 B per cell)
+//    as M^-1 sum_n w_n d_n (q_n - q_c), the same expression by linearity (ls_add /
+//    ls_solve below; flops are free on this memory-bound path).  Likewise an edge's
+//    centroid -> midpoint displacements (32 B per edge in ReconstructFaceValues) are
+//    formed from ONE stored midpoint (16 B) and the centroids already on the chip.
 //  * swe_rhs_muscl_kernel: the tiled three-phase structure of swe_kernels.h.
 //    Phase 0 stages the conserved state and the gradient of the tile's own and
 //    halo cells in LDS; phase 1 reconstructs the two limited face states of every
@@ -51,30 +57,62 @@ __device__ __forceinline__ uint2 load_u2(const void *p) {
 
 struct MusclArgs {
   double       *grad;   // [num_cells][6]: dh/dx, dh/dy, dhu/dx, dhu/dy, dhv/dx, dhv/dy (local cell index)
-  const double *e_geo;  // [nrec][4]: edge midpoint minus left centroid (x, y), minus right centroid (x, y)
-  const double *gcx;    // [S][stride] least-squares coefficient of each slot's neighbour difference (q_nbr - q_self)
-  const double *gcy;
+  const double *e_mid;  // [nrec][2]: edge midpoint (x, y) of each tile edge record
+  const double *cxy;    // [num_cells][2]: cell centroid (x, y), local cell index
   // fused kernel only: the second ring of each tile and the stencils of its first-ring cells
   const int32_t  *hcells2;  // second-ring cells of each tile (local cell ids): neighbours of first-ring cells outside the tile
   const int32_t  *c_off;    // [ntiles+1] first hcells2 entry of each tile
   const uint16_t *bn_idx;   // [halo entries][4] LDS slot of each first-ring cell's s-th neighbour; BN_NONE: no neighbour in that
                             //                   slot; BN_GLOBAL: a ghost cell, its gradient comes from `grad` (exchanged)
-  const double   *bn_c;     // [halo entries][S][2] the first-ring cell's least-squares coefficients (copies of gcx, gcy)
   int32_t         hmax2;    // largest first + second ring of a tile (LDS sizing)
 };
 constexpr uint16_t BN_NONE = 0xFFFF, BN_GLOBAL = 0xFFFE;
 
-// One neighbour's contribution to a cell's gradient.  Explicit fma, shared by every kernel that forms a
-// gradient: a cell's gradient is computed by its own tile, by every tile that has it in its first ring and (for
-// the exchange between ranks) by muscl_gradient_kernel, and a cut edge is conservative only if all of them get
-// the same bits.
-__device__ __forceinline__ void grad_add(double (&g)[6], double cx, double cy, double d0, double d1, double d2) {
-  g[0] = fma(cx, d0, g[0]);
-  g[1] = fma(cy, d0, g[1]);
-  g[2] = fma(cx, d1, g[2]);
-  g[3] = fma(cy, d1, g[3]);
-  g[4] = fma(cx, d2, g[4]);
-  g[5] = fma(cy, d2, g[5]);
+// Weighted least-squares gradient of a cell (PrecomputeLSGradCoeffs + ComputeLeastSquaresGradients,
+// src/operator_fluxes_ceed.c:884-1042) accumulated neighbour by neighbour: with d = centroid_n - centroid_c,
+// w = 1/|d|, M += w d d^T and b_k += w d (q_n,k - q_c,k); the gradient is M^-1 b_k (zero for a degenerate stencil,
+// |det M| < 1e-15, as in the reference).  Explicit fma throughout and ONE code path shared by every kernel that
+// forms a gradient: a cell's gradient is computed by its own tile, by every tile that has it in its first ring and
+// (for the exchange between ranks) by muscl_gradient_kernel, and a cut edge is conservative only if all of them
+// get the same bits.
+struct LsAcc {
+  double m00 = 0.0, m01 = 0.0, m11 = 0.0;
+  double b[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};  // (bx, by) of h, hu, hv
+};
+__device__ __forceinline__ void ls_add(LsAcc &a, double dx, double dy, double d0, double d1, double d2) {
+  const double r2 = fma(dx, dx, dy * dy);
+  // w = 1/sqrt(r2) by v_rsq_f64 + two Newton steps (<= 1 ulp); coincident centroids give w = 0 as in the reference
+  double w = __builtin_amdgcn_rsq(r2);
+  w        = w * fma(-0.5 * r2 * w, w, 1.5);
+  w        = w * fma(-0.5 * r2 * w, w, 1.5);
+  if (!(r2 > 0.0)) w = 0.0;
+  const double wdx = w * dx, wdy = w * dy;
+  a.m00  = fma(wdx, dx, a.m00);
+  a.m01  = fma(wdx, dy, a.m01);
+  a.m11  = fma(wdy, dy, a.m11);
+  a.b[0] = fma(wdx, d0, a.b[0]);
+  a.b[1] = fma(wdy, d0, a.b[1]);
+  a.b[2] = fma(wdx, d1, a.b[2]);
+  a.b[3] = fma(wdy, d1, a.b[3]);
+  a.b[4] = fma(wdx, d2, a.b[4]);
+  a.b[5] = fma(wdy, d2, a.b[5]);
+}
+__device__ __forceinline__ void ls_solve(const LsAcc &a, double (&g)[6]) {
+  const double p   = a.m01 * a.m01;
+  const double det = fma(a.m00, a.m11, -p);
+  if (fabs(det) < 1e-15) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) g[k] = 0.0;
+    return;
+  }
+  const double inv_det = rdy_rcp(det);
+  const double i00 = a.m11 * inv_det, i01 = -(a.m01 * inv_det), i11 = a.m00 * inv_det;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const double t0 = i01 * a.b[2 * k + 1], t1 = i11 * a.b[2 * k + 1];
+    g[2 * k]     = fma(i00, a.b[2 * k], t0);
+    g[2 * k + 1] = fma(i01, a.b[2 * k], t1);
+  }
 }
 
 // RDyLimiterType, include/private/rdyconfigimpl.h:67-71
@@ -92,10 +130,11 @@ __device__ __forceinline__ double limit_slope(double extrap, double half_dq) {
 // One tile edge of the second-order path: ReconstructFaceValues (src/operator_fluxes_ceed.c:1180-1203) for an
 // interior edge -- limited extrapolation of both cells' states to the edge midpoint, depth clamped from below --
 // then ComputeRiemannVelocities + the Roe flux on the reconstructed states (src/swe/swe_petsc.c:139-161); a boundary
-// edge stays first order.  `sq` / `sg`: LDS planes of the state (stride nq) and the gradient (stride ng);
-// dl / dr: edge midpoint minus the left / right centroid.  The flux is parked in LDS for phase 2.
+// edge stays first order.  `sq` / `sg`: LDS planes of the state (stride nq; planes 3 and 4: the centroid x, y) and the
+// gradient (stride ng); mid: the edge midpoint, from which the two centroid -> midpoint displacements are formed
+// (src/operator_fluxes_ceed.c:1169-1178).  The flux is parked in LDS for phase 2.
 template <int LIM>
-__device__ __forceinline__ void muscl_edge(const KernelArgs &a, const TileDesc &td, double dt, int e, uint32_t lr, double cs, double2 dl, double2 dr,
+__device__ __forceinline__ void muscl_edge(const KernelArgs &a, const TileDesc &td, double dt, int e, uint32_t lr, double cs, double2 mid,
                                            const double *sq, int nq, const double *sg, int ng, double *ef0, double *ef1, double *ef2, double *eam) {
   double cn, sn;
   edge_normal(lr, cs, cn, sn);
@@ -105,6 +144,11 @@ __device__ __forceinline__ void muscl_edge(const KernelArgs &a, const TileDesc &
   if (!(lr & EDGE_BOUNDARY)) {
     const int jr = (lr >> EDGE_R_SHIFT) & EDGE_SLOT_MASK;
     double    ql[3], qr[3];
+    double2   dl, dr;
+    dl.x = mid.x - sq[3 * nq + jl];
+    dl.y = mid.y - sq[4 * nq + jl];
+    dr.x = mid.x - sq[3 * nq + jr];
+    dr.y = mid.y - sq[4 * nq + jr];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       const double cl_ = sq[k * nq + jl], cr_ = sq[k * nq + jr];
@@ -172,10 +216,9 @@ __device__ __forceinline__ void muscl_cell_sum(uint32_t r0, uint32_t r1, const d
   }
 }
 
-// ComputeLeastSquaresGradients, src/operator_fluxes_ceed.c:998-1042, gathered per cell:
-// grad(cell) = sum over its internal edges of c_edge * (q_nbr - q_cell), where c_edge is
-// (cx_LR, cy_LR) if the cell is the edge's left cell and -(cx_RL, cy_RL) if it is the right
-// one (the reference multiplies by q_R - q_L for both).
+// ComputeLeastSquaresGradients, src/operator_fluxes_ceed.c:998-1042, gathered per cell: the cell's internal edges in
+// the reference's loop order (slot order), neighbour minus self for both the left and the right cell of an edge (the
+// reference multiplies c_LR and c_RL by q_R - q_L; the signs cancel in w d (q_n - q_c)).
 template <int S>
 __global__ __launch_bounds__(BLOCK) void muscl_gradient_kernel(const KernelArgs a, const MusclArgs g, const double *__restrict__ u) {
   int tile = blockIdx.x;
@@ -194,28 +237,32 @@ __global__ __launch_bounds__(BLOCK) void muscl_gradient_kernel(const KernelArgs 
   if (a.phase == RDYHIP_PHASE_HALO && !has_ghost) return;
   const int    c  = a.o2l ? a.o2l[o] : o;
   const double q0 = u[3 * (int64_t)c + 0], q1 = u[3 * (int64_t)c + 1], q2 = u[3 * (int64_t)c + 2];
-  double       gr[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  const double x0 = g.cxy[2 * (int64_t)c], y0 = g.cxy[2 * (int64_t)c + 1];
+  LsAcc        acc;
 #pragma unroll
   for (int s = 0; s < S; ++s) {
     if (id[s] < 0) continue;  // boundary edge or unused slot: not part of the stencil
-    const int    n  = id[s] & NBR_MASK;
-    const double cx = g.gcx[s * a.stride + o], cy = g.gcy[s * a.stride + o];
-    grad_add(gr, cx, cy, u[3 * (int64_t)n + 0] - q0, u[3 * (int64_t)n + 1] - q1, u[3 * (int64_t)n + 2] - q2);
+    const int n = id[s] & NBR_MASK;
+    ls_add(acc, g.cxy[2 * (int64_t)n] - x0, g.cxy[2 * (int64_t)n + 1] - y0, u[3 * (int64_t)n + 0] - q0, u[3 * (int64_t)n + 1] - q1,
+           u[3 * (int64_t)n + 2] - q2);
   }
+  double gr[6];
+  ls_solve(acc, gr);
   double2 *dst = reinterpret_cast<double2 *>(g.grad + 6 * (int64_t)c);
   dst[0]       = make_double2(gr[0], gr[1]);
   dst[1]       = make_double2(gr[2], gr[3]);
   dst[2]       = make_double2(gr[4], gr[5]);
 }
 
+// split form (RDYHIP_MUSCL=split): the gradients come from memory (muscl_gradient_kernel), kept for A/B
 template <int S, int SRC, bool OVW, int LIM>
 __global__ __launch_bounds__(TILE) void swe_rhs_muscl_kernel(const KernelArgs a, const MusclArgs g, const double dt, const double *__restrict__ u,
                                                               double *__restrict__ f) {
   extern __shared__ double lds[];
   const int nside = TILE + a.hmax;
-  double   *sq    = lds;              // 3 planes of nside: h, hu, hv
-  double   *sg    = lds + 3 * nside;  // 6 planes of nside: the gradient
-  double   *ef0 = lds + 9 * nside, *ef1 = ef0 + a.emax, *ef2 = ef1 + a.emax, *eam = ef2 + a.emax;
+  double   *sq    = lds;              // 5 planes of nside: h, hu, hv, centroid x, y
+  double   *sg    = lds + 5 * nside;  // 6 planes of nside: the gradient
+  double   *ef0 = lds + 11 * nside, *ef1 = ef0 + a.emax, *ef2 = ef1 + a.emax, *eam = ef2 + a.emax;
   const int tid = threadIdx.x;
 
   // the tile sequence of this (persistent) workgroup: as in swe_rhs_tiled_kernel
@@ -242,24 +289,28 @@ __global__ __launch_bounds__(TILE) void swe_rhs_muscl_kernel(const KernelArgs a,
     const int  o      = tile * TILE + tid;
     const bool active = o < a.n_owned;
 
-    // ---- phase 0: conserved state and gradient of the tile's own and halo cells -> LDS
+    // ---- phase 0: conserved state, centroid and gradient of the tile's own and halo cells -> LDS
     {
-      double q[3] = {0.0, 0.0, 0.0}, gr[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+      double q[5] = {0.0, 0.0, 0.0, 0.0, 0.0}, gr[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
       if (active) {
         const int c = a.o2l ? a.o2l[o] : o;
 #pragma unroll
         for (int k = 0; k < 3; ++k) q[k] = u[3 * (int64_t)c + k];
+        q[3] = g.cxy[2 * (int64_t)c];
+        q[4] = g.cxy[2 * (int64_t)c + 1];
 #pragma unroll
         for (int k = 0; k < 6; ++k) gr[k] = g.grad[6 * (int64_t)c + k];
       }
 #pragma unroll
-      for (int k = 0; k < 3; ++k) sq[k * nside + tid] = q[k];
+      for (int k = 0; k < 5; ++k) sq[k * nside + tid] = q[k];
 #pragma unroll
       for (int k = 0; k < 6; ++k) sg[k * nside + tid] = gr[k];
       for (int j = tid; j < nh; j += TILE) {
         const int hc = a.hcells[td.h_off + j];
 #pragma unroll
         for (int k = 0; k < 3; ++k) sq[k * nside + TILE + j] = u[3 * (int64_t)hc + k];
+        sq[3 * nside + TILE + j] = g.cxy[2 * (int64_t)hc];
+        sq[4 * nside + TILE + j] = g.cxy[2 * (int64_t)hc + 1];
 #pragma unroll
         for (int k = 0; k < 6; ++k) sg[k * nside + TILE + j] = g.grad[6 * (int64_t)hc + k];
       }
@@ -268,8 +319,8 @@ __global__ __launch_bounds__(TILE) void swe_rhs_muscl_kernel(const KernelArgs a,
 
     // ---- phase 1: every edge of the tile once
     for (int e = tid; e < ne; e += TILE) {
-      const double2 *geo = reinterpret_cast<const double2 *>(g.e_geo + 4 * ((int64_t)td.e_off + e));
-      muscl_edge<LIM>(a, td, dt, e, a.e_lr[td.e_off + e], a.e_cs[td.e_off + e], geo[0], geo[1], sq, nside, sg, nside, ef0, ef1, ef2, eam);
+      const double2 mid = *reinterpret_cast<const double2 *>(g.e_mid + 2 * ((int64_t)td.e_off + e));
+      muscl_edge<LIM>(a, td, dt, e, a.e_lr[td.e_off + e], a.e_cs[td.e_off + e], mid, sq, nside, sg, nside, ef0, ef1, ef2, eam);
     }
     __syncthreads();
 
@@ -306,22 +357,23 @@ __global__ __launch_bounds__(TILE) void swe_rhs_muscl_kernel(const KernelArgs a,
 
 // ---------------------------------------------------------------------------
 // Fused form (default): the gradients never leave the chip.  A tile stages the
-// state of its own cells, of its first ring (cells sharing an edge with a tile
-// cell) and of its second ring (the remaining neighbours of first-ring cells),
-// computes the gradients of own + first-ring cells in LDS, and goes on as above.
-// Saves the gradient array's write + read and the second read of the state
-// (120 B per cell-update) for ~20 B of second-ring state and first-ring stencils.
-// First-ring cells that are ghosts take their gradient from `grad`, filled by the
-// caller's exchange (their stencil is not local).
+// state and the centroid of its own cells, of its first ring (cells sharing an
+// edge with a tile cell) and of its second ring (the remaining neighbours of
+// first-ring cells), forms the least-squares gradients of own + first-ring
+// cells in LDS, and goes on as above.  Against the split form this saves the
+// gradient array's write + read, the second read of the state and the streamed
+// least-squares coefficients / displacements.  First-ring cells that are ghosts
+// take their gradient from `grad`, filled by the caller's exchange (their
+// stencil is not local).
 // ---------------------------------------------------------------------------
 template <int S, int SRC, bool OVW, int LIM, bool EULER = false>
 __global__ __launch_bounds__(TILE) void swe_rhs_muscl_fused_kernel(const KernelArgs a, const MusclArgs g, const double dt, const double *__restrict__ u,
                                                                     double *__restrict__ f) {
   extern __shared__ double lds[];
-  const int nq = TILE + g.hmax2;  // state planes: own, first ring, second ring
+  const int nq = TILE + g.hmax2;  // state + centroid planes: own, first ring, second ring
   const int ng = TILE + a.hmax;   // gradient planes: own, first ring
-  double   *sq = lds;
-  double   *sg = lds + 3 * nq;
+  double   *sq = lds;             // 5 planes: h, hu, hv, centroid x, centroid y
+  double   *sg = lds + 5 * nq;
   double   *ef0 = sg + 6 * ng, *ef1 = ef0 + a.emax, *ef2 = ef1 + a.emax, *eam = ef2 + a.emax;
   uint32_t *slr = reinterpret_cast<uint32_t *>(eam + a.emax);  // the tile's edge records
   const int tid = threadIdx.x;
@@ -352,6 +404,18 @@ __global__ __launch_bounds__(TILE) void swe_rhs_muscl_fused_kernel(const KernelA
     else if (tid < nh_ + nc2_) id = g.hcells2[c0_ + tid - nh_];
     return id;
   };
+  // least-squares gradient of the cell in LDS slot `self` from the cells in slots nb[0..S-1] (-1: none), slot order
+  auto lds_gradient = [&](int self, const int (&nb)[S], double (&gr)[6]) {
+    const double q0 = sq[self], q1 = sq[nq + self], q2 = sq[2 * nq + self], x0 = sq[3 * nq + self], y0 = sq[4 * nq + self];
+    LsAcc        acc;
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      const int n = nb[s];
+      if (n < 0) continue;
+      ls_add(acc, sq[3 * nq + n] - x0, sq[4 * nq + n] - y0, sq[n] - q0, sq[nq + n] - q1, sq[2 * nq + n] - q2);
+    }
+    ls_solve(acc, gr);
+  };
 
   double best      = 0.0;
   int    best_slot = -1, best_o = 0;
@@ -370,15 +434,17 @@ __global__ __launch_bounds__(TILE) void swe_rhs_muscl_fused_kernel(const KernelA
     // hipcc waits with vmcnt(0) at the first use, so one batch = one exposed latency per tile.
     const int hid = (pre_tile == tile) ? pre_hid : ring_id(td, nh, c0, nc2);
     double    q[3] = {0.0, 0.0, 0.0}, hq[3] = {0.0, 0.0, 0.0};
+    double2   cxy = make_double2(0.0, 0.0), hcxy = make_double2(0.0, 0.0);
     uint32_t  r0 = 0xFFFFFFFFu, r1 = 0xFFFFFFFFu;
-    double    gx[S], gy[S], kf[S];
+    double    kf[S];
     double    dzx = 0.0, dzy = 0.0, nman = 0.0, s0 = 0.0, s1 = 0.0, s2 = 0.0;
 #pragma unroll
-    for (int s = 0; s < S; ++s) gx[s] = gy[s] = kf[s] = 0.0;
+    for (int s = 0; s < S; ++s) kf[s] = 0.0;
     if (active) {
       const int c = a.o2l ? a.o2l[o] : o;
 #pragma unroll
       for (int k = 0; k < 3; ++k) q[k] = u[3 * (int64_t)c + k];
+      cxy = *reinterpret_cast<const double2 *>(g.cxy + 2 * (int64_t)c);
       if (S == 3) {
         r0 = RDY_MLD(&reinterpret_cast<const uint32_t *>(a.slot_ref)[o]);
       } else {
@@ -387,11 +453,7 @@ __global__ __launch_bounds__(TILE) void swe_rhs_muscl_fused_kernel(const KernelA
         r1            = w.y;
       }
 #pragma unroll
-      for (int s = 0; s < S; ++s) {
-        gx[s] = RDY_MLD(&g.gcx[s * a.stride + o]);
-        gy[s] = RDY_MLD(&g.gcy[s * a.stride + o]);
-        kf[s] = RDY_MLD(&a.coef[s * a.stride + o]);
-      }
+      for (int s = 0; s < S; ++s) kf[s] = RDY_MLD(&a.coef[s * a.stride + o]);
       dzx  = RDY_MLD(&a.dzdx[o]);
       dzy  = RDY_MLD(&a.dzdy[o]);
       nman = RDY_MLD(&a.mannings[o]);
@@ -402,33 +464,22 @@ __global__ __launch_bounds__(TILE) void swe_rhs_muscl_fused_kernel(const KernelA
     if (hid >= 0) {
 #pragma unroll
       for (int k = 0; k < 3; ++k) hq[k] = u[3 * (int64_t)hid + k];
+      hcxy = *reinterpret_cast<const double2 *>(g.cxy + 2 * (int64_t)hid);
     }
-    uint2  bw = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);  // first-ring stencil of ring cell j = tid
-    double bc[2 * S];
-#pragma unroll
-    for (int s = 0; s < 2 * S; ++s) bc[s] = 0.0;
-    if (tid < nh) {
-      const int64_t entry = (int64_t)td.h_off + tid;
-      bw                  = load_u2(g.bn_idx + 4 * entry);
-#pragma unroll
-      for (int s = 0; s < 2 * S; ++s) bc[s] = RDY_MLD(&g.bn_c[entry * (2 * S) + s]);
-    }
+    uint2 bw = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);  // first-ring stencil of ring cell j = tid: the LDS slots of its neighbours
+    if (tid < nh) bw = load_u2(g.bn_idx + 4 * ((int64_t)td.h_off + tid));
     uint32_t lr0 = 0, lr1 = 0;
     double   cs0 = 0.0, cs1 = 0.0;
-    double2  gl0 = make_double2(0.0, 0.0), gr0 = gl0, gl1 = gl0, gr1 = gl0;
+    double2  md0 = make_double2(0.0, 0.0), md1 = md0;
     if (tid < ne) {
       lr0 = RDY_MLD(&a.e_lr[td.e_off + tid]);
       cs0 = RDY_MLD(&a.e_cs[td.e_off + tid]);
-      const double *geo = g.e_geo + 4 * ((int64_t)td.e_off + tid);
-      gl0 = load_d2(geo);
-      gr0 = load_d2(geo + 2);
+      md0 = load_d2(g.e_mid + 2 * ((int64_t)td.e_off + tid));
     }
     if (tid + TILE < ne) {
       lr1 = RDY_MLD(&a.e_lr[td.e_off + TILE + tid]);
       cs1 = RDY_MLD(&a.e_cs[td.e_off + TILE + tid]);
-      const double *geo = g.e_geo + 4 * ((int64_t)td.e_off + TILE + tid);
-      gl1 = load_d2(geo);
-      gr1 = load_d2(geo + 2);
+      md1 = load_d2(g.e_mid + 2 * ((int64_t)td.e_off + TILE + tid));
     }
     // the ring-cell id of the tile this workgroup takes next
     pre_tile = -1;
@@ -439,17 +490,23 @@ __global__ __launch_bounds__(TILE) void swe_rhs_muscl_fused_kernel(const KernelA
       pre_hid            = ring_id(pd, pn.h_off - pd.h_off, pc0, load_uniform(g.c_off, pre_tile + 1) - pc0);
     }
 
-    // ---- phase 0: state of own cells, first ring, second ring; the tile's edge records -> LDS
+    // ---- phase 0: state + centroid of own cells, first ring, second ring; the tile's edge records -> LDS
 #pragma unroll
     for (int k = 0; k < 3; ++k) sq[k * nq + tid] = q[k];
+    sq[3 * nq + tid] = cxy.x;
+    sq[4 * nq + tid] = cxy.y;
     if (hid >= 0) {
 #pragma unroll
       for (int k = 0; k < 3; ++k) sq[k * nq + TILE + tid] = hq[k];
+      sq[3 * nq + TILE + tid] = hcxy.x;
+      sq[4 * nq + TILE + tid] = hcxy.y;
     }
     for (int j = tid + TILE; j < nh + nc2; j += TILE) {  // only numberings with poor locality get here
       const int hc = (j < nh) ? a.hcells[td.h_off + j] : g.hcells2[c0 + j - nh];
 #pragma unroll
       for (int k = 0; k < 3; ++k) sq[k * nq + TILE + j] = u[3 * (int64_t)hc + k];
+      sq[3 * nq + TILE + j] = g.cxy[2 * (int64_t)hc];
+      sq[4 * nq + TILE + j] = g.cxy[2 * (int64_t)hc + 1];
     }
     if (tid < ne) slr[tid] = lr0;
     if (tid + TILE < ne) slr[tid + TILE] = lr1;
@@ -460,21 +517,22 @@ __global__ __launch_bounds__(TILE) void swe_rhs_muscl_fused_kernel(const KernelA
     {
       double gr[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
       if (active) {
-        const double own0 = sq[tid], own1 = sq[nq + tid], own2 = sq[2 * nq + tid];  // the own state again, from LDS (registers are scarce)
+        int nb[S];
 #pragma unroll
         for (int s = 0; s < S; ++s) {
+          nb[s]         = -1;
           const int ref = slot_edge<S>(r0, r1, s);
           if (ref < 0) continue;
           const uint32_t lr = slr[ref];
           if (lr & EDGE_BOUNDARY) continue;
           const int jl = lr & EDGE_SLOT_MASK, jr = (lr >> EDGE_R_SHIFT) & EDGE_SLOT_MASK;
-          const int nb = (jl == tid) ? jr : jl;
-          grad_add(gr, gx[s], gy[s], sq[nb] - own0, sq[nq + nb] - own1, sq[2 * nq + nb] - own2);
+          nb[s]        = (jl == tid) ? jr : jl;
         }
+        lds_gradient(tid, nb, gr);
       }
 #pragma unroll
       for (int k = 0; k < 6; ++k) sg[k * ng + tid] = gr[k];
-      auto ring_gradient = [&](int j, uint2 w, const double *c, double h0, double h1, double h2) {
+      auto ring_gradient = [&](int j, uint2 w) {
         const uint32_t ix[4] = {w.x & 0xFFFFu, w.x >> 16, w.y & 0xFFFFu, w.y >> 16};
         double         hg[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
         if (ix[0] == BN_GLOBAL) {  // a ghost cell: its gradient was computed by its owner
@@ -482,40 +540,31 @@ __global__ __launch_bounds__(TILE) void swe_rhs_muscl_fused_kernel(const KernelA
 #pragma unroll
           for (int k = 0; k < 6; ++k) hg[k] = g.grad[6 * (int64_t)hc + k];
         } else {
+          int nb[S];
 #pragma unroll
-          for (int s = 0; s < S; ++s) {
-            if (ix[s] == BN_NONE) continue;
-            const int nb = (int)ix[s];
-            grad_add(hg, c[2 * s], c[2 * s + 1], sq[nb] - h0, sq[nq + nb] - h1, sq[2 * nq + nb] - h2);
-          }
+          for (int s = 0; s < S; ++s) nb[s] = (ix[s] == BN_NONE) ? -1 : (int)ix[s];
+          lds_gradient(TILE + j, nb, hg);
         }
 #pragma unroll
         for (int k = 0; k < 6; ++k) sg[k * ng + TILE + j] = hg[k];
       };
-      if (tid < nh) ring_gradient(tid, bw, bc, hq[0], hq[1], hq[2]);
-      for (int j = tid + TILE; j < nh; j += TILE) {  // poor locality only
-        const int64_t entry = (int64_t)td.h_off + j;
-        double        c[2 * S];
-#pragma unroll
-        for (int s = 0; s < 2 * S; ++s) c[s] = g.bn_c[entry * (2 * S) + s];
-        ring_gradient(j, reinterpret_cast<const uint2 *>(g.bn_idx)[entry], c, sq[TILE + j], sq[nq + TILE + j], sq[2 * nq + TILE + j]);
-      }
+      if (tid < nh) ring_gradient(tid, bw);
+      for (int j = tid + TILE; j < nh; j += TILE)  // poor locality only
+        ring_gradient(j, reinterpret_cast<const uint2 *>(g.bn_idx)[(int64_t)td.h_off + j]);
     }
     __syncthreads();
 
     // ---- phase 1: every edge of the tile once
-    auto do_edge = [&](int e, uint32_t lr, double cs, double2 dl, double2 dr) {
-      muscl_edge<LIM>(a, td, dt, e, lr, cs, dl, dr, sq, nq, sg, ng, ef0, ef1, ef2, eam);
+    auto do_edge = [&](int e, uint32_t lr, double cs, double2 mid) {
+      muscl_edge<LIM>(a, td, dt, e, lr, cs, mid, sq, nq, sg, ng, ef0, ef1, ef2, eam);
     };
 #pragma unroll 1
     for (int r = 0; r < 2; ++r) {
       const int e = tid + r * TILE;
-      if (e < ne) do_edge(e, r == 0 ? lr0 : lr1, r == 0 ? cs0 : cs1, r == 0 ? gl0 : gl1, r == 0 ? gr0 : gr1);
+      if (e < ne) do_edge(e, r == 0 ? lr0 : lr1, r == 0 ? cs0 : cs1, r == 0 ? md0 : md1);
     }
-    for (int e = tid + 2 * TILE; e < ne; e += TILE) {
-      const double2 *geo = reinterpret_cast<const double2 *>(g.e_geo + 4 * ((int64_t)td.e_off + e));
-      do_edge(e, slr[e], a.e_cs[td.e_off + e], geo[0], geo[1]);
-    }
+    for (int e = tid + 2 * TILE; e < ne; e += TILE)
+      do_edge(e, slr[e], a.e_cs[td.e_off + e], *reinterpret_cast<const double2 *>(g.e_mid + 2 * ((int64_t)td.e_off + e)));
     __syncthreads();
 
     // ---- phase 2: per-cell sum in the reference's edge order, source terms, stores

@@ -125,7 +125,7 @@ struct RDyHipOperator_s {
   // second order (muscl_kernels.h)
   bool             muscl = false;
   bool             muscl_fused = true;  // gradients formed in LDS by the flux kernel (RDYHIP_MUSCL=split: separate gradient launch)
-  DevBuf<double>   d_grad, d_e_geo, d_gcx, d_gcy, d_bn_c;
+  DevBuf<double>   d_grad, d_e_mid, d_cxy;
   DevBuf<int32_t>  d_hcells2, d_c_off;
   DevBuf<uint16_t> d_bn_idx;
   int32_t          hmax2 = 0;
@@ -152,7 +152,7 @@ struct RDyHipOperator_s {
     d_blk_pos.release(); d_courant.release(); d_stage_vals.release(); d_stage_ids.release(); d_scratch_f.release();
     d_tiles.release(); d_e_lr.release(); d_hcells.release(); d_tile_bk.release(); d_halo_tiles.release();
     d_e_cs.release(); d_slot_ref.release(); d_slot_ref3.release(); d_zc_local.release();
-    d_grad.release(); d_e_geo.release(); d_gcx.release(); d_gcy.release(); d_bn_c.release(); d_hcells2.release(); d_c_off.release();
+    d_grad.release(); d_e_mid.release(); d_cxy.release(); d_hcells2.release(); d_c_off.release();
     d_bn_idx.release();
   }
 };
@@ -223,13 +223,11 @@ MusclKernelFn muscl_kernel_fn(int S, int src, bool ovw, int limiter, bool fused)
 MusclArgs muscl_args(RDyHipOperator op) {
   MusclArgs g{};
   g.grad  = op->d_grad.p;
-  g.e_geo = op->d_e_geo.p;
-  g.gcx   = op->d_gcx.p;
-  g.gcy   = op->d_gcy.p;
+  g.e_mid = op->d_e_mid.p;
+  g.cxy   = op->d_cxy.p;
   g.hcells2 = op->d_hcells2.p;
   g.c_off   = op->d_c_off.p;
   g.bn_idx  = op->d_bn_idx.p;
-  g.bn_c    = op->d_bn_c.p;
   g.hmax2   = op->hmax2;
   return g;
 }
@@ -422,7 +420,7 @@ struct HostLayout {
   bool    prefix = true, hr_on = false, muscl_on = false, muscl_fused = true;
   size_t  lds_bytes = 0, lds_muscl = 0;
   std::vector<int32_t>  o2l, boff, nbr, pos, btype, bleft, bedge, bghost, halo, hcells, tile_bk, halo_tiles, hcells2, c_off;
-  std::vector<double>   cn, sn, coef, gcx, gcy, bcn, bsn, e_cs, e_geo, bn_c, dzdx, dzdy;
+  std::vector<double>   cn, sn, coef, bcn, bsn, e_cs, e_mid, dzdx, dzdy;
   std::vector<TileDesc> tiles;
   std::vector<uint32_t> e_lr;
   std::vector<uint16_t> slot_ref, bn_idx;
@@ -519,53 +517,12 @@ static int layout_build_slots(const RDyHipConfig *config, const RDyHipMesh *mesh
   std::vector<int32_t> nbr((size_t)(S * stride), NBR_EMPTY), pos((size_t)(S * stride), -1);
   std::vector<double>  cn((size_t)(S * stride), 0.0), sn((size_t)(S * stride), 0.0), coef((size_t)(S * stride), 0.0);
   std::fill(cnt.begin(), cnt.end(), 0);
-  // second order: PrecomputeLSGradCoeffs (src/operator_fluxes_ceed.c:884-980), the reference's arithmetic on the host
-  std::vector<double> ls;  // [ni][4]: cx_LR, cy_LR, cx_RL, cy_RL
-  std::vector<double> gcx, gcy;
   if (muscl_on) {
-    auto cdiff = [&](int32_t l, int32_t r, double &dx, double &dy, double &w) {
-      dx             = mesh->cell_centroids[3 * (size_t)r + 0] - mesh->cell_centroids[3 * (size_t)l + 0];
-      dy             = mesh->cell_centroids[3 * (size_t)r + 1] - mesh->cell_centroids[3 * (size_t)l + 1];
-      const double d = std::sqrt(dx * dx + dy * dy);
-      w              = (d > 0.0) ? 1.0 / d : 0.0;
-    };
-    std::vector<double> M((size_t)nc * 3, 0.0), inv((size_t)nc * 4, 0.0);
+    // every internal edge needs both cells for the second-order stencils (src/operator_fluxes_ceed.c:897-901)
     for (int32_t p = 0; p < ni; ++p) {
       const int32_t e = mesh->edge_internal_ids[p];
-      const int32_t l = mesh->edge_cell_ids[2 * e], r = mesh->edge_cell_ids[2 * e + 1];
-      if (r == -1) return fail(RDYHIP_ERR_USER, "second_order: internal edge %d has no right cell", e);
-      double dx, dy, w;
-      cdiff(l, r, dx, dy, w);
-      for (int32_t c : {l, r}) {
-        M[(size_t)c * 3 + 0] += w * dx * dx;
-        M[(size_t)c * 3 + 1] += w * dx * dy;
-        M[(size_t)c * 3 + 2] += w * dy * dy;
-      }
+      if (mesh->edge_cell_ids[2 * e + 1] == -1) return fail(RDYHIP_ERR_USER, "second_order: internal edge %d has no right cell", e);
     }
-    for (int32_t c = 0; c < nc; ++c) {
-      const double m00 = M[(size_t)c * 3 + 0], m01 = M[(size_t)c * 3 + 1], m11 = M[(size_t)c * 3 + 2];
-      const double det = m00 * m11 - m01 * m01;
-      if (std::fabs(det) < 1e-15) continue;  // degenerate stencil: zero gradient
-      const double inv_det  = 1.0 / det;
-      inv[(size_t)c * 4 + 0] = m11 * inv_det;
-      inv[(size_t)c * 4 + 1] = -m01 * inv_det;
-      inv[(size_t)c * 4 + 2] = -m01 * inv_det;
-      inv[(size_t)c * 4 + 3] = m00 * inv_det;
-    }
-    ls.assign((size_t)ni * 4, 0.0);
-    for (int32_t p = 0; p < ni; ++p) {
-      const int32_t e = mesh->edge_internal_ids[p];
-      const int32_t l = mesh->edge_cell_ids[2 * e], r = mesh->edge_cell_ids[2 * e + 1];
-      double        dx, dy, w;
-      cdiff(l, r, dx, dy, w);
-      const double wdx = w * dx, wdy = w * dy;
-      ls[(size_t)p * 4 + 0] = inv[(size_t)l * 4 + 0] * wdx + inv[(size_t)l * 4 + 1] * wdy;
-      ls[(size_t)p * 4 + 1] = inv[(size_t)l * 4 + 2] * wdx + inv[(size_t)l * 4 + 3] * wdy;
-      ls[(size_t)p * 4 + 2] = inv[(size_t)r * 4 + 0] * wdx + inv[(size_t)r * 4 + 1] * wdy;
-      ls[(size_t)p * 4 + 3] = inv[(size_t)r * 4 + 2] * wdx + inv[(size_t)r * 4 + 3] * wdy;
-    }
-    gcx.assign((size_t)(S * stride), 0.0);
-    gcy.assign((size_t)(S * stride), 0.0);
   }
   auto put = [&](int32_t o, int32_t id, double c, double s, double k, int32_t p) {
     const int64_t idx = (int64_t)cnt[o]++ * stride + o;
@@ -574,12 +531,6 @@ static int layout_build_slots(const RDyHipConfig *config, const RDyHipMesh *mesh
     sn[idx]           = s;
     coef[idx]         = k;
     pos[idx]          = p;
-    if (muscl_on && p < ni) {
-      // the cell is the edge's left cell (k < 0): c_LR times (q_R - q_L) = c_LR (q_nbr - q_self);
-      // right cell: c_RL (q_R - q_L) = (-c_RL) (q_nbr - q_self)
-      gcx[idx] = (k < 0.0) ? ls[(size_t)p * 4 + 0] : -ls[(size_t)p * 4 + 2];
-      gcy[idx] = (k < 0.0) ? ls[(size_t)p * 4 + 1] : -ls[(size_t)p * 4 + 3];
-    }
   };
   for (int32_t p = 0; p < ni; ++p) {
     const int32_t e = mesh->edge_internal_ids[p];
@@ -619,7 +570,7 @@ static int layout_build_slots(const RDyHipConfig *config, const RDyHipMesh *mesh
   L.nc = nc; L.no = no; L.ne = ne; L.ni = ni; L.K = K; L.S = S; L.stride = stride; L.prefix = prefix; L.muscl_on = muscl_on;
   L.o2l = std::move(o2l); L.boff = std::move(boff); L.nbr = std::move(nbr); L.pos = std::move(pos); L.btype = std::move(btype);
   L.bleft = std::move(bleft); L.bedge = std::move(bedge); L.bghost = std::move(bghost); L.halo = std::move(halo);
-  L.cn = std::move(cn); L.sn = std::move(sn); L.coef = std::move(coef); L.gcx = std::move(gcx); L.gcy = std::move(gcy);
+  L.cn = std::move(cn); L.sn = std::move(sn); L.coef = std::move(coef);
   L.bcn = std::move(bcn); L.bsn = std::move(bsn);
   return 0;
 }
@@ -631,13 +582,12 @@ static int layout_build_tiles(const RDyHipMesh *mesh, HostLayout &L) {
   const int64_t stride   = L.stride;
   const bool    muscl_on = L.muscl_on;
   const auto &nbr = L.nbr; const auto &pos = L.pos; const auto &bedge = L.bedge; const auto &bleft = L.bleft;
-  const auto &gcx = L.gcx; const auto &gcy = L.gcy;
   // ---- tiles of 256 consecutive owned cells: edge list, halo cells, boundary edges (tiled kernel) ----
   const int32_t         ntiles = (no + TILE - 1) / TILE;
   std::vector<TileDesc> tiles((size_t)ntiles + 1);
   std::vector<uint32_t> e_lr;
   std::vector<int32_t>  hcells, tile_bk, halo_tiles;
-  std::vector<double>   e_cs, e_geo, bn_c;
+  std::vector<double>   e_cs, e_mid;
   std::vector<int32_t>  hslot2, touched2, hcells2, c_off;
   std::vector<uint16_t> bn_idx;
   int32_t               hmax2 = 0;
@@ -698,20 +648,16 @@ static int layout_build_tiles(const RDyHipMesh *mesh, HostLayout &L) {
             e  = mesh->edge_internal_ids[last];
             lr = slot_of(mesh->edge_cell_ids[2 * e]) | (slot_of(mesh->edge_cell_ids[2 * e + 1]) << EDGE_R_SHIFT);
             if (muscl_on) {
-              // centroid -> edge midpoint displacements of ReconstructFaceValues (src/operator_fluxes_ceed.c:1169-1178)
+              // the edge midpoint of ReconstructFaceValues (src/operator_fluxes_ceed.c:1169-1172); the kernel subtracts the
+              // two cell centroids itself (1175-1178)
               const int32_t v0 = mesh->edge_vertex_ids[2 * e], v1 = mesh->edge_vertex_ids[2 * e + 1];
               if (v0 < 0 || v1 < 0 || v0 >= mesh->num_vertices || v1 >= mesh->num_vertices)
                 return fail(RDYHIP_ERR_ARG_OUTOFRANGE, "edge %d has vertex ids (%d,%d) out of range", e, v0, v1);
-              const double  x_mid = 0.5 * (mesh->vertex_points[3 * (size_t)v0 + 0] + mesh->vertex_points[3 * (size_t)v1 + 0]);
-              const double  y_mid = 0.5 * (mesh->vertex_points[3 * (size_t)v0 + 1] + mesh->vertex_points[3 * (size_t)v1 + 1]);
-              const int32_t cl = mesh->edge_cell_ids[2 * e], cr = mesh->edge_cell_ids[2 * e + 1];
-              e_geo.push_back(x_mid - mesh->cell_centroids[3 * (size_t)cl + 0]);
-              e_geo.push_back(y_mid - mesh->cell_centroids[3 * (size_t)cl + 1]);
-              e_geo.push_back(x_mid - mesh->cell_centroids[3 * (size_t)cr + 0]);
-              e_geo.push_back(y_mid - mesh->cell_centroids[3 * (size_t)cr + 1]);
+              e_mid.push_back(0.5 * (mesh->vertex_points[3 * (size_t)v0 + 0] + mesh->vertex_points[3 * (size_t)v1 + 0]));
+              e_mid.push_back(0.5 * (mesh->vertex_points[3 * (size_t)v0 + 1] + mesh->vertex_points[3 * (size_t)v1 + 1]));
             }
           } else {
-            if (muscl_on) e_geo.insert(e_geo.end(), 4, 0.0);
+            if (muscl_on) e_mid.insert(e_mid.end(), 2, 0.0);
             const int32_t k = last - ni;
             e               = bedge[k];
             lr              = slot_of(bleft[k]) | ((uint32_t)nbk << EDGE_R_SHIFT) | EDGE_BOUNDARY;
@@ -732,15 +678,14 @@ static int layout_build_tiles(const RDyHipMesh *mesh, HostLayout &L) {
         slot_ref[(size_t)(it.second >> 2) * 4 + (it.second & 3)] = (uint16_t)local;
       }
       if (muscl_on) {
-        // fused second-order kernel: the stencil of every first-ring cell (LDS slots of its neighbours, its
-        // least-squares coefficients) and the tile's second ring (neighbours of first-ring cells outside tile + ring 1)
+        // fused second-order kernel: the stencil of every first-ring cell (LDS slots of its neighbours) and the tile's
+        // second ring (neighbours of first-ring cells outside tile + ring 1)
         c_off[t]    = (int32_t)hcells2.size();
         int32_t nc2 = 0;
         touched2.clear();
         for (int32_t b = 0; b < nh; ++b) {
           const int32_t cell  = hcells[(size_t)tiles[t].h_off + b];
           uint16_t      ix[4] = {BN_NONE, BN_NONE, BN_NONE, BN_NONE};
-          double        cc[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
           if (!mesh->cell_is_owned[cell]) {
             ix[0] = ix[1] = ix[2] = ix[3] = BN_GLOBAL;  // a ghost: its stencil is on another rank
           } else {
@@ -763,13 +708,10 @@ static int layout_build_tiles(const RDyHipMesh *mesh, HostLayout &L) {
                 }
                 slot = TILE + nh + hslot2[n];
               }
-              ix[sl]         = (uint16_t)slot;
-              cc[2 * sl]     = gcx[idx];
-              cc[2 * sl + 1] = gcy[idx];
+              ix[sl] = (uint16_t)slot;
             }
           }
           bn_idx.insert(bn_idx.end(), ix, ix + 4);
-          bn_c.insert(bn_c.end(), cc, cc + 2 * S);
         }
         for (int32_t cell : touched2) hslot2[cell] = -1;
         hmax2 = std::max(hmax2, nh + nc2);
@@ -791,7 +733,7 @@ static int layout_build_tiles(const RDyHipMesh *mesh, HostLayout &L) {
   }
   L.ntiles = ntiles; L.emax = emax; L.hmax = hmax; L.hmax2 = hmax2;
   L.hcells = std::move(hcells); L.tile_bk = std::move(tile_bk); L.halo_tiles = std::move(halo_tiles); L.hcells2 = std::move(hcells2);
-  L.c_off = std::move(c_off); L.e_cs = std::move(e_cs); L.e_geo = std::move(e_geo); L.bn_c = std::move(bn_c); L.tiles = std::move(tiles);
+  L.c_off = std::move(c_off); L.e_cs = std::move(e_cs); L.e_mid = std::move(e_mid); L.tiles = std::move(tiles);
   L.e_lr = std::move(e_lr); L.slot_ref = std::move(slot_ref); L.bn_idx = std::move(bn_idx);
   return 0;
 }
@@ -811,8 +753,8 @@ static int build_host_layout(const RDyHipConfig *config, const RDyHipMesh *mesh,
   const bool   muscl_fused = !(menv && strcmp(menv, "split") == 0);
   const size_t lds_muscl   = !muscl_on ? 0
                              : muscl_fused
-                                 ? sizeof(double) * (3 * ((size_t)TILE + hmax2) + 6 * ((size_t)TILE + hmax) + 4 * (size_t)emax + ((size_t)emax + 1) / 2)
-                                 : sizeof(double) * (9 * ((size_t)TILE + hmax) + 4 * (size_t)emax);
+                                 ? sizeof(double) * (5 * ((size_t)TILE + hmax2) + 6 * ((size_t)TILE + hmax) + 4 * (size_t)emax + ((size_t)emax + 1) / 2)
+                                 : sizeof(double) * (11 * ((size_t)TILE + hmax) + 4 * (size_t)emax);
   if (std::max(lds_bytes, lds_muscl) > 160 * 1024)
     return fail(RDYHIP_ERR_USER, "tile working set (%zu B of LDS) too large: the cell numbering has no locality", std::max(lds_bytes, lds_muscl));
 
@@ -848,8 +790,8 @@ int rdyhip_create(const RDyHipConfig *config, const RDyHipMesh *mesh, int32_t nu
   const size_t  lds_bytes = L.lds_bytes, lds_muscl = L.lds_muscl;
   auto &o2l = L.o2l; auto &boff = L.boff; auto &nbr = L.nbr; auto &pos = L.pos; auto &btype = L.btype; auto &bleft = L.bleft; auto &bedge = L.bedge;
   auto &bghost = L.bghost; auto &halo = L.halo; auto &hcells = L.hcells; auto &tile_bk = L.tile_bk; auto &halo_tiles = L.halo_tiles;
-  auto &hcells2 = L.hcells2; auto &c_off = L.c_off; auto &cn = L.cn; auto &sn = L.sn; auto &coef = L.coef; auto &gcx = L.gcx; auto &gcy = L.gcy;
-  auto &bcn = L.bcn; auto &bsn = L.bsn; auto &e_cs = L.e_cs; auto &e_geo = L.e_geo; auto &bn_c = L.bn_c; auto &dzdx = L.dzdx; auto &dzdy = L.dzdy;
+  auto &hcells2 = L.hcells2; auto &c_off = L.c_off; auto &cn = L.cn; auto &sn = L.sn; auto &coef = L.coef;
+  auto &bcn = L.bcn; auto &bsn = L.bsn; auto &e_cs = L.e_cs; auto &e_mid = L.e_mid; auto &dzdx = L.dzdx; auto &dzdy = L.dzdy;
   auto &tiles = L.tiles; auto &e_lr = L.e_lr; auto &slot_ref = L.slot_ref; auto &bn_idx = L.bn_idx;
   (void)ne;
 
@@ -1003,13 +945,18 @@ int rdyhip_create(const RDyHipConfig *config, const RDyHipMesh *mesh, int32_t nu
   }
   if (muscl_on) {
     TRY_RC(op->d_grad.zeros((size_t)6 * nc));
-    TRY_RC(op->d_e_geo.upload(e_geo));
-    TRY_RC(op->d_gcx.upload(gcx));
-    TRY_RC(op->d_gcy.upload(gcy));
+    TRY_RC(op->d_e_mid.upload(e_mid));
+    {
+      std::vector<double> cxy((size_t)2 * nc);
+      for (int32_t c = 0; c < nc; ++c) {
+        cxy[2 * (size_t)c]     = mesh->cell_centroids[3 * (size_t)c + 0];
+        cxy[2 * (size_t)c + 1] = mesh->cell_centroids[3 * (size_t)c + 1];
+      }
+      TRY_RC(op->d_cxy.upload(cxy));
+    }
     TRY_RC(op->d_hcells2.upload(hcells2));
     TRY_RC(op->d_c_off.upload(c_off));
     TRY_RC(op->d_bn_idx.upload(bn_idx));
-    TRY_RC(op->d_bn_c.upload(bn_c));
   }
   TRY_RC(op->d_mannings.zeros((size_t)no));
   TRY_RC(op->d_extsrc.zeros((size_t)3 * no));
@@ -1038,8 +985,8 @@ int rdyhip_create(const RDyHipConfig *config, const RDyHipMesh *mesh, int32_t nu
                      op->d_dzdx.bytes() + op->d_dzdy.bytes() + op->d_mannings.bytes() + op->d_extsrc.bytes() +
                      op->d_pv.bytes() + op->d_bvalues.bytes() + op->d_bflux.bytes() + op->d_baccum.bytes() + op->d_blk_max.bytes() +
                      op->d_blk_pos.bytes() + op->d_tiles.bytes() + op->d_e_lr.bytes() + op->d_hcells.bytes() + op->d_tile_bk.bytes() +
-                     op->d_e_cs.bytes() + op->d_slot_ref.bytes() + op->d_slot_ref3.bytes() + op->d_grad.bytes() + op->d_e_geo.bytes() +
-                     op->d_gcx.bytes() + op->d_gcy.bytes() + op->d_hcells2.bytes() + op->d_c_off.bytes() + op->d_bn_idx.bytes() + op->d_bn_c.bytes();
+                     op->d_e_cs.bytes() + op->d_slot_ref.bytes() + op->d_slot_ref3.bytes() + op->d_grad.bytes() + op->d_e_mid.bytes() +
+                     op->d_cxy.bytes() + op->d_hcells2.bytes() + op->d_c_off.bytes() + op->d_bn_idx.bytes();
   *op_out = op;
   return 0;
 }
@@ -1423,11 +1370,12 @@ int rdyhip_layout_info(RDyHipOperator op, RDyHipLayoutInfo *info) {
     info->bytes_per_apply = (int64_t)op->n_owned * (24 + op->S * 28 + 16 + 8 + 24 + 24 + 24 + (op->prefix ? 0 : 4));
   }
   if (op->muscl) {
-    // + least-squares coefficients S*16 per cell and 32 B of displacements per edge record; fused: second-ring ids and the
-    // first-ring stencils (8 B + S*16 B per halo entry); split: the gradient array written and read (96) + the state read twice (24)
-    info->bytes_per_apply += (int64_t)op->n_owned * (op->S * 16) + op->nrec * 32;
-    if (op->muscl_fused) info->bytes_per_apply += (int64_t)op->d_hcells2.n * 4 + op->nhalo_entries * (8 + op->S * 16);
-    else info->bytes_per_apply += (int64_t)op->n_owned * (96 + 24 + op->S * 4);
+    // + the cell centroid (16 B per cell) and the edge midpoint (16 B per edge record); fused: second-ring ids and the
+    // first-ring stencils (8 B per halo entry); split: the gradient array written and read (96) + the state, the centroid and
+    // the neighbour ids read a second time (24 + 16 + S*4)
+    info->bytes_per_apply += (int64_t)op->n_owned * 16 + op->nrec * 16;
+    if (op->muscl_fused) info->bytes_per_apply += (int64_t)op->d_hcells2.n * 4 + op->nhalo_entries * 8;
+    else info->bytes_per_apply += (int64_t)op->n_owned * (96 + 24 + 16 + op->S * 4);
   }
   return 0;
 }
