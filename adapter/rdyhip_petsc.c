@@ -1,0 +1,429 @@
+/*
+ * rdyhip_petsc.c -- the RDycore-side adapter of librdyhip.so: ONE translation unit a maintainer adds to
+ * src/ (and to src/CMakeLists.txt) to put the MI355X-native SWE operator behind RDycore's own operator
+ * seam.  It is compiled only where PETSc and RDycore's private headers exist; in this repository's image
+ * neither does, so the TU is empty here (tests/test_adapter_cpu.py checks exactly that it still compiles)
+ * and nothing below could be run by this repository's tests.  No stand-in headers are used anywhere.
+ *
+ * What it implements (file:line relative to the RDycore tree):
+ *
+ *   CreateHipSWEFluxOperator    same signature as CreatePetscFluxOperator   (include/private/rdyoperatorimpl.h:234,
+ *                               src/operator_fluxes_petsc.c:17) and, with well_balancing = HR, as CreatePetscFluxHROperator (236)
+ *   CreateHipSWESourceOperator  same signature as CreatePetscSourceOperator (rdyoperatorimpl.h:238, src/operator_sources_petsc.c:13)
+ *
+ * i.e. the two PetscOperators that ApplyPetscOperator (src/operator.c:656-672) applies, built with
+ * PetscOperatorCreate(context, apply, destroy, &op) (rdyoperatorimpl.h:75-90, src/petsc_operator.c:11-21) exactly as
+ * CreatePetscSWEInteriorFluxOperator / ...BoundaryFluxOperator / ...SourceOperator are
+ * (include/private/rdysweimpl.h:10-15, src/swe/swe_petsc.c:341, 653, 948).  The native kernel fuses interior flux,
+ * boundary flux and source into one launch, so the two PetscOperators share one context (the RDyHipOperator handle):
+ *
+ *   flux.apply    (first in ApplyPetscOperator)  refreshes the device copies of the Dirichlet values the host changed
+ *                                                since the last apply (PetscObjectState of each boundary_values Vec)
+ *   VecCopy(F, flux_divergence)                  copies the still untouched F (harmless: the native source term takes
+ *                                                the flux sum from registers, not from that Vec)
+ *   source.apply  (last)                         refreshes external sources / Manning n the same way, then ONE
+ *                                                rdyhip_apply(h, dt, u_local, f_global): F += flux divergence + sources
+ *
+ * plus four small hooks the patch in INTEGRATION.md section 2 wires in: RDyHipResetDiagnostics, RDyHipUpdateDiagnostics
+ * (called by UpdateOperatorDiagnostics before its MPI_Allreduce, src/operator.c:867-883), RDyHipSyncBoundaryFluxes (called by
+ * ExtractOperatorBoundaryFluxes before it reads boundary_fluxes_accum, src/operator.c:1069-1086) and
+ * RDyHipResetBoundaryFluxesAccum (ResetAccumulatedBoundaryFluxes, src/time_series.c:505-527).
+ *
+ * Vec memory: with -dm_vec_type hip u_local and f_global are device Vecs and their arrays are handed to the kernel
+ * as they are (VecGetArrayReadAndMemType, the pattern of src/operator.c:563-573); host Vecs are staged through device
+ * scratch (correct, slow -- meant for checking the backend against the PETSc one on a workstation).
+ */
+#if defined(__has_include)
+#if __has_include(<petsc.h>) && __has_include(<private/rdyoperatorimpl.h>) && __has_include(<hip/hip_runtime_api.h>)
+#define RDYHIP_PETSC_ADAPTER 1
+#endif
+#endif
+
+#ifdef RDYHIP_PETSC_ADAPTER
+
+#include <hip/hip_runtime_api.h>
+#include <petsc.h>
+#include <private/rdycoreimpl.h>
+#include <private/rdyoperatorimpl.h>
+#include <private/rdysweimpl.h>
+#include <rdyhip.h>
+
+#define HipCall(expr)                                                                                                            \
+  do {                                                                                                                           \
+    hipError_t e_ = (expr);                                                                                                      \
+    PetscCheck(e_ == hipSuccess, PETSC_COMM_SELF, PETSC_ERR_LIB, "%s failed: %s", #expr, hipGetErrorString(e_));                 \
+  } while (0)
+#define RDyHipCall(expr)                                                                                 \
+  do {                                                                                                   \
+    int rc_ = (expr);                                                                                    \
+    PetscCheck(rc_ == 0, PETSC_COMM_SELF, (PetscErrorCode)rc_, "%s: %s", #expr, rdyhip_last_error());    \
+  } while (0)
+
+// one native operator per RDyMesh, shared by the flux and the source PetscOperator (and found again by the hooks)
+typedef struct RDyHipShared {
+  RDyMesh            *mesh;
+  RDyHipOperator      handle;
+  PetscInt            refs;
+  PetscInt            num_boundaries;
+  PetscInt           *boundary_num_edges;
+  Vec                *boundary_values, *boundary_fluxes, *boundary_fluxes_accum;  // borrowed (owned by Operator, src/operator.c:117-129)
+  PetscObjectState   *boundary_values_state;
+  Vec                 external_sources, material_properties;  // borrowed (operator.c:91-96)
+  PetscObjectState    external_sources_state, material_properties_state;
+  OperatorDiagnostics *diagnostics;  // borrowed
+  PetscReal           *d_u, *d_f;    // device staging for host Vecs
+  struct RDyHipShared *next;
+} RDyHipShared;
+
+static RDyHipShared *shared_list = NULL;
+
+static RDyHipShared *FindShared(RDyMesh *mesh) {
+  for (RDyHipShared *s = shared_list; s; s = s->next)
+    if (s->mesh == mesh) return s;
+  return NULL;
+}
+
+static PetscErrorCode ReleaseShared(RDyHipShared *s) {
+  PetscFunctionBegin;
+  if (--s->refs > 0) PetscFunctionReturn(PETSC_SUCCESS);
+  RDyHipCall(rdyhip_destroy(&s->handle));
+  if (s->d_u) HipCall(hipFree(s->d_u));
+  if (s->d_f) HipCall(hipFree(s->d_f));
+  PetscCall(PetscFree(s->boundary_num_edges));
+  PetscCall(PetscFree(s->boundary_values_state));
+  for (RDyHipShared **p = &shared_list; *p; p = &(*p)->next) {
+    if (*p == s) {
+      *p = s->next;
+      break;
+    }
+  }
+  PetscCall(PetscFree(s));
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+// PetscInt arrays as the ABI's int32 arrays: a view in a 32-bit-index build, a narrowed copy otherwise (local indices fit)
+static PetscErrorCode AsInt32(PetscInt n, const PetscInt *src, int32_t **owned_copy, const int32_t **out) {
+  PetscFunctionBegin;
+  *owned_copy = NULL;
+  if (sizeof(PetscInt) == sizeof(int32_t)) {
+    *out = (const int32_t *)src;
+  } else {
+    PetscCall(PetscMalloc1(n > 0 ? n : 1, owned_copy));
+    for (PetscInt i = 0; i < n; ++i) (*owned_copy)[i] = (int32_t)src[i];
+    *out = *owned_copy;
+  }
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+static PetscErrorCode AsInt64(PetscInt n, const PetscInt *src, int64_t **owned_copy, const int64_t **out) {
+  PetscFunctionBegin;
+  *owned_copy = NULL;
+  if (sizeof(PetscInt) == sizeof(int64_t)) {
+    *out = (const int64_t *)src;
+  } else {
+    PetscCall(PetscMalloc1(n > 0 ? n : 1, owned_copy));
+    for (PetscInt i = 0; i < n; ++i) (*owned_copy)[i] = (int64_t)src[i];
+    *out = *owned_copy;
+  }
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+// rdyhip_create from the RDyMesh / RDyConfig / boundaries the reference's factories receive
+static PetscErrorCode CreateShared(RDyConfig *config, RDyMesh *mesh, PetscInt num_boundaries, RDyBoundary *boundaries, RDyCondition *conditions,
+                                   Vec *boundary_values, Vec *boundary_fluxes, Vec *boundary_fluxes_accum, OperatorDiagnostics *diagnostics,
+                                   RDyHipShared **shared) {
+  PetscFunctionBegin;
+  PetscCheck(config->physics.flow.mode == FLOW_SWE, PETSC_COMM_WORLD, PETSC_ERR_USER, "SWE is the only supported flow model!");  // operator_fluxes_petsc.c:24
+  PetscCheck(config->physics.sediment.num_classes == 0, PETSC_COMM_WORLD, PETSC_ERR_USER, "the native HIP operator has no tracers");
+  RDyHipShared *s;
+  PetscCall(PetscCalloc1(1, &s));
+  s->mesh = mesh;
+
+  const PetscInt nc = mesh->num_cells, ne = mesh->num_edges;
+  int32_t       *c_is_owned, *c_l2o, *c_cells, *c_internal, *c_vertex = NULL;
+  int64_t       *c_cgid, *c_egid;
+  const int32_t *l2o, *ecells, *einternal, *evertex = NULL;
+  const int64_t *cgid, *egid;
+  PetscCall(PetscMalloc1(nc > 0 ? nc : 1, &c_is_owned));  // PetscBool is an enum: copy, do not cast
+  for (PetscInt c = 0; c < nc; ++c) c_is_owned[c] = mesh->cells.is_owned[c] ? 1 : 0;
+  PetscCall(AsInt32(nc, mesh->cells.local_to_owned, &c_l2o, &l2o));
+  PetscCall(AsInt64(nc, mesh->cells.global_ids, &c_cgid, &cgid));
+  PetscCall(AsInt32(2 * ne, mesh->edges.cell_ids, &c_cells, &ecells));
+  PetscCall(AsInt32(mesh->num_internal_edges, mesh->edges.internal_edge_ids, &c_internal, &einternal));
+  PetscCall(AsInt64(ne, mesh->edges.global_ids, &c_egid, &egid));
+
+  RDyHipMesh hm = {0};
+  hm.num_cells           = (int32_t)nc;
+  hm.num_owned_cells     = (int32_t)mesh->num_owned_cells;
+  hm.num_edges           = (int32_t)ne;
+  hm.num_internal_edges  = (int32_t)mesh->num_internal_edges;
+  hm.cell_is_owned       = c_is_owned;
+  hm.cell_local_to_owned = l2o;
+  hm.cell_global_ids     = cgid;
+  hm.cell_areas          = mesh->cells.areas;
+  hm.cell_dz_dx          = mesh->cells.dz_dx;
+  hm.cell_dz_dy          = mesh->cells.dz_dy;
+  hm.edge_cell_ids       = ecells;
+  hm.edge_internal_ids   = einternal;
+  hm.edge_global_ids     = egid;
+  hm.edge_lengths        = mesh->edges.lengths;
+  hm.edge_cn             = mesh->edges.cn;
+  hm.edge_sn             = mesh->edges.sn;
+
+  // hydrostatic reconstruction: the per-cell bed elevation of CreatePetscSWEInteriorFluxHROperator (src/swe/swe_petsc.c:1209-1224)
+  PetscReal *zc = NULL;
+  if (config->physics.flow.well_balancing == WELL_BALANCING_HR) {
+    PetscCall(PetscMalloc1(nc > 0 ? nc : 1, &zc));
+    for (PetscInt c = 0; c < nc; ++c) {
+      if (config->grid.cell_elevation.file[0]) {
+        zc[c] = mesh->cells.centroids[c].X[2];
+      } else {
+        PetscReal z_sum = 0.0;
+        for (PetscInt v = mesh->cells.vertex_offsets[c]; v < mesh->cells.vertex_offsets[c + 1]; v++) z_sum += mesh->vertices.points[mesh->cells.vertex_ids[v]].X[2];
+        zc[c] = z_sum / (PetscReal)mesh->cells.num_vertices[c];
+      }
+    }
+    hm.cell_zc = zc;
+  }
+  // second order: what PrecomputeLSGradCoeffs / ReconstructFaceValues read (src/operator_fluxes_ceed.c:884-980, 1155-1206)
+  if (config->numerics.second_order) {
+    PetscCall(AsInt32(2 * ne, mesh->edges.vertex_ids, &c_vertex, &evertex));
+    hm.num_vertices    = (int32_t)mesh->num_vertices;
+    hm.cell_centroids  = (const double *)mesh->cells.centroids;  // RDyPoint is PetscReal X[3]
+    hm.edge_vertex_ids = evertex;
+    hm.vertex_points   = (const double *)mesh->vertices.points;
+  }
+
+  RDyHipBoundary *hb;
+  int32_t       **c_bedges;
+  PetscCall(PetscCalloc1(num_boundaries > 0 ? num_boundaries : 1, &hb));
+  PetscCall(PetscCalloc1(num_boundaries > 0 ? num_boundaries : 1, &c_bedges));
+  PetscCall(PetscCalloc1(num_boundaries > 0 ? num_boundaries : 1, &s->boundary_num_edges));
+  PetscCall(PetscCalloc1(num_boundaries > 0 ? num_boundaries : 1, &s->boundary_values_state));
+  for (PetscInt b = 0; b < num_boundaries; ++b) {
+    const int32_t *ids;
+    PetscCall(AsInt32(boundaries[b].num_edges, boundaries[b].edge_ids, &c_bedges[b], &ids));
+    hb[b].num_edges          = (int32_t)boundaries[b].num_edges;
+    hb[b].edge_ids           = ids;
+    hb[b].condition_type     = (int32_t)conditions[b].flow->type;  // RDyConditionType: the ABI shares its values (include/rdycore.h:133-139)
+    s->boundary_num_edges[b] = boundaries[b].num_edges;
+    s->boundary_values_state[b] = (PetscObjectState)-1;
+  }
+
+  // the limiter after the -no_limiter / -van_leer overrides of src/swe/swe_petsc.c:357-367
+  int32_t   limiter    = RDYHIP_LIMITER_MINMOD;
+  PetscBool no_limiter = PETSC_FALSE, van_leer = PETSC_FALSE;
+  PetscCall(PetscOptionsGetBool(NULL, NULL, "-no_limiter", &no_limiter, NULL));
+  PetscCall(PetscOptionsGetBool(NULL, NULL, "-van_leer", &van_leer, NULL));
+  if (no_limiter) limiter = RDYHIP_LIMITER_NONE;
+  else if (van_leer) limiter = RDYHIP_LIMITER_VANLEER;
+
+  RDyHipConfig hc = {0};
+  hc.tiny_h           = config->physics.flow.tiny_h;
+  hc.h_anuga_regular  = config->physics.flow.h_anuga_regular;
+  hc.xq2018_threshold = config->physics.flow.source.xq2018_threshold;
+  hc.source_method    = (int32_t)config->physics.flow.source.method;   // RDyFlowSourceMethod: shared values (rdyconfigimpl.h:52-56)
+  hc.riemann          = (int32_t)config->numerics.riemann;
+  hc.well_balancing   = (int32_t)config->physics.flow.well_balancing;  // none | HR (BS2002 is CEED-only, src/operator.c:388)
+  hc.second_order     = config->numerics.second_order ? 1 : 0;
+  hc.limiter          = limiter;
+  RDyHipCall(rdyhip_create(&hc, &hm, (int32_t)num_boundaries, hb, &s->handle));  // the arrays above are borrowed during the call only
+
+  for (PetscInt b = 0; b < num_boundaries; ++b) PetscCall(PetscFree(c_bedges[b]));
+  PetscCall(PetscFree(c_bedges));
+  PetscCall(PetscFree(hb));
+  PetscCall(PetscFree(zc));
+  PetscCall(PetscFree(c_is_owned));
+  PetscCall(PetscFree(c_l2o));
+  PetscCall(PetscFree(c_cgid));
+  PetscCall(PetscFree(c_cells));
+  PetscCall(PetscFree(c_internal));
+  PetscCall(PetscFree(c_egid));
+  PetscCall(PetscFree(c_vertex));
+
+  s->num_boundaries             = num_boundaries;
+  s->boundary_values            = boundary_values;
+  s->boundary_fluxes            = boundary_fluxes;
+  s->boundary_fluxes_accum      = boundary_fluxes_accum;
+  s->diagnostics                = diagnostics;
+  s->external_sources_state     = (PetscObjectState)-1;
+  s->material_properties_state  = (PetscObjectState)-1;
+  s->next                       = shared_list;
+  shared_list                   = s;
+  *shared                       = s;
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+// copies a (host or device) Vec's array over a device array of the operator if the Vec changed since the last copy
+static PetscErrorCode RefreshField(Vec v, PetscObjectState *seen, double *d_dst, int64_t nvalues) {
+  PetscFunctionBegin;
+  PetscObjectState st;
+  PetscCall(PetscObjectStateGet((PetscObject)v, &st));
+  if (st == *seen) PetscFunctionReturn(PETSC_SUCCESS);
+  PetscInt n;
+  PetscCall(VecGetLocalSize(v, &n));
+  PetscCheck((int64_t)n == nvalues, PETSC_COMM_SELF, PETSC_ERR_ARG_SIZ, "Vec of %" PetscInt_FMT " values for a device field of %lld", n, (long long)nvalues);
+  const PetscScalar *a;
+  PetscMemType       mt;
+  PetscCall(VecGetArrayReadAndMemType(v, &a, &mt));
+  HipCall(hipDeviceSynchronize());  // an RHS in flight may still read the field
+  HipCall(hipMemcpy(d_dst, a, sizeof(double) * (size_t)n, PetscMemTypeDevice(mt) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+  PetscCall(VecRestoreArrayReadAndMemType(v, &a));
+  *seen = st;
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+//-------------------------------------------------------------------------------------------------
+// flux operator: the Dirichlet values (SetOperatorBoundaryValues writes the boundary_values Vecs, src/operator.c:1045-1061)
+//-------------------------------------------------------------------------------------------------
+static PetscErrorCode ApplyHipFlux(void *context, PetscOperatorFields fields, PetscReal dt, Vec u_local, Vec f_global) {
+  PetscFunctionBegin;
+  RDyHipShared *s = context;
+  for (PetscInt b = 0; b < s->num_boundaries; ++b) {
+    PetscObjectState st;
+    PetscCall(PetscObjectStateGet((PetscObject)s->boundary_values[b], &st));
+    if (st == s->boundary_values_state[b] || s->boundary_num_edges[b] == 0) continue;
+    const PetscScalar *a;
+    PetscCall(VecGetArrayRead(s->boundary_values[b], &a));  // VECSEQ in the PETSc backend (operator.c:47-75): a host array [edge][3]
+    RDyHipCall(rdyhip_set_boundary_values(s->handle, (int32_t)b, 0, 3, (int32_t)s->boundary_num_edges[b], a));
+    PetscCall(VecRestoreArrayRead(s->boundary_values[b], &a));
+    s->boundary_values_state[b] = st;
+  }
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+static PetscErrorCode DestroyHipFlux(void *context) {
+  PetscFunctionBegin;
+  PetscCall(ReleaseShared(context));
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+PetscErrorCode CreateHipSWEFluxOperator(RDyConfig *config, RDyMesh *mesh, MPI_Comm comm, PetscInt num_boundaries, RDyBoundary *boundaries,
+                                        RDyCondition *boundary_conditions, Vec *boundary_values, Vec *boundary_fluxes, Vec *boundary_fluxes_accum,
+                                        OperatorDiagnostics *diagnostics, PetscOperator *flux_op) {
+  PetscFunctionBegin;
+  (void)comm;
+  RDyHipShared *s;
+  PetscCall(CreateShared(config, mesh, num_boundaries, boundaries, boundary_conditions, boundary_values, boundary_fluxes, boundary_fluxes_accum,
+                         diagnostics, &s));
+  s->refs = 1;
+  PetscCall(PetscOperatorCreate(s, ApplyHipFlux, DestroyHipFlux, flux_op));
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+//-------------------------------------------------------------------------------------------------
+// source operator: sources, Manning n, and the ONE launch that evaluates flux divergence + sources
+//-------------------------------------------------------------------------------------------------
+static PetscErrorCode ApplyHipSource(void *context, PetscOperatorFields fields, PetscReal dt, Vec u_local, Vec f_global) {
+  PetscFunctionBegin;
+  RDyHipShared *s = context;
+  double       *d_ext, *d_man;
+  int64_t       n_ext, n_man;
+  RDyHipCall(rdyhip_field_ptr(s->handle, RDYHIP_FIELD_EXTERNAL_SOURCES, &d_ext, &n_ext));
+  RDyHipCall(rdyhip_field_ptr(s->handle, RDYHIP_FIELD_MANNINGS, &d_man, &n_man));
+  // the Vecs' layouts are the device fields' ([owned][3] and [owned][1], operator.c:91-96): whole-array copies when they changed
+  PetscCall(RefreshField(s->external_sources, &s->external_sources_state, d_ext, n_ext));
+  PetscCall(RefreshField(s->material_properties, &s->material_properties_state, d_man, n_man));
+
+  const PetscScalar *u;
+  PetscScalar       *f;
+  PetscMemType       mu, mf;
+  PetscInt           nu, nf;
+  PetscCall(VecGetLocalSize(u_local, &nu));
+  PetscCall(VecGetLocalSize(f_global, &nf));
+  PetscCall(VecGetArrayReadAndMemType(u_local, &u, &mu));
+  PetscCall(VecGetArrayAndMemType(f_global, &f, &mf));
+  if (PetscMemTypeDevice(mu) && PetscMemTypeDevice(mf)) {
+    // -dm_vec_type hip: the Vecs' device arrays as they are, on PETSc's stream; F += flux divergence + sources as the
+    // reference's sub-operators do (src/swe/swe_petsc.c:301-305, 783-785)
+    RDyHipCall(rdyhip_apply(s->handle, dt, u, f, NULL));
+  } else {
+    if (!s->d_u) HipCall(hipMalloc((void **)&s->d_u, sizeof(double) * (size_t)(nu > 0 ? nu : 1)));
+    if (!s->d_f) HipCall(hipMalloc((void **)&s->d_f, sizeof(double) * (size_t)(nf > 0 ? nf : 1)));
+    HipCall(hipMemcpy(s->d_u, u, sizeof(double) * (size_t)nu, PetscMemTypeDevice(mu) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+    HipCall(hipMemcpy(s->d_f, f, sizeof(double) * (size_t)nf, PetscMemTypeDevice(mf) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+    RDyHipCall(rdyhip_apply(s->handle, dt, s->d_u, s->d_f, NULL));
+    HipCall(hipMemcpy(f, s->d_f, sizeof(double) * (size_t)nf, PetscMemTypeDevice(mf) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost));
+  }
+  PetscCall(VecRestoreArrayAndMemType(f_global, &f));
+  PetscCall(VecRestoreArrayReadAndMemType(u_local, &u));
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+static PetscErrorCode DestroyHipSource(void *context) {
+  PetscFunctionBegin;
+  PetscCall(ReleaseShared(context));
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+PetscErrorCode CreateHipSWESourceOperator(RDyConfig *config, RDyMesh *mesh, Vec external_sources, Vec material_properties, PetscOperator *source_op) {
+  PetscFunctionBegin;
+  (void)config;
+  RDyHipShared *s = FindShared(mesh);
+  PetscCheck(s, PETSC_COMM_WORLD, PETSC_ERR_ORDER, "CreateHipSWEFluxOperator must be called before CreateHipSWESourceOperator (as in CreateOperatorSubOperators, src/operator.c:195-214)");
+  s->external_sources    = external_sources;
+  s->material_properties = material_properties;
+  s->refs++;
+  PetscCall(PetscOperatorCreate(s, ApplyHipSource, DestroyHipSource, source_op));
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+//-------------------------------------------------------------------------------------------------
+// hooks (INTEGRATION.md section 2 shows where the three calls go)
+//-------------------------------------------------------------------------------------------------
+
+// ResetOperatorDiagnostics (src/operator.c:772-784): the device-side running maximum as well
+PetscErrorCode RDyHipResetDiagnostics(RDyMesh *mesh) {
+  PetscFunctionBegin;
+  RDyHipShared *s = FindShared(mesh);
+  if (s) RDyHipCall(rdyhip_reset_diagnostics(s->handle, NULL));
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+// UpdateOperatorDiagnostics (src/operator.c:867-883), before its MPI_Allreduce with MPI_MAX_COURANT_NUMBER: the local
+// {max_courant_num, global_edge_id, global_cell_id} comes from the device (16 bytes), where the PETSc operators update it in place
+PetscErrorCode RDyHipUpdateDiagnostics(RDyMesh *mesh) {
+  PetscFunctionBegin;
+  RDyHipShared *s = FindShared(mesh);
+  if (!s) PetscFunctionReturn(PETSC_SUCCESS);
+  RDyHipCourant c;
+  RDyHipCall(rdyhip_update_diagnostics(s->handle, NULL));
+  RDyHipCall(rdyhip_get_diagnostics(s->handle, &c));
+  s->diagnostics->courant_number.max_courant_num = c.max_courant_num;
+  s->diagnostics->courant_number.global_edge_id  = (PetscInt)c.global_edge_id;
+  s->diagnostics->courant_number.global_cell_id  = (PetscInt)c.global_cell_id;
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+// ExtractOperatorBoundaryFluxes (rdyoperatorimpl.h:256) reads boundary_fluxes[b] / boundary_fluxes_accum[b]: bring them
+// over from the device first (O(boundary edges), only when somebody asks)
+PetscErrorCode RDyHipSyncBoundaryFluxes(RDyMesh *mesh) {
+  PetscFunctionBegin;
+  RDyHipShared *s = FindShared(mesh);
+  if (!s) PetscFunctionReturn(PETSC_SUCCESS);
+  for (PetscInt b = 0; b < s->num_boundaries; ++b) {
+    if (s->boundary_num_edges[b] == 0) continue;
+    PetscScalar *a;
+    PetscCall(VecGetArray(s->boundary_fluxes[b], &a));
+    RDyHipCall(rdyhip_get_boundary_fluxes(s->handle, (int32_t)b, 0, (int32_t)s->boundary_num_edges[b], a));
+    PetscCall(VecRestoreArray(s->boundary_fluxes[b], &a));
+    PetscCall(VecGetArray(s->boundary_fluxes_accum[b], &a));
+    RDyHipCall(rdyhip_get_boundary_fluxes(s->handle, (int32_t)b, 1, (int32_t)s->boundary_num_edges[b], a));
+    PetscCall(VecRestoreArray(s->boundary_fluxes_accum[b], &a));
+  }
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+// ResetAccumulatedBoundaryFluxes (src/time_series.c:505-527) zeroes the boundary_fluxes_accum Vecs after each time-series
+// record: the device-side accumulation starts over with them
+PetscErrorCode RDyHipResetBoundaryFluxesAccum(RDyMesh *mesh) {
+  PetscFunctionBegin;
+  RDyHipShared *s = FindShared(mesh);
+  if (s) RDyHipCall(rdyhip_reset_boundary_fluxes_accum(s->handle));
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+#else  /* no PETSc / RDycore headers in this build environment: the adapter is not part of the build */
+
+typedef int rdyhip_petsc_adapter_not_built;
+
+#endif

@@ -52,7 +52,11 @@ def check_all(case, f_gpu, f_ref, op, orc):
     op.update_diagnostics()
     d = op.get_diagnostics()
     cmax, ce, cc = orc.diagnostics()
-    assert abs(d.max_courant_num - cmax) <= 1e-12 * max(1.0, cmax)
+    # first order: the same arithmetic up to FMA contraction.  Second order: the gradients are formed as M^-1 (sum w d dq) on
+    # the chip instead of sum (M^-1 w d) dq with host-made coefficients -- equal by linearity, different by cond(M) x rounding,
+    # which unlimited extrapolation on jittered meshes passes on to the wave speeds; the bar there is the RHS's 1e-10
+    ctol = 1e-10 if case.config.second_order else 1e-12
+    assert abs(d.max_courant_num - cmax) <= ctol * max(1.0, cmax)
     if case.mesh.num_owned_cells == case.mesh.num_cells:
         assert (d.global_edge_id, d.global_cell_id) == (ce, cc)
     # boundary fluxes and their dt-weighted accumulation
