@@ -203,10 +203,13 @@ def cpu_baseline_all_cores(args, argv):
                       f"(upper bound on an MPI run), slowest part {tmax * 1e3:.1f} ms/RHS"}
 
 
-def kernel_sha() -> str:
-    """hash of the kernel sources: ties a stored PMC traffic figure to the code it was measured on"""
+def kernel_sha(second_order: bool = False) -> str:
+    """hash of the kernel sources: ties a stored PMC traffic figure to the code it was measured on (the first-order /
+    HR kernels do not depend on muscl_kernels.h)"""
     h = hashlib.sha256()
     for name in KERNEL_SOURCES:
+        if name == "muscl_kernels.h" and not second_order:
+            continue
         with open(os.path.join(ROOT, "rdycore_amd", "csrc", name), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
