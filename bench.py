@@ -79,6 +79,9 @@ def parse(argv=None):
     p.add_argument("--kernel", default=None, choices=["tiled", "cell"], help="kernel variant (default: library default = tiled)")
     p.add_argument("--cpu-sample", default=None, help="nx x ny of the CPU-baseline sample mesh")
     p.add_argument("--launch-timeout", type=float, default=1500.0, help="N > 1 self-launch: give up after this many seconds")
+    p.add_argument("--watchdog-seconds", type=float, default=1200.0,
+                   help="every rank dumps its Python stacks and exits non-zero if it is still running after this long (a hung "
+                        "collective then becomes a reported failure instead of a silent hang); 0: off")
     a = p.parse_args(argv)
     defaults = {"c3": (2500, 2000), "c2": (1000, 500), "dambreak_quads": (5120, 2560), "c5": (5000, 5000)}
     if a.nx is None:
@@ -240,6 +243,9 @@ def load_traffic(workload_key: str):
 
 
 def run_rank(args, argv):
+    if args.watchdog_seconds > 0:
+        import faulthandler
+        faulthandler.dump_traceback_later(args.watchdog_seconds, exit=True)
     import numpy as np
     import torch
     import torch.distributed as dist

@@ -225,7 +225,7 @@ def test_rccl_self_exchange_one_rank(rdyhip_kernel):
     op.destroy()
 
 
-@pytest.mark.timeout(600)
+@pytest.mark.timeout(900)
 def test_bench_self_launches_two_ranks(rdyhip_kernel):
     """`python bench.py --gpus 2` started as a plain command launches its own ranks (rdycore_amd/launch.py) and prints
     one line; BENCH_BACKEND=gloo lets both ranks share this box's one GPU"""
@@ -238,8 +238,8 @@ def test_bench_self_launches_two_ranks(rdyhip_kernel):
     env.pop("RANK", None)
     for extra, driver in (([], "torch"), (["--halo", "c"], "c"), (["--workload", "c5", "--nx", "160", "--ny", "160", "--halo", "c"], "c")):
         cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--nx", "200", "--ny", "200",
-               "--condition-seconds", "0.2"] + extra
-        out = subprocess.run(cmd, capture_output=True, text=True, timeout=500, cwd=ROOT, env=env)
+               "--condition-seconds", "0.2", "--watchdog-seconds", "150", "--launch-timeout", "200"] + extra
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
         assert out.returncode == 0, out.stderr[-3000:]
         lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
         assert len(lines) == 1, lines
