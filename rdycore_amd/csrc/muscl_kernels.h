@@ -397,17 +397,9 @@ __global__ __launch_bounds__(TILE) void swe_rhs_muscl_fused_kernel(const KernelA
     d.e_off = v.x; d.h_off = v.y; d.b_off = v.z; d.halo = v.w;
     return d;
   };
-  auto next_valid = [&](int i) -> int {  // INTERIOR phase skips tiles that need ghost data (wave-uniform)
-    if (a.phase == RDYHIP_PHASE_INTERIOR) {
-      while (i < hi && tile_desc(tile_at(i)).halo) i += step;
-    }
-    return i;
-  };
-  // id of the ring cell (first or second ring) this thread stages for tile t, -1 if none
-  auto ring_id = [&](int t) -> int {
-    const TileDesc td_ = tile_desc(t), tn_ = tile_desc(t + 1);
-    const int      nh_ = tn_.h_off - td_.h_off, c0_ = load_uniform(g.c_off, t), nc2_ = load_uniform(g.c_off, t + 1) - c0_;
-    int            id  = -1;
+  // id of the ring cell (first or second ring) this thread stages for a tile
+  auto ring_id = [&](const TileDesc &td_, int nh_, int c0_, int nc2_) -> int {
+    int id = -1;
     if (tid < nh_) id = a.hcells[td_.h_off + tid];
     else if (tid < nh_ + nc2_) id = g.hcells2[c0_ + tid - nh_];
     return id;
@@ -427,251 +419,189 @@ __global__ __launch_bounds__(TILE) void swe_rhs_muscl_fused_kernel(const KernelA
 
   double best      = 0.0;
   int    best_slot = -1, best_o = 0;
+  int    pre_tile = -1, pre_hid = -1;  // ring-cell id fetched one tile ahead (breaks the id -> state load chain)
 
-  // ---- software pipeline (the structure of swe_rhs_tiled_kernel): what a tile's phase 0 parks in LDS -- the state and
-  // centroid of its own and ring cells, its edge records -- and what phases G / 1 / 2 read from registers (first-ring
-  // stencils, slot references, edge normals and midpoints) is loaded a whole tile ahead; the per-cell streams of phase 2
-  // ride in the same load batch for the CURRENT tile.  The batch is issued after phase 0's barrier and its first use is
-  // phase 2, so a tile has ONE wait on global loads, two phases after they were issued.
-  struct Pre0 {  // loaded a tile ahead, consumed by phase 0 (parked in LDS): the SAME registers are reloaded right after it
-    double   q0, q1, q2, hq0, hq1, hq2;
-    double2  cxy, hcxy;
-    uint32_t lr0, lr1;
-  };
-  struct Pre1 {  // loaded a tile ahead, read from registers in phases G, 1 and 2: two generations are live
-    uint2    bw;
-    uint32_t r0, r1;
-    double   cs0, cs1;
-    double2  md0, md1;
-  };
-  auto load_pre = [&](int t, int hid_, Pre0 &p, Pre1 &p1) {
-    const TileDesc td_ = tile_desc(t), tn_ = tile_desc(t + 1);
-    const int      ne_ = tn_.e_off - td_.e_off, nh_ = tn_.h_off - td_.h_off;
-    const int      o_  = t * TILE + tid;
-    p.q0 = p.q1 = p.q2 = p.hq0 = p.hq1 = p.hq2 = 0.0;
-    p.cxy = p.hcxy = make_double2(0.0, 0.0);
-    p1.bw = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
-    p1.r0 = p1.r1 = 0xFFFFFFFFu;
-    p.lr0 = p.lr1 = 0;
-    p1.cs0 = p1.cs1 = 0.0;
-    p1.md0 = p1.md1 = make_double2(0.0, 0.0);
-    if (o_ < a.n_owned) {
-      const int c = a.o2l ? a.o2l[o_] : o_;
-      p.q0  = u[3 * (int64_t)c + 0];
-      p.q1  = u[3 * (int64_t)c + 1];
-      p.q2  = u[3 * (int64_t)c + 2];
-      p.cxy = *reinterpret_cast<const double2 *>(g.cxy + 2 * (int64_t)c);
+  for (; idx < hi; idx += step) {
+    const int      tile = tile_at(idx);
+    const TileDesc td = tile_desc(tile), tn = tile_desc(tile + 1);
+    if (a.phase == RDYHIP_PHASE_INTERIOR && td.halo) continue;  // wave-uniform
+    const int  ne = tn.e_off - td.e_off, nh = tn.h_off - td.h_off;
+    const int  c0 = load_uniform(g.c_off, tile), nc2 = load_uniform(g.c_off, tile + 1) - c0;
+    const int  o      = tile * TILE + tid;
+    const bool active = o < a.n_owned;
+
+    // ---- the tile's load batch: everything the four phases read from global memory that does not depend on LDS.
+    // hipcc waits with vmcnt(0) at the first use, so one batch = one exposed latency per tile.
+    const int hid = (pre_tile == tile) ? pre_hid : ring_id(td, nh, c0, nc2);
+    double    q[3] = {0.0, 0.0, 0.0}, hq[3] = {0.0, 0.0, 0.0};
+    double2   cxy = make_double2(0.0, 0.0), hcxy = make_double2(0.0, 0.0);
+    uint32_t  r0 = 0xFFFFFFFFu, r1 = 0xFFFFFFFFu;
+    double    kf[S];
+    double    dzx = 0.0, dzy = 0.0, nman = 0.0, s0 = 0.0, s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int s = 0; s < S; ++s) kf[s] = 0.0;
+    if (active) {
+      const int c = a.o2l ? a.o2l[o] : o;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) q[k] = u[3 * (int64_t)c + k];
+      cxy = *reinterpret_cast<const double2 *>(g.cxy + 2 * (int64_t)c);
       if (S == 3) {
-        p1.r0 = RDY_MLD(&reinterpret_cast<const uint32_t *>(a.slot_ref)[o_]);
+        r0 = RDY_MLD(&reinterpret_cast<const uint32_t *>(a.slot_ref)[o]);
       } else {
-        const uint2 w = reinterpret_cast<const uint2 *>(a.slot_ref)[o_];
-        p1.r0         = w.x;
-        p1.r1         = w.y;
+        const uint2 w = reinterpret_cast<const uint2 *>(a.slot_ref)[o];
+        r0            = w.x;
+        r1            = w.y;
       }
-    }
-    if (hid_ >= 0) {
-      p.hq0  = u[3 * (int64_t)hid_ + 0];
-      p.hq1  = u[3 * (int64_t)hid_ + 1];
-      p.hq2  = u[3 * (int64_t)hid_ + 2];
-      p.hcxy = *reinterpret_cast<const double2 *>(g.cxy + 2 * (int64_t)hid_);
-    }
-    if (tid < nh_) p1.bw = load_u2(g.bn_idx + 4 * ((int64_t)td_.h_off + tid));
-    if (tid < ne_) {
-      p.lr0  = RDY_MLD(&a.e_lr[td_.e_off + tid]);
-      p1.cs0 = RDY_MLD(&a.e_cs[td_.e_off + tid]);
-      p1.md0 = load_d2(g.e_mid + 2 * ((int64_t)td_.e_off + tid));
-    }
-    if (tid + TILE < ne_) {
-      p.lr1  = RDY_MLD(&a.e_lr[td_.e_off + TILE + tid]);
-      p1.cs1 = RDY_MLD(&a.e_cs[td_.e_off + TILE + tid]);
-      p1.md1 = load_d2(g.e_mid + 2 * ((int64_t)td_.e_off + TILE + tid));
-    }
-  };
-
-  idx = next_valid(idx);
-  if (idx < hi) {
-    Pre0 pre;  // phase-0 operands of the tile about to start
-    Pre1 cur;  // its register-resident operands
-    int  tile = tile_at(idx);
-    int  hid  = ring_id(tile);
-    load_pre(tile, hid, pre, cur);
-    int idx1 = next_valid(idx + step);
-    int tile1 = 0, hid1 = -1;
-    if (idx1 < hi) {
-      tile1 = tile_at(idx1);
-      hid1  = ring_id(tile1);
-    }
-
-    while (true) {
-      const TileDesc td = tile_desc(tile), tn = tile_desc(tile + 1);
-      const int      ne = tn.e_off - td.e_off, nh = tn.h_off - td.h_off;
-      const int      c0 = load_uniform(g.c_off, tile), nc2 = load_uniform(g.c_off, tile + 1) - c0;
-      const int      o      = tile * TILE + tid;
-      const bool     active = o < a.n_owned;
-
-      // ---- phase 0: state + centroid of own cells, first ring, second ring; the tile's edge records -> LDS
-      sq[tid]          = pre.q0;
-      sq[nq + tid]     = pre.q1;
-      sq[2 * nq + tid] = pre.q2;
-      sq[3 * nq + tid] = pre.cxy.x;
-      sq[4 * nq + tid] = pre.cxy.y;
-      if (hid >= 0) {
-        sq[TILE + tid]          = pre.hq0;
-        sq[nq + TILE + tid]     = pre.hq1;
-        sq[2 * nq + TILE + tid] = pre.hq2;
-        sq[3 * nq + TILE + tid] = pre.hcxy.x;
-        sq[4 * nq + TILE + tid] = pre.hcxy.y;
-      }
-      for (int j = tid + TILE; j < nh + nc2; j += TILE) {  // only numberings with poor locality get here
-        const int hc = (j < nh) ? a.hcells[td.h_off + j] : g.hcells2[c0 + j - nh];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) sq[k * nq + TILE + j] = u[3 * (int64_t)hc + k];
-        sq[3 * nq + TILE + j] = g.cxy[2 * (int64_t)hc];
-        sq[4 * nq + TILE + j] = g.cxy[2 * (int64_t)hc + 1];
-      }
-      if (tid < ne) slr[tid] = pre.lr0;
-      if (tid + TILE < ne) slr[tid + TILE] = pre.lr1;
-      for (int e = tid + 2 * TILE; e < ne; e += TILE) slr[e] = a.e_lr[td.e_off + e];
-      if (td.halo) {
-        // first-ring cells that are ghosts: their gradient was computed by its owner and exchanged.  Read here, before
-        // the load batch below is issued, so that the wait it needs cannot hold up the batch (halo tiles only: ~1 %)
-        for (int j = tid; j < nh; j += TILE) {
-          const uint2 w = (j == tid) ? cur.bw : reinterpret_cast<const uint2 *>(g.bn_idx)[(int64_t)td.h_off + j];
-          if ((w.x & 0xFFFFu) == BN_GLOBAL) {
-            const int hc = a.hcells[td.h_off + j];
+      for (int s = 0; s < S; ++s) kf[s] = RDY_MLD(&a.coef[s * a.stride + o]);
+      dzx  = RDY_MLD(&a.dzdx[o]);
+      dzy  = RDY_MLD(&a.dzdy[o]);
+      nman = RDY_MLD(&a.mannings[o]);
+      s0   = RDY_MLD(&a.extsrc[3 * (int64_t)o + 0]);
+      s1   = RDY_MLD(&a.extsrc[3 * (int64_t)o + 1]);
+      s2   = RDY_MLD(&a.extsrc[3 * (int64_t)o + 2]);
+    }
+    if (hid >= 0) {
 #pragma unroll
-            for (int k = 0; k < 6; ++k) sg[k * ng + TILE + j] = g.grad[6 * (int64_t)hc + k];
-          }
-        }
-      }
-      __syncthreads();
+      for (int k = 0; k < 3; ++k) hq[k] = u[3 * (int64_t)hid + k];
+      hcxy = *reinterpret_cast<const double2 *>(g.cxy + 2 * (int64_t)hid);
+    }
+    uint2 bw = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);  // first-ring stencil of ring cell j = tid: the LDS slots of its neighbours
+    if (tid < nh) bw = load_u2(g.bn_idx + 4 * ((int64_t)td.h_off + tid));
+    uint32_t lr0 = 0, lr1 = 0;
+    double   cs0 = 0.0, cs1 = 0.0;
+    double2  md0 = make_double2(0.0, 0.0), md1 = md0;
+    if (tid < ne) {
+      lr0 = RDY_MLD(&a.e_lr[td.e_off + tid]);
+      cs0 = RDY_MLD(&a.e_cs[td.e_off + tid]);
+      md0 = load_d2(g.e_mid + 2 * ((int64_t)td.e_off + tid));
+    }
+    if (tid + TILE < ne) {
+      lr1 = RDY_MLD(&a.e_lr[td.e_off + TILE + tid]);
+      cs1 = RDY_MLD(&a.e_cs[td.e_off + TILE + tid]);
+      md1 = load_d2(g.e_mid + 2 * ((int64_t)td.e_off + TILE + tid));
+    }
+    // the ring-cell id of the tile this workgroup takes next
+    pre_tile = -1;
+    if (idx + step < hi) {
+      pre_tile            = tile_at(idx + step);
+      const TileDesc pd = tile_desc(pre_tile), pn = tile_desc(pre_tile + 1);
+      const int      pc0 = load_uniform(g.c_off, pre_tile);
+      pre_hid            = ring_id(pd, pn.h_off - pd.h_off, pc0, load_uniform(g.c_off, pre_tile + 1) - pc0);
+    }
 
-      // ---- the load batch: the per-cell streams of THIS tile (first used in phase 2), everything the next tile needs
-      // before its phase 2, and the ring-cell id of the tile after
-      __builtin_amdgcn_s_setprio(3);
-      double kf[S];
-      double dzx = 0.0, dzy = 0.0, nman = 0.0, s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    // ---- phase 0: state + centroid of own cells, first ring, second ring; the tile's edge records -> LDS
 #pragma unroll
-      for (int s = 0; s < S; ++s) kf[s] = 0.0;
+    for (int k = 0; k < 3; ++k) sq[k * nq + tid] = q[k];
+    sq[3 * nq + tid] = cxy.x;
+    sq[4 * nq + tid] = cxy.y;
+    if (hid >= 0) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) sq[k * nq + TILE + tid] = hq[k];
+      sq[3 * nq + TILE + tid] = hcxy.x;
+      sq[4 * nq + TILE + tid] = hcxy.y;
+    }
+    for (int j = tid + TILE; j < nh + nc2; j += TILE) {  // only numberings with poor locality get here
+      const int hc = (j < nh) ? a.hcells[td.h_off + j] : g.hcells2[c0 + j - nh];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) sq[k * nq + TILE + j] = u[3 * (int64_t)hc + k];
+      sq[3 * nq + TILE + j] = g.cxy[2 * (int64_t)hc];
+      sq[4 * nq + TILE + j] = g.cxy[2 * (int64_t)hc + 1];
+    }
+    if (tid < ne) slr[tid] = lr0;
+    if (tid + TILE < ne) slr[tid + TILE] = lr1;
+    for (int e = tid + 2 * TILE; e < ne; e += TILE) slr[e] = a.e_lr[td.e_off + e];
+    __syncthreads();
+
+    // ---- phase G: least-squares gradients of own and first-ring cells -> LDS
+    {
+      double gr[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
       if (active) {
+        int nb[S];
 #pragma unroll
-        for (int s = 0; s < S; ++s) kf[s] = RDY_MLD(&a.coef[s * a.stride + o]);
-        dzx  = RDY_MLD(&a.dzdx[o]);
-        dzy  = RDY_MLD(&a.dzdy[o]);
-        nman = RDY_MLD(&a.mannings[o]);
-        s0   = RDY_MLD(&a.extsrc[3 * (int64_t)o + 0]);
-        s1   = RDY_MLD(&a.extsrc[3 * (int64_t)o + 1]);
-        s2   = RDY_MLD(&a.extsrc[3 * (int64_t)o + 2]);
-      }
-      Pre1 nxt;
-      int  idx2 = hi, tile2 = 0, hid2 = -1;
-      if (idx1 < hi) {
-        load_pre(tile1, hid1, pre, nxt);  // `pre` was consumed by phase 0: its registers are the destination again
-        idx2 = next_valid(idx1 + step);
-        if (idx2 < hi) {
-          tile2 = tile_at(idx2);
-          hid2  = ring_id(tile2);
+        for (int s = 0; s < S; ++s) {
+          nb[s]         = -1;
+          const int ref = slot_edge<S>(r0, r1, s);
+          if (ref < 0) continue;
+          const uint32_t lr = slr[ref];
+          if (lr & EDGE_BOUNDARY) continue;
+          const int jl = lr & EDGE_SLOT_MASK, jr = (lr >> EDGE_R_SHIFT) & EDGE_SLOT_MASK;
+          nb[s]        = (jl == tid) ? jr : jl;
         }
-      } else {
-        nxt = cur;
+        lds_gradient(tid, nb, gr);
       }
-      __builtin_amdgcn_s_setprio(0);
-
-      // ---- phase G: least-squares gradients of own and first-ring cells -> LDS (operands from LDS only)
-      {
-        double gr[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-        if (active) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) sg[k * ng + tid] = gr[k];
+      auto ring_gradient = [&](int j, uint2 w) {
+        const uint32_t ix[4] = {w.x & 0xFFFFu, w.x >> 16, w.y & 0xFFFFu, w.y >> 16};
+        double         hg[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        if (ix[0] == BN_GLOBAL) {  // a ghost cell: its gradient was computed by its owner
+          const int hc = a.hcells[td.h_off + j];
+#pragma unroll
+          for (int k = 0; k < 6; ++k) hg[k] = g.grad[6 * (int64_t)hc + k];
+        } else {
           int nb[S];
-#pragma unroll
-          for (int s = 0; s < S; ++s) {
-            nb[s]         = -1;
-            const int ref = slot_edge<S>(cur.r0, cur.r1, s);
-            if (ref < 0) continue;
-            const uint32_t lr = slr[ref];
-            if (lr & EDGE_BOUNDARY) continue;
-            const int jl = lr & EDGE_SLOT_MASK, jr = (lr >> EDGE_R_SHIFT) & EDGE_SLOT_MASK;
-            nb[s]        = (jl == tid) ? jr : jl;
-          }
-          lds_gradient(tid, nb, gr);
-        }
-#pragma unroll
-        for (int k = 0; k < 6; ++k) sg[k * ng + tid] = gr[k];
-        auto ring_gradient = [&](int j, uint2 w) {
-          const uint32_t ix[4] = {w.x & 0xFFFFu, w.x >> 16, w.y & 0xFFFFu, w.y >> 16};
-          if (ix[0] == BN_GLOBAL) return;  // a ghost: phase 0 stored its exchanged gradient
-          double hg[6];
-          int    nb[S];
 #pragma unroll
           for (int s = 0; s < S; ++s) nb[s] = (ix[s] == BN_NONE) ? -1 : (int)ix[s];
           lds_gradient(TILE + j, nb, hg);
+        }
 #pragma unroll
-          for (int k = 0; k < 6; ++k) sg[k * ng + TILE + j] = hg[k];
-        };
-        if (tid < nh) ring_gradient(tid, cur.bw);
-        for (int j = tid + TILE; j < nh; j += TILE)  // poor locality only
-          ring_gradient(j, reinterpret_cast<const uint2 *>(g.bn_idx)[(int64_t)td.h_off + j]);
-      }
-      __syncthreads();
-
-      // ---- phase 1: every edge of the tile once (records from LDS, normals and midpoints from registers)
-      auto do_edge = [&](int e, double cs, double2 mid) {
-        muscl_edge<LIM>(a, td, dt, e, slr[e], cs, mid, sq, nq, sg, ng, ef0, ef1, ef2, eam);
+        for (int k = 0; k < 6; ++k) sg[k * ng + TILE + j] = hg[k];
       };
-#pragma unroll 1
-      for (int r = 0; r < 2; ++r) {
-        const int e = tid + r * TILE;
-        if (e < ne) do_edge(e, r == 0 ? cur.cs0 : cur.cs1, r == 0 ? cur.md0 : cur.md1);
-      }
-      for (int e = tid + 2 * TILE; e < ne; e += TILE)
-        do_edge(e, a.e_cs[td.e_off + e], *reinterpret_cast<const double2 *>(g.e_mid + 2 * ((int64_t)td.e_off + e)));
-      __syncthreads();
-
-      // ---- phase 2: per-cell sum in the reference's edge order, source terms, stores
-      double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, res[3] = {0.0, 0.0, 0.0}, pu = 0.0, pv_ = 0.0;
-      const double h = sq[tid], hu = sq[nq + tid], hv = sq[2 * nq + tid];
-      if (active) {
-        if (!OVW) {
-          acc0 = f[3 * (int64_t)o + 0];
-          acc1 = f[3 * (int64_t)o + 1];
-          acc2 = f[3 * (int64_t)o + 2];
-        }
-        muscl_cell_sum<S>(cur.r0, cur.r1, kf, ef0, ef1, ef2, eam, dt, o, acc0, acc1, acc2, best, best_slot, best_o);
-        const RiemannSide self = riemann_side(h, hu, hv, a.tiny_h, a.h_anuga_sq);
-        pu                     = self.u;
-        pv_                    = self.v;
-        cell_results<SRC>(a, dt, h, hu, hv, acc0, acc1, acc2, dzx, dzy, nman, s0, s1, s2, res);
-      }
-      const bool last = idx1 >= hi;
-      // the prefetched registers are "used" here, before this tile's stores are issued (vmcnt counts stores too)
-      asm volatile("" ::"v"(pre.q0), "v"(pre.q1), "v"(pre.q2), "v"(pre.hq0), "v"(pre.hq1), "v"(pre.hq2), "v"(pre.cxy.x), "v"(pre.cxy.y),
-                   "v"(pre.hcxy.x), "v"(pre.hcxy.y), "v"(nxt.bw.x), "v"(nxt.bw.y), "v"(nxt.r0), "v"(nxt.r1), "v"(pre.lr0), "v"(pre.lr1));
-      asm volatile("" ::"v"(nxt.cs0), "v"(nxt.cs1), "v"(nxt.md0.x), "v"(nxt.md0.y), "v"(nxt.md1.x), "v"(nxt.md1.y), "v"(hid2));
-      cur = nxt;
-      idx = idx1; tile = tile1; hid = hid1;
-      idx1 = idx2; tile1 = tile2; hid1 = hid2;
-      __builtin_amdgcn_sched_barrier(0);
-      {  // whole-line stores of the [cell][3] rows (wave_store_rows3, swe_kernels.h); all 64 lanes take part
-        const int     lane  = tid & 63;
-        const int64_t base  = 3 * ((int64_t)o - lane);
-        const int     ncell = a.n_owned - (o - lane);
-        if (a.fdiv) wave_store_rows3(a.fdiv, base, lane, ncell, acc0, acc1, acc2);
-        if (!EULER || f) wave_store_rows3(f, base, lane, ncell, res[0], res[1], res[2]);
-        wave_store_rows3(a.pv, base, lane, ncell, h, pu, pv_);
-        if (EULER) {  // rdyhip_euler_step: the forward-Euler update rides on the stores, F only if asked for
-          const double n0 = h + dt * res[0], n1 = hu + dt * res[1], n2 = hv + dt * res[2];
-          if (!a.o2l) {
-            wave_store_rows3(a.u_out, base, lane, ncell, n0, n1, n2);
-          } else if (active) {
-            const int64_t c = a.o2l[o];
-            RDY_MST(&a.u_out[3 * c + 0], n0);
-            RDY_MST(&a.u_out[3 * c + 1], n1);
-            RDY_MST(&a.u_out[3 * c + 2], n2);
-          }
-        }
-      }
-      if (last) break;
-      __syncthreads();  // the LDS planes are rewritten by the next tile
+      if (tid < nh) ring_gradient(tid, bw);
+      for (int j = tid + TILE; j < nh; j += TILE)  // poor locality only
+        ring_gradient(j, reinterpret_cast<const uint2 *>(g.bn_idx)[(int64_t)td.h_off + j]);
     }
+    __syncthreads();
+
+    // ---- phase 1: every edge of the tile once
+    auto do_edge = [&](int e, uint32_t lr, double cs, double2 mid) {
+      muscl_edge<LIM>(a, td, dt, e, lr, cs, mid, sq, nq, sg, ng, ef0, ef1, ef2, eam);
+    };
+#pragma unroll 1
+    for (int r = 0; r < 2; ++r) {
+      const int e = tid + r * TILE;
+      if (e < ne) do_edge(e, r == 0 ? lr0 : lr1, r == 0 ? cs0 : cs1, r == 0 ? md0 : md1);
+    }
+    for (int e = tid + 2 * TILE; e < ne; e += TILE)
+      do_edge(e, slr[e], a.e_cs[td.e_off + e], *reinterpret_cast<const double2 *>(g.e_mid + 2 * ((int64_t)td.e_off + e)));
+    __syncthreads();
+
+    // ---- phase 2: per-cell sum in the reference's edge order, source terms, stores
+    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, res[3] = {0.0, 0.0, 0.0}, pu = 0.0, pv_ = 0.0;
+    const double h = sq[tid], hu = sq[nq + tid], hv = sq[2 * nq + tid];
+    if (active) {
+      if (!OVW) {
+        acc0 = f[3 * (int64_t)o + 0];
+        acc1 = f[3 * (int64_t)o + 1];
+        acc2 = f[3 * (int64_t)o + 2];
+      }
+      muscl_cell_sum<S>(r0, r1, kf, ef0, ef1, ef2, eam, dt, o, acc0, acc1, acc2, best, best_slot, best_o);
+      const RiemannSide self = riemann_side(h, hu, hv, a.tiny_h, a.h_anuga_sq);
+      pu                     = self.u;
+      pv_                    = self.v;
+      cell_results<SRC>(a, dt, h, hu, hv, acc0, acc1, acc2, dzx, dzy, nman, s0, s1, s2, res);
+    }
+    {  // whole-line stores of the [cell][3] rows (wave_store_rows3, swe_kernels.h); all 64 lanes take part
+      const int     lane  = tid & 63;
+      const int64_t base  = 3 * ((int64_t)o - lane);
+      const int     ncell = a.n_owned - (o - lane);
+      if (a.fdiv) wave_store_rows3(a.fdiv, base, lane, ncell, acc0, acc1, acc2);
+      if (!EULER || f) wave_store_rows3(f, base, lane, ncell, res[0], res[1], res[2]);
+      wave_store_rows3(a.pv, base, lane, ncell, h, pu, pv_);
+      if (EULER) {  // rdyhip_euler_step: the forward-Euler update rides on the stores, F only if asked for
+        const double n0 = h + dt * res[0], n1 = hu + dt * res[1], n2 = hv + dt * res[2];
+        if (!a.o2l) {
+          wave_store_rows3(a.u_out, base, lane, ncell, n0, n1, n2);
+        } else if (active) {
+          const int64_t c = a.o2l[o];
+          RDY_MST(&a.u_out[3 * c + 0], n0);
+          RDY_MST(&a.u_out[3 * c + 1], n1);
+          RDY_MST(&a.u_out[3 * c + 2], n2);
+        }
+      }
+    }
+    __syncthreads();  // the LDS planes are rewritten by the next tile
   }
   block_courant_reduce<TILE>(a, best, best_slot, best_o);
 }
