@@ -304,12 +304,25 @@ def run_rank(args, argv):
     # after 5 warm-up steps would otherwise measure the ramp, not the kernel
     n_cond = 0
     if args.condition_seconds > 0:
+        # the number of launches is agreed between the ranks (a step holds an exchange: a rank that left a time-based loop
+        # one round earlier than its neighbour would leave that neighbour waiting for ever): one batch is timed, the slowest
+        # rank's time decides the count for everybody
+        torch.cuda.synchronize()
         t_c = time.perf_counter()
-        while time.perf_counter() - t_c < args.condition_seconds:
+        for _ in range(10):
+            step()
+        torch.cuda.synchronize()
+        t_batch = time.perf_counter() - t_c
+        if world > 1:
+            tb = torch.tensor([t_batch], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(tb, op=dist.ReduceOp.MAX)
+            t_batch = float(tb.item())
+        n_batches = int(min(2000, max(0, np.ceil(args.condition_seconds / max(t_batch, 1e-6)) - 1)))
+        for _ in range(n_batches):
             for _ in range(10):
                 step()
             torch.cuda.synchronize()
-            n_cond += 10
+        n_cond = 10 * (n_batches + 1)
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()

@@ -68,6 +68,21 @@ struct MusclArgs {
 };
 constexpr uint16_t BN_NONE = 0xFFFF, BN_GLOBAL = 0xFFFE;
 
+// LDS layout of the second-order kernels: array-of-structs -- a cell's (h, hu, hv, centroid x, centroid y) are five
+// consecutive doubles, its gradient six, an edge's (f0, f1, f2, amax) four -- so that every access to a record is ONE
+// address (slot x record size) plus immediate offsets the compiler folds into ds_read2_b64 / ds_write2_b64.  With one plane
+// per component (-DRDYHIP_MUSCL_LDS_SOA, the layout of swe_kernels.h) every plane's runtime offset costs an SGPR, and
+// the kernel ran out of them: phase 1 alone held 161 v_readlane_b32 of spilled plane offsets and 87 address adds.
+#ifdef RDYHIP_MUSCL_LDS_SOA
+#define MSQ(k, j) sq[(k) * nq + (j)]
+#define MSG(k, j) sg[(k) * ng + (j)]
+#define MEF(c, e) ef[(c) * a.emax + (e)]
+#else
+#define MSQ(k, j) sq[5 * (j) + (k)]
+#define MSG(k, j) sg[6 * (j) + (k)]
+#define MEF(c, e) ef[4 * (e) + (c)]
+#endif
+
 // Weighted least-squares gradient of a cell (PrecomputeLSGradCoeffs + ComputeLeastSquaresGradients,
 // src/operator_fluxes_ceed.c:884-1042) accumulated neighbour by neighbour: with d = centroid_n - centroid_c,
 // w = 1/|d|, M += w d d^T and b_k += w d (q_n,k - q_c,k); the gradient is M^-1 b_k (zero for a degenerate stencil,
@@ -81,10 +96,13 @@ struct LsAcc {
 };
 __device__ __forceinline__ void ls_add(LsAcc &a, double dx, double dy, double d0, double d1, double d2) {
   const double r2 = fma(dx, dx, dy * dy);
-  // w = 1/sqrt(r2) by v_rsq_f64 + two Newton steps (<= 1 ulp); coincident centroids give w = 0 as in the reference
+  // w = 1/sqrt(r2) by v_rsq_f64 + Newton (a few ulp: every copy of a gradient goes through this same code, so they all
+  // agree bit for bit, and the parity bar is 1e-10); coincident centroids give w = 0 as in the reference
   double w = __builtin_amdgcn_rsq(r2);
   w        = w * fma(-0.5 * r2 * w, w, 1.5);
+#ifdef RDYHIP_LS_TWO_NEWTON
   w        = w * fma(-0.5 * r2 * w, w, 1.5);
+#endif
   if (!(r2 > 0.0)) w = 0.0;
   const double wdx = w * dx, wdy = w * dy;
   a.m00  = fma(wdx, dx, a.m00);
@@ -122,6 +140,11 @@ constexpr int LIMITER_MINMOD = 0, LIMITER_NONE = 1, LIMITER_VANLEER = 2;
 template <int LIM>
 __device__ __forceinline__ double limit_slope(double extrap, double half_dq) {
   if (LIM == LIMITER_NONE) return extrap;
+#ifndef RDYHIP_MINMOD_BRANCHY
+  // minmod(a, b) = "0 if the signs differ, else the one of smaller magnitude" is the median of (a, b, 0): four min / max
+  // operations instead of a multiply, two compares and two 64-bit selects
+  if (LIM == LIMITER_MINMOD) return fmax(fmin(extrap, half_dq), fmin(fmax(extrap, half_dq), 0.0));
+#endif
   if (extrap * half_dq <= 0.0) return 0.0;
   if (LIM == LIMITER_VANLEER) return 2.0 * extrap * half_dq * rdy_rcp(extrap + half_dq);
   return fabs(extrap) < fabs(half_dq) ? extrap : half_dq;
@@ -135,7 +158,7 @@ __device__ __forceinline__ double limit_slope(double extrap, double half_dq) {
 // (src/operator_fluxes_ceed.c:1169-1178).  The flux is parked in LDS for phase 2.
 template <int LIM>
 __device__ __forceinline__ void muscl_edge(const KernelArgs &a, const TileDesc &td, double dt, int e, uint32_t lr, double cs, double2 mid,
-                                           const double *sq, int nq, const double *sg, int ng, double *ef0, double *ef1, double *ef2, double *eam) {
+                                           const double *sq, int nq, const double *sg, int ng, double *ef) {
   double cn, sn;
   edge_normal(lr, cs, cn, sn);
   const int jl = lr & EDGE_SLOT_MASK;
@@ -145,15 +168,15 @@ __device__ __forceinline__ void muscl_edge(const KernelArgs &a, const TileDesc &
     const int jr = (lr >> EDGE_R_SHIFT) & EDGE_SLOT_MASK;
     double    ql[3], qr[3];
     double2   dl, dr;
-    dl.x = mid.x - sq[3 * nq + jl];
-    dl.y = mid.y - sq[4 * nq + jl];
-    dr.x = mid.x - sq[3 * nq + jr];
-    dr.y = mid.y - sq[4 * nq + jr];
+    dl.x = mid.x - MSQ(3, jl);
+    dl.y = mid.y - MSQ(4, jl);
+    dr.x = mid.x - MSQ(3, jr);
+    dr.y = mid.y - MSQ(4, jr);
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      const double cl_ = sq[k * nq + jl], cr_ = sq[k * nq + jr];
-      const double extrap_l = sg[(2 * k) * ng + jl] * dl.x + sg[(2 * k + 1) * ng + jl] * dl.y;
-      const double extrap_r = sg[(2 * k) * ng + jr] * dr.x + sg[(2 * k + 1) * ng + jr] * dr.y;
+      const double cl_ = MSQ(k, jl), cr_ = MSQ(k, jr);
+      const double extrap_l = MSG(2 * k, jl) * dl.x + MSG(2 * k + 1, jl) * dl.y;
+      const double extrap_r = MSG(2 * k, jr) * dr.x + MSG(2 * k + 1, jr) * dr.y;
       const double dq       = cr_ - cl_;
       ql[k]                 = cl_ + limit_slope<LIM>(extrap_l, 0.5 * dq);
       qr[k]                 = cr_ + limit_slope<LIM>(extrap_r, -0.5 * dq);
@@ -165,17 +188,17 @@ __device__ __forceinline__ void muscl_edge(const KernelArgs &a, const TileDesc &
     fl                  = roe_flux(L, R, sn, cn);
     wet                 = !(R.h < a.tiny_h && L.h < a.tiny_h);  // swe_petsc.c:184
   } else {
-    const RiemannSide L  = riemann_side(sq[jl], sq[nq + jl], sq[2 * nq + jl], a.tiny_h, a.h_anuga_sq);
+    const RiemannSide L  = riemann_side(MSQ(0, jl), MSQ(1, jl), MSQ(2, jl), a.tiny_h, a.h_anuga_sq);
     const int         k  = a.tile_bk[td.b_off + ((lr >> EDGE_R_SHIFT) & EDGE_SLOT_MASK)];
     BoundaryFlux      bf = boundary_flux(a.btype[k], true, L, a.bvalues + 3 * (int64_t)k, sn, cn, a.tiny_h, a.h_anuga_sq);
     fl                   = bf.flux;
     wet                  = bf.wet;
     store_boundary_flux(a, k, fl, dt);
   }
-  ef0[e] = fl.f0;
-  ef1[e] = fl.f1;
-  ef2[e] = fl.f2;
-  eam[e] = wet ? fl.amax : -1.0;  // -1 marks a dry-dry edge (skipped, swe_petsc.c:184)
+  MEF(0, e) = fl.f0;
+  MEF(1, e) = fl.f1;
+  MEF(2, e) = fl.f2;
+  MEF(3, e) = wet ? fl.amax : -1.0;  // -1 marks a dry-dry edge (skipped, swe_petsc.c:184)
 }
 
 // index of slot s's edge in the tile's edge list, or -1 for an unused slot
@@ -193,19 +216,19 @@ __device__ __forceinline__ int slot_edge(uint32_t r0, uint32_t r1, int s) {
 // Phase 2 of both second-order kernels: a cell's flux sum in the reference's edge order + the Courant number
 // (src/swe/swe_petsc.c:184-201); kf[s] = -+len/area of slot s.
 template <int S>
-__device__ __forceinline__ void muscl_cell_sum(uint32_t r0, uint32_t r1, const double (&kf)[S], const double *ef0, const double *ef1, const double *ef2,
-                                               const double *eam, double dt, int o, double &acc0, double &acc1, double &acc2, double &best,
+__device__ __forceinline__ void muscl_cell_sum(const KernelArgs &a, uint32_t r0, uint32_t r1, const double (&kf)[S], const double *ef, double dt, int o,
+                                               double &acc0, double &acc1, double &acc2, double &best,
                                                int &best_slot, int &best_o) {
 #pragma unroll
   for (int s = 0; s < S; ++s) {
     const int ref = slot_edge<S>(r0, r1, s);
     if (ref < 0) continue;
-    const double am = eam[ref];
+    const double am = MEF(3, ref);
     if (am != -1.0) {
       const double k = kf[s];
-      acc0 += ef0[ref] * k;
-      acc1 += ef1[ref] * k;
-      acc2 += ef2[ref] * k;
+      acc0 += MEF(0, ref) * k;
+      acc1 += MEF(1, ref) * k;
+      acc2 += MEF(2, ref) * k;
       const double cnum = am * fabs(k) * dt;  // len/area_self: the max over the two cells is len / min(area_l, area_r)
       if (cnum > best) {
         best      = cnum;
@@ -262,7 +285,8 @@ __global__ __launch_bounds__(TILE) void swe_rhs_muscl_kernel(const KernelArgs a,
   const int nside = TILE + a.hmax;
   double   *sq    = lds;              // 5 planes of nside: h, hu, hv, centroid x, y
   double   *sg    = lds + 5 * nside;  // 6 planes of nside: the gradient
-  double   *ef0 = lds + 11 * nside, *ef1 = ef0 + a.emax, *ef2 = ef1 + a.emax, *eam = ef2 + a.emax;
+  double   *ef = lds + 11 * nside;  // 4 x emax: the edge fluxes
+  const int nq = nside, ng = nside;
   const int tid = threadIdx.x;
 
   // the tile sequence of this (persistent) workgroup: as in swe_rhs_tiled_kernel
@@ -302,17 +326,17 @@ __global__ __launch_bounds__(TILE) void swe_rhs_muscl_kernel(const KernelArgs a,
         for (int k = 0; k < 6; ++k) gr[k] = g.grad[6 * (int64_t)c + k];
       }
 #pragma unroll
-      for (int k = 0; k < 5; ++k) sq[k * nside + tid] = q[k];
+      for (int k = 0; k < 5; ++k) MSQ(k, tid) = q[k];
 #pragma unroll
-      for (int k = 0; k < 6; ++k) sg[k * nside + tid] = gr[k];
+      for (int k = 0; k < 6; ++k) MSG(k, tid) = gr[k];
       for (int j = tid; j < nh; j += TILE) {
         const int hc = a.hcells[td.h_off + j];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) sq[k * nside + TILE + j] = u[3 * (int64_t)hc + k];
-        sq[3 * nside + TILE + j] = g.cxy[2 * (int64_t)hc];
-        sq[4 * nside + TILE + j] = g.cxy[2 * (int64_t)hc + 1];
+        for (int k = 0; k < 3; ++k) MSQ(k, TILE + j) = u[3 * (int64_t)hc + k];
+        MSQ(3, TILE + j) = g.cxy[2 * (int64_t)hc];
+        MSQ(4, TILE + j) = g.cxy[2 * (int64_t)hc + 1];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) sg[k * nside + TILE + j] = g.grad[6 * (int64_t)hc + k];
+        for (int k = 0; k < 6; ++k) MSG(k, TILE + j) = g.grad[6 * (int64_t)hc + k];
       }
     }
     __syncthreads();
@@ -320,7 +344,7 @@ __global__ __launch_bounds__(TILE) void swe_rhs_muscl_kernel(const KernelArgs a,
     // ---- phase 1: every edge of the tile once
     for (int e = tid; e < ne; e += TILE) {
       const double2 mid = *reinterpret_cast<const double2 *>(g.e_mid + 2 * ((int64_t)td.e_off + e));
-      muscl_edge<LIM>(a, td, dt, e, a.e_lr[td.e_off + e], a.e_cs[td.e_off + e], mid, sq, nside, sg, nside, ef0, ef1, ef2, eam);
+      muscl_edge<LIM>(a, td, dt, e, a.e_lr[td.e_off + e], a.e_cs[td.e_off + e], mid, sq, nside, sg, nside, ef);
     }
     __syncthreads();
 
@@ -343,8 +367,8 @@ __global__ __launch_bounds__(TILE) void swe_rhs_muscl_kernel(const KernelArgs a,
       double kf[S];
 #pragma unroll
       for (int s = 0; s < S; ++s) kf[s] = a.coef[s * a.stride + o];
-      muscl_cell_sum<S>(r0, r1, kf, ef0, ef1, ef2, eam, dt, o, acc0, acc1, acc2, best, best_slot, best_o);
-      const double      h = sq[tid], hu = sq[nside + tid], hv = sq[2 * nside + tid];
+      muscl_cell_sum<S>(a, r0, r1, kf, ef, dt, o, acc0, acc1, acc2, best, best_slot, best_o);
+      const double      h = MSQ(0, tid), hu = MSQ(1, tid), hv = MSQ(2, tid);
       const RiemannSide self = riemann_side(h, hu, hv, a.tiny_h, a.h_anuga_sq);
       cell_epilogue<SRC>(a, o, dt, h, hu, hv, self.u, self.v, acc0, acc1, acc2, a.dzdx[o], a.dzdy[o], a.mannings[o], a.extsrc[3 * (int64_t)o + 0],
                          a.extsrc[3 * (int64_t)o + 1], a.extsrc[3 * (int64_t)o + 2], f);
@@ -374,8 +398,8 @@ __global__ __launch_bounds__(TILE) void swe_rhs_muscl_fused_kernel(const KernelA
   const int ng = TILE + a.hmax;   // gradient planes: own, first ring
   double   *sq = lds;             // 5 planes: h, hu, hv, centroid x, centroid y
   double   *sg = lds + 5 * nq;
-  double   *ef0 = sg + 6 * ng, *ef1 = ef0 + a.emax, *ef2 = ef1 + a.emax, *eam = ef2 + a.emax;
-  uint32_t *slr = reinterpret_cast<uint32_t *>(eam + a.emax);  // the tile's edge records
+  double   *ef = sg + 6 * ng;  // 4 x emax: the edge fluxes
+  uint32_t *slr = reinterpret_cast<uint32_t *>(ef + 4 * a.emax);  // the tile's edge records
   const int tid = threadIdx.x;
 
   int idx, step, hi;
@@ -406,13 +430,13 @@ __global__ __launch_bounds__(TILE) void swe_rhs_muscl_fused_kernel(const KernelA
   };
   // least-squares gradient of the cell in LDS slot `self` from the cells in slots nb[0..S-1] (-1: none), slot order
   auto lds_gradient = [&](int self, const int (&nb)[S], double (&gr)[6]) {
-    const double q0 = sq[self], q1 = sq[nq + self], q2 = sq[2 * nq + self], x0 = sq[3 * nq + self], y0 = sq[4 * nq + self];
+    const double q0 = MSQ(0, self), q1 = MSQ(1, self), q2 = MSQ(2, self), x0 = MSQ(3, self), y0 = MSQ(4, self);
     LsAcc        acc;
 #pragma unroll
     for (int s = 0; s < S; ++s) {
       const int n = nb[s];
       if (n < 0) continue;
-      ls_add(acc, sq[3 * nq + n] - x0, sq[4 * nq + n] - y0, sq[n] - q0, sq[nq + n] - q1, sq[2 * nq + n] - q2);
+      ls_add(acc, MSQ(3, n) - x0, MSQ(4, n) - y0, MSQ(0, n) - q0, MSQ(1, n) - q1, MSQ(2, n) - q2);
     }
     ls_solve(acc, gr);
   };
@@ -492,21 +516,21 @@ __global__ __launch_bounds__(TILE) void swe_rhs_muscl_fused_kernel(const KernelA
 
     // ---- phase 0: state + centroid of own cells, first ring, second ring; the tile's edge records -> LDS
 #pragma unroll
-    for (int k = 0; k < 3; ++k) sq[k * nq + tid] = q[k];
-    sq[3 * nq + tid] = cxy.x;
-    sq[4 * nq + tid] = cxy.y;
+    for (int k = 0; k < 3; ++k) MSQ(k, tid) = q[k];
+    MSQ(3, tid) = cxy.x;
+    MSQ(4, tid) = cxy.y;
     if (hid >= 0) {
 #pragma unroll
-      for (int k = 0; k < 3; ++k) sq[k * nq + TILE + tid] = hq[k];
-      sq[3 * nq + TILE + tid] = hcxy.x;
-      sq[4 * nq + TILE + tid] = hcxy.y;
+      for (int k = 0; k < 3; ++k) MSQ(k, TILE + tid) = hq[k];
+      MSQ(3, TILE + tid) = hcxy.x;
+      MSQ(4, TILE + tid) = hcxy.y;
     }
     for (int j = tid + TILE; j < nh + nc2; j += TILE) {  // only numberings with poor locality get here
       const int hc = (j < nh) ? a.hcells[td.h_off + j] : g.hcells2[c0 + j - nh];
 #pragma unroll
-      for (int k = 0; k < 3; ++k) sq[k * nq + TILE + j] = u[3 * (int64_t)hc + k];
-      sq[3 * nq + TILE + j] = g.cxy[2 * (int64_t)hc];
-      sq[4 * nq + TILE + j] = g.cxy[2 * (int64_t)hc + 1];
+      for (int k = 0; k < 3; ++k) MSQ(k, TILE + j) = u[3 * (int64_t)hc + k];
+      MSQ(3, TILE + j) = g.cxy[2 * (int64_t)hc];
+      MSQ(4, TILE + j) = g.cxy[2 * (int64_t)hc + 1];
     }
     if (tid < ne) slr[tid] = lr0;
     if (tid + TILE < ne) slr[tid + TILE] = lr1;
@@ -531,7 +555,7 @@ __global__ __launch_bounds__(TILE) void swe_rhs_muscl_fused_kernel(const KernelA
         lds_gradient(tid, nb, gr);
       }
 #pragma unroll
-      for (int k = 0; k < 6; ++k) sg[k * ng + tid] = gr[k];
+      for (int k = 0; k < 6; ++k) MSG(k, tid) = gr[k];
       auto ring_gradient = [&](int j, uint2 w) {
         const uint32_t ix[4] = {w.x & 0xFFFFu, w.x >> 16, w.y & 0xFFFFu, w.y >> 16};
         double         hg[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
@@ -546,7 +570,7 @@ __global__ __launch_bounds__(TILE) void swe_rhs_muscl_fused_kernel(const KernelA
           lds_gradient(TILE + j, nb, hg);
         }
 #pragma unroll
-        for (int k = 0; k < 6; ++k) sg[k * ng + TILE + j] = hg[k];
+        for (int k = 0; k < 6; ++k) MSG(k, TILE + j) = hg[k];
       };
       if (tid < nh) ring_gradient(tid, bw);
       for (int j = tid + TILE; j < nh; j += TILE)  // poor locality only
@@ -556,27 +580,35 @@ __global__ __launch_bounds__(TILE) void swe_rhs_muscl_fused_kernel(const KernelA
 
     // ---- phase 1: every edge of the tile once
     auto do_edge = [&](int e, uint32_t lr, double cs, double2 mid) {
-      muscl_edge<LIM>(a, td, dt, e, lr, cs, mid, sq, nq, sg, ng, ef0, ef1, ef2, eam);
+      muscl_edge<LIM>(a, td, dt, e, lr, cs, mid, sq, nq, sg, ng, ef);
     };
+#ifdef RDYHIP_MUSCL_ROUND_LOOP
 #pragma unroll 1
     for (int r = 0; r < 2; ++r) {
       const int e = tid + r * TILE;
       if (e < ne) do_edge(e, r == 0 ? lr0 : lr1, r == 0 ? cs0 : cs1, r == 0 ? md0 : md1);
     }
+#else
+    // the two register-resident rounds one after the other (no per-value selects between the rounds' registers); the
+    // scheduling barrier keeps the compiler from interleaving them, which would double the live registers
+    if (tid < ne) do_edge(tid, lr0, cs0, md0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (tid + TILE < ne) do_edge(tid + TILE, lr1, cs1, md1);
+#endif
     for (int e = tid + 2 * TILE; e < ne; e += TILE)
       do_edge(e, slr[e], a.e_cs[td.e_off + e], *reinterpret_cast<const double2 *>(g.e_mid + 2 * ((int64_t)td.e_off + e)));
     __syncthreads();
 
     // ---- phase 2: per-cell sum in the reference's edge order, source terms, stores
     double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, res[3] = {0.0, 0.0, 0.0}, pu = 0.0, pv_ = 0.0;
-    const double h = sq[tid], hu = sq[nq + tid], hv = sq[2 * nq + tid];
+    const double h = MSQ(0, tid), hu = MSQ(1, tid), hv = MSQ(2, tid);
     if (active) {
       if (!OVW) {
         acc0 = f[3 * (int64_t)o + 0];
         acc1 = f[3 * (int64_t)o + 1];
         acc2 = f[3 * (int64_t)o + 2];
       }
-      muscl_cell_sum<S>(r0, r1, kf, ef0, ef1, ef2, eam, dt, o, acc0, acc1, acc2, best, best_slot, best_o);
+      muscl_cell_sum<S>(a, r0, r1, kf, ef, dt, o, acc0, acc1, acc2, best, best_slot, best_o);
       const RiemannSide self = riemann_side(h, hu, hv, a.tiny_h, a.h_anuga_sq);
       pu                     = self.u;
       pv_                    = self.v;
