@@ -287,7 +287,23 @@ def run_rank(args, argv):
     mesh = case.mesh
     op = CS.create_operator(case)
     halo_mode = args.halo or ("c" if backend == "nccl" else "torch")
-    halo = HaloExchange(mesh, dev, transport=halo_mode, op=op) if world > 1 else None
+    halo, halo_note = None, None
+    if world > 1:
+        try:
+            halo = HaloExchange(mesh, dev, transport=halo_mode, op=op)
+            ok = 1
+        except Exception as exc:      # e.g. RCCL refuses to build the library's own communicator on this node
+            ok, halo_note = 0, repr(exc)
+            print(f"bench.py rank {rank}: halo transport '{halo_mode}' failed: {exc!r}", file=sys.stderr)
+        agree = torch.tensor([ok], dtype=torch.int32, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(agree, op=dist.ReduceOp.MIN)       # every rank must drive the exchange the same way
+        if int(agree.item()) == 0:
+            if halo_mode == "torch":
+                raise SystemExit(f"halo exchange setup failed: {halo_note}")
+            if halo is not None:
+                halo.destroy()
+            halo = HaloExchange(mesh, dev, transport="torch", op=op)
+            halo_note = f"fell back from the C-side RCCL exchange to torch.distributed P2P: {halo_note}"
     u = torch.tensor(case.u_local, dtype=torch.float64, device=dev)
     f = torch.empty((mesh.num_owned_cells, 3), dtype=torch.float64, device=dev)
     setup_s = time.time() - t0
@@ -517,7 +533,7 @@ def run_rank(args, argv):
                        "world_size": dist.get_world_size() if world > 1 else 1,
                        "backend": (backend if world > 1 else None),
                        "rccl_version": ".".join(map(str, torch.cuda.nccl.version())) if world > 1 and backend == "nccl" else None,
-                       "halo_driver": (halo.transport if halo is not None else None),
+                       "halo_driver": (halo.transport if halo is not None else None), "halo_note": halo_note,
                        "well_balancing": "hydrostatic_reconstruction" if args.hr else "none",
                        "spatial_order": ("second (MUSCL, %s limiter)" % args.limiter) if args.second_order else "first",
                        "halo_bytes_per_rank": halo.bytes_sent_per_exchange if halo else 0,

@@ -393,13 +393,19 @@ __global__ __launch_bounds__(TILE) void swe_rhs_muscl_kernel(const KernelArgs a,
 template <int S, int SRC, bool OVW, int LIM, bool EULER = false>
 __global__ __launch_bounds__(TILE) void swe_rhs_muscl_fused_kernel(const KernelArgs a, const MusclArgs g, const double dt, const double *__restrict__ u,
                                                                     double *__restrict__ f) {
+  // LDS: gradients of own + first-ring cells | state of own + first-ring cells | a region that holds, before the edge
+  // phase, the second ring's state (its head, contiguous with the first ring's records) and the tile's edge records
+  // (its tail), and from the edge phase on the edge fluxes, which overwrite both: the second ring is only read by the
+  // gradient phase and the records' LDS copy only by the gradient phase (the edge phase has them in registers).  That
+  // overlay is what lets FOUR workgroups share a CU's 160 KB on a well-numbered triangle mesh (39.8 KB each).
   extern __shared__ double lds[];
-  const int nq = TILE + g.hmax2;  // state + centroid planes: own, first ring, second ring
-  const int ng = TILE + a.hmax;   // gradient planes: own, first ring
-  double   *sq = lds;             // 5 planes: h, hu, hv, centroid x, centroid y
-  double   *sg = lds + 5 * nq;
-  double   *ef = sg + 6 * ng;  // 4 x emax: the edge fluxes
-  uint32_t *slr = reinterpret_cast<uint32_t *>(ef + 4 * a.emax);  // the tile's edge records
+  const int nq = TILE + g.hmax2;  // state + centroid records: own, first ring, second ring
+  const int ng = TILE + a.hmax;   // gradient records: own, first ring
+  double   *sg = lds;             // [ng][6]
+  double   *sq = lds + 6 * ng;    // [nq][5]: h, hu, hv, centroid x, centroid y
+  double   *ef = sq + 5 * ng;     // [emax][4]: the edge fluxes (over the second ring's records and the edge records)
+  const int ovl = max(4 * a.emax, 5 * (g.hmax2 - a.hmax) + (a.emax + 1) / 2);
+  uint32_t *slr = reinterpret_cast<uint32_t *>(ef + ovl) - ((a.emax + 1) / 2) * 2;  // [emax] the tile's edge records
   const int tid = threadIdx.x;
 
   int idx, step, hi;
@@ -596,7 +602,7 @@ __global__ __launch_bounds__(TILE) void swe_rhs_muscl_fused_kernel(const KernelA
     if (tid + TILE < ne) do_edge(tid + TILE, lr1, cs1, md1);
 #endif
     for (int e = tid + 2 * TILE; e < ne; e += TILE)
-      do_edge(e, slr[e], a.e_cs[td.e_off + e], *reinterpret_cast<const double2 *>(g.e_mid + 2 * ((int64_t)td.e_off + e)));
+      do_edge(e, a.e_lr[td.e_off + e], a.e_cs[td.e_off + e], *reinterpret_cast<const double2 *>(g.e_mid + 2 * ((int64_t)td.e_off + e)));  // not slr: the fluxes overwrite it
     __syncthreads();
 
     // ---- phase 2: per-cell sum in the reference's edge order, source terms, stores

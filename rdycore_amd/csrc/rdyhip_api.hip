@@ -753,7 +753,7 @@ static int build_host_layout(const RDyHipConfig *config, const RDyHipMesh *mesh,
   const bool   muscl_fused = !(menv && strcmp(menv, "split") == 0);
   const size_t lds_muscl   = !muscl_on ? 0
                              : muscl_fused
-                                 ? sizeof(double) * (5 * ((size_t)TILE + hmax2) + 6 * ((size_t)TILE + hmax) + 4 * (size_t)emax + ((size_t)emax + 1) / 2)
+                                 ? sizeof(double) * (11 * ((size_t)TILE + hmax) + std::max<size_t>(4 * (size_t)emax, 5 * (size_t)(hmax2 - hmax) + ((size_t)emax + 1) / 2))
                                  : sizeof(double) * (11 * ((size_t)TILE + hmax) + 4 * (size_t)emax);
   if (std::max(lds_bytes, lds_muscl) > 160 * 1024)
     return fail(RDYHIP_ERR_USER, "tile working set (%zu B of LDS) too large: the cell numbering has no locality", std::max(lds_bytes, lds_muscl));
