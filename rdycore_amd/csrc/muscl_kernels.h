@@ -178,8 +178,13 @@ __device__ __forceinline__ void muscl_edge(const KernelArgs &a, const TileDesc &
       const double extrap_l = MSG(2 * k, jl) * dl.x + MSG(2 * k + 1, jl) * dl.y;
       const double extrap_r = MSG(2 * k, jr) * dr.x + MSG(2 * k + 1, jr) * dr.y;
       const double dq       = cr_ - cl_;
+#ifndef RDYHIP_EXP_NO_RECON
       ql[k]                 = cl_ + limit_slope<LIM>(extrap_l, 0.5 * dq);
       qr[k]                 = cr_ + limit_slope<LIM>(extrap_r, -0.5 * dq);
+#else
+      ql[k] = cl_ + 1e-300 * (extrap_l + dq);  // timing experiment: operands read, no limiter
+      qr[k] = cr_ + 1e-300 * extrap_r;
+#endif
     }
     ql[0] = fmax(0.0, ql[0]);  // 1201-1203, swe_petsc.c:143-146
     qr[0] = fmax(0.0, qr[0]);
@@ -442,7 +447,11 @@ __global__ __launch_bounds__(TILE) void swe_rhs_muscl_fused_kernel(const KernelA
     for (int s = 0; s < S; ++s) {
       const int n = nb[s];
       if (n < 0) continue;
+#ifndef RDYHIP_EXP_NO_GRAD
       ls_add(acc, MSQ(3, n) - x0, MSQ(4, n) - y0, MSQ(0, n) - q0, MSQ(1, n) - q1, MSQ(2, n) - q2);
+#else
+      acc.b[0] += MSQ(0, n) - q0;  // timing experiment: the LDS traffic without the arithmetic
+#endif
     }
     ls_solve(acc, gr);
   };
