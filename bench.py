@@ -68,6 +68,11 @@ def parse(argv=None):
     p.add_argument("--limiter", default="minmod", choices=sorted(LIMITERS))
     p.add_argument("--emulate-world", type=int, default=0, help="with --gpus 1: time the part one rank of an N-rank strong-scaling run would own")
     p.add_argument("--emulate-rank", type=int, default=0)
+    p.add_argument("--self-exchange", action="store_true",
+                   help="with --gpus 1 --emulate-world W: run the multi-rank step (rdyhip_rhs_overlapped: pack, RCCL send/recv, unpack on the "
+                        "exchange stream, interior tiles meanwhile, halo tiles after) with a one-rank RCCL communicator whose only peer is "
+                        "this rank -- the ghost rows receive this rank's own boundary cells.  Same launches, same bytes through RCCL, no "
+                        "xGMI hop: what the N > 1 step costs on the GPU apart from the link")
     p.add_argument("--condition-seconds", type=float, default=1.0,
                    help="untimed RHS launches for this long before --warmup (brings the device out of the idle clock state the host-only "
                         "setup leaves it in; disclosed in config.conditioning)")
@@ -279,7 +284,8 @@ def run_rank(args, argv):
     t0 = time.time()
     if world == 1 and args.emulate_world > 1:
         sav = args.scaling
-        args.scaling = "strong"
+        if not args.self_exchange:
+            args.scaling = "strong"
         case = build_case(args, args.emulate_rank, args.emulate_world)
         args.scaling = sav
     else:
@@ -304,6 +310,32 @@ def run_rank(args, argv):
                 halo.destroy()
             halo = HaloExchange(mesh, dev, transport="torch", op=op)
             halo_note = f"fell back from the C-side RCCL exchange to torch.distributed P2P: {halo_note}"
+    self_halo = None
+    if args.self_exchange:
+        if world != 1 or args.emulate_world < 2:
+            raise SystemExit("--self-exchange needs --gpus 1 and --emulate-world W")
+        import ctypes as C
+        from rdycore_amd import _lib
+        lib = _lib.load()
+        ghost = np.nonzero(mesh.cell_is_owned == 0)[0].astype(np.int32)
+        # the owned cell across each ghost cell's cut edge: what a neighbour would ask this rank for
+        gset = np.zeros(mesh.num_cells, dtype=bool)
+        gset[ghost] = True
+        cl, cr = mesh.edge_cell_ids[0::2], mesh.edge_cell_ids[1::2]
+        cut = (cr >= 0) & (gset[cl] != gset[np.maximum(cr, 0)])
+        sendc = np.unique(np.where(gset[cl[cut]], cr[cut], cl[cut])).astype(np.int32)
+        n = min(sendc.size, ghost.size)
+        sendc, ghost = np.ascontiguousarray(sendc[:n]), np.ascontiguousarray(ghost[:n])
+        uid = C.create_string_buffer(128)
+        _lib.check(lib.rdyhip_comm_unique_id(uid))
+        comm = C.c_void_p()
+        _lib.check(lib.rdyhip_comm_init_rank(1, 0, uid.raw, C.byref(comm)))
+        hh = C.c_void_p()
+        i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+        pp = lambda a: a.ctypes.data_as(_lib.c_int32_p)
+        cnt = i32([n])
+        _lib.check(lib.rdyhip_halo_create(op._h, comm, 1, pp(i32([0])), pp(cnt), pp(sendc), pp(cnt), pp(ghost), C.byref(hh)))
+        self_halo = (lib, hh, comm, n)
     u = torch.tensor(case.u_local, dtype=torch.float64, device=dev)
     f = torch.empty((mesh.num_owned_cells, 3), dtype=torch.float64, device=dev)
     setup_s = time.time() - t0
@@ -312,6 +344,9 @@ def run_rank(args, argv):
     def step():
         if halo is not None:
             halo.rhs_overlapped(op, case.dt, u, f)
+        elif self_halo is not None:
+            _lib.check(self_halo[0].rdyhip_rhs_overlapped(op._h, self_halo[1], float(case.dt), int(u.data_ptr()), int(f.data_ptr()),
+                                                          int(torch.cuda.current_stream().cuda_stream)))
         else:
             op.rhs_function(case.dt, u, f)
 
@@ -376,6 +411,8 @@ def run_rank(args, argv):
     ends = [torch.cuda.Event(enable_timing=True) for _ in range(k_iters)]
 
     def kernel_only():
+        if self_halo is not None:
+            return step()
         if args.second_order and halo is not None:
             # the ghost gradients of the last timed step are still in place: the flux launch alone
             op.apply_phase(0, True, case.dt, u, f, reset_diagnostics=True, gradients_ready=True)
@@ -489,6 +526,9 @@ def run_rank(args, argv):
         part = "single" if world == 1 else (f"rcb_{world}" if args.scaling == "strong" else f"strips_x{world}")
         if world == 1 and args.emulate_world > 1:
             part = f"rank {args.emulate_rank} of rcb_{args.emulate_world} (ghost cells present, not exchanged)"
+            if self_halo is not None:
+                part = (f"rank {args.emulate_rank} of strips_x{args.emulate_world}; every step is rdyhip_rhs_overlapped with a one-rank RCCL "
+                        f"communicator whose only peer is this rank ({self_halo[3]} cells = {self_halo[3] * 24} B sent to and received from itself)")
         friction = f"{args.source} friction"
         if args.workload == "c3":
             workload = (f"C3: synthetic {nxg}x{args.ny}x2 = {total_cells}-cell triangle mesh "
@@ -577,6 +617,10 @@ def run_rank(args, argv):
         print(json.dumps(out), flush=True)
     if halo is not None:
         halo.destroy()
+    if self_halo is not None:
+        import ctypes as C
+        _lib.check(self_halo[0].rdyhip_halo_destroy(C.byref(self_halo[1])))
+        _lib.check(self_halo[0].rdyhip_comm_destroy(self_halo[2]))
     op.destroy()
     if world > 1:
         dist.barrier()
