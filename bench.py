@@ -211,6 +211,41 @@ def cpu_baseline_all_cores(args, argv):
                       f"(upper bound on an MPI run), slowest part {tmax * 1e3:.1f} ms/RHS"}
 
 
+def cpu_baseline_openmp(args):
+    """SURVEY.md 8.d (ii), second line: ONE process, all host cores through OpenMP -- oracle/libswe_oracle_omp.so, the
+    oracle's own source built with -fopenmp (Riemann batch and source terms over all cores, each cell's flux sum by one
+    thread in the serial order: bitwise the serial result, tests/test_oracle_openmp.py)."""
+    import numpy as np
+    cores = len(os.sched_getaffinity(0))
+    os.environ["OMP_NUM_THREADS"] = str(cores)
+    os.environ.setdefault("OMP_PROC_BIND", "true")
+    from oracle import oracle as O  # noqa: F401  test infrastructure; used here only as the timed CPU baseline
+    nx, ny = map(int, args.cpu_sample.split("x"))
+    case = build_case(args, 0, 1, nx, ny, "rowmajor")
+    cfg = case.config
+    if cfg.second_order or cfg.well_balancing:
+        return {"skipped": "the OpenMP build parallelises the first-order path only"}
+    orc = O.OracleOperator(case.mesh, case.condition_types, cfg.tiny_h, cfg.h_anuga_regular, cfg.xq2018_threshold, cfg.source_method,
+                           cfg.well_balancing, openmp=True)
+    orc.mannings[:] = case.mannings
+    orc.external_sources[:] = case.ext_src
+    for b, vals in case.boundary_values.items():
+        orc.boundary_values[b][:] = vals
+    f = np.zeros((case.mesh.num_owned_cells, 3))
+    orc.apply(case.dt, case.u_local, f)
+    ts = []
+    for _ in range(10):
+        f[:] = 0.0
+        t0 = time.perf_counter()
+        orc.apply(case.dt, case.u_local, f)
+        ts.append(time.perf_counter() - t0)
+    med = float(np.median(ts))
+    nc = case.mesh.num_owned_cells
+    return {"value": round(nc / med / 1e6, 2), "unit": "M cell-updates/s", "cores": cores, "kind": "port",
+            "sample": f"10 RHS evaluations on the {nx}x{ny}-square = {nc}-cell sample mesh, oracle/swe_oracle.c built with -fopenmp, "
+                      f"{cores} threads in one process, median {med * 1e3:.1f} ms/RHS"}
+
+
 def kernel_sha(second_order: bool = False) -> str:
     """hash of the kernel sources: ties a stored PMC traffic figure to the code it was measured on (the first-order /
     HR kernels do not depend on muscl_kernels.h)"""
@@ -614,6 +649,10 @@ def run_rank(args, argv):
                     out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(args, argv)
                 except Exception as exc:  # a reported extra, never a reason to lose the bench line
                     out["cpu_baseline_all_cores"] = {"error": repr(exc)}
+                try:
+                    out["cpu_baseline_openmp"] = cpu_baseline_openmp(args)
+                except Exception as exc:
+                    out["cpu_baseline_openmp"] = {"error": repr(exc)}
         print(json.dumps(out), flush=True)
     if halo is not None:
         halo.destroy()

@@ -45,18 +45,33 @@ class OracleCourant(C.Structure):
     _fields_ = [("max_courant_num", C.c_double), ("global_edge_id", C.c_longlong), ("global_cell_id", C.c_longlong)]
 
 
-def build(force: bool = False) -> str:
-    so = os.path.join(_HERE, "libswe_oracle.so")
+def build(force: bool = False, openmp: bool = False) -> str:
+    name = "libswe_oracle_omp.so" if openmp else "libswe_oracle.so"
+    so = os.path.join(_HERE, name)
     srcs = [os.path.join(_HERE, f) for f in ("swe_oracle.c", "forcing_oracle.c", "swe_oracle.h")]
     if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(s) for s in srcs):
-        subprocess.check_call(["make", "-C", _HERE, "-B", "libswe_oracle.so"], stdout=subprocess.DEVNULL)
+        subprocess.check_call(["make", "-C", _HERE, "-B", name], stdout=subprocess.DEVNULL)
     return so
 
 
-def lib():
-    global _LIB
+_LIB_OMP = None
+
+
+def lib(openmp: bool = False):
+    """the serial oracle, or (openmp=True) the same source built with -fopenmp: all host cores, bitwise the same results
+    for the first-order path (the HR and second-order interior-flux loops stay serial)"""
+    global _LIB, _LIB_OMP
+    if openmp:
+        if _LIB_OMP is None:
+            _LIB_OMP = _bind(C.CDLL(build(openmp=True)))
+        return _LIB_OMP
     if _LIB is None:
-        L = C.CDLL(build())
+        _LIB = _bind(C.CDLL(build()))
+    return _LIB
+
+
+def _bind(L):
+    if True:
         L.oracle_create.restype = C.c_void_p
         L.oracle_create.argtypes = [C.POINTER(OracleMesh), C.POINTER(OracleConfig), C.c_int, C.POINTER(OracleBoundary)]
         L.oracle_destroy.argtypes = [C.c_void_p]
@@ -80,8 +95,7 @@ def lib():
         L.oracle_reset_diagnostics.argtypes = [C.c_void_p]
         L.oracle_get_diagnostics.argtypes = [C.c_void_p, C.POINTER(OracleCourant)]
         L.oracle_roe_flux.argtypes = [C.c_double] * 8 + [c_double_p, c_double_p]
-        _LIB = L
-    return _LIB
+    return L
 
 
 def _dp(a):
@@ -108,11 +122,11 @@ class OracleOperator:
 
     def __init__(self, mesh, bc_types: Sequence[int], tiny_h=1e-7, h_anuga_regular=0.0, xq2018_threshold=1e-10,
                  source_method=0, well_balancing=0, second_order=False, limiter=0,
-                 all_edges_local=False):
+                 all_edges_local=False, openmp=False):
         """all_edges_local (second order only): treat every local internal edge as owned by this rank, i.e. solve the
         cut edges redundantly on both ranks instead of the reference's owner-computes + reverse-add -- the scheme
         of the HIP path; the owned rows of F are then complete without the reverse exchange."""
-        L = lib()
+        L = self._L = lib(openmp)
         self.mesh = mesh
         self._keep = []
 
@@ -187,7 +201,7 @@ class OracleOperator:
         if f_global is None:
             f_global = np.zeros((self.mesh.num_owned_cells, 3))
         assert f_global.flags.c_contiguous and f_global.size == 3 * self.mesh.num_owned_cells
-        rc = getattr(lib(), "oracle_apply" + stage)(self._h, float(dt), _dp(u), _dp(f_global))
+        rc = getattr(self._L, "oracle_apply" + stage)(self._h, float(dt), _dp(u), _dp(f_global))
         if rc != 0:
             raise RuntimeError("oracle_apply failed")
         return f_global
@@ -201,26 +215,26 @@ class OracleOperator:
     def compute_gradients(self, u_local: np.ndarray):
         """ComputeLeastSquaresGradients into self.gradients (ghost rows incomplete, as in the reference)."""
         u = np.ascontiguousarray(u_local, dtype=np.float64)
-        lib().oracle_compute_gradients(self._h, _dp(u))
+        self._L.oracle_compute_gradients(self._h, _dp(u))
 
     def set_gradients_ready(self, ready: bool):
-        lib().oracle_set_gradients_ready(self._h, int(ready))
+        self._L.oracle_set_gradients_ready(self._h, int(ready))
 
     def gradients6(self) -> np.ndarray:
         """[num_cells, 6] = (dh/dx, dh/dy, dhu/dx, dhu/dy, dhv/dx, dhv/dy): the layout of the HIP operator's gradient array"""
         return np.concatenate(self.gradients, axis=1)
 
     def reset_diagnostics(self):
-        lib().oracle_reset_diagnostics(self._h)
+        self._L.oracle_reset_diagnostics(self._h)
 
     def diagnostics(self):
         d = OracleCourant()
-        lib().oracle_get_diagnostics(self._h, C.byref(d))
+        self._L.oracle_get_diagnostics(self._h, C.byref(d))
         return d.max_courant_num, d.global_edge_id, d.global_cell_id
 
     def close(self):
         if self._h:
-            lib().oracle_destroy(self._h)
+            self._L.oracle_destroy(self._h)
             self._h = None
 
     def __del__(self):

@@ -86,11 +86,18 @@ struct OracleOperator {
   double *rhs_local;        /* [num_cells][3] */
   Side    left2, right2;    /* Riemann batch of the owned internal edges */
   Batch   edges2;
+  /* OpenMP build only (libswe_oracle_omp.so, the all-cores CPU line of bench.py): owned cell -> the positions e of its
+   * internal edges in internal_edge_ids, ascending, so that a cell's contributions can be summed by ONE thread in the
+   * serial loop's order (bitwise the serial result) */
+  int *ce_off, *ce_idx;
 };
 
 /* ------------------------------------------------------------------------ */
 /* ComputeRiemannVelocities, src/swe/swe_petsc.c:57-73                       */
 static void velocities(double tiny_h, double h_anuga, Side *s) {
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
   for (int i = 0; i < s->n; ++i) {
     if (s->h[i] < tiny_h) {
       s->u[i] = 0.0;
@@ -166,6 +173,9 @@ void oracle_roe_flux(double hl, double ul, double vl, double hr, double ur, doub
 }
 
 static void roe_batch(const Side *l, const Side *r, Batch *b, double *flux_out) {
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
   for (int i = 0; i < b->n; ++i) {
     oracle_roe_flux(l->h[i], l->u[i], l->v[i], r->h[i], r->u[i], r->v[i], b->sn[i], b->cn[i], &flux_out[3 * i], &b->amax[i]);
   }
@@ -180,6 +190,9 @@ static void apply_interior_flux(OracleOperator *op, double dt, const double *u, 
   Batch            *E = &op->edges;
 
   /* gather (244-257) */
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
   for (int e = 0; e < m->num_internal_edges; ++e) {
     int edge = m->internal_edge_ids[e];
     int cl   = m->cell_ids[2 * edge];
@@ -198,6 +211,38 @@ static void apply_interior_flux(OracleOperator *op, double dt, const double *u, 
   velocities(tiny_h, op->config.h_anuga_regular, R);
   roe_batch(L, R, E, E->flux);
 
+#ifdef _OPENMP
+  /* the serial loop below split in two so that threads never add into the same row of f: (i) the Courant diagnostic,
+   * one pass in edge order (first edge that reaches the maximum, as in the serial loop); (ii) per owned cell, its
+   * edges' contributions in ascending edge order -- the order in which the serial loop adds them */
+  for (int e = 0; e < m->num_internal_edges; ++e) {
+    int edge = m->internal_edge_ids[e];
+    int cl   = m->cell_ids[2 * edge];
+    int cr   = m->cell_ids[2 * edge + 1];
+    if (cr == -1 || (R->h[e] < tiny_h && L->h[e] < tiny_h)) continue;
+    double areal = m->areas[cl], arear = m->areas[cr];
+    double cnum  = E->amax[e] * m->lengths[edge] / fmin(areal, arear) * dt;
+    if (cnum > op->courant.max_courant_num) {
+      op->courant.max_courant_num = cnum;
+      op->courant.global_edge_id  = m->edge_global_ids[edge];
+      op->courant.global_cell_id  = (areal < arear) ? m->cell_global_ids[cl] : m->cell_global_ids[cr];
+    }
+  }
+#pragma omp parallel for schedule(static)
+  for (int c = 0; c < m->num_cells; ++c) {
+    if (!m->is_owned[c]) continue;
+    const int o = m->local_to_owned[c];
+    for (int k = op->ce_off[o]; k < op->ce_off[o + 1]; ++k) {
+      const int e = op->ce_idx[k], edge = m->internal_edge_ids[e];
+      const int cl = m->cell_ids[2 * edge], cr = m->cell_ids[2 * edge + 1];
+      if (R->h[e] < tiny_h && L->h[e] < tiny_h) continue;
+      const double len = m->lengths[edge];
+      const double w   = (c == cl) ? (-len / m->areas[cl]) : (len / m->areas[cr]);
+      for (int q = 0; q < 3; ++q) f[3 * o + q] += E->flux[3 * e + q] * w;
+    }
+  }
+  return;
+#endif
   /* accumulate into owned cells + Courant diagnostic (275-310) */
   for (int e = 0; e < m->num_internal_edges; ++e) {
     int edge = m->internal_edge_ids[e];
@@ -410,6 +455,9 @@ static void apply_source_semi_implicit(OracleOperator *op, double dt, const doub
   /* SourceOperator.include_bed_slope: false under HR, where the flux's pressure
    * correction carries the bed slope (src/swe/swe_petsc.c:700, 1243) */
   const int bed_slope = op->config.well_balancing != ORACLE_WB_HR;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
   for (int c = 0; c < m->num_cells; ++c) {
     if (!m->is_owned[c]) continue;
     int    o  = m->local_to_owned[c];
@@ -460,6 +508,9 @@ static void apply_source_xq2018(OracleOperator *op, double dt, const double *u, 
   /* SourceOperator.include_bed_slope: false under HR, where the flux's pressure
    * correction carries the bed slope (src/swe/swe_petsc.c:700, 1243) */
   const int bed_slope = op->config.well_balancing != ORACLE_WB_HR;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
   for (int c = 0; c < m->num_cells; ++c) {
     if (!m->is_owned[c]) continue;
     int    o  = m->local_to_owned[c];
@@ -750,6 +801,28 @@ OracleOperator *oracle_create(const OracleMesh *mesh, const OracleConfig *config
     }
   }
 
+#ifdef _OPENMP
+  {
+    const int nown = mesh->num_owned_cells;
+    op->ce_off     = calloc((size_t)nown + 2, sizeof(int));
+    for (int e = 0; e < ni; ++e) {
+      int edge = mesh->internal_edge_ids[e], cl = mesh->cell_ids[2 * edge], cr = mesh->cell_ids[2 * edge + 1];
+      if (cr == -1) continue;
+      if (mesh->is_owned[cl]) op->ce_off[mesh->local_to_owned[cl] + 1]++;
+      if (mesh->is_owned[cr]) op->ce_off[mesh->local_to_owned[cr] + 1]++;
+    }
+    for (int o = 0; o < nown; ++o) op->ce_off[o + 1] += op->ce_off[o];
+    op->ce_idx = calloc((size_t)(op->ce_off[nown] > 0 ? op->ce_off[nown] : 1), sizeof(int));
+    int *fill  = calloc((size_t)nown + 1, sizeof(int));
+    for (int e = 0; e < ni; ++e) {  /* ascending e: each cell's list comes out in the serial loop's order */
+      int edge = mesh->internal_edge_ids[e], cl = mesh->cell_ids[2 * edge], cr = mesh->cell_ids[2 * edge + 1];
+      if (cr == -1) continue;
+      if (mesh->is_owned[cl]) { int o = mesh->local_to_owned[cl]; op->ce_idx[op->ce_off[o] + fill[o]++] = e; }
+      if (mesh->is_owned[cr]) { int o = mesh->local_to_owned[cr]; op->ce_idx[op->ce_off[o] + fill[o]++] = e; }
+    }
+    free(fill);
+  }
+#endif
   int no                  = mesh->num_owned_cells > 0 ? mesh->num_owned_cells : 1;
   op->external_sources    = calloc(3 * no, sizeof(double));
   op->material_properties = calloc(no, sizeof(double));
@@ -760,6 +833,8 @@ OracleOperator *oracle_create(const OracleMesh *mesh, const OracleConfig *config
 
 void oracle_destroy(OracleOperator *op) {
   if (!op) return;
+  free(op->ce_off);
+  free(op->ce_idx);
   side_free(&op->left);
   side_free(&op->right);
   batch_free(&op->edges);
