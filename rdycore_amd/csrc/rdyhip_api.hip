@@ -99,6 +99,7 @@ struct RDyHipOperator_s {
   bool         prefix = true;
   int          grid = 0, xcd_chunks = 0;        // cell kernel
   int          pgrid = 0, tiled_xcd_chunks = 0; // tiled (persistent) kernel
+  int          interior_shrink = 32;            // the INTERIOR phase leaves 1/interior_shrink of the workgroup slots free (0: none)
   bool         keep_fdiv = false;
 
   DevBuf<int32_t> d_o2l, d_nbr, d_pos, d_halo_list, d_btype, d_bleft, d_bghost_list;
@@ -354,7 +355,7 @@ int launch_rhs(RDyHipOperator op, int32_t phase, int32_t overwrite, int reset_di
       a.n_work = op->ntiles;
       // While the interior phase runs, the halo exchange's pack / RCCL / unpack kernels need somewhere
       // to run: the persistent grid would otherwise fill every SIMD's register file for the whole launch.
-      const int pg = (phase == RDYHIP_PHASE_INTERIOR) ? std::max(8, pgrid - pgrid / 32) : pgrid;
+      const int pg = (phase == RDYHIP_PHASE_INTERIOR && op->interior_shrink > 0) ? std::max(8, pgrid - pgrid / op->interior_shrink) : pgrid;
       if (op->tiled_xcd_chunks > 0) {
         a.xcd_chunks = op->tiled_xcd_chunks;
         grid         = std::min(pg & ~7, op->tiled_xcd_chunks * 8);
@@ -890,6 +891,7 @@ int rdyhip_create(const RDyHipConfig *config, const RDyHipMesh *mesh, int32_t nu
       op->pgrid_muscl = std::max(8, cus * per_cu_m);
     }
     op->tiled_xcd_chunks = (swz && ntiles >= 64) ? (ntiles + 7) / 8 : 0;
+    if (const char *e3 = getenv("RDYHIP_INTERIOR_SHRINK")) op->interior_shrink = std::max(0, atoi(e3));  // measurement knob
   }
   const int maxgrid = std::max(std::max(std::max(op->grid, op->pgrid), op->pgrid_muscl), 1);
 
