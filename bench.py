@@ -47,7 +47,7 @@ LIMITERS = {"minmod": 0, "none": 1, "van_leer": 2}
 # centroids twice (24 + 16)
 ALG_BYTES_PER_CELL_SECOND_ORDER = 176.0 + 16.0 + 24.0
 ALG_BYTES_PER_CELL_SECOND_ORDER_SPLIT = ALG_BYTES_PER_CELL_SECOND_ORDER + 96.0 + 24.0 + 16.0
-KERNEL_SOURCES = ["rdyhip_api.hip", "swe_kernels.h", "swe_device.h", "muscl_kernels.h"]
+KERNEL_SOURCES = ["swe_kernels.h", "swe_device.h", "muscl_kernels.h"]
 
 
 def parse(argv=None):
@@ -258,11 +258,12 @@ def kernel_sha(second_order: bool = False) -> str:
     return h.hexdigest()[:16]
 
 
-def load_traffic(workload_key: str):
+def load_traffic(workload_key: str, layout_bytes: int, second_order: bool = False):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic.json), only if they were
-    collected on exactly this kernel source; a stale file is reported as such, never silently."""
+    collected on exactly these kernel sources AND this device layout (the layout is made by the host code in
+    rdyhip_api.hip: its byte count per launch is compared); a stale entry is reported as such, never silently."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
-    sha = kernel_sha()
+    sha = kernel_sha(second_order)
     src = {"source": "profiles/traffic.json", "key": workload_key, "kernel_sha": sha}
     try:
         with open(path) as fh:
@@ -274,9 +275,10 @@ def load_traffic(workload_key: str):
     if not ent:
         src["status"] = "no PMC passes for this workload"
         return None, src
-    if ent.get("kernel_sha") != sha:
-        src["status"] = f"STALE: measured on kernel_sha {ent.get('kernel_sha')}, current sources are {sha} -- rerun tools/profile_gpu.sh"
-        print(f"bench.py: profiles/traffic.json[{workload_key}] is stale ({ent.get('kernel_sha')} != {sha}); roofline.traffic = null", file=sys.stderr)
+    if ent.get("kernel_sha") != sha or int(ent.get("layout_bytes_per_launch", -1)) != int(layout_bytes):
+        src["status"] = (f"STALE: measured on kernel_sha {ent.get('kernel_sha')} / layout {ent.get('layout_bytes_per_launch')} B, "
+                         f"current: {sha} / {layout_bytes} B -- rerun tools/profile_gpu.sh")
+        print(f"bench.py: profiles/traffic.json[{workload_key}] is stale; roofline.traffic = null", file=sys.stderr)
         return None, src
     src["status"] = "measured on this kernel source"
     return ent.get("hbm_bytes_per_launch"), src
@@ -582,8 +584,10 @@ def run_rank(args, argv):
                         f"{total_cells} cells in this run ({n_owned} on rank 0), {dry:.0%} of them dry, rain 1e-5 m/s, Manning 0.03, "
                         f"critical-outflow segment + reflecting walls, hydrostatic reconstruction, {friction}, dt = 0.05 s")
         traffic, traffic_src = (None, None)
-        if world == 1 and not args.second_order and args.emulate_world <= 1:
-            traffic, traffic_src = load_traffic(f"{args.workload}_{args.nx}x{args.ny}_{args.order}_{args.source}" + ("_hr" if args.hr and args.workload != "c5" else ""))
+        if world == 1 and args.emulate_world <= 1:
+            traffic, traffic_src = load_traffic(f"{args.workload}_{args.nx}x{args.ny}_{args.order}_{args.source}" + ("_hr" if args.hr and args.workload != "c5" else "")
+                                                + ("_second_order_" + args.limiter if args.second_order else ""),
+                                                int(info["bytes_per_apply"]), args.second_order)
         if args.second_order:
             kname = (("swe_rhs_muscl_fused_kernel<%d,%d>" if info["second_order_fused"] else "muscl_gradient_kernel<%d> + swe_rhs_muscl_kernel<.,%d>")
                      % (info["slots_per_cell"], 0 if args.source == "semi_implicit" else 1))

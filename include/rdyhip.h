@@ -297,7 +297,7 @@ int rdyhip_unpack_rows(double *dst, int32_t ncomp, const int32_t *row_ids, int32
 
 /* ---- the ghost update and its overlap with the interior cells, behind the ABI ----
  * OperatorRHSFunction's DMGlobalToLocalBegin/End (src/rdysetup.c:1133-1134) for a C host: the operator packs the owned
- * cells its neighbours need, exchanges them and unpacks into its ghost cells on an internal high-priority stream, while
+ * cells its neighbours need, exchanges them and unpacks into its ghost cells on an internal stream, while
  * the cells without ghost neighbours are evaluated on the caller's stream; the ghost-adjacent cells follow.
  *
  *   rdyhip_halo_create   the exchange pattern of this rank: for each of `npeers` neighbour ranks, the LOCAL ids of the

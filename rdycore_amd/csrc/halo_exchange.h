@@ -5,7 +5,7 @@
 //
 // One exchange = one pack launch (every peer's cells into one contiguous buffer, a slice per peer), one
 // ncclGroupStart .. ncclSend/ncclRecv per peer .. ncclGroupEnd over xGMI, one unpack launch -- all on an internal
-// high-priority stream that is forked from and joined back into the caller's stream with HIP events, so the interior
+// stream that is forked from and joined back into the caller's stream with HIP events, so the interior
 // tiles (rdyhip_apply_phase(INTERIOR)) run on the caller's stream meanwhile.  Included by rdyhip_api.hip only.
 #pragma once
 #include <rccl/rccl.h>
@@ -20,11 +20,25 @@ struct RDyHipHalo_s {
   DevBuf<double>  d_send, d_recv;  // [cells][max_comp]
   int32_t         max_comp = 3;
   hipStream_t     cs = nullptr;  // exchange stream
-  hipEvent_t      ev_fork = nullptr, ev_join = nullptr;
+  // fork / join events: a ring, one pair per step in flight (re-recording an event whose previous record has not
+  // completed yet makes hipEventRecord wait for it on this runtime, which serialises the host with the device)
+  static constexpr int NEV = 8;
+  hipEvent_t      ev_fork_ring[NEV] = {}, ev_join_ring[NEV] = {};
+  hipEvent_t      ev_fork = nullptr, ev_join = nullptr;  // the pair of the current step
+  unsigned        step = 0;
+  void next_events() {
+    const int env_ring = ring;
+    ev_fork = ev_fork_ring[step % env_ring];
+    ev_join = ev_join_ring[step % env_ring];
+    ++step;
+  }
+  int ring = NEV;
   ~RDyHipHalo_s() {
     d_send_ids.release(); d_recv_ids.release(); d_send.release(); d_recv.release();
-    if (ev_fork) (void)hipEventDestroy(ev_fork);
-    if (ev_join) (void)hipEventDestroy(ev_join);
+    for (int i = 0; i < NEV; ++i) {
+      if (ev_fork_ring[i]) (void)hipEventDestroy(ev_fork_ring[i]);
+      if (ev_join_ring[i]) (void)hipEventDestroy(ev_join_ring[i]);
+    }
     if (cs) (void)hipStreamDestroy(cs);
   }
 };
@@ -105,16 +119,20 @@ int overlapped(RDyHipOperator op, RDyHipHalo h, double dt, double *u, double *f,
     return launch_rhs(op, phase, 1, reset, dt, u, f, st, ready, u_out);
   };
   int rc;
+  h->next_events();
   // fork: the exchange starts once everything already enqueued on the caller's stream (the update that produced u) is done
   HIP_TRY(hipEventRecord(h->ev_fork, st));
   HIP_TRY(hipStreamWaitEvent(h->cs, h->ev_fork, 0));
   if (!op->muscl) {
-    // the pack launch goes first, then the interior tiles are enqueued BEFORE the transfer is started: a transport that
-    // blocks the host (a callback) then blocks while the device already works on the interior
+    // RCCL: the whole exchange is enqueued first and the interior tiles after it (enqueueing the send / recv group behind
+    // an already running persistent kernel cost 0.25 ms of host time per step on this runtime: tools/step_breakdown.py).
+    // A transport callback may block the host: there the interior tiles are enqueued before it is called, so that it
+    // blocks while the device already works.
     rc = halo_pack(h, u, 3, h->cs);
-    if (!rc) rc = part(RDYHIP_PHASE_INTERIOR, 1, false);
+    if (!rc && h->transport) rc = part(RDYHIP_PHASE_INTERIOR, 1, false);
     if (!rc) rc = halo_transfer(h, 3, h->cs);
     if (!rc) rc = halo_unpack(h, u, 3, h->cs);
+    if (!rc && !h->transport) rc = part(RDYHIP_PHASE_INTERIOR, 1, false);
     if (rc) return rc;
     HIP_TRY(hipEventRecord(h->ev_join, h->cs));
     HIP_TRY(hipStreamWaitEvent(st, h->ev_join, 0));
@@ -126,9 +144,10 @@ int overlapped(RDyHipOperator op, RDyHipHalo h, double dt, double *u, double *f,
     // tiles whose cells and first ring touch no ghost need nothing from other ranks and hide the state exchange; only the
     // ghost-adjacent cells' gradients go through memory
     rc = halo_pack(h, u, 3, h->cs);
-    if (!rc) rc = part(RDYHIP_PHASE_INTERIOR, 1, true);
+    if (!rc && h->transport) rc = part(RDYHIP_PHASE_INTERIOR, 1, true);
     if (!rc) rc = halo_transfer(h, 3, h->cs);
     if (!rc) rc = halo_unpack(h, u, 3, h->cs);
+    if (!rc && !h->transport) rc = part(RDYHIP_PHASE_INTERIOR, 1, true);
     if (rc) return rc;
     HIP_TRY(hipEventRecord(h->ev_join, h->cs));
     HIP_TRY(hipStreamWaitEvent(st, h->ev_join, 0));
@@ -141,20 +160,23 @@ int overlapped(RDyHipOperator op, RDyHipHalo h, double dt, double *u, double *f,
   // split kernels: the gradients of the cells without ghost neighbours hide the state exchange, the fluxes of the tiles
   // without ghost-adjacent cells (which read owned gradient rows only) hide the gradient exchange
   rc = halo_pack(h, u, 3, h->cs);
-  if (!rc) rc = launch_gradients(op, RDYHIP_PHASE_INTERIOR, u, st);
+  if (!rc && h->transport) rc = launch_gradients(op, RDYHIP_PHASE_INTERIOR, u, st);
   if (!rc) rc = halo_transfer(h, 3, h->cs);
   if (!rc) rc = halo_unpack(h, u, 3, h->cs);
+  if (!rc && !h->transport) rc = launch_gradients(op, RDYHIP_PHASE_INTERIOR, u, st);
   if (rc) return rc;
   HIP_TRY(hipEventRecord(h->ev_join, h->cs));
   HIP_TRY(hipStreamWaitEvent(st, h->ev_join, 0));
   rc = launch_gradients(op, RDYHIP_PHASE_HALO, u, st);
   if (rc) return rc;
+  h->next_events();
   HIP_TRY(hipEventRecord(h->ev_fork, st));
   HIP_TRY(hipStreamWaitEvent(h->cs, h->ev_fork, 0));
   rc = halo_pack(h, op->d_grad.p, 6, h->cs);
-  if (!rc) rc = part(RDYHIP_PHASE_INTERIOR, 1, true);
+  if (!rc && h->transport) rc = part(RDYHIP_PHASE_INTERIOR, 1, true);
   if (!rc) rc = halo_transfer(h, 6, h->cs);
   if (!rc) rc = halo_unpack(h, op->d_grad.p, 6, h->cs);
+  if (!rc && !h->transport) rc = part(RDYHIP_PHASE_INTERIOR, 1, true);
   if (rc) return rc;
   HIP_TRY(hipEventRecord(h->ev_join, h->cs));
   HIP_TRY(hipStreamWaitEvent(st, h->ev_join, 0));
@@ -212,12 +234,27 @@ int rdyhip_halo_create(RDyHipOperator op, void *nccl_comm, int32_t npeers, const
   }
   int lo = 0, hi = 0;  // hi = numerically lowest = highest priority
   if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) lo = hi = 0;
-  if (hipStreamCreateWithPriority(&h->cs, hipStreamNonBlocking, hi) != hipSuccess ||
-      hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) {
+  // Priority of the exchange stream: the DEFAULT one (0), like the streams a caller launches the RHS on.  Measured on one
+  // MI355X with the exchange looped back through a one-rank RCCL communicator (tools/step_breakdown.py, 10 M cells): at
+  // priority 0 the overlapped step takes 0.334 ms (the two compute phases alone: 0.332 ms), with a high- (or low-)
+  // priority exchange stream 0.49 ms and 0.25 ms of host time per step -- ordering work between streams of different
+  // priorities is expensive on this runtime.  The interior launch leaves 1/32 of the workgroup slots free, which is what
+  // lets the exchange's small kernels run beside it without any priority.
+  int prio = 0;
+  (void)hi;
+  if (const char *e = getenv("RDYHIP_EXCHANGE_PRIORITY")) {  // measurement knob
+    prio = atoi(e);
+    fprintf(stderr, "rdyhip: stream priority range [least %d, greatest %d], exchange stream at %d\n", lo, hi, prio);
+  }
+  bool ok = hipStreamCreateWithPriority(&h->cs, hipStreamNonBlocking, prio) == hipSuccess;
+  for (int i = 0; ok && i < RDyHipHalo_s::NEV; ++i)
+    ok = hipEventCreateWithFlags(&h->ev_fork_ring[i], hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&h->ev_join_ring[i], hipEventDisableTiming) == hipSuccess;
+  if (!ok) {
     delete h;
     return fail(RDYHIP_ERR_LIB, "cannot create the exchange stream / events");
   }
+  if (const char *e = getenv("RDYHIP_EVENT_RING")) h->ring = std::min(std::max(1, atoi(e)), (int)RDyHipHalo_s::NEV);  // measurement knob
   *halo = h;
   return 0;
 }

@@ -1,6 +1,7 @@
 """profiles/traffic.json entry from the PMC passes of tools/profile_gpu.sh.
 
 usage: python tools/make_traffic.py gpurun_out/prof_<tag>/summary.json <key> [source note]
+  (the bench line printed during the traced run, gpurun_out/prof_<tag>/bench_trace.log, supplies the layout's byte count)
   key = <workload>_<nx>x<ny>_<order>_<source>[_hr]   (what bench.py looks up)
 
 FETCH_SIZE is doubled (gfx950 counts 128-B requests as 64 B, MI355X_MICROARCH.md HBM section) and both counters are
@@ -35,7 +36,14 @@ def main():
     if fetch is None or write is None:
         raise SystemExit("no FETCH_SIZE / WRITE_SIZE for the RHS kernel in " + summ)
     rd, wr = fetch * 1024 * 2, write * 1024
-    ent = {"kernel": kname, "kernel_sha": bench.kernel_sha(), "FETCH_SIZE_KB_raw": fetch, "WRITE_SIZE_KB_raw": write,
+    second = "second_order" in key
+    layout = None
+    log = os.path.join(os.path.dirname(summ), "bench_trace.log")
+    if os.path.exists(log):
+        for ln in open(log):
+            if ln.startswith("{"):
+                layout = json.loads(ln)["roofline"]["layout_bytes_per_launch"]
+    ent = {"kernel": kname, "kernel_sha": bench.kernel_sha(second), "layout_bytes_per_launch": layout, "FETCH_SIZE_KB_raw": fetch, "WRITE_SIZE_KB_raw": write,
            "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr,
            "correction": "FETCH_SIZE x2 (gfx950 counts 128-B requests as 64 B, MI355X_MICROARCH.md HBM section); WRITE_SIZE as is",
            "source": note}

@@ -75,6 +75,21 @@ res["halo_phase_only"] = timed(lambda: op.apply_phase(2, True, case.dt, u, f))
 res["exchange_only_pack_rccl_unpack"] = timed(lambda: _lib.check(lib.rdyhip_halo_exchange(hh, up, 3, st)))
 res["pack_unpack_only"] = timed(lambda: (_lib.check(lib.rdyhip_pack_cells(up, int(d_send.data_ptr()), int(n), int(buf.data_ptr()), st)),
                                          _lib.check(lib.rdyhip_unpack_cells(up, int(d_recv.data_ptr()), int(n), int(buf.data_ptr()), st))))
+# the same step driven from Python with torch streams (round 1's halo.py): fork / join through torch events
+s2 = torch.cuda.Stream(priority=-1)
+main = torch.cuda.current_stream()
+
+
+def torch_step():
+    s2.wait_stream(main)
+    with torch.cuda.stream(s2):
+        _lib.check(lib.rdyhip_halo_exchange(hh, up, 3, int(s2.cuda_stream)))
+    op.apply_phase(1, True, case.dt, u, f, reset_diagnostics=True)
+    main.wait_stream(s2)
+    op.apply_phase(2, True, case.dt, u, f)
+
+
+res["overlapped_step_torch_streams"] = timed(torch_step)
 res["columns"] = "[ms per step on the GPU (HIP events around 200 steps), ms per step of host enqueue time]"
 print(json.dumps(res))
 _lib.check(lib.rdyhip_halo_destroy(C.byref(hh)))
