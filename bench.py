@@ -216,9 +216,8 @@ def cpu_baseline_openmp(args):
     oracle's own source built with -fopenmp (Riemann batch and source terms over all cores, each cell's flux sum by one
     thread in the serial order: bitwise the serial result, tests/test_oracle_openmp.py)."""
     import numpy as np
-    cores = len(os.sched_getaffinity(0))
-    os.environ["OMP_NUM_THREADS"] = str(cores)
-    os.environ.setdefault("OMP_PROC_BIND", "true")
+    cores = max(1, min(len(os.sched_getaffinity(0)), 32))   # as cpu_baseline_all_cores: the affinity mask of a GPU box lists more
+    os.environ["OMP_NUM_THREADS"] = str(cores)              # cores than its CPU share holds
     from oracle import oracle as O  # noqa: F401  test infrastructure; used here only as the timed CPU baseline
     nx, ny = map(int, args.cpu_sample.split("x"))
     case = build_case(args, 0, 1, nx, ny, "rowmajor")
@@ -288,6 +287,11 @@ def run_rank(args, argv):
     if args.watchdog_seconds > 0:
         import faulthandler
         faulthandler.dump_traceback_later(args.watchdog_seconds, exit=True)
+    # ONE line on stdout, whatever the libraries print: RCCL writes a version banner to stdout when a communicator is
+    # created.  File descriptor 1 is pointed at stderr for the whole run; the JSON line goes to the saved descriptor.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -510,6 +514,9 @@ def run_rank(args, argv):
     def fused_step():
         if halo is not None:
             halo.step_overlapped(op, case.dt, u, u2)
+        elif self_halo is not None:
+            _lib.check(self_halo[0].rdyhip_euler_step_overlapped(op._h, self_halo[1], float(case.dt), int(u.data_ptr()), int(u2.data_ptr()), None,
+                                                                 int(torch.cuda.current_stream().cuda_stream)))
         else:
             op.euler_step(case.dt, u, u2)
 
@@ -657,7 +664,8 @@ def run_rank(args, argv):
                     out["cpu_baseline_openmp"] = cpu_baseline_openmp(args)
                 except Exception as exc:
                     out["cpu_baseline_openmp"] = {"error": repr(exc)}
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if halo is not None:
         halo.destroy()
     if self_halo is not None:
