@@ -217,8 +217,9 @@ def cpu_baseline_openmp(args):
     thread in the serial order: bitwise the serial result, tests/test_oracle_openmp.py)."""
     import numpy as np
     cores = max(1, min(len(os.sched_getaffinity(0)), 32))   # as cpu_baseline_all_cores: the affinity mask of a GPU box lists more
-    os.environ["OMP_NUM_THREADS"] = str(cores)              # cores than its CPU share holds
+                                                            # cores than its CPU share holds
     from oracle import oracle as O  # noqa: F401  test infrastructure; used here only as the timed CPU baseline
+    cores = int(O.lib(openmp=True).oracle_set_num_threads(cores))   # not OMP_NUM_THREADS: torch has initialised libgomp long ago
     nx, ny = map(int, args.cpu_sample.split("x"))
     case = build_case(args, 0, 1, nx, ny, "rowmajor")
     cfg = case.config

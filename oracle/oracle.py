@@ -93,6 +93,8 @@ def _bind(L):
             getattr(L, name).restype = c_double_p
             getattr(L, name).argtypes = [C.c_void_p]
         L.oracle_reset_diagnostics.argtypes = [C.c_void_p]
+        L.oracle_set_num_threads.argtypes = [C.c_int]
+        L.oracle_set_num_threads.restype = C.c_int
         L.oracle_get_diagnostics.argtypes = [C.c_void_p, C.POINTER(OracleCourant)]
         L.oracle_roe_flux.argtypes = [C.c_double] * 8 + [c_double_p, c_double_p]
     return L

@@ -901,6 +901,21 @@ double *oracle_material_properties(OracleOperator *op) { return op->material_pro
 double *oracle_flux_divergence(OracleOperator *op) { return op->flux_divergence; }
 double *oracle_primitive_variables(OracleOperator *op) { return op->primitive_variables; }
 
+/* OpenMP build: the number of threads (the environment variable is read once per process by libgomp, which a host
+ * such as torch has usually initialised already); a no-op in the serial build */
+#ifdef _OPENMP
+#include <omp.h>
+int oracle_set_num_threads(int n) {
+  if (n > 0) omp_set_num_threads(n);
+  return omp_get_max_threads();
+}
+#else
+int oracle_set_num_threads(int n) {
+  (void)n;
+  return 1;
+}
+#endif
+
 void oracle_reset_diagnostics(OracleOperator *op) {
   op->courant.max_courant_num = 0.0;
   op->courant.global_edge_id  = -1;

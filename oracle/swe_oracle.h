@@ -111,6 +111,7 @@ double *oracle_rhs_local(OracleOperator *op);        /* [num_cells][3] interior-
 double *oracle_ls_grad_coeffs(OracleOperator *op);   /* [num_internal_edges][4] (PrecomputeLSGradCoeffs) */
 
 void oracle_reset_diagnostics(OracleOperator *op); /* ResetOperatorDiagnostics, src/operator.c:772-784 */
+int  oracle_set_num_threads(int n); /* OpenMP build only: threads of the parallel loops; returns the count in effect */
 void oracle_get_diagnostics(OracleOperator *op, OracleCourant *out);
 
 /* ComputeSWERoeFlux for one edge (src/swe/swe_roe_flux_petsc.h:91-132) */

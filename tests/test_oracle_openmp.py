@@ -26,7 +26,7 @@ def run(case, openmp):
 @pytest.mark.parametrize("source", [0, 1])
 @pytest.mark.parametrize("kind", ["tri", "quad_hole", "ghosts"])
 def test_openmp_oracle_is_bitwise_the_serial_oracle(kind, source):
-    os.environ["OMP_NUM_THREADS"] = "4"
+    assert O.lib(openmp=True).oracle_set_num_threads(4) == 4 and O.lib().oracle_set_num_threads(4) == 1
     K = 2 * np.pi / 37
     if kind == "tri":
         mesh = M.structured_tri_mesh(60, 44, 1.0, zfunc=CS.mms_bathymetry(K=K), order="tiled", tile=8)
