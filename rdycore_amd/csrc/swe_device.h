@@ -61,6 +61,27 @@ __device__ __forceinline__ double rdy_sqrt(double x) {
 #endif
 }
 
+// sqrt(x) and 1/sqrt(x) from ONE v_rsq_f64: the Goldschmidt pair (g -> sqrt x, h -> 1/(2 sqrt x)) refined together;
+// the square root gets the residual correction of rdy_sqrt (<= 1 ulp), the reciprocal root is 2 h (a few ulp).
+// Saves the separate reciprocal where both are wanted: 1/h = (1/sqrt h)^2 next to sqrt(h), 1/chat next to chat.
+struct SqrtPair {
+  double s, r;
+};
+__device__ __forceinline__ SqrtPair rdy_sqrt_rsqrt(double x) {
+  const double y = __builtin_amdgcn_rsq(x);
+  double       g = x * y;
+  double       h = 0.5 * y;
+  const double r = fma(-h, g, 0.5);
+  g              = fma(g, r, g);
+  h              = fma(h, r, h);
+  const double d = fma(-g, g, x);
+  g              = fma(d, h, g);
+  SqrtPair o;
+  o.s = (x == 0.0 || x == __builtin_inf()) ? x : g;
+  o.r = h + h;
+  return o;
+}
+
 struct RoeFlux {
   double f0, f1, f2, amax;
 };
@@ -78,6 +99,19 @@ struct RiemannSide {
 __device__ __forceinline__ RiemannSide riemann_side(double h, double hu, double hv, double tiny_h, double h_anuga_sq) {
   RiemannSide s;
   s.h = h;
+#if !defined(RDYHIP_STUB_FLUX) && !defined(RDYHIP_IEEE_DIV) && !defined(RDYHIP_IEEE_SQRT) && !defined(RDYHIP_NO_SQRT_PAIR)
+  if (h_anuga_sq == 0.0) {
+    // the default (h_anuga_regular = 0, src/yaml_input.c:855): hu h / (h^2 + 0) = hu / h, and 1/h = (1/sqrt h)^2 comes with
+    // the square root the Roe solver needs anyway (wave-uniform branch)
+    const SqrtPair p   = rdy_sqrt_rsqrt(h);
+    const double   inv = p.r * p.r;
+    s.u                = (h < tiny_h) ? 0.0 : hu * inv;
+    s.v                = (h < tiny_h) ? 0.0 : hv * inv;
+    s.sqh              = p.s;
+    s.c                = SQRT_GRAVITY * s.sqh;
+    return s;
+  }
+#endif
   if (h < tiny_h) {
     s.u = 0.0;
     s.v = 0.0;
@@ -115,7 +149,14 @@ __device__ __forceinline__ RoeFlux roe_flux(const RiemannSide &L, const RiemannS
   const double inv_sum = rdy_rcp(duml + dumr);
   const double uhat    = (duml * ul + dumr * ur) * inv_sum;
   const double vhat    = (duml * vl + dumr * vr) * inv_sum;
-  const double chat    = rdy_sqrt(0.5 * GRAVITY * (hl + hr));
+#if !defined(RDYHIP_IEEE_DIV) && !defined(RDYHIP_IEEE_SQRT) && !defined(RDYHIP_NO_SQRT_PAIR)
+  const SqrtPair cp       = rdy_sqrt_rsqrt(0.5 * GRAVITY * (hl + hr));
+  const double   chat     = cp.s;
+  const double   inv_chat = cp.r;  // 1/chat with the square root, instead of a separate reciprocal
+#else
+  const double chat     = rdy_sqrt(0.5 * GRAVITY * (hl + hr));
+  const double inv_chat = rdy_rcp(chat);
+#endif
   const double uperp   = uhat * cn + vhat * sn;
 
   const double dh     = hr - hl;
@@ -139,7 +180,7 @@ __device__ __forceinline__ RoeFlux roe_flux(const RiemannSide &L, const RiemannS
   const double da3 = fmax(0.0, 2.0 * ((uperpr + cr) - (uperpl + cl)));
   if (a3 < da3) a3 = 0.5 * (a3 * a3 / da3 + da3);
 
-  const double t   = hhat * duperp * rdy_rcp(chat);
+  const double t   = hhat * duperp * inv_chat;
   const double dw0 = 0.5 * (dh - t);
   const double dw1 = hhat * dupar;
   const double dw2 = 0.5 * (dh + t);
