@@ -11,7 +11,8 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("extra", [[], ["--second-order"], ["--hr"], ["--workload", "dambreak_quads", "--nx", "160", "--ny", "80", "--cpu-sample", "80x40"],
-                                   ["--workload", "c5", "--nx", "100", "--ny", "100", "--cpu-sample", "50x50", "--emulate-world", "4", "--emulate-rank", "1"]])
+                                   ["--workload", "c5", "--nx", "100", "--ny", "100", "--cpu-sample", "50x50", "--emulate-world", "4", "--emulate-rank", "1"],
+                                   ["--emulate-world", "3", "--emulate-rank", "1", "--self-exchange"]])
 def test_bench_line_has_the_contract_keys(extra, rdyhip_kernel):
     if rdyhip_kernel == "cell":
         pytest.skip("one kernel variant is enough")
@@ -30,6 +31,8 @@ def test_bench_line_has_the_contract_keys(extra, rdyhip_kernel):
     assert d["higher_is_better"] is True and d["scaling"] == ("strong" if strong else "weak") and d["vs_baseline"] is None and d["dtype"] == "f64" and d["data"] == "synthetic"
     assert "untimed RHS launches" in d["config"]["conditioning"] and d["config"]["world_size"] == 1
     assert "workload" in d["config"] and "model" not in d["config"] and d["config"]["finite"] is True
+    if "--self-exchange" in extra:      # the multi-rank step on one GPU: exchange looped back through a one-rank RCCL communicator
+        assert "one-rank RCCL communicator" in d["config"]["partition"] and d["config"]["cells_per_gpu"] == 2 * 120 * 90
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert "traffic" in r and r["achieved"] > 0 and r["steady_state_period_median_ms"] > 0
