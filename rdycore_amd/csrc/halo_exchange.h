@@ -20,19 +20,17 @@ struct RDyHipHalo_s {
   DevBuf<double>  d_send, d_recv;  // [cells][max_comp]
   int32_t         max_comp = 3;
   hipStream_t     cs = nullptr;  // exchange stream
-  // fork / join events: a ring, one pair per step in flight (re-recording an event whose previous record has not
-  // completed yet makes hipEventRecord wait for it on this runtime, which serialises the host with the device)
+  // fork / join events: a small ring, one pair per step, so that steps still in flight never share an event (the host
+  // runs several steps ahead of the device)
   static constexpr int NEV = 8;
   hipEvent_t      ev_fork_ring[NEV] = {}, ev_join_ring[NEV] = {};
   hipEvent_t      ev_fork = nullptr, ev_join = nullptr;  // the pair of the current step
   unsigned        step = 0;
   void next_events() {
-    const int env_ring = ring;
-    ev_fork = ev_fork_ring[step % env_ring];
-    ev_join = ev_join_ring[step % env_ring];
+    ev_fork = ev_fork_ring[step % NEV];
+    ev_join = ev_join_ring[step % NEV];
     ++step;
   }
-  int ring = NEV;
   ~RDyHipHalo_s() {
     d_send_ids.release(); d_recv_ids.release(); d_send.release(); d_recv.release();
     for (int i = 0; i < NEV; ++i) {
@@ -124,8 +122,7 @@ int overlapped(RDyHipOperator op, RDyHipHalo h, double dt, double *u, double *f,
   HIP_TRY(hipEventRecord(h->ev_fork, st));
   HIP_TRY(hipStreamWaitEvent(h->cs, h->ev_fork, 0));
   if (!op->muscl) {
-    // RCCL: the whole exchange is enqueued first and the interior tiles after it (enqueueing the send / recv group behind
-    // an already running persistent kernel cost 0.25 ms of host time per step on this runtime: tools/step_breakdown.py).
+    // RCCL (asynchronous): the whole exchange is enqueued first, the interior tiles right behind it on the other stream.
     // A transport callback may block the host: there the interior tiles are enqueued before it is called, so that it
     // blocks while the device already works.
     rc = halo_pack(h, u, 3, h->cs);
@@ -254,7 +251,7 @@ int rdyhip_halo_create(RDyHipOperator op, void *nccl_comm, int32_t npeers, const
     delete h;
     return fail(RDYHIP_ERR_LIB, "cannot create the exchange stream / events");
   }
-  if (const char *e = getenv("RDYHIP_EVENT_RING")) h->ring = std::min(std::max(1, atoi(e)), (int)RDyHipHalo_s::NEV);  // measurement knob
+
   *halo = h;
   return 0;
 }
