@@ -400,6 +400,8 @@ def run_rank(args, argv):
         # the number of launches is agreed between the ranks (a step holds an exchange: a rank that left a time-based loop
         # one round earlier than its neighbour would leave that neighbour waiting for ever): one batch is timed, the slowest
         # rank's time decides the count for everybody
+        for _ in range(10):          # priming batch: one-time costs (RCCL connects its peers at the first send / recv) stay out
+            step()                   # of the batch time that sizes the phase
         torch.cuda.synchronize()
         t_c = time.perf_counter()
         for _ in range(10):
@@ -415,7 +417,7 @@ def run_rank(args, argv):
             for _ in range(10):
                 step()
             torch.cuda.synchronize()
-        n_cond = 10 * (n_batches + 1)
+        n_cond = 10 * (n_batches + 2)
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
