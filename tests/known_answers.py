@@ -120,6 +120,24 @@ def entries():
                                    rhs_partial=None, exact=[], tol=1e-13, flux_rows=[e for e in range(4) if abs(cn[e] - 1.0) < 1e-12],
                                    nan_rows=[e for e in range(4) if cc * cn[e] < 0.0])
 
+    # 4b. Roe's property U on an isolated shock: two states joined by ONE shock (Rankine-Hugoniot with speed s:
+    #     h_l (u_l - s) = h_r (u_r - s) = m, m^2 = g h_l h_r (h_l + h_r) / 2) are resolved exactly by the Roe linearisation;
+    #     with s > 0 the interface flux is the physical flux of the LEFT state.  Cell = pre-shock state (shallow), Dirichlet
+    #     value = post-shock state (deep) on the +x edge; only that edge's row is checked.
+    hl_, hr_ = 1.0, 2.0
+    mflux = math.sqrt(0.5 * G * hl_ * hr_ * (hl_ + hr_))
+    s_shock = 0.5
+    ul_ = s_shock + mflux / hl_
+    ur_ = s_shock + mflux / hr_
+    m = one_quad(0.0)
+    cn, sn, _ = edge_normals(m)
+    fl = np.zeros((4, 3))
+    rows = [e for e in range(4) if abs(cn[e] - 1.0) < 1e-12]
+    for e in rows:
+        fl[e] = physical_flux(hl_, ul_, 0.0, 1.0, 0.0)
+    out["roe_isolated_shock"] = dict(case=one_cell_case(m, (hl_, hl_ * ul_, 0.0), M.CONDITION_DIRICHLET, bvalues=(hr_, hr_ * ur_, 0.0)),
+                                     flux=fl, rhs=None, exact=[], tol=1e-13, flux_rows=rows)
+
     # 5. friction, closed cell at rest-pressure balance with a uniform velocity is impossible in one cell (walls reflect), so
     #    friction is isolated with a Dirichlet boundary that repeats the cell's state: the flux sum is zero (entry 3) and
     #    F = -tb.  Semi-implicit (src/swe/swe_petsc.c:764-780): tb = (hu) k/(1 + dt k), k = g n^2 h^(-1/3) |u| / h.
