@@ -155,10 +155,19 @@ __device__ __forceinline__ double limit_slope(double extrap, double half_dq) {
 // then ComputeRiemannVelocities + the Roe flux on the reconstructed states (src/swe/swe_petsc.c:139-161); a boundary
 // edge stays first order.  `sq` / `sg`: LDS planes of the state (stride nq; planes 3 and 4: the centroid x, y) and the
 // gradient (stride ng); mid: the edge midpoint, from which the two centroid -> midpoint displacements are formed
-// (src/operator_fluxes_ceed.c:1169-1178).  The flux is parked in LDS for phase 2.
+// (src/operator_fluxes_ceed.c:1169-1178).  Returns the flux; the caller parks it in LDS for phase 2 (store_edge_flux).
+struct EdgeFlux {
+  double f0, f1, f2, am;  // am: largest wave speed, -1 for a dry-dry edge (skipped, swe_petsc.c:184)
+};
+__device__ __forceinline__ void store_edge_flux(const KernelArgs &a, double *ef, int e, const EdgeFlux &r) {
+  MEF(0, e) = r.f0;
+  MEF(1, e) = r.f1;
+  MEF(2, e) = r.f2;
+  MEF(3, e) = r.am;
+}
 template <int LIM>
-__device__ __forceinline__ void muscl_edge(const KernelArgs &a, const TileDesc &td, double dt, int e, uint32_t lr, double cs, double2 mid,
-                                           const double *sq, int nq, const double *sg, int ng, double *ef) {
+__device__ __forceinline__ EdgeFlux muscl_edge(const KernelArgs &a, const TileDesc &td, double dt, uint32_t lr, double cs, double2 mid,
+                                               const double *sq, int nq, const double *sg, int ng) {
   double cn, sn;
   edge_normal(lr, cs, cn, sn);
   const int jl = lr & EDGE_SLOT_MASK;
@@ -200,10 +209,12 @@ __device__ __forceinline__ void muscl_edge(const KernelArgs &a, const TileDesc &
     wet                  = bf.wet;
     store_boundary_flux(a, k, fl, dt);
   }
-  MEF(0, e) = fl.f0;
-  MEF(1, e) = fl.f1;
-  MEF(2, e) = fl.f2;
-  MEF(3, e) = wet ? fl.amax : -1.0;  // -1 marks a dry-dry edge (skipped, swe_petsc.c:184)
+  EdgeFlux r;
+  r.f0 = fl.f0;
+  r.f1 = fl.f1;
+  r.f2 = fl.f2;
+  r.am = wet ? fl.amax : -1.0;
+  return r;
 }
 
 // index of slot s's edge in the tile's edge list, or -1 for an unused slot
@@ -349,7 +360,7 @@ __global__ __launch_bounds__(TILE) void swe_rhs_muscl_kernel(const KernelArgs a,
     // ---- phase 1: every edge of the tile once
     for (int e = tid; e < ne; e += TILE) {
       const double2 mid = *reinterpret_cast<const double2 *>(g.e_mid + 2 * ((int64_t)td.e_off + e));
-      muscl_edge<LIM>(a, td, dt, e, a.e_lr[td.e_off + e], a.e_cs[td.e_off + e], mid, sq, nside, sg, nside, ef);
+      store_edge_flux(a, ef, e, muscl_edge<LIM>(a, td, dt, a.e_lr[td.e_off + e], a.e_cs[td.e_off + e], mid, sq, nside, sg, nside));
     }
     __syncthreads();
 
@@ -395,22 +406,30 @@ __global__ __launch_bounds__(TILE) void swe_rhs_muscl_kernel(const KernelArgs a,
 // take their gradient from `grad`, filled by the caller's exchange (their
 // stencil is not local).
 // ---------------------------------------------------------------------------
-template <int S, int SRC, bool OVW, int LIM, bool EULER = false>
-__global__ __launch_bounds__(TILE) void swe_rhs_muscl_fused_kernel(const KernelArgs a, const MusclArgs g, const double dt, const double *__restrict__ u,
+#ifdef RDYHIP_MUSCL_WAVES
+#define RDY_MUSCL_OCC __attribute__((amdgpu_waves_per_eu(RDYHIP_MUSCL_WAVES, RDYHIP_MUSCL_WAVES)))
+#else
+#define RDY_MUSCL_OCC
+#endif
+template <int S, int SRC, bool OVW, int LIM, bool EULER = false, bool EFO = false>
+__global__ __launch_bounds__(TILE) RDY_MUSCL_OCC void swe_rhs_muscl_fused_kernel(const KernelArgs a, const MusclArgs g, const double dt, const double *__restrict__ u,
                                                                     double *__restrict__ f) {
-  // LDS: gradients of own + first-ring cells | state of own + first-ring cells | a region that holds, before the edge
-  // phase, the second ring's state (its head, contiguous with the first ring's records) and the tile's edge records
-  // (its tail), and from the edge phase on the edge fluxes, which overwrite both: the second ring is only read by the
-  // gradient phase and the records' LDS copy only by the gradient phase (the edge phase has them in registers).  That
-  // overlay is what lets FOUR workgroups share a CU's 160 KB on a well-numbered triangle mesh (39.8 KB each).
+  // LDS: gradients of own + first-ring cells | state of own + first-ring cells | a region that holds the second ring's
+  // state (its head, contiguous with the first ring's records) and the tile's edge records (its tail), both read by
+  // the gradient phase only (the edge phase has its records in registers).  The edge fluxes take over dead storage:
+  // with EFO (a tile has at most 2 TILE edges: every well-numbered triangle mesh) the gradients' -- 34 KB per workgroup
+  // on the 10 M-cell benchmark mesh, so FOUR workgroups share a CU's 160 KB --, otherwise that third region, grown
+  // to 4 emax doubles (43 KB on the same mesh: three workgroups).
   extern __shared__ double lds[];
   const int nq = TILE + g.hmax2;  // state + centroid records: own, first ring, second ring
   const int ng = TILE + a.hmax;   // gradient records: own, first ring
   double   *sg = lds;             // [ng][6]
   double   *sq = lds + 6 * ng;    // [nq][5]: h, hu, hv, centroid x, centroid y
-  double   *ef = sq + 5 * ng;     // [emax][4]: the edge fluxes (over the second ring's records and the edge records)
-  const int ovl = max(4 * a.emax, 5 * (g.hmax2 - a.hmax) + (a.emax + 1) / 2);
-  uint32_t *slr = reinterpret_cast<uint32_t *>(ef + ovl) - ((a.emax + 1) / 2) * 2;  // [emax] the tile's edge records
+  // EFO: the edge fluxes take the place of the gradients (dead once every edge has been evaluated; the fluxes wait
+  // in registers for a barrier), else they follow the first ring's records, over the second ring and the edge records
+  double   *ef  = EFO ? sg : sq + 5 * ng;  // [emax][4]
+  const int ovl = EFO ? 5 * (g.hmax2 - a.hmax) + (a.emax + 1) / 2 : max(4 * a.emax, 5 * (g.hmax2 - a.hmax) + (a.emax + 1) / 2);
+  uint32_t *slr = reinterpret_cast<uint32_t *>(sq + 5 * ng + ovl) - ((a.emax + 1) / 2) * 2;  // [emax] the tile's edge records
   const int tid = threadIdx.x;
 
   int idx, step, hi;
@@ -491,6 +510,7 @@ __global__ __launch_bounds__(TILE) void swe_rhs_muscl_fused_kernel(const KernelA
         r0            = w.x;
         r1            = w.y;
       }
+#ifdef RDYHIP_MUSCL_EARLY_STREAMS
 #pragma unroll
       for (int s = 0; s < S; ++s) kf[s] = RDY_MLD(&a.coef[s * a.stride + o]);
       dzx  = RDY_MLD(&a.dzdx[o]);
@@ -499,6 +519,7 @@ __global__ __launch_bounds__(TILE) void swe_rhs_muscl_fused_kernel(const KernelA
       s0   = RDY_MLD(&a.extsrc[3 * (int64_t)o + 0]);
       s1   = RDY_MLD(&a.extsrc[3 * (int64_t)o + 1]);
       s2   = RDY_MLD(&a.extsrc[3 * (int64_t)o + 2]);
+#endif
     }
     if (hid >= 0) {
 #pragma unroll
@@ -594,24 +615,41 @@ __global__ __launch_bounds__(TILE) void swe_rhs_muscl_fused_kernel(const KernelA
     __syncthreads();
 
     // ---- phase 1: every edge of the tile once
-    auto do_edge = [&](int e, uint32_t lr, double cs, double2 mid) {
-      muscl_edge<LIM>(a, td, dt, e, lr, cs, mid, sq, nq, sg, ng, ef);
+    auto do_edge = [&](uint32_t lr, double cs, double2 mid) -> EdgeFlux {
+      return muscl_edge<LIM>(a, td, dt, lr, cs, mid, sq, nq, sg, ng);
     };
-#ifdef RDYHIP_MUSCL_ROUND_LOOP
-#pragma unroll 1
-    for (int r = 0; r < 2; ++r) {
-      const int e = tid + r * TILE;
-      if (e < ne) do_edge(e, r == 0 ? lr0 : lr1, r == 0 ? cs0 : cs1, r == 0 ? md0 : md1);
-    }
-#else
     // the two register-resident rounds one after the other (no per-value selects between the rounds' registers); the
     // scheduling barrier keeps the compiler from interleaving them, which would double the live registers
-    if (tid < ne) do_edge(tid, lr0, cs0, md0);
+    EdgeFlux x0 = {0.0, 0.0, 0.0, -1.0}, x1 = x0;
+    if (tid < ne) x0 = do_edge(lr0, cs0, md0);
+    if (!EFO && tid < ne) store_edge_flux(a, ef, tid, x0);
     __builtin_amdgcn_sched_barrier(0);
-    if (tid + TILE < ne) do_edge(tid + TILE, lr1, cs1, md1);
+    if (tid + TILE < ne) x1 = do_edge(lr1, cs1, md1);
+    if (!EFO && tid + TILE < ne) store_edge_flux(a, ef, tid + TILE, x1);
+    if (!EFO) {
+      for (int e = tid + 2 * TILE; e < ne; e += TILE)  // not slr: the fluxes overwrite it
+        store_edge_flux(a, ef, e, do_edge(a.e_lr[td.e_off + e], a.e_cs[td.e_off + e], *reinterpret_cast<const double2 *>(g.e_mid + 2 * ((int64_t)td.e_off + e))));
+    }
+#ifndef RDYHIP_MUSCL_EARLY_STREAMS
+    // the per-cell streams of phase 2 are requested only here: held from the tile's top they would cost 18 registers
+    // through the edge phase (129 instead of 111 VGPRs, three waves per SIMD instead of four); the barriers and the
+    // flux stores below cover most of their latency, the other resident workgroups the rest
+    if (active) {
+#pragma unroll
+      for (int s = 0; s < S; ++s) kf[s] = RDY_MLD(&a.coef[s * a.stride + o]);
+      dzx  = RDY_MLD(&a.dzdx[o]);
+      dzy  = RDY_MLD(&a.dzdy[o]);
+      nman = RDY_MLD(&a.mannings[o]);
+      s0   = RDY_MLD(&a.extsrc[3 * (int64_t)o + 0]);
+      s1   = RDY_MLD(&a.extsrc[3 * (int64_t)o + 1]);
+      s2   = RDY_MLD(&a.extsrc[3 * (int64_t)o + 2]);
+    }
 #endif
-    for (int e = tid + 2 * TILE; e < ne; e += TILE)
-      do_edge(e, a.e_lr[td.e_off + e], a.e_cs[td.e_off + e], *reinterpret_cast<const double2 *>(g.e_mid + 2 * ((int64_t)td.e_off + e)));  // not slr: the fluxes overwrite it
+    if (EFO) {
+      __syncthreads();  // every edge has read its gradients: the fluxes may overwrite them
+      if (tid < ne) store_edge_flux(a, ef, tid, x0);
+      if (tid + TILE < ne) store_edge_flux(a, ef, tid + TILE, x1);
+    }
     __syncthreads();
 
     // ---- phase 2: per-cell sum in the reference's edge order, source terms, stores

@@ -126,6 +126,7 @@ struct RDyHipOperator_s {
   // second order (muscl_kernels.h)
   bool             muscl = false;
   bool             muscl_fused = true;  // gradients formed in LDS by the flux kernel (RDYHIP_MUSCL=split: separate gradient launch)
+  bool             muscl_efo   = false; // fused form: edge fluxes stored over the gradients (layout_build)
   DevBuf<double>   d_grad, d_e_mid, d_cxy;
   DevBuf<int32_t>  d_hcells2, d_c_off;
   DevBuf<uint16_t> d_bn_idx;
@@ -192,32 +193,46 @@ MusclKernelFn muscl_kernel_fn_lim(int S, int src, bool ovw) {
   if (src) return ovw ? swe_rhs_muscl_kernel<4, 1, true, LIM> : swe_rhs_muscl_kernel<4, 1, false, LIM>;
   return ovw ? swe_rhs_muscl_kernel<4, 0, true, LIM> : swe_rhs_muscl_kernel<4, 0, false, LIM>;
 }
-template <int LIM>
+template <int LIM, bool EFO>
 MusclKernelFn muscl_fused_fn_lim(int S, int src, bool ovw) {
   if (S == 3) {
-    if (src) return ovw ? swe_rhs_muscl_fused_kernel<3, 1, true, LIM> : swe_rhs_muscl_fused_kernel<3, 1, false, LIM>;
-    return ovw ? swe_rhs_muscl_fused_kernel<3, 0, true, LIM> : swe_rhs_muscl_fused_kernel<3, 0, false, LIM>;
+    if (src) return ovw ? swe_rhs_muscl_fused_kernel<3, 1, true, LIM, false, EFO> : swe_rhs_muscl_fused_kernel<3, 1, false, LIM, false, EFO>;
+    return ovw ? swe_rhs_muscl_fused_kernel<3, 0, true, LIM, false, EFO> : swe_rhs_muscl_fused_kernel<3, 0, false, LIM, false, EFO>;
   }
+  // EFO is a triangle-mesh layout (layout_build: S == 3 and emax <= 2 TILE)
   if (src) return ovw ? swe_rhs_muscl_fused_kernel<4, 1, true, LIM> : swe_rhs_muscl_fused_kernel<4, 1, false, LIM>;
   return ovw ? swe_rhs_muscl_fused_kernel<4, 0, true, LIM> : swe_rhs_muscl_fused_kernel<4, 0, false, LIM>;
 }
-template <int LIM>
+template <int LIM, bool EFO>
 MusclKernelFn muscl_fused_euler_fn_lim(int S, int src) {
-  if (S == 3) return src ? swe_rhs_muscl_fused_kernel<3, 1, true, LIM, true> : swe_rhs_muscl_fused_kernel<3, 0, true, LIM, true>;
+  if (S == 3) return src ? swe_rhs_muscl_fused_kernel<3, 1, true, LIM, true, EFO> : swe_rhs_muscl_fused_kernel<3, 0, true, LIM, true, EFO>;
   return src ? swe_rhs_muscl_fused_kernel<4, 1, true, LIM, true> : swe_rhs_muscl_fused_kernel<4, 0, true, LIM, true>;
 }
-MusclKernelFn muscl_fused_euler_fn(int S, int src, int limiter) {
+template <bool EFO>
+MusclKernelFn muscl_fused_euler_fn_e(int S, int src, int limiter) {
   switch (limiter) {
-    case RDYHIP_LIMITER_NONE: return muscl_fused_euler_fn_lim<LIMITER_NONE>(S, src);
-    case RDYHIP_LIMITER_VANLEER: return muscl_fused_euler_fn_lim<LIMITER_VANLEER>(S, src);
-    default: return muscl_fused_euler_fn_lim<LIMITER_MINMOD>(S, src);
+    case RDYHIP_LIMITER_NONE: return muscl_fused_euler_fn_lim<LIMITER_NONE, EFO>(S, src);
+    case RDYHIP_LIMITER_VANLEER: return muscl_fused_euler_fn_lim<LIMITER_VANLEER, EFO>(S, src);
+    default: return muscl_fused_euler_fn_lim<LIMITER_MINMOD, EFO>(S, src);
   }
 }
-MusclKernelFn muscl_kernel_fn(int S, int src, bool ovw, int limiter, bool fused) {
+MusclKernelFn muscl_fused_euler_fn(int S, int src, int limiter, bool efo) {
+  return efo ? muscl_fused_euler_fn_e<true>(S, src, limiter) : muscl_fused_euler_fn_e<false>(S, src, limiter);
+}
+template <bool EFO>
+MusclKernelFn muscl_fused_fn_e(int S, int src, bool ovw, int limiter) {
   switch (limiter) {
-    case RDYHIP_LIMITER_NONE: return fused ? muscl_fused_fn_lim<LIMITER_NONE>(S, src, ovw) : muscl_kernel_fn_lim<LIMITER_NONE>(S, src, ovw);
-    case RDYHIP_LIMITER_VANLEER: return fused ? muscl_fused_fn_lim<LIMITER_VANLEER>(S, src, ovw) : muscl_kernel_fn_lim<LIMITER_VANLEER>(S, src, ovw);
-    default: return fused ? muscl_fused_fn_lim<LIMITER_MINMOD>(S, src, ovw) : muscl_kernel_fn_lim<LIMITER_MINMOD>(S, src, ovw);
+    case RDYHIP_LIMITER_NONE: return muscl_fused_fn_lim<LIMITER_NONE, EFO>(S, src, ovw);
+    case RDYHIP_LIMITER_VANLEER: return muscl_fused_fn_lim<LIMITER_VANLEER, EFO>(S, src, ovw);
+    default: return muscl_fused_fn_lim<LIMITER_MINMOD, EFO>(S, src, ovw);
+  }
+}
+MusclKernelFn muscl_kernel_fn(int S, int src, bool ovw, int limiter, bool fused, bool efo) {
+  if (fused) return efo ? muscl_fused_fn_e<true>(S, src, ovw, limiter) : muscl_fused_fn_e<false>(S, src, ovw, limiter);
+  switch (limiter) {
+    case RDYHIP_LIMITER_NONE: return muscl_kernel_fn_lim<LIMITER_NONE>(S, src, ovw);
+    case RDYHIP_LIMITER_VANLEER: return muscl_kernel_fn_lim<LIMITER_VANLEER>(S, src, ovw);
+    default: return muscl_kernel_fn_lim<LIMITER_MINMOD>(S, src, ovw);
   }
 }
 
@@ -365,8 +380,8 @@ int launch_rhs(RDyHipOperator op, int32_t phase, int32_t overwrite, int reset_di
       }
     }
     if (op->muscl) {
-      MusclKernelFn kfn = euler_fused ? muscl_fused_euler_fn(op->S, xq ? 1 : 0, op->config.limiter)
-                                      : muscl_kernel_fn(op->S, xq ? 1 : 0, overwrite != 0, op->config.limiter, op->muscl_fused);
+      MusclKernelFn kfn = euler_fused ? muscl_fused_euler_fn(op->S, xq ? 1 : 0, op->config.limiter, op->muscl_efo)
+                                      : muscl_kernel_fn(op->S, xq ? 1 : 0, overwrite != 0, op->config.limiter, op->muscl_fused, op->muscl_efo);
       hipLaunchKernelGGL(HIP_KERNEL_NAME(kfn), dim3(grid), dim3(TILE), op->lds_muscl, st, a, muscl_args(op), dt, u, f);
     } else if (euler_fused) {
       hipLaunchKernelGGL(HIP_KERNEL_NAME(tiled_euler_fn(op->S, xq ? 1 : 0, op->hr)), dim3(grid), dim3(TILE), op->lds_bytes, st, a, dt, u, f);
@@ -418,7 +433,7 @@ int launch_rhs(RDyHipOperator op, int32_t phase, int32_t overwrite, int reset_di
 struct HostLayout {
   int32_t nc = 0, no = 0, ne = 0, ni = 0, K = 0, S = 3, ntiles = 0, emax = 0, hmax = 0, hmax2 = 0;
   int64_t stride = 0;
-  bool    prefix = true, hr_on = false, muscl_on = false, muscl_fused = true;
+  bool    prefix = true, hr_on = false, muscl_on = false, muscl_fused = true, muscl_efo = false;
   size_t  lds_bytes = 0, lds_muscl = 0;
   std::vector<int32_t>  o2l, boff, nbr, pos, btype, bleft, bedge, bghost, halo, hcells, tile_bk, halo_tiles, hcells2, c_off;
   std::vector<double>   cn, sn, coef, bcn, bsn, e_cs, e_mid, dzdx, dzdy;
@@ -752,10 +767,15 @@ static int build_host_layout(const RDyHipConfig *config, const RDyHipMesh *mesh,
   const size_t lds_bytes = sizeof(double) * ((hr_on ? 6 : 5) * ((size_t)TILE + hmax) + 2 * (size_t)TILE + (hr_on ? 8 : 4) * (size_t)emax);
   const char  *menv        = getenv("RDYHIP_MUSCL");
   const bool   muscl_fused = !(menv && strcmp(menv, "split") == 0);
-  const size_t lds_muscl   = !muscl_on ? 0
-                             : muscl_fused
-                                 ? sizeof(double) * (11 * ((size_t)TILE + hmax) + std::max<size_t>(4 * (size_t)emax, 5 * (size_t)(hmax2 - hmax) + ((size_t)emax + 1) / 2))
-                                 : sizeof(double) * (11 * ((size_t)TILE + hmax) + 4 * (size_t)emax);
+  // second order, fused form: where the edge fluxes live (muscl_kernels.h) -- over the gradients when a tile's edges fit
+  // two register rounds and the gradients' storage (every triangle mesh numbered with some locality), else behind the
+  // first ring's records.  RDYHIP_MUSCL_EF_OVERLAY=0: measurement knob
+  const char  *eenv      = getenv("RDYHIP_MUSCL_EF_OVERLAY");
+  const bool   muscl_efo = muscl_on && muscl_fused && L.S == 3 && emax <= 2 * TILE && 4 * (size_t)emax <= 6 * ((size_t)TILE + hmax) &&
+                         !(eenv && atoi(eenv) == 0);
+  const size_t ring2     = 5 * (size_t)(hmax2 - hmax) + ((size_t)emax + 1) / 2;
+  const size_t lds_muscl = !muscl_on ? 0
+                           : sizeof(double) * (11 * ((size_t)TILE + hmax) + (!muscl_fused ? 4 * (size_t)emax : muscl_efo ? ring2 : std::max<size_t>(4 * (size_t)emax, ring2)));
   if (std::max(lds_bytes, lds_muscl) > 160 * 1024)
     return fail(RDYHIP_ERR_USER, "tile working set (%zu B of LDS) too large: the cell numbering has no locality", std::max(lds_bytes, lds_muscl));
 
@@ -766,7 +786,7 @@ static int build_host_layout(const RDyHipConfig *config, const RDyHipMesh *mesh,
     dzdy[o] = mesh->cell_dz_dy[o2l[o]];
   }
 
-  L.hr_on = hr_on; L.muscl_fused = muscl_fused; L.lds_bytes = lds_bytes; L.lds_muscl = lds_muscl;
+  L.hr_on = hr_on; L.muscl_fused = muscl_fused; L.muscl_efo = muscl_efo; L.lds_bytes = lds_bytes; L.lds_muscl = lds_muscl;
   L.dzdx = std::move(dzdx); L.dzdy = std::move(dzdy);
   return 0;
 }
@@ -830,6 +850,7 @@ int rdyhip_create(const RDyHipConfig *config, const RDyHipMesh *mesh, int32_t nu
   }
   op->muscl       = muscl_on;
   op->muscl_fused = muscl_fused;
+  op->muscl_efo   = L.muscl_efo;
   op->hmax2       = hmax2;
   op->lds_muscl   = lds_muscl;
   if (lds_muscl > 64 * 1024) {
@@ -837,9 +858,9 @@ int rdyhip_create(const RDyHipConfig *config, const RDyHipMesh *mesh, int32_t nu
     bool      ok = true;
     for (int ovw = 0; ovw < 2; ++ovw)
       for (int src = 0; src < 2; ++src)
-        ok = ok && hipFuncSetAttribute((const void *)muscl_kernel_fn(S, src, ovw != 0, config->limiter, muscl_fused),
+        ok = ok && hipFuncSetAttribute((const void *)muscl_kernel_fn(S, src, ovw != 0, config->limiter, muscl_fused, L.muscl_efo),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, nb) == hipSuccess &&
-             (!muscl_fused || hipFuncSetAttribute((const void *)muscl_fused_euler_fn(S, src, config->limiter),
+             (!muscl_fused || hipFuncSetAttribute((const void *)muscl_fused_euler_fn(S, src, config->limiter, L.muscl_efo),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, nb) == hipSuccess);
     if (!ok) {
       delete op;
@@ -883,7 +904,7 @@ int rdyhip_create(const RDyHipConfig *config, const RDyHipMesh *mesh, int32_t nu
     if (muscl_on) {
       int qm = 0, per_cu_m = 2;
       const void *mfn =
-          (const void *)muscl_kernel_fn(S, config->source_method == RDYHIP_SOURCE_IMPLICIT_XQ2018 ? 1 : 0, true, config->limiter, muscl_fused);
+          (const void *)muscl_kernel_fn(S, config->source_method == RDYHIP_SOURCE_IMPLICIT_XQ2018 ? 1 : 0, true, config->limiter, muscl_fused, L.muscl_efo);
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&qm, mfn, TILE, lds_muscl) == hipSuccess && qm > 0) per_cu_m = qm;
       if (const char *e2 = getenv("RDYHIP_BLOCKS_PER_CU")) {
         if (atoi(e2) > 0) per_cu_m = atoi(e2);
@@ -1336,7 +1357,7 @@ int rdyhip_probe_layout(const RDyHipConfig *config, const RDyHipMesh *mesh, int3
   tmp.n_cells = L.nc; tmp.n_owned = L.no; tmp.S = L.S; tmp.K = L.K; tmp.n_halo = (int32_t)L.halo.size(); tmp.use_tiled = true;
   tmp.ntiles = L.ntiles; tmp.n_halo_tiles = (int32_t)L.halo_tiles.size(); tmp.emax = L.emax; tmp.hmax = L.hmax;
   tmp.nhalo_entries = (int64_t)L.hcells.size(); tmp.nrec = (int64_t)L.e_lr.size(); tmp.prefix = L.prefix; tmp.muscl = L.muscl_on;
-  tmp.muscl_fused = L.muscl_fused; tmp.hmax2 = L.hmax2; tmp.d_hcells2.n = L.hcells2.size(); tmp.lds_bytes = L.lds_bytes; tmp.lds_muscl = L.lds_muscl;
+  tmp.muscl_fused = L.muscl_fused; tmp.muscl_efo = L.muscl_efo; tmp.hmax2 = L.hmax2; tmp.d_hcells2.n = L.hcells2.size(); tmp.lds_bytes = L.lds_bytes; tmp.lds_muscl = L.lds_muscl;
   const int rc2 = rdyhip_layout_info(&tmp, info);
   tmp.d_hcells2.n = 0;
   return rc2;
