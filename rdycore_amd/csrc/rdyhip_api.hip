@@ -771,11 +771,12 @@ static int build_host_layout(const RDyHipConfig *config, const RDyHipMesh *mesh,
   // two register rounds and the gradients' storage (every triangle mesh numbered with some locality), else behind the
   // first ring's records.  RDYHIP_MUSCL_EF_OVERLAY=0: measurement knob
   const char  *eenv      = getenv("RDYHIP_MUSCL_EF_OVERLAY");
-  const bool   muscl_efo = muscl_on && muscl_fused && L.S == 3 && emax <= 2 * TILE && 4 * (size_t)emax <= 6 * ((size_t)TILE + hmax) &&
+  const bool   muscl_efo = muscl_on && muscl_fused && L.S == 3 && emax <= 2 * TILE && MUSCL_ES * (size_t)emax <= MUSCL_GS * ((size_t)TILE + hmax) &&
                          !(eenv && atoi(eenv) == 0);
   const size_t ring2     = 5 * (size_t)(hmax2 - hmax) + ((size_t)emax + 1) / 2;
   const size_t lds_muscl = !muscl_on ? 0
-                           : sizeof(double) * (11 * ((size_t)TILE + hmax) + (!muscl_fused ? 4 * (size_t)emax : muscl_efo ? ring2 : std::max<size_t>(4 * (size_t)emax, ring2)));
+                           : sizeof(double) * ((5 + MUSCL_GS) * ((size_t)TILE + hmax) +
+                                               (!muscl_fused ? MUSCL_ES * (size_t)emax : muscl_efo ? ring2 : std::max<size_t>(MUSCL_ES * (size_t)emax, ring2)));
   if (std::max(lds_bytes, lds_muscl) > 160 * 1024)
     return fail(RDYHIP_ERR_USER, "tile working set (%zu B of LDS) too large: the cell numbering has no locality", std::max(lds_bytes, lds_muscl));
 
