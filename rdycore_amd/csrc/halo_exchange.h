@@ -138,20 +138,19 @@ int overlapped(RDyHipOperator op, RDyHipHalo h, double dt, double *u, double *f,
   // ApplyInteriorFlux2R (src/swe/swe_petsc.c:98-213) needs two exchanges: the state, then the gradients of the ghost
   // cells (CommunicateCellGradients).  No reverse exchange: every rank evaluates all edges of its owned cells.
   if (op->muscl_fused) {
-    // tiles whose cells and first ring touch no ghost need nothing from other ranks and hide the state exchange; only the
-    // ghost-adjacent cells' gradients go through memory
+    // tiles whose cells and first ring touch no ghost need nothing from other ranks and hide BOTH exchanges: the state,
+    // then -- still on the exchange stream -- the gradients of the ghost-adjacent owned cells (the only ones that go
+    // through memory; the interior tiles neither read nor write that array) and their exchange
     rc = halo_pack(h, u, 3, h->cs);
     if (!rc && h->transport) rc = part(RDYHIP_PHASE_INTERIOR, 1, true);
     if (!rc) rc = halo_transfer(h, 3, h->cs);
     if (!rc) rc = halo_unpack(h, u, 3, h->cs);
     if (!rc && !h->transport) rc = part(RDYHIP_PHASE_INTERIOR, 1, true);
+    if (!rc) rc = launch_gradients(op, RDYHIP_PHASE_HALO, u, h->cs);
+    if (!rc) rc = halo_exchange_on(h, op->d_grad.p, 6, h->cs);
     if (rc) return rc;
     HIP_TRY(hipEventRecord(h->ev_join, h->cs));
     HIP_TRY(hipStreamWaitEvent(st, h->ev_join, 0));
-    rc = launch_gradients(op, RDYHIP_PHASE_HALO, u, st);
-    if (rc) return rc;
-    rc = halo_exchange_on(h, op->d_grad.p, 6, st);
-    if (rc) return rc;
     return part(RDYHIP_PHASE_HALO, 0, true);
   }
   // split kernels: the gradients of the cells without ghost neighbours hide the state exchange, the fluxes of the tiles

@@ -313,11 +313,13 @@ class HaloExchange:
             # edges of its cells.
             if self._fused(op):
                 # fused kernel: tiles whose cells and first ring touch no ghost need nothing from other ranks and
-                # hide the state exchange; only the ghost-adjacent cells' gradients go through memory
+                # hide both exchanges; only the ghost-adjacent cells' gradients go through memory, on the exchange
+                # stream (the interior tiles neither read nor write that array) -- as csrc/halo_exchange.h does
                 part(1, reset=True, ready=True)
+                with torch.cuda.stream(self.comm_stream):
+                    op.compute_gradients(u_local, phase=2)
+                    self.exchange(op.gradients)
                 main.wait_stream(self.comm_stream)
-                op.compute_gradients(u_local, phase=2)
-                self.exchange(op.gradients)
                 part(2, ready=True)
                 return
             # split kernels.  Hidden behind the exchanges: the gradients of the cells without ghost neighbours,
