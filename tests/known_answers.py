@@ -197,3 +197,58 @@ def hr_two_cell_step():
     u = np.array([[1.0, 0.0, 0.0], [0.6, 0.0, 0.0]])
     case = CS.Case("hr_step", m, RDyFlowConfig(well_balancing=WELL_BALANCING_HR), [M.CONDITION_REFLECTING], u, np.zeros(2), np.zeros((2, 3)), {}, 0.1)
     return case, np.zeros((2, 3))
+
+
+def second_order_linear_field(nx=9, ny=7, jitter=0.2, seed=5):
+    """Second order without a limiter on a state that is LINEAR in the conserved variables, flat frictionless bed, no
+    sources: the least-squares gradient of a cell with two non-collinear neighbours is exact, so both reconstructions at
+    an edge midpoint give the field's value there, the Roe flux of two equal states is the physical flux, and a cell
+    none of whose edges lies on the boundary (and none of whose neighbours has a degenerate stencil) must receive
+        F = -(1/A) sum_edges  F_phys(q(x_mid)) . n_out  len
+    (ApplyInteriorFlux2R, src/swe/swe_petsc.c:98-213; ReconstructFaceValues, src/operator_fluxes_ceed.c:1155-1206).
+    Returns (case, expected rows, mask of the cells the statement holds for)."""
+    from rdycore_amd.operator import LIMITER_NONE
+    rng = np.random.default_rng(seed)
+    m0 = M.structured_tri_mesh(nx, ny)
+    xyz = m0.xyz.copy()
+    lo, hi = xyz[:, :2].min(0), xyz[:, :2].max(0)
+    inner = np.all((xyz[:, :2] > lo + 1e-9) & (xyz[:, :2] < hi - 1e-9), axis=1)
+    dx = (hi - lo) / np.array([nx, ny])
+    xyz[inner, :2] += jitter * dx * (rng.random((int(inner.sum()), 2)) - 0.5)
+    xyz[:, 2] = 0.0
+    m = M.build_mesh(xyz, m0.cell_conn[:, :3].astype(np.int32), boundary_classifier=M.single_boundary())
+
+    def q(x, y):
+        return np.stack([2.0 + 0.10 * x + 0.05 * y, 0.3 + 0.02 * x - 0.01 * y, -0.2 + 0.01 * x + 0.03 * y], axis=-1)
+
+    u = q(m.cell_centroids[:, 0], m.cell_centroids[:, 1])
+    no = m.num_owned_cells
+    cfg = RDyFlowConfig(second_order=True, limiter=LIMITER_NONE)
+    case = CS.Case("so_linear", m, cfg, [M.CONDITION_REFLECTING], u, np.zeros(no), np.zeros((no, 3)), {}, 0.1)
+    # midpoint-rule flux integral, edge by edge, from the mesh's own edge geometry (normal = left -> right)
+    rhs = np.zeros((m.num_cells, 3))
+    interior = np.ones(m.num_cells, bool)
+    v = m.edge_vertex_ids.reshape(-1, 2)
+    mid = 0.5 * (m.xyz[v[:, 0], :2] + m.xyz[v[:, 1], :2])
+    qm = q(mid[:, 0], mid[:, 1])
+    fl = physical_flux(qm[:, 0], qm[:, 1] / qm[:, 0], qm[:, 2] / qm[:, 0], m.edge_cn, m.edge_sn) * m.edge_lengths[:, None]
+    for e in range(m.num_edges):
+        l, r = m.edge_cell_ids[2 * e], m.edge_cell_ids[2 * e + 1]
+        if r < 0:
+            interior[l] = False
+            continue
+        rhs[l] -= fl[e] / m.cell_areas[l]
+        rhs[r] += fl[e] / m.cell_areas[r]
+    # a neighbour with fewer than two internal edges (a corner triangle) has a degenerate stencil -> zero gradient
+    # (operator_fluxes_ceed.c:947-955): its reconstruction is not exact, so its neighbours are left out as well
+    nn = np.zeros(m.num_cells, int)
+    for e in m.edge_internal_ids:
+        nn[m.edge_cell_ids[2 * e]] += 1
+        nn[m.edge_cell_ids[2 * e + 1]] += 1
+    for e in m.edge_internal_ids:
+        l, r = m.edge_cell_ids[2 * e], m.edge_cell_ids[2 * e + 1]
+        if nn[l] < 2:
+            interior[r] = False
+        if nn[r] < 2:
+            interior[l] = False
+    return case, rhs[:no], interior[:no]

@@ -35,3 +35,13 @@ def test_hydrostatic_reconstruction_is_well_balanced_on_a_bed_step(rdyhip_kernel
     f, op = gpu_apply(case)
     assert np.max(np.abs(f - rhs)) <= 1e-14
     op.destroy()
+
+
+def test_second_order_is_exact_for_a_linear_state(rdyhip_kernel):
+    if rdyhip_kernel == "cell":
+        pytest.skip("second order is implemented by the tiled kernels")
+    case, rhs, interior = KA.second_order_linear_field()
+    f, op = gpu_apply(case)
+    err = np.abs(f[interior] - rhs[interior]).max() / np.abs(rhs[interior]).max()
+    assert err <= 1e-12, err
+    op.destroy()

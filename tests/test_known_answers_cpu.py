@@ -67,3 +67,12 @@ def test_hydrostatic_reconstruction_is_well_balanced_on_a_bed_step():
     case.config.well_balancing = 0
     f0 = oracle_from_case(case).apply(case.dt, case.u_local)
     assert np.max(np.abs(f0[:, 1])) > 1.0
+
+
+def test_second_order_is_exact_for_a_linear_state():
+    """oracle-independent answer for the second-order path (gradient, reconstruction, flux): tests/known_answers.py"""
+    case, rhs, interior = KA.second_order_linear_field()
+    assert interior.sum() > 40
+    f = oracle_from_case(case).apply(case.dt, case.u_local)
+    err = np.abs(f[interior] - rhs[interior]).max() / np.abs(rhs[interior]).max()
+    assert err <= 1e-12, err
