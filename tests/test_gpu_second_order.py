@@ -269,3 +269,28 @@ def test_mixed_tri_quad_mesh_second_order():
     f, fr, op, orc = run_both(case)
     check_all(case, f, fr, op, orc)
     assert op.layout_info()["slots_per_cell"] == 4
+
+
+@pytest.mark.parametrize("limiter", [LIMITER_MINMOD, LIMITER_VANLEER])
+def test_both_flux_storage_layouts_give_the_same_bits(limiter, muscl_mode, monkeypatch):
+    """fused kernel: edge fluxes stored over the gradients (tiles of <= 2 x 256 edges, four workgroups per CU) or behind
+    the first ring's records (RDYHIP_MUSCL_EF_OVERLAY=0, the layout of every other mesh) -- storage only, same arithmetic"""
+    if muscl_mode != "fused":
+        pytest.skip("layouts of the fused kernel")
+    torch = _torch()
+    case = second_order(tri_mms_case(64, 48, SOURCE_SEMI_IMPLICIT, order="tiled"), limiter)
+    u = torch.tensor(case.u_local, dtype=torch.float64, device="cuda")
+    out, lds = [], []
+    for overlay in ("1", "0"):
+        monkeypatch.setenv("RDYHIP_MUSCL_EF_OVERLAY", overlay)
+        op = CS.create_operator(case)
+        f = torch.empty((case.mesh.num_owned_cells, 3), dtype=torch.float64, device="cuda")
+        op.rhs_function(case.dt, u, f)
+        torch.cuda.synchronize()
+        op.update_diagnostics()
+        out.append((f.cpu().numpy(), op.get_diagnostics()))
+        lds.append(op.layout_info()["lds_bytes"])
+        op.destroy()
+    assert lds[0] < lds[1]
+    assert np.array_equal(out[0][0], out[1][0])
+    assert out[0][1] == out[1][1]
