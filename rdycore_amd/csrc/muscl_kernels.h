@@ -69,19 +69,13 @@ struct MusclArgs {
 constexpr uint16_t BN_NONE = 0xFFFF, BN_GLOBAL = 0xFFFE;
 
 // LDS layout of the second-order kernels: array-of-structs -- a cell's (h, hu, hv, centroid x, centroid y) are five
-// consecutive doubles, its gradient six, an edge's (f0, f1, f2, amax) four -- so that every access to a record is ONE
-// address (slot x record size) plus immediate offsets the compiler folds into ds_read2_b64 / ds_write2_b64.  With one plane
-// per component (-DRDYHIP_MUSCL_LDS_SOA, the layout of swe_kernels.h) every plane's runtime offset costs an SGPR, and
-// the kernel ran out of them: phase 1 alone held 161 v_readlane_b32 of spilled plane offsets and 87 address adds.
-#ifdef RDYHIP_MUSCL_LDS_SOA
-#define MSQ(k, j) sq[(k) * nq + (j)]
-#define MSG(k, j) sg[(k) * ng + (j)]
-#define MEF(c, e) ef[(c) * a.emax + (e)]
-#else
+// consecutive doubles, its gradient six (+ one of padding), an edge's (f0, f1, f2, amax) four -- so that every access to a
+// record is ONE address (slot x record size) plus immediate offsets the compiler folds into ds_read2_b64 / ds_write2_b64.
+// With one plane per component (the layout of swe_kernels.h) every plane's runtime offset costs an SGPR, and the kernel
+// ran out of them: phase 1 alone held 161 v_readlane_b32 of spilled plane offsets and 87 address adds.
 #define MSQ(k, j) sq[5 * (j) + (k)]
 #define MSG(k, j) sg[MUSCL_GS * (j) + (k)]
 #define MEF(c, e) ef[MUSCL_ES * (e) + (c)]
-#endif
 // record strides in doubles (gradient: 6 values, edge flux: 4 values).  The gradient records are padded to 7: an odd
 // stride spreads consecutive records over all LDS banks (6 -> 7: -1.6 % on the 10 M-cell RHS; padding the flux records
 // to 5 as well changes nothing more)
@@ -150,11 +144,9 @@ constexpr int LIMITER_MINMOD = 0, LIMITER_NONE = 1, LIMITER_VANLEER = 2;
 template <int LIM>
 __device__ __forceinline__ double limit_slope(double extrap, double half_dq) {
   if (LIM == LIMITER_NONE) return extrap;
-#ifndef RDYHIP_MINMOD_BRANCHY
   // minmod(a, b) = "0 if the signs differ, else the one of smaller magnitude" is the median of (a, b, 0): four min / max
   // operations instead of a multiply, two compares and two 64-bit selects
   if (LIM == LIMITER_MINMOD) return fmax(fmin(extrap, half_dq), fmin(fmax(extrap, half_dq), 0.0));
-#endif
   if (extrap * half_dq <= 0.0) return 0.0;
   if (LIM == LIMITER_VANLEER) return 2.0 * extrap * half_dq * rdy_rcp(extrap + half_dq);
   return fabs(extrap) < fabs(half_dq) ? extrap : half_dq;
