@@ -764,7 +764,7 @@ static int build_host_layout(const RDyHipConfig *config, const RDyHipMesh *mesh,
   const bool    muscl_on = L.muscl_on;
   const auto   &o2l      = L.o2l;
   const bool   hr_on     = config->well_balancing == RDYHIP_WELL_BALANCING_HR;
-  const size_t lds_bytes = sizeof(double) * ((hr_on ? 6 : 5) * ((size_t)TILE + hmax) + 2 * (size_t)TILE + (hr_on ? 8 : 4) * (size_t)emax);
+  const size_t lds_bytes = sizeof(double) * ((hr_on ? 6 : 5) * ((size_t)TILE + hmax) + 2 * (size_t)TILE + (hr_on ? 6 : 4) * (size_t)emax);
   const char  *menv        = getenv("RDYHIP_MUSCL");
   const bool   muscl_fused = !(menv && strcmp(menv, "split") == 0);
   // second order, fused form: where the edge fluxes live (muscl_kernels.h) -- over the gradients when a tile's edges fit

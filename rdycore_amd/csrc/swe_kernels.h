@@ -331,8 +331,9 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
   double   *sd_h = lds, *sd_u = lds + nside, *sd_v = lds + 2 * nside, *sd_sq = lds + 3 * nside, *sd_c = lds + 4 * nside;
   double   *sd_hu = lds + 5 * nside, *sd_hv = sd_hu + TILE;
   double   *ef0 = sd_hv + TILE, *ef1 = ef0 + a.emax, *ef2 = ef1 + a.emax, *eam = ef2 + a.emax;
-  // HR only: bed elevation per slot; per edge the two pressure corrections and the normal
-  double   *sd_zc = eam + a.emax, *ecl = sd_zc + nside, *ecr = ecl + a.emax, *ecn = ecr + a.emax, *esn = ecn + a.emax;
+  // HR only: bed elevation per slot; per edge the momentum flux as the RIGHT cell sees it (ef1 / ef2 then hold the left
+  // cell's: the Roe flux plus each side's own pressure correction)
+  double   *sd_zc = eam + a.emax, *efr1 = sd_zc + nside, *efr2 = efr1 + a.emax;
   const int tid = threadIdx.x;
 
   // ---- this workgroup's tile sequence.  Block ids are dealt round-robin to the
@@ -515,19 +516,25 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
             fl     = roe_flux(Lr, Rr, sn, cn);
             const bool outer = !(R.h < a.tiny_h && L.h < a.tiny_h);       // 1094
             wet              = outer && (Lr.h > a.tiny_h || Rr.h > a.tiny_h);  // inner guard, 1112
-            // pressure correction, applied whenever the outer guard holds (1136-1152)
-            ecl[e] = outer ? 0.5 * GRAVITY * (L.h * L.h - Lr.h * Lr.h) : 0.0;
-            ecr[e] = outer ? 0.5 * GRAVITY * (R.h * R.h - Rr.h * Rr.h) : 0.0;
-            ecn[e] = cn;
-            esn[e] = sn;
+            // pressure correction g (h^2 - h*^2) / 2 n of each side, applied whenever the outer guard holds (1136-1152), the
+            // Roe flux only under the inner one: both folded into one momentum flux per side here, so that phase 2 reads
+            // four values per slot instead of seven
+            const double pl = outer ? 0.5 * GRAVITY * (L.h * L.h - Lr.h * Lr.h) : 0.0;
+            const double pr = outer ? 0.5 * GRAVITY * (R.h * R.h - Rr.h * Rr.h) : 0.0;
+            if (!wet) fl.f0 = fl.f1 = fl.f2 = 0.0;
+            efr1[e] = fma(pr, cn, fl.f1);
+            efr2[e] = fma(pr, sn, fl.f2);
+            fl.f1   = fma(pl, cn, fl.f1);
+            fl.f2   = fma(pl, sn, fl.f2);
           }
         } else {
-          if (HR) { ecl[e] = 0.0; ecr[e] = 0.0; ecn[e] = cn; esn[e] = sn; }  // boundary edges: HR is a no-op (operator_fluxes_petsc.c:57-58)
+          // boundary edges: HR is a no-op (operator_fluxes_petsc.c:57-58); their cell is the left one
           const int    k  = a.tile_bk[td.b_off + ((lr >> EDGE_R_SHIFT) & EDGE_SLOT_MASK)];
           BoundaryFlux bf = boundary_flux(a.btype[k], true, L, a.bvalues + 3 * (int64_t)k, sn, cn, a.tiny_h, a.h_anuga_sq);
           fl              = bf.flux;
           wet             = bf.wet;
           store_boundary_flux(a, k, fl, dt);
+          if (HR && !wet) fl.f0 = fl.f1 = fl.f2 = 0.0;  // phase 2 of the HR variant adds every edge's flux
         }
         ef0[e] = fl.f0;
         ef1[e] = fl.f1;
@@ -569,11 +576,19 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
             if (ref == SLOT_EMPTY) continue;
           }
           const double am = eam[ref];
-          if (am != -1.0) {
-            const double k = cur.coef[s];
+          const double k  = cur.coef[s];
+          if (HR) {
+            // a dry-dry edge (am == -1) carries zero Roe flux here but still its pressure correction
+            const bool left = k < 0.0;  // this cell is the edge's left (k < 0) or right cell
+            acc0 += ef0[ref] * k;
+            acc1 += (left ? ef1 : efr1)[ref] * k;
+            acc2 += (left ? ef2 : efr2)[ref] * k;
+          } else if (am != -1.0) {
             acc0 += ef0[ref] * k;
             acc1 += ef1[ref] * k;
             acc2 += ef2[ref] * k;
+          }
+          if (am != -1.0) {
             // len/area_self: the max over an edge's two cells is len / min(area_l, area_r) (swe_petsc.c:289)
             const double cnum = am * fabs(k) * dt;
             if (cnum > best) {
@@ -581,12 +596,6 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
               best_slot = s;
               best_o    = o;
             }
-          }
-          if (HR) {
-            const double k    = cur.coef[s];
-            const double corr = (k < 0.0) ? ecl[ref] : ecr[ref];  // this cell is the edge's left (k < 0) or right cell
-            acc1 += corr * ecn[ref] * k;
-            acc2 += corr * esn[ref] * k;
           }
         }
         acc_fdiv[0] = acc0;
