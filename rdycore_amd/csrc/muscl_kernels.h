@@ -628,9 +628,15 @@ __global__ __launch_bounds__(TILE) RDY_MUSCL_OCC void swe_rhs_muscl_fused_kernel
     __builtin_amdgcn_sched_barrier(0);
     if (tid + TILE < ne) x1 = do_edge(lr1, cs1, md1);
     if (!EFO && tid + TILE < ne) store_edge_flux(a, ef, tid + TILE, x1);
+    EdgeFlux x2 = {0.0, 0.0, 0.0, -1.0};
     if (!EFO) {
       for (int e = tid + 2 * TILE; e < ne; e += TILE)  // not slr: the fluxes overwrite it
         store_edge_flux(a, ef, e, do_edge(a.e_lr[td.e_off + e], a.e_cs[td.e_off + e], *reinterpret_cast<const double2 *>(g.e_mid + 2 * ((int64_t)td.e_off + e))));
+    } else if (S == 4) {
+      // quads: a 16 x 16 block has 544 edge records; the third round loads its records here (EFO: emax <= 3 TILE)
+      __builtin_amdgcn_sched_barrier(0);
+      const int e = tid + 2 * TILE;
+      if (e < ne) x2 = do_edge(a.e_lr[td.e_off + e], a.e_cs[td.e_off + e], *reinterpret_cast<const double2 *>(g.e_mid + 2 * ((int64_t)td.e_off + e)));
     }
 #ifndef RDYHIP_MUSCL_EARLY_STREAMS
     // the per-cell streams of phase 2 are requested only here: held from the tile's top they would cost 18 registers
@@ -651,6 +657,7 @@ __global__ __launch_bounds__(TILE) RDY_MUSCL_OCC void swe_rhs_muscl_fused_kernel
       __syncthreads();  // every edge has read its gradients: the fluxes may overwrite them
       if (tid < ne) store_edge_flux(a, ef, tid, x0);
       if (tid + TILE < ne) store_edge_flux(a, ef, tid + TILE, x1);
+      if (S == 4 && tid + 2 * TILE < ne) store_edge_flux(a, ef, tid + 2 * TILE, x2);
     }
     __syncthreads();
 

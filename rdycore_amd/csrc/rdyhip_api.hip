@@ -199,14 +199,13 @@ MusclKernelFn muscl_fused_fn_lim(int S, int src, bool ovw) {
     if (src) return ovw ? swe_rhs_muscl_fused_kernel<3, 1, true, LIM, false, EFO> : swe_rhs_muscl_fused_kernel<3, 1, false, LIM, false, EFO>;
     return ovw ? swe_rhs_muscl_fused_kernel<3, 0, true, LIM, false, EFO> : swe_rhs_muscl_fused_kernel<3, 0, false, LIM, false, EFO>;
   }
-  // EFO is a triangle-mesh layout (layout_build: S == 3 and emax <= 2 TILE)
-  if (src) return ovw ? swe_rhs_muscl_fused_kernel<4, 1, true, LIM> : swe_rhs_muscl_fused_kernel<4, 1, false, LIM>;
-  return ovw ? swe_rhs_muscl_fused_kernel<4, 0, true, LIM> : swe_rhs_muscl_fused_kernel<4, 0, false, LIM>;
+  if (src) return ovw ? swe_rhs_muscl_fused_kernel<4, 1, true, LIM, false, EFO> : swe_rhs_muscl_fused_kernel<4, 1, false, LIM, false, EFO>;
+  return ovw ? swe_rhs_muscl_fused_kernel<4, 0, true, LIM, false, EFO> : swe_rhs_muscl_fused_kernel<4, 0, false, LIM, false, EFO>;
 }
 template <int LIM, bool EFO>
 MusclKernelFn muscl_fused_euler_fn_lim(int S, int src) {
   if (S == 3) return src ? swe_rhs_muscl_fused_kernel<3, 1, true, LIM, true, EFO> : swe_rhs_muscl_fused_kernel<3, 0, true, LIM, true, EFO>;
-  return src ? swe_rhs_muscl_fused_kernel<4, 1, true, LIM, true> : swe_rhs_muscl_fused_kernel<4, 0, true, LIM, true>;
+  return src ? swe_rhs_muscl_fused_kernel<4, 1, true, LIM, true, EFO> : swe_rhs_muscl_fused_kernel<4, 0, true, LIM, true, EFO>;
 }
 template <bool EFO>
 MusclKernelFn muscl_fused_euler_fn_e(int S, int src, int limiter) {
@@ -771,7 +770,7 @@ static int build_host_layout(const RDyHipConfig *config, const RDyHipMesh *mesh,
   // two register rounds and the gradients' storage (every triangle mesh numbered with some locality), else behind the
   // first ring's records.  RDYHIP_MUSCL_EF_OVERLAY=0: measurement knob
   const char  *eenv      = getenv("RDYHIP_MUSCL_EF_OVERLAY");
-  const bool   muscl_efo = muscl_on && muscl_fused && L.S == 3 && emax <= 2 * TILE && MUSCL_ES * (size_t)emax <= MUSCL_GS * ((size_t)TILE + hmax) &&
+  const bool   muscl_efo = muscl_on && muscl_fused && emax <= (L.S == 3 ? 2 : 3) * TILE && MUSCL_ES * (size_t)emax <= MUSCL_GS * ((size_t)TILE + hmax) &&
                          !(eenv && atoi(eenv) == 0);
   const size_t ring2     = 5 * (size_t)(hmax2 - hmax) + ((size_t)emax + 1) / 2;
   const size_t lds_muscl = !muscl_on ? 0

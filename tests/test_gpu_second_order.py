@@ -271,14 +271,21 @@ def test_mixed_tri_quad_mesh_second_order():
     assert op.layout_info()["slots_per_cell"] == 4
 
 
+@pytest.mark.parametrize("kind", ["tri", "quad"])
 @pytest.mark.parametrize("limiter", [LIMITER_MINMOD, LIMITER_VANLEER])
-def test_both_flux_storage_layouts_give_the_same_bits(limiter, muscl_mode, monkeypatch):
-    """fused kernel: edge fluxes stored over the gradients (tiles of <= 2 x 256 edges, four workgroups per CU) or behind
-    the first ring's records (RDYHIP_MUSCL_EF_OVERLAY=0, the layout of every other mesh) -- storage only, same arithmetic"""
+def test_both_flux_storage_layouts_give_the_same_bits(limiter, kind, muscl_mode, monkeypatch):
+    """fused kernel: edge fluxes stored over the gradients (tiles whose edges fit the register rounds -- 2 x 256 for
+    triangles, 3 x 256 for quads --, four workgroups per CU) or behind the first ring's records
+    (RDYHIP_MUSCL_EF_OVERLAY=0, the layout of every other mesh) -- storage only, same arithmetic"""
     if muscl_mode != "fused":
         pytest.skip("layouts of the fused kernel")
     torch = _torch()
-    case = second_order(tri_mms_case(64, 48, SOURCE_SEMI_IMPLICIT, order="tiled"), limiter)
+    if kind == "tri":
+        case = second_order(tri_mms_case(64, 48, SOURCE_SEMI_IMPLICIT, order="tiled"), limiter)
+    else:
+        K = 2 * np.pi / 37
+        mesh = M.structured_quad_mesh(80, 64, 1.0, 1.0, zfunc=CS.mms_bathymetry(K=K))
+        case = second_order(CS.friction_slope_case(mesh, 80, 64, dt=1e-2, K=K), limiter)
     u = torch.tensor(case.u_local, dtype=torch.float64, device="cuda")
     out, lds = [], []
     for overlay in ("1", "0"):

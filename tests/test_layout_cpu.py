@@ -102,3 +102,29 @@ def test_argument_errors_of_create_without_a_device():
     assert _code(lambda: probe_layout(RDyFlowConfig(well_balancing=1), base)) == 83                        # BS2002: CEED only
     assert _code(lambda: probe_layout(RDyFlowConfig(source_method=5), base)) == 83
     assert _code(lambda: probe_layout(RDyFlowConfig(second_order=True, limiter=9), base)) == 83
+
+
+def test_second_order_flux_storage_is_chosen_from_the_tiles(monkeypatch):
+    """fused second-order kernel: the edge fluxes take the gradients' LDS storage when every tile's edges fit the kernel's
+    register rounds (2 x 256 for triangles, 3 x 256 for quads) -- a smaller workgroup footprint, four per CU on the
+    benchmark meshes -- and the separate region otherwise (rdyhip_api.hip: layout_build; RDYHIP_MUSCL_EF_OVERLAY=0 forces it)"""
+    def lds(mesh, case, overlay):
+        monkeypatch.setenv("RDYHIP_MUSCL_EF_OVERLAY", overlay)
+        case.config.second_order = True
+        return probe_layout(case.config, mesh, case.condition_types)
+
+    tri = M.structured_tri_mesh(96, 64, order="tiled")
+    ctri = CS.friction_slope_case(tri, 96.0, 64.0, dt=1e-3)
+    a, b = lds(tri, ctri, "1"), lds(tri, ctri, "0")
+    assert a["max_tile_edges"] <= 512 and a["lds_bytes"] < b["lds_bytes"] and a["lds_bytes"] <= 40 * 1024
+    quad = CS.dam_break_quads_mesh(640, 320, 0, 1, order="tiled")
+    cq = CS.dam_break_quads_case(quad)
+    a, b = lds(quad, cq, "1"), lds(quad, cq, "0")
+    assert 512 < a["max_tile_edges"] <= 768 and a["lds_bytes"] < b["lds_bytes"] and a["lds_bytes"] <= 40 * 1024
+    # a numbering without locality: more edges per tile than the register rounds hold -> the separate region either way
+    rng = np.random.default_rng(0)
+    xyz, conn, _, _ = M.structured_tri_connectivity(96, 64)
+    rnd = M.build_mesh(xyz, conn[rng.permutation(conn.shape[0])], boundary_classifier=M.box_side_boundaries(0.0, 96.0, 0.0, 64.0))
+    cr = CS.friction_slope_case(rnd, 96.0, 64.0, dt=1e-3)
+    a, b = lds(rnd, cr, "1"), lds(rnd, cr, "0")
+    assert a["max_tile_edges"] > 512 and a["lds_bytes"] == b["lds_bytes"]
