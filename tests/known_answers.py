@@ -65,8 +65,9 @@ def entries():
         m = one_quad(theta)
         cn, sn, _ = edge_normals(m)
         fl = np.stack([np.zeros(4), 0.5 * G * h * h * cn, 0.5 * G * h * h * sn], axis=1)
+        # Courant number (swe_petsc.c:589-596): amax len / area dt with amax = chat + |uhat.n| = sqrt(g h) against a mirror state
         out[name] = dict(case=one_cell_case(m, (h, 0.0, 0.0), M.CONDITION_REFLECTING), flux=fl, rhs=np.zeros((1, 3)),
-                         exact=[("flux", 0)] if theta == 0.0 else [], tol=1e-14)
+                         exact=[("flux", 0)] if theta == 0.0 else [], tol=1e-14, courant=math.sqrt(G * h) * 0.1)
 
     # 2. reflecting wall, axis-aligned, flow along +x with speed u0: the walls with n = +-y see tangential flow only (pure
     #    pressure flux), the wall n = +x is hit head on (un = u0 >= 0: h u0^2 + g h^2/2 + h u0 sqrt(g h)), the wall n = -x
@@ -86,16 +87,20 @@ def entries():
                 a = 0.5 * (c * c / d + d)
         p = 0.5 * G * h * h
         fl[e] = [0.0, (h * un * un + p) * cn[e] + a * h * un * cn[e], p * sn[e]]
+    #    Courant number: the mirror state has uhat.n = 0 on every wall, so amax = sqrt(g h) on all four (the entropy fix
+    #    changes the dissipation, not amax)
     out["reflecting_normal_flow"] = dict(case=one_cell_case(m, (h, h * u0, 0.0), M.CONDITION_REFLECTING), flux=fl, rhs=None,
-                                         exact=[("flux", 0)], tol=1e-14)
+                                         exact=[("flux", 0)], tol=1e-14, courant=math.sqrt(G * h) * 0.1)
 
     # 3. Dirichlet boundary whose value is the cell's own state: identical states -> the physical flux; the closed sum over
     #    the cell vanishes, so F = 0
     st = (1.7, 1.7 * 0.4, 1.7 * -0.3)
     m = one_quad(0.21)
     cn, sn, _ = edge_normals(m)
+    #    Courant number: identical states -> uhat = u, chat = sqrt(g h): the largest |u.n| + c over the four edges
     out["dirichlet_same_state"] = dict(case=one_cell_case(m, st, M.CONDITION_DIRICHLET, bvalues=st),
-                                       flux=physical_flux(st[0], 0.4, -0.3, cn, sn), rhs=np.zeros((1, 3)), exact=[], tol=1e-14)
+                                       flux=physical_flux(st[0], 0.4, -0.3, cn, sn), rhs=np.zeros((1, 3)), exact=[], tol=1e-14,
+                                       courant=float(np.max(np.abs(0.4 * cn - 0.3 * sn)) + math.sqrt(G * st[0])) * 0.1)
 
     # 4. critical outflow (src/swe/swe_petsc.c:465-503): the outside state has the discharge of the inside one at Froude
     #    number 1: h_r = (q^2/g)^(1/3), velocity sqrt(g h_r) n.  If the inside flow is itself critical towards the edge

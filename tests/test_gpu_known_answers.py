@@ -24,7 +24,8 @@ def gpu_apply(case):
 def test_hip_operator_reproduces_the_known_answer(name, rdyhip_kernel):
     ent = KA.entries()[name]
     f, op = gpu_apply(ent["case"])
-    check(name, ent, f, op.boundary_fluxes(0), bitwise=False)
+    op.update_diagnostics()
+    check(name, ent, f, op.boundary_fluxes(0), bitwise=False, courant=op.get_diagnostics().max_courant_num)
     op.destroy()
 
 

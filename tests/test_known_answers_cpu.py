@@ -8,8 +8,10 @@ import known_answers as KA
 from helpers import oracle_from_case
 
 
-def check(name, ent, f, bflux, bitwise=True):
+def check(name, ent, f, bflux, bitwise=True, courant=None):
     tol = ent["tol"]
+    if ent.get("courant") is not None:
+        assert courant is not None and abs(courant - ent["courant"]) <= 1e-14 * ent["courant"], (name, courant, ent["courant"])
     scale = lambda a: max(1.0, float(np.nanmax(np.abs(a)))) if np.size(a) else 1.0
     if ent.get("rhs") is not None:
         assert np.max(np.abs(f - ent["rhs"])) <= tol * scale(ent["rhs"]) , (name, f, ent["rhs"])
@@ -36,7 +38,7 @@ def test_oracle_reproduces_the_known_answer(name):
     case = ent["case"]
     orc = oracle_from_case(case)
     f = orc.apply(case.dt, case.u_local)
-    check(name, ent, f, orc.boundary_fluxes[0].copy())
+    check(name, ent, f, orc.boundary_fluxes[0].copy(), courant=orc.diagnostics()[0])
 
 
 def test_critical_outflow_inflow_side_contributes_nothing():
