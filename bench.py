@@ -247,14 +247,19 @@ def cpu_baseline_openmp(args):
 
 
 def kernel_sha(second_order: bool = False) -> str:
-    """hash of the kernel sources: ties a stored PMC traffic figure to the code it was measured on (the first-order /
-    HR kernels do not depend on muscl_kernels.h)"""
+    """hash of the kernel sources (comments and white space stripped): ties a stored PMC traffic figure to the code it was
+    measured on (the first-order / HR kernels do not depend on muscl_kernels.h)"""
+    import re
     h = hashlib.sha256()
     for name in KERNEL_SOURCES:
         if name == "muscl_kernels.h" and not second_order:
             continue
-        with open(os.path.join(ROOT, "rdycore_amd", "csrc", name), "rb") as fh:
-            h.update(fh.read())
+        with open(os.path.join(ROOT, "rdycore_amd", "csrc", name), "r") as fh:
+            text = fh.read()
+        # the code, not its commentary: comments and white space do not change what the compiler sees
+        text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+        text = re.sub(r"//[^\n]*", " ", text)
+        h.update(" ".join(text.split()).encode())
     return h.hexdigest()[:16]
 
 
