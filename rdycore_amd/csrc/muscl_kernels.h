@@ -419,9 +419,10 @@ __global__ __launch_bounds__(TILE) RDY_MUSCL_OCC void swe_rhs_muscl_fused_kernel
   // LDS: gradients of own + first-ring cells | state of own + first-ring cells | a region that holds the second ring's
   // state (its head, contiguous with the first ring's records) and the tile's edge records (its tail), both read by
   // the gradient phase only (the edge phase has its records in registers).  The edge fluxes take over dead storage:
-  // with EFO (a tile has at most 2 TILE edges: every well-numbered triangle mesh) the gradients' -- 34 KB per workgroup
-  // on the 10 M-cell benchmark mesh, so FOUR workgroups share a CU's 160 KB --, otherwise that third region, grown
-  // to 4 emax doubles (43 KB on the same mesh: three workgroups).
+  // with EFO (a tile's edges fit the register rounds of the edge phase: 2 TILE for triangles, 3 TILE for quads -- every
+  // mesh numbered with some locality) the gradients' -- 37 KB per workgroup on the 10 M-cell benchmark mesh, so FOUR
+  // workgroups share a CU's 160 KB --, otherwise that third region, grown to 4 emax doubles (45 KB on the same mesh:
+  // three workgroups).
   extern __shared__ double lds[];
   const int nq = TILE + g.hmax2;  // state + centroid records: own, first ring, second ring
   const int ng = TILE + a.hmax;   // gradient records: own, first ring

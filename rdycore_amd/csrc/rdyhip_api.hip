@@ -767,8 +767,8 @@ static int build_host_layout(const RDyHipConfig *config, const RDyHipMesh *mesh,
   const char  *menv        = getenv("RDYHIP_MUSCL");
   const bool   muscl_fused = !(menv && strcmp(menv, "split") == 0);
   // second order, fused form: where the edge fluxes live (muscl_kernels.h) -- over the gradients when a tile's edges fit
-  // two register rounds and the gradients' storage (every triangle mesh numbered with some locality), else behind the
-  // first ring's records.  RDYHIP_MUSCL_EF_OVERLAY=0: measurement knob
+  // the kernel's register rounds (two for triangles, three for quads) and the gradients' storage (every mesh numbered
+  // with some locality), else behind the first ring's records.  RDYHIP_MUSCL_EF_OVERLAY=0: measurement knob
   const char  *eenv      = getenv("RDYHIP_MUSCL_EF_OVERLAY");
   const bool   muscl_efo = muscl_on && muscl_fused && emax <= (L.S == 3 ? 2 : 3) * TILE && MUSCL_ES * (size_t)emax <= MUSCL_GS * ((size_t)TILE + hmax) &&
                          !(eenv && atoi(eenv) == 0);
