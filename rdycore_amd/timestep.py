@@ -7,6 +7,10 @@ evaluations, with the state kept on the GPU.
     one pass over the mesh (rdyhip_euler_step: the update rides on the RHS kernel's
     stores, F is never written, two state arrays ping-pong); `fused=False` keeps the
     RHS + axpy pair.
+  * classical Runge-Kutta (`temporal="rk4"`: the reference's `numerics.temporal: rk4` = TSRK with TSRK4,
+    src/rdysetup.c:1187-1189): four RHS evaluations per step on the stage states U, U + dt/2 k1, U + dt/2 k2, U + dt k3
+    -- each one OperatorRHSFunction with its ghost update and the FULL step's dt in the friction term (TSGetTimeStep,
+    src/rdysetup.c:1129) -- then U += dt/6 (k1 + 2 k2 + 2 k3 + k4).  Stage vectors stay on the device.
   * RDyAdvance (src/rdyadvance.c:261-383): advance to the next coupling time
     with the last step shortened to land on it (TS_EXACTFINALTIME_MATCHSTEP),
     and, when adaptive time stepping is on, rescale dt from the previous
@@ -56,7 +60,13 @@ class AdaptiveTime:
 
 
 class EulerStepper:
-    def __init__(self, op, halo=None, adaptive: Optional[AdaptiveTime] = None, fused: bool = True, forcing=None):
+    """the explicit TS of RDyAdvance: forward Euler (default) or, with temporal="rk4", classical Runge-Kutta"""
+
+    def __init__(self, op, halo=None, adaptive: Optional[AdaptiveTime] = None, fused: bool = True, forcing=None, temporal: str = "euler"):
+        if temporal not in ("euler", "rk4"):
+            raise ValueError(f"temporal = {temporal!r}: the explicit path has euler and rk4 (include/private/rdyconfigimpl.h:110-115)")
+        self.temporal = temporal
+        self._stage = None           # rk4: the stage state (local size) and k1..k4 (owned rows)
         self.op = op
         self.forcing = forcing   # rdycore_amd.forcing.Forcing: applied at the start of every interval, as the
                                  # driver calls RDyApplyForcing before each RDyAdvance (driver/main.c time loop)
@@ -100,7 +110,9 @@ class EulerStepper:
             self._u2 = torch.empty_like(u_local)
         while self.time < t_end * (1.0 - 1e-14):
             h = min(dt, t_end - self.time)       # TS_EXACTFINALTIME_MATCHSTEP
-            if self.fused:
+            if self.temporal == "rk4":
+                self._rk4_step(h, u_local)
+            elif self.fused:
                 nxt = self._u2 if cur is u_local else u_local
                 if self.halo is not None and self.halo.world > 1:
                     self.halo.step_overlapped(self.op, h, cur, nxt)
@@ -113,10 +125,25 @@ class EulerStepper:
             self.time += h
             self.step += 1
         if cur is not u_local:
-            u_local.copy_(cur)                   # an odd number of steps ended in the second buffer
+            u_local.copy_(cur)                   # an odd number of steps ended in the second buffer (euler, fused)
         if a is not None:
             # UpdateOperatorDiagnostics: local 16-byte copy + the MPI_Allreduce(max) of src/operator.c:879
             self.op.update_diagnostics()
             self.courant = reduce_courant(self.op.get_diagnostics(), u_local.device)
             self.max_courant = self.courant.max_courant_num
         return dt
+
+    def _rk4_step(self, h: float, u_local: torch.Tensor):
+        """TSStep_RK with the TSRK4 tableau (A = [[0], [1/2], [0, 1/2], [0, 0, 1]], b = [1/6, 1/3, 1/3, 1/6]): every stage
+        is one OperatorRHSFunction on the stage state; the diagnostics left behind are the last stage's, as in the reference"""
+        no = self.op.mesh.num_owned_cells
+        if self._stage is None or self._stage[0].shape != u_local.shape:
+            self._stage = [torch.empty_like(u_local)] + [torch.empty((no, 3), dtype=torch.float64, device=u_local.device) for _ in range(4)]
+        y, k = self._stage[0], self._stage[1:]
+        self.rhs(h, u_local, k[0])
+        for j, a in ((1, 0.5), (2, 0.5), (3, 1.0)):
+            y.copy_(u_local)                       # ghost rows are refreshed by the stage's own exchange
+            self.op.axpy_owned(a * h, k[j - 1], y)
+            self.rhs(h, y, k[j])
+        for j, b in enumerate((1.0 / 6.0, 1.0 / 3.0, 1.0 / 3.0, 1.0 / 6.0)):
+            self.op.axpy_owned(b * h, k[j], u_local)

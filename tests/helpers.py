@@ -57,3 +57,16 @@ def second_order_oracle_ranks(cases):
     for o, c, f in zip(orcs, cases, fs):
         o.apply_rest(c.dt, c.u_local, f)
     return fs, orcs
+
+
+def oracle_rk4(orc, u, dt, nsteps):
+    """classical Runge-Kutta (TSRK4, src/rdysetup.c:1187-1189) driven by the oracle's RHS on one rank: every stage
+    is OperatorRHSFunction with the full step's dt (src/rdysetup.c:1129)"""
+    u = u.copy()
+    for _ in range(nsteps):
+        k1 = orc.apply(dt, u)
+        k2 = orc.apply(dt, u + 0.5 * dt * k1)
+        k3 = orc.apply(dt, u + 0.5 * dt * k2)
+        k4 = orc.apply(dt, u + dt * k3)
+        u = u + dt * (k1 / 6.0 + k2 / 3.0 + k3 / 3.0 + k4 / 6.0)
+    return u

@@ -312,3 +312,27 @@ def test_flat_dam_break_state_one_million_cells(rdyhip_kernel):
     assert rel_linf(f, fo) <= TOL
     op.update_diagnostics()
     assert abs(op.get_diagnostics().max_courant_num - orc.diagnostics()[0]) <= 1e-12
+
+
+def test_rk4_advance_matches_oracle_loop():
+    """numerics.temporal: rk4 (TSRK4, src/rdysetup.c:1187-1189) on ex2b: the device-resident stages of
+    rdycore_amd/timestep.py against the oracle-driven Runge-Kutta loop, 40 steps"""
+    torch = _torch()
+    from rdycore_amd.timestep import EulerStepper
+    from helpers import oracle_rk4
+    case = CS.ex2b_case(os.path.join(ROOT, "tests", "golden", "planar_dam_10x5.msh"))
+    op = CS.create_operator(case)
+    orc = oracle_from_case(case)
+    u = torch.tensor(case.u_local, dtype=torch.float64, device="cuda")
+    st = EulerStepper(op, temporal="rk4")
+    dt, n = 0.01, 40
+    st.advance(u, dt, n * dt)
+    torch.cuda.synchronize()
+    assert st.step == n
+    ref = oracle_rk4(orc, case.u_local, dt, n)
+    assert rel_linf(u.cpu().numpy(), ref) <= 1e-10
+    # and it is not the Euler trajectory
+    ue = torch.tensor(case.u_local, dtype=torch.float64, device="cuda")
+    EulerStepper(op).advance(ue, dt, n * dt)
+    assert rel_linf(ue.cpu().numpy(), ref) > 1e-6
+    op.destroy()

@@ -113,6 +113,20 @@ def _worker(rank, world, port, kernel, q, second_order=False, transport="torch",
         g2row = {int(g): i for i, g in enumerate(gc.mesh.cell_global_ids)}
         rows = np.array([g2row[int(g)] for g in mesh.cell_global_ids[mesh.cell_owned_to_local]])
         err = rel_linf(f.cpu().numpy(), fg[rows])
+        if kind == "strips":
+            # two classical Runge-Kutta steps (temporal: rk4): four overlapped RHS evaluations each, against the
+            # single-rank oracle loop on the undivided mesh
+            from rdycore_amd.timestep import EulerStepper
+            from helpers import oracle_rk4
+            urk = torch.tensor(case.u_local, dtype=torch.float64, device=dev)
+            EulerStepper(op, halo=halo, temporal="rk4").advance(urk, case.dt, 2 * case.dt)
+            torch.cuda.synchronize()
+            ug = oracle_rk4(og, gc.u_local, gc.dt, 2)
+            own = mesh.cell_owned_to_local
+            err = max(err, rel_linf(urk.cpu().numpy()[own], ug[rows]))
+            halo.rhs_overlapped(op, case.dt, u, f)       # diagnostics of a plain RHS again
+            og.reset_diagnostics()
+            og.apply(gc.dt, gc.u_local)
         # UpdateOperatorDiagnostics: local 16 bytes + the struct-max across ranks, ids included (src/operator.c:705-715, 879)
         op.update_diagnostics()
         red = reduce_courant(op.get_diagnostics(), dev)
@@ -248,3 +262,26 @@ def test_bench_self_launches_two_ranks(rdyhip_kernel):
         assert d["scaling"] == ("strong" if "c5" in extra else "weak") and d["value"] > 0
         assert d["config"]["halo_driver"] == driver and d["config"]["halo_bytes_per_rank"] > 0
         assert d["config"]["max_courant"] > 0 and d["config"]["max_courant_cell"] >= 0
+
+
+@pytest.mark.timeout(600)
+def test_bench_under_torch_distributed_run(rdyhip_kernel):
+    """the driver's other way of starting N ranks: `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`
+    (RANK / WORLD_SIZE come from the launcher, bench.py must not start ranks of its own): one line, from rank 0"""
+    if rdyhip_kernel == "cell":
+        pytest.skip("one kernel variant is enough")
+    import json
+    import subprocess
+    from rdycore_amd.launch import free_port
+    env = dict(os.environ, BENCH_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5",
+           "--nx", "200", "--ny", "200", "--condition-seconds", "0.2", "--watchdog-seconds", "150"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=400, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.lstrip().startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["world_size"] == 2 and d["config"]["finite"] is True and d["value"] > 0
