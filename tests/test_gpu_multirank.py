@@ -124,6 +124,26 @@ def _worker(rank, world, port, kernel, q, second_order=False, transport="torch",
             ug = oracle_rk4(og, gc.u_local, gc.dt, 2)
             own = mesh.cell_owned_to_local
             err = max(err, rel_linf(urk.cpu().numpy()[own], ug[rows]))
+            # the water-volume budget ACROSS ranks over six overlapped Euler steps: a cut edge is evaluated by both ranks
+            # from identical operands, so what one rank's cell loses the other rank's cell gains, to the last bit
+            ub = torch.tensor(case.u_local, dtype=torch.float64, device=dev)
+            area = mesh.cell_areas[own]
+            v0 = float((area * ub.cpu().numpy()[own, 0]).sum())
+            st = EulerStepper(op, halo=halo)
+            out = 0.0
+            dtb = 0.1 * case.dt                          # small enough for the second-order scheme at this case's dry disc
+            for _ in range(6):
+                st.advance(ub, dtb, dtb)
+                for b, bnd in enumerate(mesh.boundaries):
+                    mine = mesh.cell_is_owned[mesh.edge_cell_ids[2 * bnd.edge_ids]] != 0
+                    fl = op.boundary_fluxes(b)[:, 0]
+                    out += dtb * float(np.nansum((fl * mesh.edge_lengths[bnd.edge_ids])[mine]))
+            torch.cuda.synchronize()
+            v1 = float((area * ub.cpu().numpy()[own, 0]).sum())
+            rain = 6 * dtb * float((area * case.ext_src[:, 0]).sum())
+            tot = torch.tensor([v1 - v0, rain - out, v0], dtype=torch.float64)
+            dist.all_reduce(tot)
+            assert abs(float(tot[0] - tot[1])) <= 1e-12 * float(tot[2]), ("volume budget across ranks", tot.tolist())
             halo.rhs_overlapped(op, case.dt, u, f)       # diagnostics of a plain RHS again
             og.reset_diagnostics()
             og.apply(gc.dt, gc.u_local)
