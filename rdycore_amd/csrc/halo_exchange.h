@@ -121,6 +121,13 @@ int overlapped(RDyHipOperator op, RDyHipHalo h, double dt, double *u, double *f,
   // fork: the exchange starts once everything already enqueued on the caller's stream (the update that produced u) is done
   HIP_TRY(hipEventRecord(h->ev_fork, st));
   HIP_TRY(hipStreamWaitEvent(h->cs, h->ev_fork, 0));
+  // an error after the fork still joins the exchange stream back, so that the caller's stream stays ordered behind
+  // whatever was enqueued there
+  auto bail = [&](int code) -> int {
+    (void)hipEventRecord(h->ev_join, h->cs);
+    (void)hipStreamWaitEvent(st, h->ev_join, 0);
+    return code;
+  };
   if (!op->muscl) {
     // RCCL (asynchronous): the whole exchange is enqueued first, the interior tiles right behind it on the other stream.
     // A transport callback may block the host: there the interior tiles are enqueued before it is called, so that it
@@ -130,7 +137,7 @@ int overlapped(RDyHipOperator op, RDyHipHalo h, double dt, double *u, double *f,
     if (!rc) rc = halo_transfer(h, 3, h->cs);
     if (!rc) rc = halo_unpack(h, u, 3, h->cs);
     if (!rc && !h->transport) rc = part(RDYHIP_PHASE_INTERIOR, 1, false);
-    if (rc) return rc;
+    if (rc) return bail(rc);
     HIP_TRY(hipEventRecord(h->ev_join, h->cs));
     HIP_TRY(hipStreamWaitEvent(st, h->ev_join, 0));
     return part(RDYHIP_PHASE_HALO, 0, false);
@@ -148,7 +155,7 @@ int overlapped(RDyHipOperator op, RDyHipHalo h, double dt, double *u, double *f,
     if (!rc && !h->transport) rc = part(RDYHIP_PHASE_INTERIOR, 1, true);
     if (!rc) rc = launch_gradients(op, RDYHIP_PHASE_HALO, u, h->cs);
     if (!rc) rc = halo_exchange_on(h, op->d_grad.p, 6, h->cs);
-    if (rc) return rc;
+    if (rc) return bail(rc);
     HIP_TRY(hipEventRecord(h->ev_join, h->cs));
     HIP_TRY(hipStreamWaitEvent(st, h->ev_join, 0));
     return part(RDYHIP_PHASE_HALO, 0, true);
@@ -160,11 +167,11 @@ int overlapped(RDyHipOperator op, RDyHipHalo h, double dt, double *u, double *f,
   if (!rc) rc = halo_transfer(h, 3, h->cs);
   if (!rc) rc = halo_unpack(h, u, 3, h->cs);
   if (!rc && !h->transport) rc = launch_gradients(op, RDYHIP_PHASE_INTERIOR, u, st);
-  if (rc) return rc;
+  if (rc) return bail(rc);
   HIP_TRY(hipEventRecord(h->ev_join, h->cs));
   HIP_TRY(hipStreamWaitEvent(st, h->ev_join, 0));
   rc = launch_gradients(op, RDYHIP_PHASE_HALO, u, st);
-  if (rc) return rc;
+  if (rc) return bail(rc);
   h->next_events();
   HIP_TRY(hipEventRecord(h->ev_fork, st));
   HIP_TRY(hipStreamWaitEvent(h->cs, h->ev_fork, 0));
@@ -173,7 +180,7 @@ int overlapped(RDyHipOperator op, RDyHipHalo h, double dt, double *u, double *f,
   if (!rc) rc = halo_transfer(h, 6, h->cs);
   if (!rc) rc = halo_unpack(h, op->d_grad.p, 6, h->cs);
   if (!rc && !h->transport) rc = part(RDYHIP_PHASE_INTERIOR, 1, true);
-  if (rc) return rc;
+  if (rc) return bail(rc);
   HIP_TRY(hipEventRecord(h->ev_join, h->cs));
   HIP_TRY(hipStreamWaitEvent(st, h->ev_join, 0));
   return part(RDYHIP_PHASE_HALO, 0, true);
