@@ -315,6 +315,7 @@ int rdyhip_unpack_rows(double *dst, int32_t ncomp, const int32_t *row_ids, int32
  *                        second-order gradients, CommunicateCellGradients), all on `stream`
  *   rdyhip_rhs_overlapped        = halo update of u_local + rdyhip_rhs_function, overlapped (the whole OperatorRHSFunction)
  *   rdyhip_euler_step_overlapped = halo update of u_local + rdyhip_euler_step(PHASE_ALL), overlapped
+ * The tiles that need ghost data follow the unpack on the library's stream, beside the tail of the other tiles.
  * Second order: the state exchange hides behind the tiles that need no ghost data, then the ghost-adjacent gradients are
  * computed, exchanged (6 values per cell) and the remaining tiles follow.  The exchanges are ordered after everything
  * already enqueued on `stream`; when the call returns all work is enqueued and later work on `stream` is ordered after it. */

@@ -109,12 +109,20 @@ int overlapped(RDyHipOperator op, RDyHipHalo h, double dt, double *u, double *f,
     if (rc0) return rc0;
   }
   op->courant = RDyHipCourant{0.0, -1, -1};
+  // The halo tiles go on the exchange stream right behind the unpack, i.e. they run beside the interior tiles' tail
+  // instead of in a launch of their own after the join (-10 us per step): the two launches write disjoint rows, and
+  // each owns one half of the Courant buckets.  Not with the separate Euler update of the cell-centric kernel, which
+  // reads all of F once the halo phase is through, nor with the split second-order form (its own schedule below).
+  // RDYHIP_HALO_CONCURRENT=0: measurement knob
+  const char *cenv = getenv("RDYHIP_HALO_CONCURRENT");
+  const bool  conc = !(cenv && atoi(cenv) == 0) && (!op->muscl || op->muscl_fused) && (!u_out || op->use_tiled);
   auto part = [&](int32_t phase, int reset, bool ready) -> int {
+    if (conc && phase == RDYHIP_PHASE_HALO) return launch_rhs(op, phase, 1, 1, dt, u, f, h->cs, ready, u_out, 2);
     if (reset && phase == RDYHIP_PHASE_HALO && (op->use_tiled ? op->n_halo_tiles == 0 : op->n_halo == 0)) {
       const int rc = rdyhip_reset_diagnostics(op, (void *)st);
       if (rc) return rc;
     }
-    return launch_rhs(op, phase, 1, reset, dt, u, f, st, ready, u_out);
+    return launch_rhs(op, phase, 1, reset, dt, u, f, st, ready, u_out, conc && phase == RDYHIP_PHASE_INTERIOR ? 1 : 0);
   };
   int rc;
   h->next_events();
@@ -137,10 +145,11 @@ int overlapped(RDyHipOperator op, RDyHipHalo h, double dt, double *u, double *f,
     if (!rc) rc = halo_transfer(h, 3, h->cs);
     if (!rc) rc = halo_unpack(h, u, 3, h->cs);
     if (!rc && !h->transport) rc = part(RDYHIP_PHASE_INTERIOR, 1, false);
+    if (!rc && conc) rc = part(RDYHIP_PHASE_HALO, 0, false);
     if (rc) return bail(rc);
     HIP_TRY(hipEventRecord(h->ev_join, h->cs));
     HIP_TRY(hipStreamWaitEvent(st, h->ev_join, 0));
-    return part(RDYHIP_PHASE_HALO, 0, false);
+    return conc ? 0 : part(RDYHIP_PHASE_HALO, 0, false);
   }
   // ApplyInteriorFlux2R (src/swe/swe_petsc.c:98-213) needs two exchanges: the state, then the gradients of the ghost
   // cells (CommunicateCellGradients).  No reverse exchange: every rank evaluates all edges of its owned cells.
@@ -155,10 +164,11 @@ int overlapped(RDyHipOperator op, RDyHipHalo h, double dt, double *u, double *f,
     if (!rc && !h->transport) rc = part(RDYHIP_PHASE_INTERIOR, 1, true);
     if (!rc) rc = launch_gradients(op, RDYHIP_PHASE_HALO, u, h->cs);
     if (!rc) rc = halo_exchange_on(h, op->d_grad.p, 6, h->cs);
+    if (!rc && conc) rc = part(RDYHIP_PHASE_HALO, 0, true);
     if (rc) return bail(rc);
     HIP_TRY(hipEventRecord(h->ev_join, h->cs));
     HIP_TRY(hipStreamWaitEvent(st, h->ev_join, 0));
-    return part(RDYHIP_PHASE_HALO, 0, true);
+    return conc ? 0 : part(RDYHIP_PHASE_HALO, 0, true);
   }
   // split kernels: the gradients of the cells without ghost neighbours hide the state exchange, the fluxes of the tiles
   // without ghost-adjacent cells (which read owned gradient rows only) hide the gradient exchange

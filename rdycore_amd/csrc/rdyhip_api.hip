@@ -281,8 +281,11 @@ int launch_gradients(RDyHipOperator op, int32_t phase, const double *u, hipStrea
   return 0;
 }
 
+// bucket_half: which of the Courant buckets (one per workgroup, merged on demand) the launch owns -- 0: all of them (every
+// ordinary launch); 1 / 2: the first / second half, for the interior and the halo launch of rdyhip_rhs_overlapped, which
+// run side by side on two streams and must not share a bucket
 int launch_rhs(RDyHipOperator op, int32_t phase, int32_t overwrite, int reset_diag, double dt, const double *u, double *f, hipStream_t st,
-               bool gradients_ready = false, double *u_out = nullptr) {
+               bool gradients_ready = false, double *u_out = nullptr, int bucket_half = 0) {
   if (!op) return fail(RDYHIP_ERR_USER, "null operator");
   // rdyhip_euler_step: the first-order / HR tiled kernel has the update fused into its stores (F optional); the
   // other kernels evaluate F (into a scratch vector if the caller wants none) and a separate update follows
@@ -332,6 +335,14 @@ int launch_rhs(RDyHipOperator op, int32_t phase, int32_t overwrite, int reset_di
   a.blk_max    = op->d_blk_max.p;
   a.blk_pos    = op->d_blk_pos.p;
   a.n_buckets  = (int32_t)op->d_blk_max.n;
+  if (bucket_half) {
+    const int32_t half = a.n_buckets / 2;
+    a.n_buckets = half;
+    if (bucket_half == 2) {
+      a.blk_max += half;
+      a.blk_pos += half;
+    }
+  }
   a.reset_diag = reset_diag ? 1 : 0;
   a.tiny_h     = op->config.tiny_h;
   a.h_anuga_sq = op->config.h_anuga_regular * op->config.h_anuga_regular;
@@ -987,8 +998,8 @@ int rdyhip_create(const RDyHipConfig *config, const RDyHipMesh *mesh, int32_t nu
   TRY_RC(op->d_bflux.zeros((size_t)3 * K));
   TRY_RC(op->d_baccum.zeros((size_t)3 * K));
   TRY_RC(op->d_pv.zeros((size_t)3 * no));
-  TRY_RC(op->d_blk_max.zeros((size_t)maxgrid));
-  TRY_RC(op->d_blk_pos.zeros((size_t)maxgrid));
+  TRY_RC(op->d_blk_max.zeros((size_t)2 * maxgrid));  // two halves: see launch_rhs(bucket_half)
+  TRY_RC(op->d_blk_pos.zeros((size_t)2 * maxgrid));
   TRY_RC(op->d_courant.zeros(1));
 #undef TRY_RC
   hipLaunchKernelGGL(courant_reset_kernel, dim3(4), dim3(1024), 0, 0, (int)op->d_blk_max.n, op->d_blk_max.p, op->d_blk_pos.p);
