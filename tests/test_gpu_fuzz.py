@@ -4,6 +4,8 @@ nearly-dry cells around tiny_h, supercritical and transcritical jumps (the Roe e
 src/swe/swe_roe_flux_petsc.h:56-67), inflow through critical-outflow edges, ANUGA velocity
 regularisation (h_anuga_regular > 0) -- for both friction methods, first and second order and
 hydrostatic reconstruction.  Tolerance 1e-10 as everywhere."""
+import os
+
 import numpy as np
 import pytest
 
@@ -66,7 +68,7 @@ def random_case(rng, mesh, cfg):
     return CS.Case("fuzz", mesh, cfg, ctypes, u, rng.uniform(0.01, 0.06, no), src, bvals, float(rng.choice([1e-3, 1e-2, 0.1])))
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("RDYHIP_FUZZ_SEEDS", "6"))))   # RDYHIP_FUZZ_SEEDS=200: a longer soak
 @pytest.mark.parametrize("variant", ["first", "second_minmod", "second_vanleer", "second_none", "hr"])
 def test_random_meshes_and_states(seed, variant, rdyhip_kernel):
     if rdyhip_kernel == "cell" and variant != "first":
