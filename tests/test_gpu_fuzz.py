@@ -81,7 +81,8 @@ def test_random_meshes_and_states(seed, variant, rdyhip_kernel):
         cfg.limiter = {"second_minmod": 0, "second_none": 1, "second_vanleer": 2}[variant]
     if variant == "hr":
         cfg.well_balancing = 2
-    mesh = random_tri_mesh(rng, int(rng.integers(9, 30)), int(rng.integers(7, 22)), project_2d=(variant == "hr"))
+    scale = int(os.environ.get("RDYHIP_FUZZ_SCALE", "1"))    # larger meshes for a soak run (many tiles per mesh)
+    mesh = random_tri_mesh(rng, scale * int(rng.integers(9, 30)), scale * int(rng.integers(7, 22)), project_2d=(variant == "hr"))
     case = random_case(rng, mesh, cfg)
     f, fr, op, orc = run_both(case)
     assert np.isfinite(fr).all()
