@@ -57,6 +57,9 @@ def _cases(kind, rank, world, second_order):
         gc = CS.dam_break_quads_case(g)
         for c in (case, gc):                  # a moving state (the benchmark's initial state is at rest)
             xc, yc = c.mesh.cell_centroids[:, 0], c.mesh.cell_centroids[:, 1]
+            # (the tilt of the depth makes the maximal Courant number unique: on the two flat pools several edges reach the
+            # same value to the last bit, and which of them a run reports depends on its loop order, i.e. on the partition)
+            c.u_local[:, 0] *= 1.0 + 1e-3 * xc / 10.0 + 2e-3 * yc / 5.0
             c.u_local[:, 1] = 0.3 * c.u_local[:, 0] * np.sin(1.7 * xc + 0.9 * yc)
             c.u_local[:, 2] = 0.2 * c.u_local[:, 0] * np.cos(1.1 * xc - 2.3 * yc)
         ekey = lambda e: e
@@ -153,6 +156,8 @@ def _worker(rank, world, port, kernel, q, second_order=False, transport="torch",
         cg, eg, cellg = og.diagnostics()
         ids_ok = red.global_cell_id == cellg and (red.global_edge_id == ekey(eg) if eg >= 0 else red.global_edge_id == -1)
         info = op.layout_info()
+        if not ids_ok:
+            print(f"rank {rank}: Courant struct-max {red} vs the oracle's ({cg}, edge {eg} = key {ekey(eg) if eg >= 0 else -1}, cell {cellg})", file=sys.stderr)
         q.put((rank, err, abs(red.max_courant_num - cg), bool(ids_ok), info["num_halo_tiles"], info["num_tiles"]))
         halo.destroy()
         op.destroy()
@@ -305,3 +310,15 @@ def test_bench_under_torch_distributed_run(rdyhip_kernel):
     assert len(lines) == 1, out.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["world_size"] == 2 and d["config"]["finite"] is True and d["value"] > 0
+
+
+@pytest.mark.timeout(300)
+def test_three_rcb_ranks_one_gpu_second_order_quads(rdyhip_kernel):
+    """second order on RCB parts of the dam-break quad mesh: irregular halos (a first ring that touches ghosts on two
+    sides of a part), the quads' three-round flux layout, the gradient exchange -- against the oracle on the undivided mesh"""
+    if rdyhip_kernel == "cell":
+        pytest.skip("second order is implemented by the tiled kernels")
+    for rank, err, cerr, ids_ok, nhalo_tiles, ntiles in _run(3, (rdyhip_kernel, True, "c", "rcb_quads")):
+        assert err <= 1e-10, (rank, err)
+        assert cerr <= 1e-10 and ids_ok
+        assert 0 < nhalo_tiles < ntiles
