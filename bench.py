@@ -48,6 +48,7 @@ LIMITERS = {"minmod": 0, "none": 1, "van_leer": 2}
 ALG_BYTES_PER_CELL_SECOND_ORDER = 176.0 + 16.0 + 24.0
 ALG_BYTES_PER_CELL_SECOND_ORDER_SPLIT = ALG_BYTES_PER_CELL_SECOND_ORDER + 96.0 + 24.0 + 16.0
 KERNEL_SOURCES = ["swe_kernels.h", "swe_device.h", "muscl_kernels.h"]
+HOUSTON_DATA = os.path.join(ROOT, "tests", "golden", "houston")   # the reference's Houston1km fixtures (data files, in the repo)
 
 
 def parse(argv=None):
@@ -55,13 +56,16 @@ def parse(argv=None):
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=200)
     p.add_argument("--warmup", type=int, default=20)
-    p.add_argument("--workload", default="c3", choices=["c3", "c2", "dambreak_quads", "c5"])
+    p.add_argument("--workload", default="c3", choices=["c3", "c2", "dambreak_quads", "c5", "houston_refined", "delaunay"])
+    p.add_argument("--levels", type=int, default=6, help="houston_refined: refinement levels of the 2 746-triangle Houston1km mesh (6: 11.2 M cells)")
     p.add_argument("--nx", type=int, default=None, help="squares along x (weak scaling: per rank; strong: of the whole mesh)")
     p.add_argument("--ny", type=int, default=None, help="squares along y")
     p.add_argument("--scaling", default=None, choices=["weak", "strong"],
                    help="weak: per-rank work fixed (default for c3 / c2); strong: one mesh cut into N parts by RCB (default for dambreak_quads / c5)")
-    p.add_argument("--order", default="tiled", choices=["rowmajor", "tiled", "hilbert"],
-                   help="cell numbering of the synthetic mesh: generator order, 16x16-square blocks, or squares along a Hilbert curve")
+    p.add_argument("--order", default=None, choices=["rowmajor", "tiled", "hilbert", "natural", "random"],
+                   help="cell numbering of the mesh: generator order, 16x16-square blocks (default of the structured workloads), cells along "
+                        "a Hilbert curve (default of the unstructured ones); unstructured only: natural = the order refinement / the "
+                        "triangulator leaves, random = a seeded permutation")
     p.add_argument("--source", default="semi_implicit", choices=["semi_implicit", "implicit_xq2018"])
     p.add_argument("--hr", action="store_true", help="hydrostatic-reconstruction variant of the operator (SURVEY 8.f row 2)")
     p.add_argument("--second-order", action="store_true", help="MUSCL second-order variant (SURVEY 8.f row 4)")
@@ -88,17 +92,28 @@ def parse(argv=None):
                    help="every rank dumps its Python stacks and exits non-zero if it is still running after this long (a hung "
                         "collective then becomes a reported failure instead of a silent hang); 0: off")
     a = p.parse_args(argv)
-    defaults = {"c3": (2500, 2000), "c2": (1000, 500), "dambreak_quads": (5120, 2560), "c5": (5000, 5000)}
+    defaults = {"c3": (2500, 2000), "c2": (1000, 500), "dambreak_quads": (5120, 2560), "c5": (5000, 5000), "houston_refined": (0, 0),
+                "delaunay": (1210, 1210)}
+    unstructured = a.workload in ("houston_refined", "delaunay")
+    if a.order is None:
+        a.order = "hilbert" if unstructured else "tiled"
+    if a.order not in (("hilbert", "natural", "random") if unstructured else ("rowmajor", "tiled", "hilbert")):
+        p.error(f"--order {a.order} does not apply to --workload {a.workload}")
     if a.nx is None:
         a.nx = defaults[a.workload][0]
     if a.ny is None:
         a.ny = defaults[a.workload][1]
+    if a.workload == "houston_refined":
+        a.nx, a.ny = a.levels, 0          # build_case's nx is the number of refinement levels here
+    if a.workload == "delaunay":
+        a.ny = a.nx
     if a.scaling is None:
-        a.scaling = "strong" if a.workload in ("dambreak_quads", "c5") else "weak"
-    if a.workload == "c5":
+        a.scaling = "strong" if a.workload in ("dambreak_quads", "c5", "houston_refined", "delaunay") else "weak"
+    if a.workload in ("c5", "delaunay"):
         a.hr = True
     if a.cpu_sample is None:
-        a.cpu_sample = {"c3": "1000x500", "c2": "1000x500", "dambreak_quads": "1280x640", "c5": "700x700"}[a.workload]
+        a.cpu_sample = {"c3": "1000x500", "c2": "1000x500", "dambreak_quads": "1280x640", "c5": "700x700", "houston_refined": "4x0",
+                        "delaunay": "500x500"}[a.workload]
     return a
 
 
@@ -134,6 +149,14 @@ def build_case(args, rank, world, nx=None, ny=None, order=None):
         nxg = nx if (strong or world == 1) else nx * world
         mesh = CS.dam_break_quads_mesh(nxg, ny, rank, world, order=order)
         case = CS.dam_break_quads_case(mesh)
+        case.config.source_method = src
+    elif wl == "houston_refined":
+        case = CS.houston_refined_case(HOUSTON_DATA, nx,      # nx = refinement levels here order if order in ("hilbert", "natural", "random") else "hilbert", hr=args.hr,
+                                       rank=rank, world=world)
+        case.config.source_method = src
+    elif wl == "delaunay":
+        mesh = CS.delaunay_mesh(nx, rank, world, order=order if order in ("hilbert", "natural", "random") else "hilbert")
+        case = CS.c5_case(mesh, nx * 1.0, nx * 1.0)
         case.config.source_method = src
     else:
         nxg = nx if (strong or world == 1) else nx * world
@@ -593,6 +616,18 @@ def run_rank(args, argv):
             workload = (f"the reference's dam-break benchmark (docs/user/example-cases/dam-break): {nxg}x{args.ny} quads minus the dam = "
                         f"{total_cells} cells ({n_owned} on rank 0), dx = dy = 10 m / {nxg}, h = 10 / 5 m at rest, Manning 0.015, "
                         f"all walls reflecting, {friction}, dt = 1.5625e-5 s")
+        elif args.workload == "houston_refined":
+            dry = float((case.u_local[mesh.cell_owned_to_local, 0] == 0.0).mean())
+            workload = (f"the reference's Houston1km real-DEM mesh (share/meshes/Houston1km_with_z.exo, 2746 triangles, ragged outline) refined "
+                        f"{args.levels} times as -dm_refine does = {total_cells} triangles ({n_owned} on rank 0), vertex z interpolated; state = the "
+                        f"parents' water surface of Houston1km.ic clipped at each child's bed ({dry:.0%} of the cells dry), rain and Dirichlet stage "
+                        f"from the reference's Houston1km.rain / .bc series at t = 7200 s, Manning 0.015, other boundary edges reflecting, "
+                        f"{friction}, dt = {case.dt:g} s")
+        elif args.workload == "delaunay":
+            dry = float((case.u_local[mesh.cell_owned_to_local, 0] == 0.0).mean())
+            workload = (f"genuinely unstructured: Delaunay triangulation of a jittered, smoothly graded {args.nx + 1}^2 point set (vertex valences "
+                        f"3..11, cell areas 1:9+) = {total_cells} triangles ({n_owned} on rank 0) over the C5 DEM, {dry:.0%} of the cells dry, rain "
+                        f"1e-5 m/s, Manning 0.03, critical-outflow segment + reflecting walls, hydrostatic reconstruction, {friction}, dt = 0.05 s")
         else:
             dry = float((case.u_local[mesh.cell_owned_to_local, 0] == 0.0).mean())
             workload = (f"C5 stand-in for the Harvey mesh: synthetic {nxg}x{args.ny}x2 triangles over a rough analytic DEM (ramp + 3 sinusoids), "
@@ -600,7 +635,7 @@ def run_rank(args, argv):
                         f"critical-outflow segment + reflecting walls, hydrostatic reconstruction, {friction}, dt = 0.05 s")
         traffic, traffic_src = (None, None)
         if world == 1 and args.emulate_world <= 1:
-            traffic, traffic_src = load_traffic(f"{args.workload}_{args.nx}x{args.ny}_{args.order}_{args.source}" + ("_hr" if args.hr and args.workload != "c5" else "")
+            traffic, traffic_src = load_traffic(f"{args.workload}_{args.nx}x{args.ny}_{args.order}_{args.source}" + ("_hr" if args.hr and args.workload not in ("c5", "delaunay") else "")
                                                 + ("_second_order_" + args.limiter if args.second_order else ""),
                                                 int(info["bytes_per_apply"]), args.second_order)
         if args.second_order:
@@ -642,6 +677,7 @@ def run_rank(args, argv):
                          "kernel": kname,
                          "algorithmic_bytes_per_cell": alg,
                          "tile_edge_records_per_cell": round(info["num_edge_records"] / max(n_owned, 1), 4),
+                         "halo_cells_per_tile": round(info["num_halo_entries"] / max(info["num_tiles"], 1), 2),
                          "kernel_avg_ms": round(kern_ms, 5),
                          "kernel_isolated_avg_ms": round(kern_isolated_ms, 5), "kernel_isolated_median_ms": round(float(np.median(kern_all)), 5),
                          "kernel_isolated_min_ms": round(float(np.min(kern_all)), 5),

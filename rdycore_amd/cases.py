@@ -288,3 +288,181 @@ def c5_case(mesh: RDyMesh, lx: float, ly: float, dt: float = 0.05) -> Case:
     src[:, 0] = 1e-5
     ctypes = [CONDITION_CRITICAL_OUTFLOW if b.name == "outlet" else CONDITION_REFLECTING for b in mesh.boundaries]
     return Case("c5_flood", mesh, RDyFlowConfig(well_balancing=WELL_BALANCING_HR), ctypes, u, np.full(no, 0.03), src, {}, dt)
+
+
+# ---------------------------------------------------------------------------
+# an UNSTRUCTURED real-DEM mesh at benchmark scale: the reference's Houston1km mesh refined as `-dm_refine` does
+# (src/rdydm.c:82-188); harvey-flooding.md:3-7 describes the production case this stands in for (Turning_30m, 2 926 532
+# triangles over a real DEM, rain forcing, an ocean stage boundary)
+# ---------------------------------------------------------------------------
+
+HOUSTON_DT = 30.0   # Houston1km.DirichletBC.yaml:13-18, halved with every refinement level
+
+
+def houston_refined_mesh(data_dir: str, levels: int = 6, order: str = "hilbert", project_2d: bool = False,
+                         rank: int = 0, world: int = 1):
+    """share/meshes/Houston1km_with_z.exo (2 746 triangles over the real DEM, in its file order) refined `levels` times by
+    edge midpoints, vertex z interpolated: 2 746 x 4^levels triangles (6 levels: 11 247 616) with the irregular valences,
+    the ragged outline and the side set of the original.  `order`: "natural" = children 4c..4c+3 of cell c (what DMPlex's
+    refinement leaves), "hilbert" = cells renumbered along a Hilbert curve through their centroids (what INTEGRATION.md asks
+    of a host before CreateOperator), "random" = a seeded permutation (worst case).  world > 1: this rank's RCB part.
+    Returns (mesh, parent): parent[c] = Houston1km cell that local cell c descends from."""
+    import os
+    from . import mesh as M
+    xyz, conn, side_sets = M.read_exodus(os.path.join(data_dir, "Houston1km_with_z.exo"))
+    te = M.side_sets_to_tagged_edges(side_sets, conn)
+    conn = conn[:, :3]
+    parent = np.arange(conn.shape[0], dtype=np.int64)
+    for _ in range(levels):
+        xyz, conn, te = M.refine_triangles(xyz, conn, te)
+        parent = np.repeat(parent, 4)
+    cent = (xyz[conn[:, 0], :2] + xyz[conn[:, 1], :2] + xyz[conn[:, 2], :2]) / 3.0
+    if order == "hilbert":
+        perm = M.hilbert_cell_order(cent)
+    elif order == "random":
+        perm = np.random.default_rng(20170826).permutation(conn.shape[0])
+    elif order == "natural":
+        perm = None
+    else:
+        raise ValueError(order)
+    if perm is not None:
+        conn, parent, cent = conn[perm], parent[perm], cent[perm]
+    if order == "hilbert":
+        # vertices along the same curve, so that cells and their vertices stay close in memory (host-side build speed only)
+        vperm = M.hilbert_cell_order(xyz)
+        vinv = np.empty(xyz.shape[0], dtype=np.int64)
+        vinv[vperm] = np.arange(xyz.shape[0])
+        xyz, conn = xyz[vperm], vinv[conn].astype(np.int32)
+        te = np.concatenate([vinv[te[:, :2]], te[:, 2:]], axis=1)
+    cls = M.boundaries_from_tagged_edges(te, {1: "bottom_wall"}, num_vertices=xyz.shape[0])
+    if world == 1:
+        return M.build_mesh(xyz, conn, boundary_classifier=cls, project_2d=project_2d), parent
+    from . import partition as P
+    part = P.rcb_partition(cent, world)
+    nvg = xyz.shape[0]
+
+    def cls_local(mesh):   # the tags are in global vertex ids
+        vg = mesh._vertex_global_ids
+        be = mesh.edge_boundary_ids
+        # artificial outer edges of ghost cells are no boundary of the domain: keep edges whose (only) cell is owned
+        own = mesh.cell_is_owned[mesh.edge_cell_ids[2 * be]] != 0
+        sub = dataclasses.replace(mesh, edge_boundary_ids=be[own], edge_vertex_ids=vg[mesh.edge_vertex_ids].astype(np.int64))
+        return cls(sub)
+    owned = part == rank
+    lm = _extract_with_vertex_ids(xyz, conn, owned, cls_local, project_2d, nvg)
+    keep = lm._cell_sel
+    return lm, parent[keep]
+
+
+def _extract_with_vertex_ids(xyz, conn, owned, classifier, project_2d, nvg):
+    """mesh.extract_local_mesh, with the selection of cells and the global vertex ids left on the mesh object for the
+    caller (parent lookup, boundary tags in global vertex ids)"""
+    from . import mesh as M
+    conn4 = np.concatenate([conn, -np.ones((conn.shape[0], 1), conn.dtype)], axis=1) if conn.shape[1] == 3 else conn
+    # the same selection extract_local_mesh makes (owned first, then the edge-adjacent ghosts in source order)
+    nv = xyz.shape[0]
+    a = np.concatenate([conn[:, 0], conn[:, 1], conn[:, 2]]).astype(np.int64)
+    b = np.concatenate([conn[:, 1], conn[:, 2], conn[:, 0]]).astype(np.int64)
+    cell = np.tile(np.arange(conn.shape[0]), 3)
+    key = np.minimum(a, b) * nv + np.maximum(a, b)
+    o = np.argsort(key, kind="stable")
+    ks = key[o]
+    same = ks[1:] == ks[:-1]
+    c1, c2 = cell[o[:-1]][same], cell[o[1:]][same]
+    keep = owned.copy()
+    keep[c2[owned[c1]]] = True
+    keep[c1[owned[c2]]] = True
+    sel = np.concatenate([np.nonzero(owned)[0], np.nonzero(keep & ~owned)[0]])
+    used = np.unique(conn[sel])
+
+    def wrapped(mesh):
+        mesh._vertex_global_ids = used
+        return classifier(mesh)
+    lm = M.extract_local_mesh(xyz, conn4, owned, boundary_classifier=wrapped, project_2d=project_2d,
+                              vertex_global_ids=np.arange(nv, dtype=np.int64), num_vertices_global=nvg)
+    lm._cell_sel = sel
+    assert lm.num_cells == sel.size
+    return lm
+
+
+def houston_refined_case(data_dir: str, levels: int = 6, order: str = "hilbert", hr: bool = False, time: float = 7200.0,
+                         rank: int = 0, world: int = 1) -> Case:
+    """The state and forcing of the reference's Houston1km test (Houston1km.DirichletBC.yaml with the homogeneous rain and
+    stage series of driver/tests/swe_roe/CMakeLists.txt:110-130, taken at `time`) on the refined mesh: every child cell
+    starts from its parent's water SURFACE (parent bed + parent depth, clipped at the child's own bed: wet/dry fronts along
+    every slope) and the parent's velocity; Manning 0.015; rain from Houston1km.rain.*.bin; side set 1 a Dirichlet stage
+    boundary from Houston1km.bc.*.bin (temporally interpolated), every other boundary edge reflecting; dt = 30 s / 2^levels."""
+    import os
+    from . import mesh as M
+    from .operator import WELL_BALANCING_HR
+    mesh, parent = houston_refined_mesh(data_dir, levels, order, project_2d=hr, rank=rank, world=world)
+    # the parents' bed elevation (vertex mean) and state, in the file's natural cell order
+    xyz0, conn0, _ = M.read_exodus(os.path.join(data_dir, "Houston1km_with_z.exo"))
+    zc0 = xyz0[conn0[:, :3], 2].mean(axis=1)
+    u0 = M.read_petsc_vec(os.path.join(data_dir, "Houston1km.ic.int32.bin")).reshape(-1, 3)
+    eta = zc0 + u0[:, 0]
+    vel = u0[:, 1:] / u0[:, :1]
+    h = np.maximum(0.0, eta[parent] - mesh.cell_zc)
+    h = np.where(h < 1e-3, 0.0, h)            # no sub-millimetre films: cells are either wet or exactly dry
+    u = np.stack([h, h * vel[parent, 0], h * vel[parent, 1]], axis=1)
+    rain = M.read_petsc_vec(os.path.join(data_dir, "Houston1km.rain.int32.bin")).reshape(-1, 2)
+    bc = M.read_petsc_vec(os.path.join(data_dir, "Houston1km.bc.int32.bin")).reshape(-1, 2)
+    i = int(np.searchsorted(rain[:, 0], time, side="right") - 1)
+    rate = float(rain[max(i, 0), 1])                                        # piecewise constant (no -temporally_interpolate)
+    stage = float(np.interp(time, bc[:, 0], bc[:, 1]))                      # -temporally_interpolate_bc
+    no = mesh.num_owned_cells
+    src = np.zeros((no, 3))
+    src[:, 0] = rate
+    ctypes = [CONDITION_DIRICHLET if b.name == "bottom_wall" else CONDITION_REFLECTING for b in mesh.boundaries]
+    bvals = {i: np.tile([stage, 0.0, 0.0], (b.num_edges, 1)) for i, b in enumerate(mesh.boundaries) if b.name == "bottom_wall"}
+    cfg = RDyFlowConfig(well_balancing=WELL_BALANCING_HR) if hr else RDyFlowConfig()
+    return Case("houston_refined", mesh, cfg, ctypes, u, np.full(no, 0.015), src, bvals, HOUSTON_DT / 2 ** levels)
+
+
+# ---------------------------------------------------------------------------
+# a genuinely unstructured triangulation (vertex valences 3 .. 11, cell areas graded 1 : 9) with the C5 physics
+# ---------------------------------------------------------------------------
+
+def delaunay_mesh(n: int = 1210, rank: int = 0, world: int = 1, order: str = "hilbert", d: float = 1.0, seed: int = 2017) -> RDyMesh:
+    """Delaunay triangulation (scipy / Qhull) of an (n+1)^2 lattice whose interior points are jittered by +-0.42 d and then
+    warped smoothly (x += 0.08 L sin(2 pi x / L), likewise y: spacings 0.5 .. 1.5 d, areas 1 : 9) over the C5 DEM: about 2 n^2
+    triangles (n = 1210: 2.93 M, the size of the reference's Turning_30m Harvey mesh, harvey-flooding.md:3-7) with the valence
+    spread of a real mesh generator's output instead of a lattice's constant 6.  Cell order: "natural" = Qhull's, "hilbert",
+    "random".  world > 1: this rank's RCB part with its edge-adjacent ghost layer."""
+    from scipy.spatial import Delaunay
+    from . import mesh as M
+    from . import partition as P
+    L = n * d
+    rng = np.random.default_rng(seed)
+    ii, jj = np.meshgrid(np.arange(n + 1), np.arange(n + 1), indexing="xy")
+    ii, jj = ii.ravel(), jj.ravel()
+    pts = np.stack([ii * d, jj * d], axis=1).astype(np.float64)
+    inner = (ii > 0) & (ii < n) & (jj > 0) & (jj < n)
+    pts[inner] += rng.uniform(-0.42 * d, 0.42 * d, (int(inner.sum()), 2))
+    pts += 0.08 * L * np.sin(2.0 * np.pi * pts / L)          # monotone (derivative 1 +- 0.5): the box maps onto itself
+    pts[ii == 0, 0], pts[ii == n, 0], pts[jj == 0, 1], pts[jj == n, 1] = 0.0, L, 0.0, L
+    conn = Delaunay(pts).simplices.astype(np.int32)
+    xyz = np.zeros((pts.shape[0], 3))
+    xyz[:, :2] = pts
+    xyz[:, 2] = c5_dem(L, L)(pts[:, 0], pts[:, 1])
+    cent = (pts[conn[:, 0]] + pts[conn[:, 1]] + pts[conn[:, 2]]) / 3.0
+    if order == "hilbert":
+        perm = M.hilbert_cell_order(cent)
+    elif order == "random":
+        perm = np.random.default_rng(seed + 1).permutation(conn.shape[0])
+    elif order == "natural":
+        perm = np.arange(conn.shape[0])
+    else:
+        raise ValueError(order)
+    conn, cent = conn[perm], cent[perm]
+    if order == "hilbert":
+        vperm = M.hilbert_cell_order(xyz)
+        vinv = np.empty(xyz.shape[0], dtype=np.int64)
+        vinv[vperm] = np.arange(xyz.shape[0])
+        xyz, conn = xyz[vperm], vinv[conn].astype(np.int32)
+    cls = c5_boundaries(L, L)
+    if world == 1:
+        return M.build_mesh(xyz, conn, boundary_classifier=cls, project_2d=True)
+    owned = P.rcb_owned_mask(cent, world, rank)
+    return M.extract_local_mesh(xyz, conn, owned, boundary_classifier=cls, project_2d=True,
+                                vertex_global_ids=np.arange(xyz.shape[0], dtype=np.int64), num_vertices_global=xyz.shape[0])

@@ -489,9 +489,13 @@ def hilbert_cell_order(centroids: np.ndarray) -> np.ndarray:
     return np.argsort(d, kind="stable")
 
 
-def refine_triangles(xyz: np.ndarray, conn: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+def refine_triangles(xyz: np.ndarray, conn: np.ndarray, tagged_edges: Optional[np.ndarray] = None):
     """Regular refinement: every triangle -> 4 by edge midpoints (what
-    `-dm_refine` does to a simplex DMPlex, used by src/rdymms.c:945-948)."""
+    `-dm_refine` does to a simplex DMPlex, used by src/rdymms.c:945-948 and by
+    src/rdydm.c:82-188 for production meshes).  Children 4c .. 4c+3 of cell c.
+    `tagged_edges` [n,3] = (vertex a, vertex b, tag) of labelled edges (side
+    sets): returned refined as well, each edge split in two at its midpoint
+    (DMPlex carries labels through refinement the same way)."""
     conn = np.asarray(conn)[:, :3].astype(np.int64)
     nv = xyz.shape[0]
     a = np.concatenate([conn[:, 0], conn[:, 1], conn[:, 2]])
@@ -512,7 +516,57 @@ def refine_triangles(xyz: np.ndarray, conn: np.ndarray) -> Tuple[np.ndarray, np.
     new_conn[1::4] = np.stack([m01, v1, m12], 1)
     new_conn[2::4] = np.stack([m20, m12, v2], 1)
     new_conn[3::4] = np.stack([m01, m12, m20], 1)
-    return new_xyz, new_conn
+    if tagged_edges is None:
+        return new_xyz, new_conn
+    te = np.asarray(tagged_edges, dtype=np.int64).reshape(-1, 3)
+    tk = np.minimum(te[:, 0], te[:, 1]) * nv + np.maximum(te[:, 0], te[:, 1])
+    j = np.searchsorted(uk, tk)
+    if te.shape[0] and (np.any(j >= uk.size) or np.any(uk[np.minimum(j, uk.size - 1)] != tk)):
+        raise ValueError("a tagged edge is not an edge of the mesh")
+    m = nv + j
+    new_te = np.concatenate([np.stack([te[:, 0], m, te[:, 2]], 1), np.stack([m, te[:, 1], te[:, 2]], 1)], axis=0)
+    return new_xyz, new_conn, new_te
+
+
+def boundaries_from_tagged_edges(tagged_edges: np.ndarray, names: Optional[Dict[int, str]] = None, num_vertices: Optional[int] = None):
+    """Boundary classifier from (vertex a, vertex b, tag) rows (vectorised form of `boundaries_from_side_sets`, for
+    refined meshes with many boundary edges); untagged boundary edges form one extra "unassigned" boundary whose id is
+    the first id no tag uses."""
+    names = names or {}
+    te = np.asarray(tagged_edges, dtype=np.int64).reshape(-1, 3)
+
+    def f(mesh: RDyMesh) -> List[RDyBoundary]:
+        nv = int(num_vertices) if num_vertices is not None else mesh.num_vertices
+        tk = np.minimum(te[:, 0], te[:, 1]) * nv + np.maximum(te[:, 0], te[:, 1])
+        srt = np.argsort(tk)
+        tks, tts = tk[srt], te[srt, 2]
+        be = mesh.edge_boundary_ids
+        v = mesh.edge_vertex_ids[be].astype(np.int64)
+        bk = np.minimum(v[:, 0], v[:, 1]) * nv + np.maximum(v[:, 0], v[:, 1])
+        tags = np.full(be.shape[0], -1, dtype=np.int64)
+        if tks.size:
+            j = np.minimum(np.searchsorted(tks, bk), tks.size - 1)
+            hit = tks[j] == bk
+            tags[hit] = tts[j[hit]]
+        used = sorted(set(te[:, 2].tolist()))
+        out = [RDyBoundary(int(t), names.get(int(t), f"boundary_{t}"), be[tags == t].astype(np.int32)) for t in used if (tags == t).any()]
+        if (tags == -1).any():
+            free = 0
+            while free in used:
+                free += 1
+            out.append(RDyBoundary(free, "unassigned", be[tags == -1].astype(np.int32)))
+        return out
+    return f
+
+
+def side_sets_to_tagged_edges(side_sets, conn: np.ndarray) -> np.ndarray:
+    """Exodus side sets {id: [(cell, local edge)]} as (vertex a, vertex b, tag) rows"""
+    rows = []
+    for sid, sides in side_sets.items():
+        for cell, side in sides:
+            nv = int((conn[cell] >= 0).sum())
+            rows.append((int(conn[cell][side % nv]), int(conn[cell][(side + 1) % nv]), int(sid)))
+    return np.array(rows, dtype=np.int64).reshape(-1, 3)
 
 
 # ---------------------------------------------------------------------------

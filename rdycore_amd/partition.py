@@ -44,9 +44,16 @@ def _bisect(points: np.ndarray, idx: np.ndarray, part0: int, nparts: int, out: O
     k = int(round(idx.size * n_lo / nparts))           # points that go to the lower half
     key = pts[:, axis]
     if 0 < k < idx.size:
-        order = np.argpartition(key, k - 1)
-        lo_sel = np.zeros(idx.size, dtype=bool)
-        lo_sel[order[:k]] = True
+        # the k smallest keys go low.  Points whose key EQUALS the k-th smallest (a whole column of a structured grid) are
+        # split once, contiguously along the other axis -- argpartition alone would deal them out arbitrarily and turn the
+        # cut inside that column into salt and pepper (more cut edges, more ghost cells, more halo tiles).
+        kth = np.partition(key, k - 1)[k - 1]
+        lo_sel = key < kth
+        ties = np.nonzero(key == kth)[0]
+        need = k - int(np.count_nonzero(lo_sel))
+        if need > 0:
+            t_order = np.argsort(pts[ties, 1 - axis], kind="stable")
+            lo_sel[ties[t_order[:need]]] = True
     else:
         lo_sel = np.zeros(idx.size, dtype=bool) if k <= 0 else np.ones(idx.size, dtype=bool)
     lo, hi = idx[lo_sel], idx[~lo_sel]                  # both ascending again

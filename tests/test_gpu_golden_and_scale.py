@@ -336,3 +336,102 @@ def test_rk4_advance_matches_oracle_loop():
     EulerStepper(op).advance(ue, dt, n * dt)
     assert rel_linf(ue.cpu().numpy(), ref) > 1e-6
     op.destroy()
+
+
+def _check_whole_rhs_against_oracle(case, second_state=None, ids=True):
+    """the WHOLE right-hand side of `case` on the device against the oracle: F, primitive variables, Courant number (and
+    ids), every boundary's fluxes with their NaN pattern, the water-mass balance; returns the operator"""
+    torch = _torch()
+    mesh = case.mesh
+    op = CS.create_operator(case)
+    orc = oracle_from_case(case)
+    f = torch.empty((mesh.num_owned_cells, 3), dtype=torch.float64, device="cuda")
+    for state in [case.u_local] + ([second_state] if second_state is not None else []):
+        u = torch.tensor(state, dtype=torch.float64, device="cuda")
+        op.rhs_function(case.dt, u, f)
+        torch.cuda.synchronize()
+        fh = f.cpu().numpy()
+        fo = orc.apply(case.dt, state)
+        assert np.isfinite(fh).all()
+        assert rel_linf(fh, fo) <= TOL
+        assert rel_linf(op.primitive_variables.cpu().numpy(), orc.primitive_variables) <= TOL
+        op.update_diagnostics()
+        d = op.get_diagnostics()
+        cmax, ce, cc = orc.diagnostics()
+        assert abs(d.max_courant_num - cmax) <= 1e-12 * max(1.0, cmax)
+        if ids:
+            assert (d.global_edge_id, d.global_cell_id) == (ce, cc)
+        flux_out = 0.0
+        for b, bnd in enumerate(mesh.boundaries):
+            got, ref = op.boundary_fluxes(b), orc.boundary_fluxes[b]
+            assert np.array_equal(np.isnan(got), np.isnan(ref))
+            assert rel_linf(np.nan_to_num(got), np.nan_to_num(ref)) <= TOL
+            wet = ~np.isnan(got[:, 0])
+            flux_out += (got[wet, 0] * mesh.edge_lengths[bnd.edge_ids][wet]).sum()
+        own = mesh.cell_owned_to_local
+        lhs = (fh[:, 0] * mesh.cell_areas[own]).sum()
+        rhs = (case.ext_src[:, 0] * mesh.cell_areas[own]).sum() - flux_out
+        if mesh.num_cells == mesh.num_owned_cells:      # one rank of a partition exchanges mass with its neighbours
+            assert abs(lhs - rhs) <= 1e-9 * max(1.0, abs(rhs), np.abs(fh[:, 0] * mesh.cell_areas[own]).sum())
+        orc.reset_diagnostics()
+    return op
+
+
+@pytest.mark.timeout(1500)
+@pytest.mark.parametrize("hr", [False, True])
+def test_houston_refined_full_size(hr, rdyhip_kernel):
+    """the unstructured real-DEM workload of bench.py (--workload houston_refined): the reference's Houston1km mesh refined six
+    times as -dm_refine does (src/rdydm.c:82-188) = 11,247,616 triangles, Hilbert-ordered, wet/dry fronts, the reference's rain
+    and stage series -- the whole RHS against the oracle, with and without hydrostatic reconstruction"""
+    if rdyhip_kernel == "cell":
+        pytest.skip("one kernel variant is enough at this size")
+    case = CS.houston_refined_case(os.path.join(ROOT, "tests", "golden", "houston"), 6, "hilbert", hr=hr)
+    assert case.mesh.num_cells == 2746 * 4 ** 6
+    dry = (case.u_local[:, 0] == 0).mean()
+    assert 0.2 < dry < 0.6
+    op = _check_whole_rhs_against_oracle(case)
+    info = op.layout_info()
+    assert info["num_edge_records"] / case.mesh.num_cells < 1.70 and info["max_tile_edges"] <= 512
+    op.destroy()
+
+
+@pytest.mark.timeout(900)
+def test_delaunay_unstructured_full_size(rdyhip_kernel):
+    """bench.py --workload delaunay: a Delaunay triangulation of 1211^2 jittered, graded points (2.93 M triangles, the size of the
+    reference's Turning_30m Harvey mesh; vertex valences 3..11) with the C5 physics (HR, ~40 % dry, rain, critical outflow)"""
+    if rdyhip_kernel == "cell":
+        pytest.skip("hydrostatic reconstruction is implemented by the tiled kernel")
+    mesh = CS.delaunay_mesh(1210)
+    val = np.bincount(mesh.cell_conn[:, :3].ravel())
+    assert val.min() <= 3 and val.max() >= 10 and 2_900_000 < mesh.num_cells < 2_960_000
+    case = CS.c5_case(mesh, 1210.0, 1210.0)
+    op = _check_whole_rhs_against_oracle(case)
+    op.destroy()
+
+
+@pytest.mark.timeout(900)
+def test_hydrostatic_reconstruction_ten_million_cells(rdyhip_kernel):
+    """bench.py --hr at its own size: the 2500 x 2000 x 2 C3 mesh with x-y projected geometry and ApplyInteriorFluxHR
+    (src/swe/swe_petsc.c:1000-1161) against the oracle, all cells"""
+    if rdyhip_kernel == "cell":
+        pytest.skip("hydrostatic reconstruction is implemented by the tiled kernel")
+    from rdycore_amd.operator import WELL_BALANCING_HR
+    K = 2 * np.pi / 200.0
+    mesh = M.structured_tri_mesh(2500, 2000, 1.0, zfunc=CS.mms_bathymetry(K=K), order="tiled", project_2d=True)
+    case = CS.friction_slope_case(mesh, 2500.0, 2000.0, dt=1e-3, K=K)
+    case.config.well_balancing = WELL_BALANCING_HR
+    op = _check_whole_rhs_against_oracle(case)
+    op.destroy()
+
+
+@pytest.mark.timeout(900)
+def test_c5_rank_3_of_8_full_size(rdyhip_kernel):
+    """bench.py --workload c5 --emulate-world 8 --emulate-rank 3: one rank's 3.1 M-square part of the 5000 x 5000 C5 mesh (6.25 M
+    owned triangles + its ghost layer, HR, wet/dry) against the oracle on the same local mesh"""
+    if rdyhip_kernel == "cell":
+        pytest.skip("hydrostatic reconstruction is implemented by the tiled kernel")
+    mesh = CS.c5_mesh(5000, 5000, 3, 8)
+    assert mesh.num_owned_cells == 6_250_000 and mesh.num_cells > mesh.num_owned_cells
+    case = CS.c5_case(mesh, 5000.0, 5000.0)
+    op = _check_whole_rhs_against_oracle(case)
+    op.destroy()

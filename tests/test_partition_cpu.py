@@ -36,6 +36,26 @@ def test_rcb_handles_massive_ties_of_structured_grids():
     assert np.array_equal(np.bincount(parts), np.full(6, 64 * 48 // 6))
 
 
+@pytest.mark.parametrize("world", [3, 5, 6])
+def test_rcb_cut_inside_a_grid_column_is_contiguous(world):
+    """a cut that lands inside a column of a structured grid splits that column once (ties broken along the other axis):
+    the number of cut edges stays at the perimeter of compact parts, not a salt-and-pepper column"""
+    nx, ny = 100, 64
+    qi, qj = np.meshgrid(np.arange(nx), np.arange(ny), indexing="xy")
+    pts = np.stack([qi.ravel() + 0.5, qj.ravel() + 0.5], axis=1)
+    parts = P.rcb_partition(pts, world).reshape(ny, nx)
+    cut = int((parts[:, 1:] != parts[:, :-1]).sum() + (parts[1:, :] != parts[:-1, :]).sum())
+    # every bisection adds at most one straight cut across the shorter extent of what it splits, plus one step
+    assert cut <= (world - 1) * (min(nx, ny) + 2)
+    for r in range(world):                     # each part is one 4-connected piece whose columns are contiguous runs
+        m = parts == r
+        cols = np.nonzero(m.any(axis=0))[0]
+        assert cols.max() - cols.min() + 1 == cols.size
+        for c in cols:
+            rows = np.nonzero(m[:, c])[0]
+            assert rows.max() - rows.min() + 1 == rows.size
+
+
 def _global_and_parts(make_mesh, make_case, world):
     gm = make_mesh(0, 1)
     gc = make_case(gm)
