@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RDYHIP_VERSION 105
+#define RDYHIP_VERSION 106
 
 /* error codes = PETSc's values */
 #define RDYHIP_SUCCESS 0
@@ -336,7 +336,46 @@ int rdyhip_euler_step_overlapped(RDyHipOperator op, RDyHipHalo halo, double dt, 
 int rdyhip_comm_unique_id(char id[RDYHIP_COMM_ID_BYTES]);
 int rdyhip_comm_init_rank(int32_t nranks, int32_t rank, const char id[RDYHIP_COMM_ID_BYTES], void **nccl_comm);
 int rdyhip_comm_destroy(void *nccl_comm);
+int rdyhip_comm_count(void *nccl_comm, int32_t *nranks);   /* ncclCommCount: how many ranks the communicator really spans */
 int32_t rdyhip_rccl_version(void);
+
+/* ---- planning the exchange and the local numbering (host only: no device is touched, testable without a GPU) ----
+ * What the DM's point SF knows (PetscSFGetGraph on DMGetPointSF(dm): for every ghost cell its owner rank and the owner's
+ * index for it; the 1-cell overlap of src/rdydm.c:145-157) turned into rdyhip_halo_create's arguments.  The send side is the
+ * transpose of the receive side, which needs ONE all-to-all; the library leaves that to the caller's own communicator:
+ *
+ *   rdyhip_halo_plan_create(world, rank, num_ghosts, ghost_cell_ids, ghost_owner_ranks, ghost_keys, &plan)
+ *        ghost_cell_ids[i]    local id of my i-th ghost cell
+ *        ghost_owner_ranks[i] the rank that owns it (iremote[i].rank)
+ *        ghost_keys[i]        the OWNER's name for it: its local cell id there (iremote[i].index - cStart), or a global
+ *                             cell id -- whichever rdyhip_halo_plan_finish is told the owner's cells are keyed by
+ *   rdyhip_halo_plan_requests(plan, &counts, &keys)
+ *        counts[r] = number of cells I need from rank r; keys = their keys grouped by r, ascending inside a group (the
+ *        order both sides use).  Caller: MPI_Alltoall(counts -> incoming_counts), MPI_Alltoallv(keys -> incoming_keys).
+ *   rdyhip_halo_plan_finish(plan, incoming_counts, incoming_keys, num_cells, cell_is_owned, cell_keys)
+ *        resolves what the others ask of me to my local cells: cell_keys == NULL: a key IS my local cell id; else
+ *        cell_keys[c] is the key of local cell c (e.g. cells.global_ids).  Every request must name a cell I own.
+ *   rdyhip_halo_plan_get(plan, &npeers, &peers, &send_counts, &send_cell_ids, &recv_counts, &recv_cell_ids)
+ *        exactly the arguments of rdyhip_halo_create (pointers valid until rdyhip_halo_plan_destroy).
+ *
+ *   rdyhip_hilbert_cell_order(num_cells, xy, stride, cell_is_owned, perm): perm[new] = old local cell id, owned cells first
+ *        (so that they are a prefix: the owned rows of a local Vec are then one block), each group along a Hilbert curve
+ *        through the centroids xy[c*stride + 0..1].  The tiles of the operator are runs of 256 consecutive owned cells, so
+ *        this is the numbering a host should give its local cells before it builds RDyMesh (DMPlexPermute; DESIGN.md
+ *        section 7 note 7 has the measurements: row-major -18 %, random order 3x slower than a curve order).
+ *   rdyhip_copy_owned_rows(op, u_global, u_local, stream): u_local[owned cell o] = u_global[o] -- the local half of
+ *        DMGlobalToLocal (device pointers; one contiguous copy when the owned cells are numbered first) */
+typedef struct RDyHipHaloPlan_s *RDyHipHaloPlan;
+int rdyhip_halo_plan_create(int32_t world, int32_t rank, int32_t num_ghosts, const int32_t *ghost_cell_ids, const int32_t *ghost_owner_ranks,
+                            const int64_t *ghost_keys, RDyHipHaloPlan *plan);
+int rdyhip_halo_plan_requests(RDyHipHaloPlan plan, const int32_t **request_counts, const int64_t **request_keys);
+int rdyhip_halo_plan_finish(RDyHipHaloPlan plan, const int32_t *incoming_counts, const int64_t *incoming_keys, int32_t num_cells,
+                            const int32_t *cell_is_owned, const int64_t *cell_keys);
+int rdyhip_halo_plan_get(RDyHipHaloPlan plan, int32_t *npeers, const int32_t **peers, const int32_t **send_counts, const int32_t **send_cell_ids,
+                         const int32_t **recv_counts, const int32_t **recv_cell_ids);
+int rdyhip_halo_plan_destroy(RDyHipHaloPlan *plan);
+int rdyhip_hilbert_cell_order(int32_t num_cells, const double *xy, int32_t stride, const int32_t *cell_is_owned, int32_t *perm);
+int rdyhip_copy_owned_rows(RDyHipOperator op, const double *u_global, double *u_local, void *stream);
 
 /* ---- explicit update kept on the device (what TSEULER does between RHS calls)
  * u_local[owned cell o] += dt * f_global[o]   (PETSc TSStep_Euler VecAXPY; the

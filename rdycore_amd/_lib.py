@@ -96,6 +96,15 @@ SYMBOLS = {
     "rdyhip_comm_init_rank": (C.c_int, [C.c_int32, C.c_int32, C.c_char_p, C.POINTER(C.c_void_p)]),
     "rdyhip_comm_destroy": (C.c_int, [C.c_void_p]),
     "rdyhip_rccl_version": (C.c_int32, []),
+    "rdyhip_comm_count": (C.c_int, [C.c_void_p, c_int32_p]),
+    "rdyhip_halo_plan_create": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, c_int32_p, c_int32_p, c_int64_p, C.POINTER(C.c_void_p)]),
+    "rdyhip_halo_plan_requests": (C.c_int, [C.c_void_p, C.POINTER(c_int32_p), C.POINTER(c_int64_p)]),
+    "rdyhip_halo_plan_finish": (C.c_int, [C.c_void_p, c_int32_p, c_int64_p, C.c_int32, c_int32_p, c_int64_p]),
+    "rdyhip_halo_plan_get": (C.c_int, [C.c_void_p, c_int32_p, C.POINTER(c_int32_p), C.POINTER(c_int32_p), C.POINTER(c_int32_p),
+                                       C.POINTER(c_int32_p), C.POINTER(c_int32_p)]),
+    "rdyhip_halo_plan_destroy": (C.c_int, [C.POINTER(C.c_void_p)]),
+    "rdyhip_hilbert_cell_order": (C.c_int, [C.c_int32, c_double_p, C.c_int32, c_int32_p, c_int32_p]),
+    "rdyhip_copy_owned_rows": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rdyhip_probe_layout": (C.c_int, [C.POINTER(RDyHipConfig), C.POINTER(RDyHipMesh), C.c_int32, C.POINTER(RDyHipBoundary),
                                       C.POINTER(RDyHipLayoutInfo)]),
     "rdyhip_layout_info": (C.c_int, [_H, C.POINTER(RDyHipLayoutInfo)]),

@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(CSRC, "librdyhip.so")
 SOURCES = ["rdyhip_api.hip"]
-DEPS = SOURCES + ["swe_device.h", "swe_kernels.h", "forcing_kernels.h", "muscl_kernels.h", "halo_exchange.h"]
+DEPS = SOURCES + ["swe_device.h", "swe_kernels.h", "forcing_kernels.h", "muscl_kernels.h", "halo_exchange.h", "halo_plan.h"]
 ARCH = "gfx950"
 ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 

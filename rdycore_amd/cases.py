@@ -349,12 +349,12 @@ def houston_refined_mesh(data_dir: str, levels: int = 6, order: str = "hilbert",
         sub = dataclasses.replace(mesh, edge_boundary_ids=be[own], edge_vertex_ids=vg[mesh.edge_vertex_ids].astype(np.int64))
         return cls(sub)
     owned = part == rank
-    lm = _extract_with_vertex_ids(xyz, conn, owned, cls_local, project_2d, nvg)
+    lm = _extract_with_vertex_ids(xyz, conn, owned, cls_local, project_2d, nvg, part)
     keep = lm._cell_sel
     return lm, parent[keep]
 
 
-def _extract_with_vertex_ids(xyz, conn, owned, classifier, project_2d, nvg):
+def _extract_with_vertex_ids(xyz, conn, owned, classifier, project_2d, nvg, parts=None):
     """mesh.extract_local_mesh, with the selection of cells and the global vertex ids left on the mesh object for the
     caller (parent lookup, boundary tags in global vertex ids)"""
     from . import mesh as M
@@ -379,7 +379,7 @@ def _extract_with_vertex_ids(xyz, conn, owned, classifier, project_2d, nvg):
         mesh._vertex_global_ids = used
         return classifier(mesh)
     lm = M.extract_local_mesh(xyz, conn4, owned, boundary_classifier=wrapped, project_2d=project_2d,
-                              vertex_global_ids=np.arange(nv, dtype=np.int64), num_vertices_global=nvg)
+                              vertex_global_ids=np.arange(nv, dtype=np.int64), num_vertices_global=nvg, cell_parts=parts)
     lm._cell_sel = sel
     assert lm.num_cells == sel.size
     return lm
@@ -463,6 +463,7 @@ def delaunay_mesh(n: int = 1210, rank: int = 0, world: int = 1, order: str = "hi
     cls = c5_boundaries(L, L)
     if world == 1:
         return M.build_mesh(xyz, conn, boundary_classifier=cls, project_2d=True)
-    owned = P.rcb_owned_mask(cent, world, rank)
-    return M.extract_local_mesh(xyz, conn, owned, boundary_classifier=cls, project_2d=True,
-                                vertex_global_ids=np.arange(xyz.shape[0], dtype=np.int64), num_vertices_global=xyz.shape[0])
+    parts = P.rcb_partition(cent, world)
+    return M.extract_local_mesh(xyz, conn, parts == rank, boundary_classifier=cls, project_2d=True,
+                                vertex_global_ids=np.arange(xyz.shape[0], dtype=np.int64), num_vertices_global=xyz.shape[0],
+                                cell_parts=parts)

@@ -73,10 +73,24 @@ int halo_transfer(RDyHipHalo h, int32_t ncomp, hipStream_t s) {
   }
   if (!h->comm) return fail(RDYHIP_ERR_USER, "the halo has neither an RCCL communicator nor a transport callback");
   NCCL_TRY(ncclGroupStart());
-  for (int32_t i = 0; i < np; ++i) {
+  // a failure inside the bracket must still close it: an open group would silently queue every later RCCL call of this
+  // thread (the caller's own communicators included)
+  ncclResult_t r = ncclSuccess;
+  const char  *what = "";
+  for (int32_t i = 0; i < np && r == ncclSuccess; ++i) {
     const size_t cnt_s = (size_t)(h->send_off[i + 1] - h->send_off[i]) * ncomp, cnt_r = (size_t)(h->recv_off[i + 1] - h->recv_off[i]) * ncomp;
-    if (cnt_s) NCCL_TRY(ncclSend(h->d_send.p + (size_t)h->send_off[i] * ncomp, cnt_s, ncclDouble, h->peers[i], h->comm, s));
-    if (cnt_r) NCCL_TRY(ncclRecv(h->d_recv.p + (size_t)h->recv_off[i] * ncomp, cnt_r, ncclDouble, h->peers[i], h->comm, s));
+    if (cnt_s) {
+      r    = ncclSend(h->d_send.p + (size_t)h->send_off[i] * ncomp, cnt_s, ncclDouble, h->peers[i], h->comm, s);
+      what = "ncclSend";
+    }
+    if (cnt_r && r == ncclSuccess) {
+      r    = ncclRecv(h->d_recv.p + (size_t)h->recv_off[i] * ncomp, cnt_r, ncclDouble, h->peers[i], h->comm, s);
+      what = "ncclRecv";
+    }
+  }
+  if (r != ncclSuccess) {
+    (void)ncclGroupEnd();
+    return fail(RDYHIP_ERR_LIB, "%s failed: %s", what, ncclGetErrorString(r));
   }
   NCCL_TRY(ncclGroupEnd());
   return 0;
@@ -136,6 +150,17 @@ int overlapped(RDyHipOperator op, RDyHipHalo h, double dt, double *u, double *f,
     (void)hipStreamWaitEvent(st, h->ev_join, 0);
     return code;
   };
+  // the join itself; if it fails, bail() tries once more and the error is reported
+  auto join = [&]() -> int {
+    hipError_t e = hipEventRecord(h->ev_join, h->cs);
+    if (e == hipSuccess) e = hipStreamWaitEvent(st, h->ev_join, 0);
+    return e == hipSuccess ? 0 : bail(fail(RDYHIP_ERR_LIB, "joining the exchange stream failed: %s", hipGetErrorString(e)));
+  };
+  auto fork = [&]() -> int {
+    hipError_t e = hipEventRecord(h->ev_fork, st);
+    if (e == hipSuccess) e = hipStreamWaitEvent(h->cs, h->ev_fork, 0);
+    return e == hipSuccess ? 0 : bail(fail(RDYHIP_ERR_LIB, "forking the exchange stream failed: %s", hipGetErrorString(e)));
+  };
   if (!op->muscl) {
     // RCCL (asynchronous): the whole exchange is enqueued first, the interior tiles right behind it on the other stream.
     // A transport callback may block the host: there the interior tiles are enqueued before it is called, so that it
@@ -147,8 +172,8 @@ int overlapped(RDyHipOperator op, RDyHipHalo h, double dt, double *u, double *f,
     if (!rc && !h->transport) rc = part(RDYHIP_PHASE_INTERIOR, 1, false);
     if (!rc && conc) rc = part(RDYHIP_PHASE_HALO, 0, false);
     if (rc) return bail(rc);
-    HIP_TRY(hipEventRecord(h->ev_join, h->cs));
-    HIP_TRY(hipStreamWaitEvent(st, h->ev_join, 0));
+    rc = join();
+    if (rc) return rc;
     return conc ? 0 : part(RDYHIP_PHASE_HALO, 0, false);
   }
   // ApplyInteriorFlux2R (src/swe/swe_petsc.c:98-213) needs two exchanges: the state, then the gradients of the ghost
@@ -166,8 +191,8 @@ int overlapped(RDyHipOperator op, RDyHipHalo h, double dt, double *u, double *f,
     if (!rc) rc = halo_exchange_on(h, op->d_grad.p, 6, h->cs);
     if (!rc && conc) rc = part(RDYHIP_PHASE_HALO, 0, true);
     if (rc) return bail(rc);
-    HIP_TRY(hipEventRecord(h->ev_join, h->cs));
-    HIP_TRY(hipStreamWaitEvent(st, h->ev_join, 0));
+    rc = join();
+    if (rc) return rc;
     return conc ? 0 : part(RDYHIP_PHASE_HALO, 0, true);
   }
   // split kernels: the gradients of the cells without ghost neighbours hide the state exchange, the fluxes of the tiles
@@ -178,21 +203,21 @@ int overlapped(RDyHipOperator op, RDyHipHalo h, double dt, double *u, double *f,
   if (!rc) rc = halo_unpack(h, u, 3, h->cs);
   if (!rc && !h->transport) rc = launch_gradients(op, RDYHIP_PHASE_INTERIOR, u, st);
   if (rc) return bail(rc);
-  HIP_TRY(hipEventRecord(h->ev_join, h->cs));
-  HIP_TRY(hipStreamWaitEvent(st, h->ev_join, 0));
+  rc = join();
+  if (rc) return rc;
   rc = launch_gradients(op, RDYHIP_PHASE_HALO, u, st);
   if (rc) return bail(rc);
   h->next_events();
-  HIP_TRY(hipEventRecord(h->ev_fork, st));
-  HIP_TRY(hipStreamWaitEvent(h->cs, h->ev_fork, 0));
+  rc = fork();
+  if (rc) return rc;
   rc = halo_pack(h, op->d_grad.p, 6, h->cs);
   if (!rc && h->transport) rc = part(RDYHIP_PHASE_INTERIOR, 1, true);
   if (!rc) rc = halo_transfer(h, 6, h->cs);
   if (!rc) rc = halo_unpack(h, op->d_grad.p, 6, h->cs);
   if (!rc && !h->transport) rc = part(RDYHIP_PHASE_INTERIOR, 1, true);
   if (rc) return bail(rc);
-  HIP_TRY(hipEventRecord(h->ev_join, h->cs));
-  HIP_TRY(hipStreamWaitEvent(st, h->ev_join, 0));
+  rc = join();
+  if (rc) return rc;
   return part(RDYHIP_PHASE_HALO, 0, true);
 }
 
@@ -236,6 +261,18 @@ int rdyhip_halo_create(RDyHipOperator op, void *nccl_comm, int32_t npeers, const
       delete h;
       return fail(RDYHIP_ERR_ARG_OUTOFRANGE, "receive cell id %d out of range", recv_cell_ids[i]);
     }
+  if (h->comm) {
+    int nranks = 0;
+    if (ncclCommCount(h->comm, &nranks) != ncclSuccess) {
+      delete h;
+      return fail(RDYHIP_ERR_LIB, "ncclCommCount failed on the communicator handed to rdyhip_halo_create");
+    }
+    for (int32_t i = 0; i < npeers; ++i)
+      if (peers[i] >= nranks) {
+        delete h;
+        return fail(RDYHIP_ERR_ARG_OUTOFRANGE, "peer rank %d outside the communicator's %d ranks", peers[i], nranks);
+      }
+  }
   h->max_comp = op->muscl ? 6 : 3;
   int rc      = h->d_send_ids.upload(std::vector<int32_t>(send_cell_ids, send_cell_ids + ns));
   if (!rc) rc = h->d_recv_ids.upload(std::vector<int32_t>(recv_cell_ids, recv_cell_ids + nr));
@@ -326,6 +363,14 @@ int rdyhip_comm_init_rank(int32_t nranks, int32_t rank, const char id[RDYHIP_COM
 
 int rdyhip_comm_destroy(void *nccl_comm) {
   if (nccl_comm) NCCL_TRY(ncclCommDestroy((ncclComm_t)nccl_comm));
+  return 0;
+}
+
+int rdyhip_comm_count(void *nccl_comm, int32_t *nranks) {
+  if (!nccl_comm || !nranks) return fail(RDYHIP_ERR_USER, "null argument");
+  int n = 0;
+  NCCL_TRY(ncclCommCount((ncclComm_t)nccl_comm, &n));
+  *nranks = (int32_t)n;
   return 0;
 }
 

@@ -1358,6 +1358,22 @@ int rdyhip_axpy_owned(RDyHipOperator op, double dt, const double *f_global, doub
   return 0;
 }
 
+int rdyhip_copy_owned_rows(RDyHipOperator op, const double *u_global, double *u_local, void *stream) {
+  if (!op) return fail(RDYHIP_ERR_USER, "null operator");
+  if (op->n_owned == 0) return 0;
+  if (!u_global || !u_local) return fail(RDYHIP_ERR_USER, "null argument");
+  if (op->prefix) {  // the owned cells are the first rows of the local vector: one contiguous copy
+    if (u_global != u_local)
+      HIP_TRY(hipMemcpyAsync(u_local, u_global, sizeof(double) * 3 * (size_t)op->n_owned, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return 0;
+  }
+  if (u_global == u_local) return fail(RDYHIP_ERR_USER, "rdyhip_copy_owned_rows in place needs owned cells numbered first");
+  const int64_t n3 = 3 * (int64_t)op->n_owned;
+  hipLaunchKernelGGL(copy_owned_rows_kernel, dim3((unsigned)((n3 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, op->n_owned, op->d_o2l.p, u_global, u_local);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 int rdyhip_probe_layout(const RDyHipConfig *config, const RDyHipMesh *mesh, int32_t num_boundaries, const RDyHipBoundary *boundaries,
                         RDyHipLayoutInfo *info) {
   if (!info) return fail(RDYHIP_ERR_USER, "null argument");
@@ -1417,3 +1433,4 @@ int rdyhip_layout_info(RDyHipOperator op, RDyHipLayoutInfo *info) {
 }  // extern "C"
 
 #include "halo_exchange.h"
+#include "halo_plan.h"

@@ -854,6 +854,13 @@ __global__ void axpy_owned_kernel(int n_owned, const int32_t *__restrict__ o2l, 
     u[i] += dt * f[i];
   }
 }
+// u_local[owned cell o] = u_global[o]: the local part of DMGlobalToLocal (src/rdysetup.c:1133-1134)
+__global__ void copy_owned_rows_kernel(int n_owned, const int32_t *__restrict__ o2l, const double *__restrict__ u_global, double *__restrict__ u_local) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 3 * (int64_t)n_owned) return;
+  const int o = (int)(i / 3), comp = (int)(i - 3 * (int64_t)o);
+  u_local[3 * (int64_t)o2l[o] + comp] = u_global[i];
+}
 // u_out[owned cell o] = u_in[o] + dt * f[o]  (fallback of rdyhip_euler_step for the kernels without the fused update)
 __global__ void euler_out_kernel(int n_owned, const int32_t *__restrict__ o2l, double dt, const double *__restrict__ f, const double *__restrict__ u_in,
                                  double *__restrict__ u_out) {

@@ -62,37 +62,74 @@ class HaloExchange:
             self._create_c_halo(op)
 
     # -- the exchange behind the C ABI (include/rdyhip.h: rdyhip_halo_create) ------------------------------
+    def _all_ok(self, ok: bool) -> bool:
+        """collective: did every rank get through the last stage?"""
+        on_dev = dist.get_backend(self.group) == "nccl"
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self.device if on_dev else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
+        return bool(t.item())
+
     def _create_c_halo(self, op):
+        """Every stage that can fail on one rank alone (drawing the id, ncclCommInitRank, rdyhip_halo_create) is followed by
+        an agreement (all-reduce MIN of an ok flag) BEFORE any rank raises, so that the ranks' collectives always match: a
+        failure anywhere becomes the same exception on every rank (bench.py then falls back to torch P2P on all of them),
+        never a hang.  Whatever was built is torn down before raising."""
         import ctypes as C
         from . import _lib
         lib = _lib.load()
-        peers = sorted(set(self.send_ids) | set(self.recv_ids))
         i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
-        send_counts = i32([int(self.send_ids[p].numel()) if p in self.send_ids else 0 for p in peers])
-        recv_counts = i32([int(self.recv_ids[p].numel()) if p in self.recv_ids else 0 for p in peers])
-        cat = lambda d: i32(np.concatenate([d[p].cpu().numpy() for p in peers if p in d])) if any(p in d for p in peers) else i32([])
-        send_ids, recv_ids, peers_a = cat(self.send_ids), cat(self.recv_ids), i32(peers)
+        peers = self._plan_peers
+        send_counts, recv_counts = i32(self._plan_send_counts), i32(self._plan_recv_counts)
+        send_ids, recv_ids, peers_a = i32(self._plan_send_cells), i32(self._plan_recv_cells), i32(peers)
         comm = C.c_void_p()
+        err = None
         if dist.get_backend(self.group) == "nccl":
             # an RCCL communicator of our own over the same ranks: rank 0 draws the id, everybody joins
             box = [None]
             if self.rank == 0:
-                buf = C.create_string_buffer(128)
-                _lib.check(lib.rdyhip_comm_unique_id(buf))
-                box[0] = buf.raw
+                try:
+                    buf = C.create_string_buffer(128)
+                    _lib.check(lib.rdyhip_comm_unique_id(buf))
+                    box[0] = buf.raw
+                except Exception as exc:        # the broadcast still happens: a None tells everybody
+                    err = exc
             dist.broadcast_object_list(box, src=0, group=self.group)
-            _lib.check(lib.rdyhip_comm_init_rank(self.world, self.rank, box[0], C.byref(comm)))
-            self._comm = comm
+            if box[0] is None:
+                raise RuntimeError(f"rank 0 could not draw an RCCL unique id: {err!r}")
+            try:
+                _lib.check(lib.rdyhip_comm_init_rank(self.world, self.rank, box[0], C.byref(comm)))
+                self._comm = comm
+            except Exception as exc:
+                err = exc
+            if not self._all_ok(err is None):
+                self.destroy()
+                raise RuntimeError(f"ncclCommInitRank failed on some rank (this rank: {err!r})")
         h = C.c_void_p()
         p = lambda a: a.ctypes.data_as(_lib.c_int32_p)
-        _lib.check(lib.rdyhip_halo_create(op._h, comm, len(peers), p(peers_a), p(send_counts), p(send_ids), p(recv_counts), p(recv_ids),
-                                          C.byref(h)))
-        self._halo = h
-        self._c_peers, self._c_send_counts, self._c_recv_counts = peers, send_counts, recv_counts
+        try:
+            _lib.check(lib.rdyhip_halo_create(op._h, comm, len(peers), p(peers_a), p(send_counts), p(send_ids), p(recv_counts), p(recv_ids),
+                                              C.byref(h)))
+            self._halo = h
+            self._c_peers, self._c_send_counts, self._c_recv_counts = list(peers), send_counts, recv_counts
+            if self._comm is None:
+                # no RCCL between ranks that share a device: the bytes go through the transport callback, staged on the host
+                self._cb = _lib.TRANSPORT_FN(self._host_staged_transport)
+                _lib.check(lib.rdyhip_halo_set_transport(h, C.cast(self._cb, C.c_void_p), None))
+        except Exception as exc:
+            err = exc
+        if not self._all_ok(err is None):
+            self.destroy()
+            raise RuntimeError(f"rdyhip_halo_create failed on some rank (this rank: {err!r})")
+
+    def rccl_ranks(self) -> Optional[int]:
+        """ncclCommCount of the library's own communicator (None when the bytes do not travel over RCCL)"""
         if self._comm is None:
-            # no RCCL between ranks that share a device: the bytes go through the transport callback, staged on the host
-            self._cb = _lib.TRANSPORT_FN(self._host_staged_transport)
-            _lib.check(lib.rdyhip_halo_set_transport(h, C.cast(self._cb, C.c_void_p), None))
+            return None
+        import ctypes as C
+        from . import _lib
+        n = C.c_int32(0)
+        _lib.check(_lib.load().rdyhip_comm_count(self._comm, C.byref(n)))
+        return int(n.value)
 
     def _host_staged_transport(self, ctx, d_send, d_recv, ncomp, stream):
         """RDyHipTransportFn: d_send's per-peer slices -> the peers' d_recv slices through the process group (gloo)"""
@@ -133,51 +170,116 @@ class HaloExchange:
             _lib.check(_lib.load().rdyhip_comm_destroy(self._comm))
             self._comm = None
 
-    # -- pattern discovery (setup only) -----------------------------------
+    # -- pattern discovery (setup only): rdyhip_halo_plan_* behind the ABI (csrc/halo_plan.h) ---------------
+    def _owners_by_query(self, ghost_gid: np.ndarray) -> np.ndarray:
+        """Owner rank of every ghost cell when the mesh does not carry it (`RDyMesh.cell_owner_rank`): every rank publishes the
+        global ids it needs, every rank answers which of them it owns.  O(world x ghosts) -- the fallback for meshes cut
+        without a part array at hand; a DMPlex host reads the owners from the point SF instead (adapter/rdyhip_petsc.c)."""
+        m = self.mesh
+        owned_gid = np.sort(m.cell_global_ids[m.cell_owned_to_local])
+        wanted: List[Optional[np.ndarray]] = [None] * self.world
+        dist.all_gather_object(wanted, ghost_gid, group=self.group)
+        mine = []
+        for peer in range(self.world):
+            req = np.asarray(wanted[peer], dtype=np.int64)
+            if peer == self.rank or req.size == 0 or owned_gid.size == 0:
+                mine.append(np.zeros(req.size, dtype=bool))
+                continue
+            idx = np.minimum(np.searchsorted(owned_gid, req), owned_gid.size - 1)
+            mine.append(owned_gid[idx] == req)
+        answers: List[Optional[List[np.ndarray]]] = [None] * self.world
+        dist.all_gather_object(answers, mine, group=self.group)
+        owner = np.full(ghost_gid.size, -1, dtype=np.int32)
+        for peer in range(self.world):
+            if peer != self.rank:
+                hit = np.asarray(answers[peer][self.rank], dtype=bool)
+                if np.any(owner[hit] >= 0):
+                    raise RuntimeError(f"rank {self.rank}: a ghost cell has two owners")
+                owner[hit] = peer
+        if np.any(owner < 0):
+            raise RuntimeError(f"rank {self.rank}: {int((owner < 0).sum())} ghost cells have no owner")
+        return owner
+
+    def _alltoall_requests(self, counts: np.ndarray, keys: np.ndarray):
+        """the one exchange the plan needs (MPI_Alltoall + MPI_Alltoallv in an MPI host): request counts to everybody, the
+        request keys point-to-point to the ranks actually asked"""
+        on_dev = dist.get_backend(self.group) == "nccl"
+        dev = self.device if on_dev else torch.device("cpu")
+        mine = torch.as_tensor(counts.astype(np.int64), device=dev)
+        table = [torch.empty_like(mine) for _ in range(self.world)]
+        dist.all_gather(table, mine, group=self.group)
+        table = torch.stack(table).cpu().numpy()               # table[r][q] = cells rank r asks of rank q
+        incoming_counts = table[:, self.rank].astype(np.int32)
+        send = torch.as_tensor(keys.astype(np.int64), device=dev)
+        recv = torch.empty(int(incoming_counts.sum()), dtype=torch.int64, device=dev)
+        ops, so, ro = [], 0, 0
+        for peer in range(self.world):
+            cs, cr = int(counts[peer]), int(incoming_counts[peer])
+            if cs:
+                ops.append(dist.P2POp(dist.isend, send[so:so + cs], peer, group=self.group))
+            if cr:
+                ops.append(dist.P2POp(dist.irecv, recv[ro:ro + cr], peer, group=self.group))
+            so, ro = so + cs, ro + cr
+        for w in (dist.batch_isend_irecv(ops) if ops else []):
+            w.wait()
+        if on_dev:
+            torch.cuda.synchronize(self.device)
+        return incoming_counts, recv.cpu().numpy()
+
     def _setup(self):
+        import ctypes as C
+        from . import _lib
         m = self.mesh
         ghost_local = np.nonzero(m.cell_is_owned == 0)[0].astype(np.int32)
-        ghost_gid = m.cell_global_ids[ghost_local]
+        ghost_gid = np.ascontiguousarray(m.cell_global_ids[ghost_local], dtype=np.int64)
+        self._plan_peers, self._plan_send_counts, self._plan_recv_counts = [], [], []
+        self._plan_send_cells = self._plan_recv_cells = np.zeros(0, dtype=np.int32)
         if self.world == 1:
             if ghost_local.size:
                 raise ValueError("mesh has ghost cells but there is only one rank")
             return
-        owned_local = m.cell_owned_to_local
-        owned_gid = m.cell_global_ids[owned_local]
-        order = np.argsort(owned_gid)
-        sorted_gid = owned_gid[order]
-        # every rank publishes the global ids of the ghosts it needs
-        wanted: List[Optional[np.ndarray]] = [None] * self.world
-        dist.all_gather_object(wanted, ghost_gid, group=self.group)
-        # which of a peer's ghosts do I own?  (answer in the peer's request order)
-        mine_for_peer: List[Optional[np.ndarray]] = []
-        for peer in range(self.world):
-            if peer == self.rank or wanted[peer] is None or len(wanted[peer]) == 0:
-                mine_for_peer.append(np.zeros(0, dtype=np.int64))
-                continue
-            req = np.asarray(wanted[peer])
-            idx = np.searchsorted(sorted_gid, req)
-            idx = np.minimum(idx, max(sorted_gid.size - 1, 0))
-            hit = (sorted_gid[idx] == req) if sorted_gid.size else np.zeros(req.size, dtype=bool)
-            self_local = owned_local[order[idx[hit]]].astype(np.int32)
-            if self_local.size:
-                self.send_ids[peer] = torch.as_tensor(self_local, device=self.device)
-            mine_for_peer.append(req[hit])
-        # tell every peer which of its requests I will serve, so it knows what arrives from me
-        served: List[Optional[List[np.ndarray]]] = [None] * self.world
-        dist.all_gather_object(served, mine_for_peer, group=self.group)
-        gid_to_local = {int(g): int(l) for g, l in zip(ghost_gid, ghost_local)}
-        covered = 0
-        for peer in range(self.world):
-            if peer == self.rank:
-                continue
-            got = np.asarray(served[peer][self.rank])
-            if got.size:
-                loc = np.array([gid_to_local[int(g)] for g in got], dtype=np.int32)
-                self.recv_ids[peer] = torch.as_tensor(loc, device=self.device)
-                covered += got.size
-        if covered != ghost_local.size:
-            raise RuntimeError(f"rank {self.rank}: {ghost_local.size - covered} ghost cells have no owner")
+        owner_all = getattr(m, "cell_owner_rank", None)
+        have = torch.tensor([1 if owner_all is not None else 0], dtype=torch.int32,
+                            device=self.device if dist.get_backend(self.group) == "nccl" else "cpu")
+        dist.all_reduce(have, op=dist.ReduceOp.MIN, group=self.group)      # the fallback is collective: all ranks or none
+        if int(have.item()):
+            owner = np.ascontiguousarray(np.asarray(owner_all)[ghost_local], dtype=np.int32)
+        else:
+            owner = self._owners_by_query(ghost_gid)
+        lib = _lib.load()
+        plan = C.c_void_p()
+        pi = lambda a: a.ctypes.data_as(_lib.c_int32_p)
+        pl = lambda a: a.ctypes.data_as(_lib.c_int64_p)
+        _lib.check(lib.rdyhip_halo_plan_create(self.world, self.rank, int(ghost_local.size), pi(ghost_local), pi(owner), pl(ghost_gid), C.byref(plan)))
+        try:
+            cptr, kptr = _lib.c_int32_p(), _lib.c_int64_p()
+            _lib.check(lib.rdyhip_halo_plan_requests(plan, C.byref(cptr), C.byref(kptr)))
+            counts = np.ctypeslib.as_array(cptr, shape=(self.world,)).copy()
+            keys = np.ctypeslib.as_array(kptr, shape=(max(int(ghost_local.size), 1),))[:ghost_local.size].copy()
+            incoming_counts, incoming_keys = self._alltoall_requests(counts, keys)
+            incoming_counts = np.ascontiguousarray(incoming_counts, dtype=np.int32)
+            incoming_keys = np.ascontiguousarray(incoming_keys, dtype=np.int64)
+            is_owned = np.ascontiguousarray(m.cell_is_owned, dtype=np.int32)
+            gids = np.ascontiguousarray(m.cell_global_ids, dtype=np.int64)
+            _lib.check(lib.rdyhip_halo_plan_finish(plan, pi(incoming_counts), pl(incoming_keys), int(m.num_cells), pi(is_owned), pl(gids)))
+            npeers = C.c_int32(0)
+            ptrs = [_lib.c_int32_p() for _ in range(5)]
+            _lib.check(lib.rdyhip_halo_plan_get(plan, C.byref(npeers), *[C.byref(q) for q in ptrs]))
+            n = int(npeers.value)
+            take = lambda q, k: np.ctypeslib.as_array(q, shape=(max(k, 1),))[:k].copy()
+            peers, sc, rc = take(ptrs[0], n), take(ptrs[1], n), take(ptrs[3], n)
+            send_cells, recv_cells = take(ptrs[2], int(sc.sum())), take(ptrs[4], int(rc.sum()))
+        finally:
+            _lib.check(lib.rdyhip_halo_plan_destroy(C.byref(plan)))
+        self._plan_peers, self._plan_send_counts, self._plan_recv_counts = [int(q) for q in peers], sc, rc
+        self._plan_send_cells, self._plan_recv_cells = send_cells, recv_cells
+        so = ro = 0
+        for q, cs, cr in zip(self._plan_peers, sc, rc):
+            if cs:
+                self.send_ids[q] = torch.as_tensor(send_cells[so:so + int(cs)], device=self.device)
+            if cr:
+                self.recv_ids[q] = torch.as_tensor(recv_cells[ro:ro + int(cr)], device=self.device)
+            so, ro = so + int(cs), ro + int(cr)
         peers_s, peers_r = sorted(self.send_ids), sorted(self.recv_ids)
         self.send_ids_all = torch.cat([self.send_ids[p] for p in peers_s]) if peers_s else torch.zeros(0, dtype=torch.int32, device=self.device)
         self.recv_ids_all = torch.cat([self.recv_ids[p] for p in peers_r]) if peers_r else torch.zeros(0, dtype=torch.int32, device=self.device)

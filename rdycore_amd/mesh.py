@@ -81,6 +81,9 @@ class RDyMesh:
     edge_sn: np.ndarray              # [Ne]
     edge_centroids: np.ndarray       # [Ne,3]
     boundaries: List[RDyBoundary] = dataclasses.field(default_factory=list)
+    # [Nc] int32 rank that owns each local cell (what DMPlex's point SF knows: iremote[].rank), or None when the mesh was
+    # cut without a part array at hand; halo.py then finds the ghosts' owners by asking (an O(world x ghosts) fallback)
+    cell_owner_rank: Optional[np.ndarray] = None
 
     # ---- convenience -----------------------------------------------------
     def owned_centroids(self) -> np.ndarray:
@@ -579,7 +582,8 @@ def extract_local_mesh(xyz: np.ndarray, conn: np.ndarray, owned_mask: np.ndarray
                        boundary_classifier=None,
                        ghosts: str = "tail", project_2d: bool = False,
                        vertex_global_ids: Optional[np.ndarray] = None,
-                       num_vertices_global: Optional[int] = None) -> RDyMesh:
+                       num_vertices_global: Optional[int] = None,
+                       cell_parts: Optional[np.ndarray] = None) -> RDyMesh:
     """Local mesh of one rank: the cells flagged in `owned_mask` plus every
     cell sharing an edge with one of them (the 1-cell overlap of
     DMPlexDistributeOverlap(dm, 1, ...), src/rdydm.c:145-157, under edge
@@ -587,7 +591,8 @@ def extract_local_mesh(xyz: np.ndarray, conn: np.ndarray, owned_mask: np.ndarray
 
     `ghosts="tail"` numbers ghosts after the owned cells; "interleaved" keeps
     the source order (owned and ghost cells mixed, as a DMPlex local numbering
-    may be).
+    may be).  `cell_parts` (the owner rank of every source cell) is carried onto
+    the local mesh as `cell_owner_rank`.
     """
     conn = np.asarray(conn)
     if conn.shape[1] == 3:
@@ -625,11 +630,14 @@ def extract_local_mesh(xyz: np.ndarray, conn: np.ndarray, owned_mask: np.ndarray
     sub_conn = np.where(sub_conn >= 0, remap[np.maximum(sub_conn, 0)], -1).astype(np.int32)
     gids = np.arange(nc, dtype=np.int64) if cell_global_ids is None else np.asarray(cell_global_ids)
     vg = used if vertex_global_ids is None else np.asarray(vertex_global_ids)[used]
-    return build_mesh(xyz[used], sub_conn, is_owned=owned_mask[sel].astype(np.int32),
-                      cell_global_ids=gids[sel],
-                      num_cells_global=num_cells_global if num_cells_global is not None else nc,
-                      boundary_classifier=boundary_classifier, project_2d=project_2d,
-                      vertex_global_ids=vg, num_vertices_global=num_vertices_global if num_vertices_global is not None else nv)
+    lm = build_mesh(xyz[used], sub_conn, is_owned=owned_mask[sel].astype(np.int32),
+                    cell_global_ids=gids[sel],
+                    num_cells_global=num_cells_global if num_cells_global is not None else nc,
+                    boundary_classifier=boundary_classifier, project_2d=project_2d,
+                    vertex_global_ids=vg, num_vertices_global=num_vertices_global if num_vertices_global is not None else nv)
+    if cell_parts is not None:
+        lm.cell_owner_rank = np.ascontiguousarray(np.asarray(cell_parts)[sel], dtype=np.int32)
+    return lm
 
 
 def strip_partition_tri_mesh(nx_per_rank: int, ny: int, rank: int, nranks: int, d: float = 1.0,
@@ -657,7 +665,8 @@ def strip_partition_tri_mesh(nx_per_rank: int, ny: int, rank: int, nranks: int, 
     vgid = jj.ravel() * (nxg + 1) + ii.ravel() + i0          # vertex (i, j) of the global (nxg+1) x (ny+1) lattice
     return extract_local_mesh(xyz, conn, owned, cell_global_ids=gids,
                               num_cells_global=2 * nxg * ny, boundary_classifier=cls,
-                              vertex_global_ids=vgid, num_vertices_global=(nxg + 1) * (ny + 1))
+                              vertex_global_ids=vgid, num_vertices_global=(nxg + 1) * (ny + 1),
+                              cell_parts=np.clip(gi // nx_per_rank, 0, nranks - 1))
 
 
 # ---------------------------------------------------------------------------
