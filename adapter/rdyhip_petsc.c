@@ -8,7 +8,9 @@
  * What it implements (file:line relative to the RDycore tree):
  *
  *   CreateHipSWEFluxOperator    same signature as CreatePetscFluxOperator   (include/private/rdyoperatorimpl.h:234,
- *                               src/operator_fluxes_petsc.c:17) and, with well_balancing = HR, as CreatePetscFluxHROperator (236)
+ *                               src/operator_fluxes_petsc.c:17); it also covers well_balancing = HR, for which the reference has the
+ *                               separate factory CreatePetscFluxHROperator (236: the same arguments WITHOUT the MPI_Comm) -- the
+ *                               dispatch in CreateOperatorSubOperators calls this one factory for both
  *   CreateHipSWESourceOperator  same signature as CreatePetscSourceOperator (rdyoperatorimpl.h:238, src/operator_sources_petsc.c:13)
  *
  * i.e. the two PetscOperators that ApplyPetscOperator (src/operator.c:656-672) applies, built with
@@ -24,6 +26,20 @@
  *   source.apply  (last)                         refreshes external sources / Manning n the same way, then ONE
  *                                                rdyhip_apply(h, dt, u_local, f_global): F += flux divergence + sources
  *
+ * and the multi-rank binding (row (h) of the scope table: the DM's 1-cell ghost halo on RCCL, overlapped with the interior):
+ *
+ *   RDyHipPermuteLocalCells   called in CreateDM right after DMPlexDistributeOverlap (src/rdydm.c:145-157), before the labels and
+ *                             RDyMeshCreateFromDM (src/rdymesh.c:95): DMPlexPermute of the local cells -- owned cells first, each
+ *                             group along a Hilbert curve through the centroids (rdyhip_hilbert_cell_order) -- so that the
+ *                             operator's tiles (runs of 256 consecutive owned cells) are compact patches
+ *   RDyHipCreateHaloFromDM    after CreateOperator (src/rdysetup.c:1108): DMGetPointSF -> PetscSFGetGraph (for every ghost cell
+ *                             its owner rank and the owner's point number) -> rdyhip_halo_plan_* with ONE MPI_Alltoall(v) for the
+ *                             transpose -> an RCCL communicator over the DM's ranks (id from rank 0 by MPI_Bcast) -> rdyhip_halo_create
+ *   OperatorRHSFunctionHip    replaces OperatorRHSFunction (src/rdysetup.c:1120-1172) in TSSetRHSFunction: the local half of
+ *                             DMGlobalToLocal (rdyhip_copy_owned_rows) and then rdyhip_rhs_overlapped = VecZeroEntries(F) + ghost
+ *                             update over RCCL on the library's stream + ResetOperatorDiagnostics + ApplyOperator, interior tiles
+ *                             meanwhile (1130-1139 in one call); second order included (state and gradient exchanges inside)
+ *
  * plus four small hooks the patch in INTEGRATION.md section 2 wires in: RDyHipResetDiagnostics, RDyHipUpdateDiagnostics
  * (called by UpdateOperatorDiagnostics before its MPI_Allreduce, src/operator.c:867-883), RDyHipSyncBoundaryFluxes (called by
  * ExtractOperatorBoundaryFluxes before it reads boundary_fluxes_accum, src/operator.c:1069-1086) and
@@ -32,6 +48,14 @@
  * Vec memory: with -dm_vec_type hip u_local and f_global are device Vecs and their arrays are handed to the kernel
  * as they are (VecGetArrayReadAndMemType, the pattern of src/operator.c:563-573); host Vecs are staged through device
  * scratch (correct, slow -- meant for checking the backend against the PETSc one on a workstation).
+ *
+ * Streams: every launch goes on the stream of PETSc's current device context (PetscDeviceContextGetStreamHandle), i.e.
+ * it is ordered with PETSc's own Vec kernels (VecAXPY of TSEULER, VecZeroEntries) without a device synchronisation.
+ *
+ * Parallel runs: through the plain PetscOperator seam (ApplyHipSource after PETSc's DMGlobalToLocal) only FIRST order
+ * is possible -- a second-order apply on a mesh with ghost cells needs the ghost gradients exchanged between its two
+ * phases (RDYHIP_PHASE_GRADIENTS_READY) and is refused by the library otherwise; ApplyHipSource says so itself.  The
+ * second-order parallel path is OperatorRHSFunctionHip.
  */
 #if defined(__has_include)
 #if __has_include(<petsc.h>) && __has_include(<private/rdyoperatorimpl.h>) && __has_include(<hip/hip_runtime_api.h>)
@@ -72,6 +96,9 @@ typedef struct RDyHipShared {
   PetscObjectState    external_sources_state, material_properties_state;
   OperatorDiagnostics *diagnostics;  // borrowed
   PetscReal           *d_u, *d_f;    // device staging for host Vecs
+  RDyHipHalo           halo;         // multi-rank: the ghost exchange (RDyHipCreateHaloFromDM), NULL on one rank
+  void                *nccl_comm;    // the library-side RCCL communicator over the DM's ranks
+  PetscBool            second_order;
   struct RDyHipShared *next;
 } RDyHipShared;
 
@@ -86,6 +113,8 @@ static RDyHipShared *FindShared(RDyMesh *mesh) {
 static PetscErrorCode ReleaseShared(RDyHipShared *s) {
   PetscFunctionBegin;
   if (--s->refs > 0) PetscFunctionReturn(PETSC_SUCCESS);
+  if (s->halo) RDyHipCall(rdyhip_halo_destroy(&s->halo));
+  if (s->nccl_comm) RDyHipCall(rdyhip_comm_destroy(s->nccl_comm));
   RDyHipCall(rdyhip_destroy(&s->handle));
   if (s->d_u) HipCall(hipFree(s->d_u));
   if (s->d_f) HipCall(hipFree(s->d_f));
@@ -136,7 +165,8 @@ static PetscErrorCode CreateShared(RDyConfig *config, RDyMesh *mesh, PetscInt nu
   PetscCheck(config->physics.sediment.num_classes == 0, PETSC_COMM_WORLD, PETSC_ERR_USER, "the native HIP operator has no tracers");
   RDyHipShared *s;
   PetscCall(PetscCalloc1(1, &s));
-  s->mesh = mesh;
+  s->mesh         = mesh;
+  s->second_order = config->numerics.second_order ? PETSC_TRUE : PETSC_FALSE;
 
   const PetscInt nc = mesh->num_cells, ne = mesh->num_edges;
   int32_t       *c_is_owned, *c_l2o, *c_cells, *c_internal, *c_vertex = NULL;
@@ -272,12 +302,20 @@ static PetscErrorCode RefreshField(Vec v, PetscObjectState *seen, double *d_dst,
   PetscFunctionReturn(PETSC_SUCCESS);
 }
 
-//-------------------------------------------------------------------------------------------------
-// flux operator: the Dirichlet values (SetOperatorBoundaryValues writes the boundary_values Vecs, src/operator.c:1045-1061)
-//-------------------------------------------------------------------------------------------------
-static PetscErrorCode ApplyHipFlux(void *context, PetscOperatorFields fields, PetscReal dt, Vec u_local, Vec f_global) {
+// the stream PETSc's own device kernels run on (the current device context's), so that our launches are ordered with them
+static PetscErrorCode PetscHipStream(hipStream_t *stream) {
   PetscFunctionBegin;
-  RDyHipShared *s = context;
+  PetscDeviceContext dctx;
+  void              *handle;
+  PetscCall(PetscDeviceContextGetCurrentContext(&dctx));
+  PetscCall(PetscDeviceContextGetStreamHandle(dctx, &handle));  // for a HIP context: a pointer to its hipStream_t
+  *stream = *(hipStream_t *)handle;
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+// the Dirichlet values the host changed since the last apply (SetOperatorBoundaryValues writes the Vecs, src/operator.c:1045-1061)
+static PetscErrorCode RefreshBoundaryValues(RDyHipShared *s) {
+  PetscFunctionBegin;
   for (PetscInt b = 0; b < s->num_boundaries; ++b) {
     PetscObjectState st;
     PetscCall(PetscObjectStateGet((PetscObject)s->boundary_values[b], &st));
@@ -288,6 +326,28 @@ static PetscErrorCode ApplyHipFlux(void *context, PetscOperatorFields fields, Pe
     PetscCall(VecRestoreArrayRead(s->boundary_values[b], &a));
     s->boundary_values_state[b] = st;
   }
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+// external sources / Manning n: whole-array copies when the Vecs changed (their layouts are the device fields', operator.c:91-96)
+static PetscErrorCode RefreshCellFields(RDyHipShared *s) {
+  PetscFunctionBegin;
+  double *d_ext, *d_man;
+  int64_t n_ext, n_man;
+  RDyHipCall(rdyhip_field_ptr(s->handle, RDYHIP_FIELD_EXTERNAL_SOURCES, &d_ext, &n_ext));
+  RDyHipCall(rdyhip_field_ptr(s->handle, RDYHIP_FIELD_MANNINGS, &d_man, &n_man));
+  PetscCall(RefreshField(s->external_sources, &s->external_sources_state, d_ext, n_ext));
+  PetscCall(RefreshField(s->material_properties, &s->material_properties_state, d_man, n_man));
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+//-------------------------------------------------------------------------------------------------
+// flux operator: the Dirichlet values (SetOperatorBoundaryValues writes the boundary_values Vecs, src/operator.c:1045-1061)
+//-------------------------------------------------------------------------------------------------
+static PetscErrorCode ApplyHipFlux(void *context, PetscOperatorFields fields, PetscReal dt, Vec u_local, Vec f_global) {
+  PetscFunctionBegin;
+  RDyHipShared *s = context;
+  PetscCall(RefreshBoundaryValues(s));
   PetscFunctionReturn(PETSC_SUCCESS);
 }
 
@@ -316,13 +376,13 @@ PetscErrorCode CreateHipSWEFluxOperator(RDyConfig *config, RDyMesh *mesh, MPI_Co
 static PetscErrorCode ApplyHipSource(void *context, PetscOperatorFields fields, PetscReal dt, Vec u_local, Vec f_global) {
   PetscFunctionBegin;
   RDyHipShared *s = context;
-  double       *d_ext, *d_man;
-  int64_t       n_ext, n_man;
-  RDyHipCall(rdyhip_field_ptr(s->handle, RDYHIP_FIELD_EXTERNAL_SOURCES, &d_ext, &n_ext));
-  RDyHipCall(rdyhip_field_ptr(s->handle, RDYHIP_FIELD_MANNINGS, &d_man, &n_man));
-  // the Vecs' layouts are the device fields' ([owned][3] and [owned][1], operator.c:91-96): whole-array copies when they changed
-  PetscCall(RefreshField(s->external_sources, &s->external_sources_state, d_ext, n_ext));
-  PetscCall(RefreshField(s->material_properties, &s->material_properties_state, d_man, n_man));
+  PetscCall(RefreshCellFields(s));
+  // second order on a partitioned mesh needs the ghost gradients exchanged between the two phases of the apply: that is
+  // OperatorRHSFunctionHip's job (the library would refuse this call with "needs RDYHIP_PHASE_GRADIENTS_READY")
+  PetscCheck(!(s->second_order && s->mesh->num_cells > s->mesh->num_owned_cells), PETSC_COMM_WORLD, PETSC_ERR_SUP,
+             "second_order on several ranks: install OperatorRHSFunctionHip (RDyHipCreateHaloFromDM) instead of the plain PetscOperator path");
+  hipStream_t stream;
+  PetscCall(PetscHipStream(&stream));
 
   const PetscScalar *u;
   PetscScalar       *f;
@@ -335,13 +395,14 @@ static PetscErrorCode ApplyHipSource(void *context, PetscOperatorFields fields, 
   if (PetscMemTypeDevice(mu) && PetscMemTypeDevice(mf)) {
     // -dm_vec_type hip: the Vecs' device arrays as they are, on PETSc's stream; F += flux divergence + sources as the
     // reference's sub-operators do (src/swe/swe_petsc.c:301-305, 783-785)
-    RDyHipCall(rdyhip_apply(s->handle, dt, u, f, NULL));
+    RDyHipCall(rdyhip_apply(s->handle, dt, u, f, (void *)stream));
   } else {
     if (!s->d_u) HipCall(hipMalloc((void **)&s->d_u, sizeof(double) * (size_t)(nu > 0 ? nu : 1)));
     if (!s->d_f) HipCall(hipMalloc((void **)&s->d_f, sizeof(double) * (size_t)(nf > 0 ? nf : 1)));
     HipCall(hipMemcpy(s->d_u, u, sizeof(double) * (size_t)nu, PetscMemTypeDevice(mu) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
     HipCall(hipMemcpy(s->d_f, f, sizeof(double) * (size_t)nf, PetscMemTypeDevice(mf) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
-    RDyHipCall(rdyhip_apply(s->handle, dt, s->d_u, s->d_f, NULL));
+    RDyHipCall(rdyhip_apply(s->handle, dt, s->d_u, s->d_f, (void *)stream));
+    HipCall(hipStreamSynchronize(stream));
     HipCall(hipMemcpy(f, s->d_f, sizeof(double) * (size_t)nf, PetscMemTypeDevice(mf) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost));
   }
   PetscCall(VecRestoreArrayAndMemType(f_global, &f));
@@ -364,6 +425,203 @@ PetscErrorCode CreateHipSWESourceOperator(RDyConfig *config, RDyMesh *mesh, Vec 
   s->material_properties = material_properties;
   s->refs++;
   PetscCall(PetscOperatorCreate(s, ApplyHipSource, DestroyHipSource, source_op));
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+//-------------------------------------------------------------------------------------------------
+// the multi-rank binding: local cell numbering, the ghost exchange from the DM's point SF, the overlapped RHS function
+//-------------------------------------------------------------------------------------------------
+
+// Renumbers the LOCAL cells of a distributed (and overlapped) DMPlex: owned cells first, ghosts after, each group along a
+// Hilbert curve through the cell centroids.  Call between DMPlexDistributeOverlap and everything that reads point numbers
+// (labels made afterwards, RDyMeshCreateFromDM, the sections).  Edges and vertices keep their numbers.
+PetscErrorCode RDyHipPermuteLocalCells(DM *dm) {
+  PetscFunctionBegin;
+  PetscInt c_start, c_end, p_start, p_end;
+  PetscCall(DMPlexGetHeightStratum(*dm, 0, &c_start, &c_end));
+  PetscCall(DMPlexGetChart(*dm, &p_start, &p_end));
+  const PetscInt nc = c_end - c_start;
+  if (nc == 0) PetscFunctionReturn(PETSC_SUCCESS);
+
+  // which cells are ghosts: the leaves of the point SF (points owned by another rank)
+  int32_t *is_owned, *perm;
+  double  *xy;
+  PetscCall(PetscMalloc3(nc, &is_owned, nc, &perm, 2 * nc, &xy));
+  for (PetscInt c = 0; c < nc; ++c) is_owned[c] = 1;
+  PetscSF            sf;
+  PetscInt           nroots, nleaves;
+  const PetscInt    *ilocal;
+  const PetscSFNode *iremote;
+  PetscCall(DMGetPointSF(*dm, &sf));
+  PetscCall(PetscSFGetGraph(sf, &nroots, &nleaves, &ilocal, &iremote));
+  for (PetscInt i = 0; i < (nroots >= 0 ? nleaves : 0); ++i) {
+    const PetscInt p = ilocal ? ilocal[i] : i;
+    if (p >= c_start && p < c_end) is_owned[p - c_start] = 0;
+  }
+  for (PetscInt c = c_start; c < c_end; ++c) {
+    PetscReal area, centroid[3], normal[3];
+    PetscCall(DMPlexComputeCellGeometryFVM(*dm, c, &area, centroid, normal));
+    xy[2 * (c - c_start)]     = centroid[0];
+    xy[2 * (c - c_start) + 1] = centroid[1];
+  }
+  RDyHipCall(rdyhip_hilbert_cell_order((int32_t)nc, xy, 2, is_owned, perm));  // perm[new cell] = old cell
+
+  // DMPlexPermute wants perm[old point] = new point, over the whole chart
+  PetscInt *new_of_old;
+  PetscCall(PetscMalloc1(p_end - p_start, &new_of_old));
+  for (PetscInt p = p_start; p < p_end; ++p) new_of_old[p - p_start] = p;
+  for (PetscInt i = 0; i < nc; ++i) new_of_old[c_start + perm[i] - p_start] = c_start + i;
+  IS is;
+  DM pdm;
+  PetscCall(ISCreateGeneral(PETSC_COMM_SELF, p_end - p_start, new_of_old, PETSC_OWN_POINTER, &is));
+  PetscCall(DMPlexPermute(*dm, is, &pdm));  // carries coordinates, labels, the local section and the point SF along
+  PetscCall(ISDestroy(&is));
+  PetscCall(PetscFree3(is_owned, perm, xy));
+  PetscCall(DMDestroy(dm));
+  *dm = pdm;
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+// The exchange pattern of this rank from the DM's point SF, and an RCCL communicator of the library's own over the DM's
+// ranks.  After CreateOperator (the native operator of `mesh` must exist).  RDyMesh numbers its cells c - cStart
+// (src/rdymesh.c:113-118), and so does every other rank: an SF leaf (p, {rank, index}) that is a cell says "my local cell
+// p - cStart is rank's local cell index - cStart(rank)"; the height-0 stratum of a DMPlex starts at point 0 on every rank.
+PetscErrorCode RDyHipCreateHaloFromDM(DM dm, RDyMesh *mesh) {
+  PetscFunctionBegin;
+  RDyHipShared *s = FindShared(mesh);
+  PetscCheck(s, PETSC_COMM_WORLD, PETSC_ERR_ORDER, "RDyHipCreateHaloFromDM must follow CreateOperator (no native operator for this mesh yet)");
+  MPI_Comm    comm;
+  PetscMPIInt size, rank;
+  PetscCall(PetscObjectGetComm((PetscObject)dm, &comm));
+  PetscCallMPI(MPI_Comm_size(comm, &size));
+  PetscCallMPI(MPI_Comm_rank(comm, &rank));
+  if (size == 1 || s->halo) PetscFunctionReturn(PETSC_SUCCESS);
+
+  PetscInt c_start, c_end;
+  PetscCall(DMPlexGetHeightStratum(dm, 0, &c_start, &c_end));
+  PetscCheck(c_start == 0, comm, PETSC_ERR_SUP, "the cells of this DMPlex do not start at point 0 (cStart = %" PetscInt_FMT ")", c_start);
+  PetscSF            sf;
+  PetscInt           nroots, nleaves;
+  const PetscInt    *ilocal;
+  const PetscSFNode *iremote;
+  PetscCall(DMGetPointSF(dm, &sf));
+  PetscCall(PetscSFGetGraph(sf, &nroots, &nleaves, &ilocal, &iremote));
+  if (nroots < 0) nleaves = 0;  // graph not set: a rank without shared points
+
+  // the ghost CELLS among the leaves: local id, owner, the owner's local id
+  int32_t *g_cell, *g_owner;
+  int64_t *g_key;
+  PetscCall(PetscMalloc3(nleaves > 0 ? nleaves : 1, &g_cell, nleaves > 0 ? nleaves : 1, &g_owner, nleaves > 0 ? nleaves : 1, &g_key));
+  int32_t ng = 0;
+  for (PetscInt i = 0; i < nleaves; ++i) {
+    const PetscInt p = ilocal ? ilocal[i] : i;
+    if (p < c_start || p >= c_end) continue;
+    PetscCheck(!mesh->cells.is_owned[p - c_start], comm, PETSC_ERR_PLIB, "SF leaf %" PetscInt_FMT " is a cell RDyMesh counts as owned", p);
+    g_cell[ng]  = (int32_t)(p - c_start);
+    g_owner[ng] = (int32_t)iremote[i].rank;
+    g_key[ng]   = (int64_t)iremote[i].index;  // = the owner's local cell id (its cStart is 0 too)
+    ++ng;
+  }
+  PetscCheck(ng == mesh->num_cells - mesh->num_owned_cells, comm, PETSC_ERR_PLIB, "%d ghost cells in the point SF, %" PetscInt_FMT " in RDyMesh", ng,
+             mesh->num_cells - mesh->num_owned_cells);
+
+  RDyHipHaloPlan plan;
+  RDyHipCall(rdyhip_halo_plan_create((int32_t)size, (int32_t)rank, ng, g_cell, g_owner, g_key, &plan));
+  const int32_t *req_counts;
+  const int64_t *req_keys;
+  RDyHipCall(rdyhip_halo_plan_requests(plan, &req_counts, &req_keys));
+  // the transpose of the leaf -> root relation: who asks ME for what (PetscSFGetRootRanks holds the same lists; one
+  // all-to-all keeps this independent of the SF's internal rank ordering)
+  PetscMPIInt *in_counts, *sdispl, *rdispl;
+  PetscCall(PetscMalloc3(size, &in_counts, size + 1, &sdispl, size + 1, &rdispl));
+  PetscCallMPI(MPI_Alltoall((void *)req_counts, 1, MPI_INT, in_counts, 1, MPI_INT, comm));
+  sdispl[0] = rdispl[0] = 0;
+  for (PetscMPIInt r = 0; r < size; ++r) {
+    sdispl[r + 1] = sdispl[r] + req_counts[r];
+    rdispl[r + 1] = rdispl[r] + in_counts[r];
+  }
+  int64_t *in_keys;
+  PetscCall(PetscMalloc1(rdispl[size] > 0 ? rdispl[size] : 1, &in_keys));
+  PetscCallMPI(MPI_Alltoallv((void *)req_keys, (int *)req_counts, sdispl, MPI_INT64_T, in_keys, in_counts, rdispl, MPI_INT64_T, comm));
+
+  int32_t *owned;
+  PetscCall(PetscMalloc1(mesh->num_cells > 0 ? mesh->num_cells : 1, &owned));
+  for (PetscInt c = 0; c < mesh->num_cells; ++c) owned[c] = mesh->cells.is_owned[c] ? 1 : 0;
+  RDyHipCall(rdyhip_halo_plan_finish(plan, in_counts, in_keys, (int32_t)mesh->num_cells, owned, NULL));  // keys are local cell ids
+  int32_t        npeers;
+  const int32_t *peers, *send_counts, *send_cells, *recv_counts, *recv_cells;
+  RDyHipCall(rdyhip_halo_plan_get(plan, &npeers, &peers, &send_counts, &send_cells, &recv_counts, &recv_cells));
+
+  // RCCL communicator over the DM's ranks: rank 0 draws the id, MPI carries it (PETSc has selected this rank's device)
+  char id[RDYHIP_COMM_ID_BYTES];
+  int  ok = 1;
+  if (rank == 0) ok = rdyhip_comm_unique_id(id) == 0;
+  PetscCallMPI(MPI_Bcast(&ok, 1, MPI_INT, 0, comm));  // a failure on rank 0 is everybody's, before anybody blocks in RCCL
+  PetscCheck(ok, comm, PETSC_ERR_LIB, "ncclGetUniqueId failed on rank 0");
+  PetscCallMPI(MPI_Bcast(id, RDYHIP_COMM_ID_BYTES, MPI_BYTE, 0, comm));
+  RDyHipCall(rdyhip_comm_init_rank((int32_t)size, (int32_t)rank, id, &s->nccl_comm));
+  RDyHipCall(rdyhip_halo_create(s->handle, s->nccl_comm, npeers, peers, send_counts, send_cells, recv_counts, recv_cells, &s->halo));
+
+  RDyHipCall(rdyhip_halo_plan_destroy(&plan));
+  PetscCall(PetscFree(owned));
+  PetscCall(PetscFree(in_keys));
+  PetscCall(PetscFree3(in_counts, sdispl, rdispl));
+  PetscCall(PetscFree3(g_cell, g_owner, g_key));
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+// OperatorRHSFunction (src/rdysetup.c:1120-1172) on the native operator: TSSetRHSFunction(ts, NULL, OperatorRHSFunctionHip, rdy)
+// when -rdy_hip_native is on and the Vecs are device Vecs (-dm_vec_type hip).
+PetscErrorCode OperatorRHSFunctionHip(TS ts, PetscReal t, Vec U, Vec F, void *ctx) {
+  PetscFunctionBegin;
+  RDy           rdy = ctx;
+  RDyHipShared *s   = FindShared(&rdy->mesh);
+  PetscCheck(s, rdy->comm, PETSC_ERR_ORDER, "no native operator for this RDy (CreateOperator with -rdy_hip_native first)");
+  PetscCheck(s->halo || rdy->mesh.num_cells == rdy->mesh.num_owned_cells, rdy->comm, PETSC_ERR_ORDER,
+             "the mesh has ghost cells: call RDyHipCreateHaloFromDM after CreateOperator");
+  (void)t;
+  PetscScalar dt;
+  PetscCall(TSGetTimeStep(ts, &dt));
+
+  // what the two PetscOperators' apply functions do before the launch: inputs the host changed since the last RHS
+  PetscCall(RefreshBoundaryValues(s));
+  PetscCall(RefreshCellFields(s));
+
+  const PetscScalar *u;
+  PetscScalar       *ul, *f;
+  PetscMemType       mu, ml, mf;
+  PetscCall(VecGetArrayReadAndMemType(U, &u, &mu));
+  PetscCall(VecGetArrayAndMemType(rdy->u_local, &ul, &ml));
+  PetscCall(VecGetArrayWriteAndMemType(F, &f, &mf));
+  PetscCheck(PetscMemTypeDevice(mu) && PetscMemTypeDevice(ml) && PetscMemTypeDevice(mf), rdy->comm, PETSC_ERR_SUP,
+             "OperatorRHSFunctionHip needs device Vecs (-dm_vec_type hip); host Vecs go through the PetscOperator path");
+  hipStream_t stream;
+  PetscCall(PetscHipStream(&stream));
+  // DMGlobalToLocal, local half: the owned rows of u_local (one contiguous copy after RDyHipPermuteLocalCells) ...
+  RDyHipCall(rdyhip_copy_owned_rows(s->handle, u, ul, (void *)stream));
+  if (s->halo) {
+    // ... and the ghost rows over RCCL, hidden behind the interior tiles; F is overwritten (VecZeroEntries + accumulate),
+    // the Courant diagnostic starts over (ResetOperatorDiagnostics)
+    RDyHipCall(rdyhip_rhs_overlapped(s->handle, s->halo, dt, ul, f, (void *)stream));
+  } else {
+    RDyHipCall(rdyhip_rhs_function(s->handle, dt, ul, f, (void *)stream));
+  }
+  PetscCall(VecRestoreArrayWriteAndMemType(F, &f));
+  PetscCall(VecRestoreArrayAndMemType(rdy->u_local, &ul));
+  PetscCall(VecRestoreArrayReadAndMemType(U, &u));
+
+  // debug-level logging as in the reference (rdysetup.c:1155-1169)
+  if (rdy->config.logging.level >= LOG_DEBUG) {
+    PetscCall(UpdateOperatorDiagnostics(rdy->operator));
+    OperatorDiagnostics diagnostics;
+    PetscCall(GetOperatorDiagnostics(rdy->operator, &diagnostics));
+    PetscReal time;
+    PetscInt  stepnum;
+    PetscCall(TSGetTime(ts, &time));
+    PetscCall(TSGetStepNumber(ts, &stepnum));
+    RDyLogDebug(rdy, "[%" PetscInt_FMT "] Time = %f [%s] Max courant number %g", stepnum, ConvertTimeFromSeconds(time, rdy->config.time.unit),
+                TimeUnitAsString(rdy->config.time.unit), diagnostics.courant_number.max_courant_num);
+  }
   PetscFunctionReturn(PETSC_SUCCESS);
 }
 

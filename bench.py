@@ -151,7 +151,8 @@ def build_case(args, rank, world, nx=None, ny=None, order=None):
         case = CS.dam_break_quads_case(mesh)
         case.config.source_method = src
     elif wl == "houston_refined":
-        case = CS.houston_refined_case(HOUSTON_DATA, nx,      # nx = refinement levels here order if order in ("hilbert", "natural", "random") else "hilbert", hr=args.hr,
+        # nx = refinement levels here
+        case = CS.houston_refined_case(HOUSTON_DATA, nx, order if order in ("hilbert", "natural", "random") else "hilbert", hr=args.hr,
                                        rank=rank, world=world)
         case.config.source_method = src
     elif wl == "delaunay":
@@ -380,7 +381,7 @@ def run_rank(args, argv):
                 halo.destroy()
             halo = HaloExchange(mesh, dev, transport="torch", op=op)
             halo_note = f"fell back from the C-side RCCL exchange to torch.distributed P2P: {halo_note}"
-    self_halo = None
+    self_halo, self_rccl_ranks = None, None
     if args.self_exchange:
         if world != 1 or args.emulate_world < 2:
             raise SystemExit("--self-exchange needs --gpus 1 and --emulate-world W")
@@ -406,6 +407,9 @@ def run_rank(args, argv):
         cnt = i32([n])
         _lib.check(lib.rdyhip_halo_create(op._h, comm, 1, pp(i32([0])), pp(cnt), pp(sendc), pp(cnt), pp(ghost), C.byref(hh)))
         self_halo = (lib, hh, comm, n)
+        nr = C.c_int32(0)
+        _lib.check(lib.rdyhip_comm_count(comm, C.byref(nr)))
+        self_rccl_ranks = int(nr.value)
     u = torch.tensor(case.u_local, dtype=torch.float64, device=dev)
     f = torch.empty((mesh.num_owned_cells, 3), dtype=torch.float64, device=dev)
     setup_s = time.time() - t0
@@ -663,6 +667,9 @@ def run_rank(args, argv):
                        "backend": (backend if world > 1 else None),
                        "rccl_version": ".".join(map(str, torch.cuda.nccl.version())) if world > 1 and backend == "nccl" else None,
                        "halo_driver": (halo.transport if halo is not None else None), "halo_note": halo_note,
+                       # ncclCommCount of the communicator the library's exchange runs on: proof that RCCL spanned N ranks
+                       "rccl_ranks": (halo.rccl_ranks() if halo is not None else (self_rccl_ranks if self_halo is not None else None)),
+                       "hsa_enable_ipc_mode_legacy": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"),
                        "well_balancing": "hydrostatic_reconstruction" if args.hr else "none",
                        "spatial_order": ("second (MUSCL, %s limiter)" % args.limiter) if args.second_order else "first",
                        "halo_bytes_per_rank": halo.bytes_sent_per_exchange if halo else 0,

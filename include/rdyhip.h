@@ -392,6 +392,14 @@ int rdyhip_axpy_owned(RDyHipOperator op, double dt, const double *f_global, doub
 int rdyhip_euler_step(RDyHipOperator op, int32_t phase, int32_t flags, double dt, const double *u_local, double *u_local_out, double *f_global,
                       void *stream);
 
+/* ---- across a host-side gap (RDyAdvance returns, the driver writes output / talks to a coupler, calls RDyAdvance again)
+ * After any idle moment the device runs its next few dozen launches 20-35 % slow (profiles/r02_launch_series.json).
+ * rdyhip_keep_warm(op, 1), called when the host starts such a gap, parks ONE sleeping wave on a side stream of the
+ * library's own (it polls a host flag, leaves at rdyhip_keep_warm(op, 0), at rdyhip_destroy, or after 250 ms at the
+ * latest); the device then stays in its working power state.  Optional; costs one wave slot and nothing else.
+ * tools/advance_pattern.py measures the loop with and without it. */
+int rdyhip_keep_warm(RDyHipOperator op, int32_t on);
+
 /* ---- introspection ----------------------------------------------------------
  * numbers describing the device layout, for DESIGN.md / bench.py */
 typedef struct {

@@ -205,8 +205,8 @@ __device__ __forceinline__ EdgeFlux muscl_edge(const KernelArgs &a, const TileDe
     wet                 = !(R.h < a.tiny_h && L.h < a.tiny_h);  // swe_petsc.c:184
   } else {
     const RiemannSide L  = riemann_side(MSQ(0, jl), MSQ(1, jl), MSQ(2, jl), a.tiny_h, a.h_anuga_sq);
-    const int         k  = a.tile_bk[td.b_off + ((lr >> EDGE_R_SHIFT) & EDGE_SLOT_MASK)];
-    BoundaryFlux      bf = boundary_flux(a.btype[k], true, L, a.bvalues + 3 * (int64_t)k, sn, cn, a.tiny_h, a.h_anuga_sq);
+    const int         k  = RDY_COLD(a, tile_bk)[td.b_off + ((lr >> EDGE_R_SHIFT) & EDGE_SLOT_MASK)];
+    BoundaryFlux      bf = boundary_flux(RDY_COLD(a, btype)[k], true, L, RDY_COLD(a, bvalues) + 3 * (int64_t)k, sn, cn, a.tiny_h, a.h_anuga_sq);
     fl                   = bf.flux;
     wet                  = bf.wet;
     store_boundary_flux(a, k, fl, dt);
@@ -269,9 +269,10 @@ __global__ __launch_bounds__(BLOCK) void muscl_gradient_kernel(const KernelArgs 
   const int o = a.list ? a.list[i] : i;
   int32_t   id[S];
   bool      has_ghost = false;
+  const int32_t *nbr  = RDY_COLD(a, nbr);
 #pragma unroll
   for (int s = 0; s < S; ++s) {
-    id[s] = a.nbr[s * a.stride + o];
+    id[s] = nbr[s * a.stride + o];
     has_ghost |= (id[s] >= 0) && (id[s] & NBR_GHOST);
   }
   if (a.phase == RDYHIP_PHASE_INTERIOR && has_ghost) return;
@@ -325,9 +326,9 @@ __global__ __launch_bounds__(TILE) void swe_rhs_muscl_kernel(const KernelArgs a,
 
   for (; idx < hi; idx += step) {
     const int      tile = __builtin_amdgcn_readfirstlane(a.list ? load_uniform(a.list, idx) : idx);
-    const TileDesc td = a.tiles[tile], tn = a.tiles[tile + 1];
-    if (a.phase == RDYHIP_PHASE_INTERIOR && td.halo) continue;  // wave-uniform
-    const int  ne = tn.e_off - td.e_off, nh = tn.h_off - td.h_off;
+    const TileDesc td = a.tiles[tile];
+    if (a.phase == RDYHIP_PHASE_INTERIOR && td.halo()) continue;  // wave-uniform
+    const int  ne = td.ne(), nh = td.nh();
     const int  o      = tile * TILE + tid;
     const bool active = o < a.n_owned;
 
@@ -451,7 +452,7 @@ __global__ __launch_bounds__(TILE) RDY_MUSCL_OCC void swe_rhs_muscl_fused_kernel
     typedef int v4i __attribute__((ext_vector_type(4)));
     const v4i v = load_uniform(reinterpret_cast<const v4i *>(a.tiles), t);
     TileDesc  d;
-    d.e_off = v.x; d.h_off = v.y; d.b_off = v.z; d.halo = v.w;
+    d.e_off = v.x; d.h_off = v.y; d.b_off = v.z; d.cnt = (uint32_t)v.w;
     return d;
   };
   // id of the ring cell (first or second ring) this thread stages for a tile
@@ -484,9 +485,9 @@ __global__ __launch_bounds__(TILE) RDY_MUSCL_OCC void swe_rhs_muscl_fused_kernel
 
   for (; idx < hi; idx += step) {
     const int      tile = tile_at(idx);
-    const TileDesc td = tile_desc(tile), tn = tile_desc(tile + 1);
-    if (a.phase == RDYHIP_PHASE_INTERIOR && td.halo) continue;  // wave-uniform
-    const int  ne = tn.e_off - td.e_off, nh = tn.h_off - td.h_off;
+    const TileDesc td = tile_desc(tile);
+    if (a.phase == RDYHIP_PHASE_INTERIOR && td.halo()) continue;  // wave-uniform
+    const int  ne = td.ne(), nh = td.nh();
     const int  c0 = load_uniform(g.c_off, tile), nc2 = load_uniform(g.c_off, tile + 1) - c0;
     const int  o      = tile * TILE + tid;
     const bool active = o < a.n_owned;
@@ -548,9 +549,9 @@ __global__ __launch_bounds__(TILE) RDY_MUSCL_OCC void swe_rhs_muscl_fused_kernel
     pre_tile = -1;
     if (idx + step < hi) {
       pre_tile            = tile_at(idx + step);
-      const TileDesc pd = tile_desc(pre_tile), pn = tile_desc(pre_tile + 1);
+      const TileDesc pd  = tile_desc(pre_tile);
       const int      pc0 = load_uniform(g.c_off, pre_tile);
-      pre_hid            = ring_id(pd, pn.h_off - pd.h_off, pc0, load_uniform(g.c_off, pre_tile + 1) - pc0);
+      pre_hid            = ring_id(pd, pd.nh(), pc0, load_uniform(g.c_off, pre_tile + 1) - pc0);
     }
 
     // ---- phase 0: state + centroid of own cells, first ring, second ring; the tile's edge records -> LDS

@@ -100,6 +100,7 @@ struct RDyHipOperator_s {
   int          grid = 0, xcd_chunks = 0;        // cell kernel
   int          pgrid = 0, tiled_xcd_chunks = 0; // tiled (persistent) kernel
   int          interior_shrink = 32;            // the INTERIOR phase leaves 1/interior_shrink of the workgroup slots free (0: none)
+  bool         balance_rounds = false;          // size the persistent grid so that all workgroups walk the same number of tiles
   bool         keep_fdiv = false;
 
   DevBuf<int32_t> d_o2l, d_nbr, d_pos, d_halo_list, d_btype, d_bleft, d_bghost_list;
@@ -107,6 +108,7 @@ struct RDyHipOperator_s {
   DevBuf<double>  d_bvalues, d_bflux, d_baccum, d_bcn, d_bsn, d_pv, d_fdiv, d_blk_max;
   DevBuf<int32_t> d_blk_pos;
   DevBuf<DeviceCourant> d_courant;
+  DevBuf<ColdArgs>      d_cold;   // the kernels' rarely read pointers (swe_kernels.h), written once at create
   int32_t n_halo = 0, n_bghost = 0;
   // tiled kernel (swe_kernels.h)
   bool             use_tiled = true;
@@ -145,13 +147,22 @@ struct RDyHipOperator_s {
   DevBuf<int32_t> d_stage_ids;
 
   int64_t device_bytes = 0;
+  // rdyhip_keep_warm: a host-coherent flag, its device view, the side stream the waiting wave runs on
+  int        *kw_flag = nullptr, *kw_flag_dev = nullptr;
+  hipStream_t kw_stream = nullptr;
 
   ~RDyHipOperator_s() {
+    if (kw_flag) {
+      *(volatile int *)kw_flag = 0;
+      if (kw_stream) (void)hipStreamSynchronize(kw_stream);
+      (void)hipHostFree(kw_flag);
+    }
+    if (kw_stream) (void)hipStreamDestroy(kw_stream);
     d_o2l.release(); d_nbr.release(); d_pos.release(); d_halo_list.release(); d_btype.release(); d_bleft.release();
     d_bghost_list.release(); d_cn.release(); d_sn.release(); d_coef.release(); d_dzdx.release(); d_dzdy.release();
     d_mannings.release(); d_extsrc.release(); d_bvalues.release(); d_bflux.release();
     d_baccum.release(); d_bcn.release(); d_bsn.release(); d_pv.release(); d_fdiv.release(); d_blk_max.release();
-    d_blk_pos.release(); d_courant.release(); d_stage_vals.release(); d_stage_ids.release(); d_scratch_f.release();
+    d_blk_pos.release(); d_courant.release(); d_cold.release(); d_stage_vals.release(); d_stage_ids.release(); d_scratch_f.release();
     d_tiles.release(); d_e_lr.release(); d_hcells.release(); d_tile_bk.release(); d_halo_tiles.release();
     d_e_cs.release(); d_slot_ref.release(); d_slot_ref3.release(); d_zc_local.release();
     d_grad.release(); d_e_mid.release(); d_cxy.release(); d_hcells2.release(); d_c_off.release();
@@ -258,7 +269,7 @@ int launch_gradients(RDyHipOperator op, int32_t phase, const double *u, hipStrea
   a.n_owned = op->n_owned;
   a.stride  = op->stride;
   a.o2l     = op->prefix ? nullptr : op->d_o2l.p;
-  a.nbr     = op->d_nbr.p;
+  a.cold    = op->d_cold.p;
   a.phase   = phase;
   int grid;
   if (phase == RDYHIP_PHASE_HALO) {
@@ -317,31 +328,20 @@ int launch_rhs(RDyHipOperator op, int32_t phase, int32_t overwrite, int reset_di
   a.n_owned    = op->n_owned;
   a.stride     = op->stride;
   a.o2l        = op->prefix ? nullptr : op->d_o2l.p;
-  a.nbr        = op->d_nbr.p;
-  a.cn         = op->d_cn.p;
-  a.sn         = op->d_sn.p;
+  a.cold       = op->d_cold.p;
   a.coef       = op->d_coef.p;
-  a.pos        = op->d_pos.p;
   a.dzdx       = op->d_dzdx.p;
   a.dzdy       = op->d_dzdy.p;
   a.mannings   = op->d_mannings.p;
   a.extsrc     = op->d_extsrc.p;
-  a.btype      = op->d_btype.p;
-  a.bvalues    = op->d_bvalues.p;
-  a.bflux      = op->d_bflux.p;
-  a.baccum     = op->d_baccum.p;
   a.pv         = op->d_pv.p;
   a.fdiv       = op->keep_fdiv ? op->d_fdiv.p : nullptr;
-  a.blk_max    = op->d_blk_max.p;
-  a.blk_pos    = op->d_blk_pos.p;
   a.n_buckets  = (int32_t)op->d_blk_max.n;
+  a.bucket_off = 0;
   if (bucket_half) {
     const int32_t half = a.n_buckets / 2;
     a.n_buckets = half;
-    if (bucket_half == 2) {
-      a.blk_max += half;
-      a.blk_pos += half;
-    }
+    if (bucket_half == 2) a.bucket_off = half;
   }
   a.reset_diag = reset_diag ? 1 : 0;
   a.tiny_h     = op->config.tiny_h;
@@ -354,7 +354,6 @@ int launch_rhs(RDyHipOperator op, int32_t phase, int32_t overwrite, int reset_di
   a.e_lr     = op->d_e_lr.p;
   a.e_cs     = op->d_e_cs.p;
   a.hcells   = op->d_hcells.p;
-  a.tile_bk  = op->d_tile_bk.p;
   a.slot_ref = op->S == 3 ? (const void *)op->d_slot_ref3.p : (const void *)op->d_slot_ref.p;
   a.zc_local = op->d_zc_local.p;
   a.emax     = op->emax;
@@ -383,7 +382,14 @@ int launch_rhs(RDyHipOperator op, int32_t phase, int32_t overwrite, int reset_di
       const int pg = (phase == RDYHIP_PHASE_INTERIOR && op->interior_shrink > 0) ? std::max(8, pgrid - pgrid / op->interior_shrink) : pgrid;
       if (op->tiled_xcd_chunks > 0) {
         a.xcd_chunks = op->tiled_xcd_chunks;
-        grid         = std::min(pg & ~7, op->tiled_xcd_chunks * 8);
+        int per_xcd  = std::max(1, std::min(pg >> 3, op->tiled_xcd_chunks));
+        if (op->balance_rounds) {
+          // every workgroup of an XCD walks the same number of tiles (+-1): a mesh of 3 907 tiles on 768 resident workgroups
+          // would otherwise run five full rounds and a sixth with 9 % of the device busy
+          const int rounds = (op->tiled_xcd_chunks + per_xcd - 1) / per_xcd;
+          per_xcd          = (op->tiled_xcd_chunks + rounds - 1) / rounds;
+        }
+        grid = per_xcd * 8;
       } else {
         a.xcd_chunks = 0;
         grid         = std::min(pg, op->ntiles);
@@ -646,7 +652,7 @@ static int layout_build_tiles(const RDyHipMesh *mesh, HostLayout &L) {
       tiles[t].e_off = (int32_t)e_lr.size();
       tiles[t].h_off = (int32_t)hcells.size();
       tiles[t].b_off = (int32_t)tile_bk.size();
-      tiles[t].halo  = halo_tile ? 1 : 0;
+      tiles[t].cnt   = halo_tile ? TILE_HALO_FLAG : 0u;   // the counts are filled in below
       if (halo_tile) halo_tiles.push_back(t);
       touched.clear();
       int32_t nh = 0, nbk = 0;
@@ -742,10 +748,13 @@ static int layout_build_tiles(const RDyHipMesh *mesh, HostLayout &L) {
         for (int32_t cell : touched2) hslot2[cell] = -1;
         hmax2 = std::max(hmax2, nh + nc2);
         if (TILE + nh + nc2 >= (int32_t)BN_GLOBAL) return fail(RDYHIP_ERR_USER, "tile working set too large: the cell numbering has no locality");
-        tiles[t].halo = halo_tile ? 1 : 0;
+        tiles[t].cnt = halo_tile ? TILE_HALO_FLAG : 0u;
         if (halo_tile && (halo_tiles.empty() || halo_tiles.back() != t)) halo_tiles.push_back(t);
       }
       for (int32_t cell : touched) hslot[cell] = -1;
+      // a tile has at most 4 x 256 edge records and as many halo cells: 11 bits each
+      if (local + 1 > 0x7FF || nh > 0x7FF) return fail(RDYHIP_ERR_ARG_SIZ, "tile %d: %d edge records / %d halo cells do not fit the tile descriptor", t, local + 1, nh);
+      tiles[t].cnt |= (uint32_t)(local + 1) | ((uint32_t)nh << 11);
       emax = std::max(emax, local + 1);
       hmax = std::max(hmax, nh);
       if ((int64_t)e_lr.size() > (int64_t)INT32_MAX - 4 * TILE) return fail(RDYHIP_ERR_ARG_SIZ, "too many tile edge records");
@@ -753,7 +762,7 @@ static int layout_build_tiles(const RDyHipMesh *mesh, HostLayout &L) {
     tiles[ntiles].e_off = (int32_t)e_lr.size();
     tiles[ntiles].h_off = (int32_t)hcells.size();
     tiles[ntiles].b_off = (int32_t)tile_bk.size();
-    tiles[ntiles].halo  = 0;
+    tiles[ntiles].cnt   = 0;
     if (muscl_on) c_off[ntiles] = (int32_t)hcells2.size();
     // a tile has at most 4*256 edges, so 256 + hmax <= 1280 slots < 2^11 and <= 1024 boundary edges
   }
@@ -924,6 +933,10 @@ int rdyhip_create(const RDyHipConfig *config, const RDyHipMesh *mesh, int32_t nu
     }
     op->tiled_xcd_chunks = (swz && ntiles >= 64) ? (ntiles + 7) / 8 : 0;
     if (const char *e3 = getenv("RDYHIP_INTERIOR_SHRINK")) op->interior_shrink = std::max(0, atoi(e3));  // measurement knob
+    if (const char *e4 = getenv("RDYHIP_PGRID")) {  // measurement knob: the persistent grid itself
+      if (atoi(e4) >= 8) op->pgrid = op->pgrid_muscl = atoi(e4) & ~7;
+    }
+    if (const char *e5 = getenv("RDYHIP_BALANCE_ROUNDS")) op->balance_rounds = atoi(e5) != 0;
   }
   const int maxgrid = std::max(std::max(std::max(op->grid, op->pgrid), op->pgrid_muscl), 1);
 
@@ -1001,6 +1014,13 @@ int rdyhip_create(const RDyHipConfig *config, const RDyHipMesh *mesh, int32_t nu
   TRY_RC(op->d_blk_max.zeros((size_t)2 * maxgrid));  // two halves: see launch_rhs(bucket_half)
   TRY_RC(op->d_blk_pos.zeros((size_t)2 * maxgrid));
   TRY_RC(op->d_courant.zeros(1));
+  {
+    ColdArgs c{};
+    c.nbr = op->d_nbr.p; c.cn = op->d_cn.p; c.sn = op->d_sn.p; c.pos = op->d_pos.p;
+    c.btype = op->d_btype.p; c.bvalues = op->d_bvalues.p; c.bflux = op->d_bflux.p; c.baccum = op->d_baccum.p;
+    c.tile_bk = op->d_tile_bk.p; c.blk_max = op->d_blk_max.p; c.blk_pos = op->d_blk_pos.p;
+    TRY_RC(op->d_cold.upload(std::vector<ColdArgs>(1, c)));
+  }
 #undef TRY_RC
   hipLaunchKernelGGL(courant_reset_kernel, dim3(4), dim3(1024), 0, 0, (int)op->d_blk_max.n, op->d_blk_max.p, op->d_blk_pos.p);
   if (hipDeviceSynchronize() != hipSuccess) {
@@ -1370,6 +1390,26 @@ int rdyhip_copy_owned_rows(RDyHipOperator op, const double *u_global, double *u_
   if (u_global == u_local) return fail(RDYHIP_ERR_USER, "rdyhip_copy_owned_rows in place needs owned cells numbered first");
   const int64_t n3 = 3 * (int64_t)op->n_owned;
   hipLaunchKernelGGL(copy_owned_rows_kernel, dim3((unsigned)((n3 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, op->n_owned, op->d_o2l.p, u_global, u_local);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int rdyhip_keep_warm(RDyHipOperator op, int32_t on) {
+  if (!op) return fail(RDYHIP_ERR_USER, "null operator");
+  if (!on) {
+    if (op->kw_flag) *(volatile int *)op->kw_flag = 0;  // the waiting wave sees it within microseconds and exits
+    return 0;
+  }
+  if (!op->kw_flag) {
+    HIP_TRY(hipHostMalloc((void **)&op->kw_flag, sizeof(int), hipHostMallocMapped | hipHostMallocCoherent));
+    *op->kw_flag = 0;
+    HIP_TRY(hipHostGetDevicePointer((void **)&op->kw_flag_dev, op->kw_flag, 0));
+    HIP_TRY(hipStreamCreateWithFlags(&op->kw_stream, hipStreamNonBlocking));
+  }
+  if (*(volatile int *)op->kw_flag) return 0;  // already waiting
+  *(volatile int *)op->kw_flag = 1;
+  // deadline: 250 ms (s_memrealtime counts at 100 MHz); a longer host gap simply lapses -- the host may call again
+  hipLaunchKernelGGL(keep_warm_kernel, dim3(1), dim3(64), 0, op->kw_stream, op->kw_flag_dev, 25000000LL);
   HIP_TRY(hipGetLastError());
   return 0;
 }

@@ -32,9 +32,9 @@ def rank_environment(rank: int, world: int, port: int, base: Optional[Dict[str, 
     env.update({
         "RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_WORLD_SIZE": str(world),
         "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port),
-        # the host driver supports dmabuf IPC only: RCCL's intra-node transport needs this (already exported on the GPU boxes)
-        "HSA_ENABLE_IPC_MODE_LEGACY": env.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
     })
+    # everything else -- HSA_ENABLE_IPC_MODE_LEGACY included, which RCCL's intra-node transport depends on -- is the
+    # caller's environment passed through unchanged: no default is invented here
     return env
 
 

@@ -307,6 +307,11 @@ class Operator:
         self._check_vecs(u_local, f_global)
         _lib.check(_lib.load().rdyhip_axpy_owned(self._h, float(dt), _ptr(f_global), _ptr(u_local), _stream()))
 
+    def copy_owned_rows(self, u_global: torch.Tensor, u_local: torch.Tensor):
+        """the local half of DMGlobalToLocal (src/rdysetup.c:1133-1134): u_local[owned cell o] = u_global[o]"""
+        self._check_vecs(u_local, u_global)
+        _lib.check(_lib.load().rdyhip_copy_owned_rows(self._h, _ptr(u_global), _ptr(u_local), _stream()))
+
     def layout_info(self) -> dict:
         info = _lib.RDyHipLayoutInfo()
         _lib.check(_lib.load().rdyhip_layout_info(self._h, C.byref(info)))

@@ -25,3 +25,25 @@ def test_adapter_uses_only_declared_abi_functions():
     # the factories carry the reference's signatures (include/private/rdyoperatorimpl.h:234, 238)
     assert re.search(r"CreateHipSWEFluxOperator\(RDyConfig \*config, RDyMesh \*mesh, MPI_Comm comm, PetscInt num_boundaries, RDyBoundary \*boundaries,", src)
     assert re.search(r"CreateHipSWESourceOperator\(RDyConfig \*config, RDyMesh \*mesh, Vec external_sources, Vec material_properties, PetscOperator \*source_op\)", src)
+
+
+def test_adapter_holds_the_multi_rank_binding_in_code():
+    """row (h): the DM-side binding of the overlapped multi-rank RHS is code in the adapter, not prose -- the point SF is read,
+    the plan goes through its one all-to-all, the halo is created on an RCCL communicator bootstrapped over MPI, and the
+    RHS function replaces src/rdysetup.c:1130-1139 by the local copy + rdyhip_rhs_overlapped (in this order)"""
+    src = open(SRC).read()
+    assert re.search(r"PetscErrorCode RDyHipPermuteLocalCells\(DM \*dm\)", src)
+    assert re.search(r"PetscErrorCode RDyHipCreateHaloFromDM\(DM dm, RDyMesh \*mesh\)", src)
+    assert re.search(r"PetscErrorCode OperatorRHSFunctionHip\(TS ts, PetscReal t, Vec U, Vec F, void \*ctx\)", src)   # TSRHSFunction
+    body = src[src.index("PetscErrorCode RDyHipCreateHaloFromDM"):src.index("PetscErrorCode OperatorRHSFunctionHip")]
+    order = ["DMGetPointSF", "PetscSFGetGraph", "rdyhip_halo_plan_create", "rdyhip_halo_plan_requests", "MPI_Alltoall(", "MPI_Alltoallv(",
+             "rdyhip_halo_plan_finish", "rdyhip_halo_plan_get", "rdyhip_comm_unique_id", "MPI_Bcast(id", "rdyhip_comm_init_rank", "rdyhip_halo_create"]
+    pos = [body.index(k) for k in order]
+    assert pos == sorted(pos)
+    rhs = src[src.index("PetscErrorCode OperatorRHSFunctionHip"):]
+    pos = [rhs.index(k) for k in ["TSGetTimeStep", "RefreshBoundaryValues", "RefreshCellFields", "rdyhip_copy_owned_rows", "rdyhip_rhs_overlapped"]]
+    assert pos == sorted(pos)
+    perm = src[src.index("PetscErrorCode RDyHipPermuteLocalCells"):src.index("PetscErrorCode RDyHipCreateHaloFromDM")]
+    assert "rdyhip_hilbert_cell_order" in perm and "DMPlexPermute" in perm and "DMPlexComputeCellGeometryFVM" in perm
+    # every launch of the adapter goes on PETSc's stream, none on the NULL stream
+    assert not re.search(r"rdyhip_(apply|rhs_function|rhs_overlapped)\([^;]*NULL\)", src)

@@ -63,6 +63,14 @@ def _cases(kind, rank, world, second_order):
             c.u_local[:, 1] = 0.3 * c.u_local[:, 0] * np.sin(1.7 * xc + 0.9 * yc)
             c.u_local[:, 2] = 0.2 * c.u_local[:, 0] * np.cos(1.1 * xc - 2.3 * yc)
         ekey = lambda e: e
+    elif kind == "rcb_houston":
+        # unstructured: the reference's Houston1km mesh refined three times (175 744 triangles), ragged outline, wet / dry
+        # fronts, rain + stage forcing; parts of very different shapes, the owners of the ghosts known from the part array
+        data = os.path.join(ROOT, "tests", "golden", "houston")
+        case = CS.houston_refined_case(data, 3, "hilbert", rank=rank, world=world)
+        gc = CS.houston_refined_case(data, 3, "hilbert")
+        g = gc.mesh
+        ekey = lambda e: M.edge_vertex_key(g, e)
     else:
         raise ValueError(kind)
     case.config.second_order = second_order
@@ -165,7 +173,8 @@ def _worker(rank, world, port, kernel, q, second_order=False, transport="torch",
         dist.destroy_process_group()
 
 
-def _run(world, args):
+def _run(world, args, join=240):
+    assert world <= 6, "at most six processes may use the GPU of a box together"
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -173,7 +182,7 @@ def _run(world, args):
     for p in procs:
         p.start()
     for p in procs:
-        p.join(240)
+        p.join(join)
     assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
     return sorted(q.get(timeout=5) for _ in range(world))
 
@@ -211,6 +220,21 @@ def test_three_rcb_ranks_one_gpu(rdyhip_kernel, kind):
     for rank, err, cerr, ids_ok, nhalo_tiles, ntiles in _run(3, (rdyhip_kernel, False, "c", kind)):
         assert err <= 1e-10, (rank, err)
         assert cerr <= 1e-12 and ids_ok
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("kind,second_order", [("strips", False), ("rcb_c5", False), ("rcb_quads", True), ("rcb_houston", False), ("rcb_houston", True)])
+def test_six_ranks_one_gpu(rdyhip_kernel, kind, second_order):
+    """the rehearsal of a full node as far as one device allows (six processes may share a card): strips with two inner
+    ranks' worth of neighbours, RCB-6 parts with three and more peers and uneven shapes, the second-order double exchange, RK4
+    (strips) -- every rank's RHS = the single-rank oracle's rows, the cross-rank Courant struct-max with its ids"""
+    if rdyhip_kernel == "cell":
+        pytest.skip("one kernel variant is enough for the six-rank rehearsal")
+    res = _run(6, (rdyhip_kernel, second_order, "c", kind), join=420)
+    for rank, err, cerr, ids_ok, nhalo_tiles, ntiles in res:
+        assert err <= 1e-10, (rank, err)
+        assert cerr <= 1e-10 and ids_ok
+        assert 0 < nhalo_tiles <= ntiles
 
 
 @pytest.mark.timeout(300)
@@ -275,7 +299,9 @@ def test_bench_self_launches_two_ranks(rdyhip_kernel):
     env = dict(os.environ, BENCH_BACKEND="gloo")
     env.pop("WORLD_SIZE", None)
     env.pop("RANK", None)
-    for extra, driver in (([], "torch"), (["--halo", "c"], "c"), (["--workload", "c5", "--nx", "160", "--ny", "160", "--halo", "c"], "c")):
+    for extra, driver in (([], "torch"), (["--halo", "c"], "c"), (["--workload", "c5", "--nx", "160", "--ny", "160", "--halo", "c"], "c"),
+                          (["--gpus", "6", "--workload", "houston_refined", "--levels", "3", "--halo", "c"], "c")):
+        n = 6 if "6" in extra else 2
         cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--nx", "200", "--ny", "200",
                "--condition-seconds", "0.2", "--watchdog-seconds", "150", "--launch-timeout", "200"] + extra
         out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
@@ -283,8 +309,9 @@ def test_bench_self_launches_two_ranks(rdyhip_kernel):
         lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
         assert len(lines) == 1, lines
         d = json.loads(lines[0])
-        assert d["n_gpus"] == 2 and d["config"]["world_size"] == 2 and d["config"]["backend"] == "gloo" and d["config"]["finite"] is True
-        assert d["scaling"] == ("strong" if "c5" in extra else "weak") and d["value"] > 0
+        assert d["n_gpus"] == n and d["config"]["world_size"] == n and d["config"]["backend"] == "gloo" and d["config"]["finite"] is True
+        assert d["config"]["rccl_ranks"] is None                 # gloo rehearsal: the bytes do not travel over RCCL, and the line says so
+        assert d["scaling"] == ("strong" if ("c5" in extra or "houston_refined" in extra) else "weak") and d["value"] > 0
         assert d["config"]["halo_driver"] == driver and d["config"]["halo_bytes_per_rank"] > 0
         assert d["config"]["max_courant"] > 0 and d["config"]["max_courant_cell"] >= 0
 

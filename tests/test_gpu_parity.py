@@ -177,6 +177,15 @@ def test_partition_with_ghost_cells(ghosts):
     assert np.array_equal(f2.cpu().numpy(), f)
     op.update_diagnostics()
     assert abs(op.get_diagnostics().max_courant_num - orc.diagnostics()[0]) <= 1e-12
+    # the local half of DMGlobalToLocal (rdyhip_copy_owned_rows): the owned rows of a global vector land in their local
+    # rows (a contiguous prefix or scattered), ghost rows are left alone
+    ug = torch.tensor(np.random.default_rng(3).random((mesh.num_owned_cells, 3)), dtype=torch.float64, device="cuda")
+    ul = torch.full((mesh.num_cells, 3), -7.0, dtype=torch.float64, device="cuda")
+    op.copy_owned_rows(ug, ul)
+    torch.cuda.synchronize()
+    want = np.full((mesh.num_cells, 3), -7.0)
+    want[mesh.cell_owned_to_local] = ug.cpu().numpy()
+    assert np.array_equal(ul.cpu().numpy(), want)
 
 
 def test_dry_bed_and_nan_free_rhs():

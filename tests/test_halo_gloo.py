@@ -110,3 +110,66 @@ def test_two_rank_halo_exchange_and_partitioned_rhs(ghosts_mode, second_order):
     for rank, err, nbytes, nghost in res:
         assert err < 1e-13
         assert nghost == 9 and nbytes == 9 * 24         # ny ghost triangles per side, 3 doubles each
+
+
+def _worker_rcb(rank, world, port, kind, q):
+    """RCB parts of an unstructured mesh: uneven part sizes, ranks with three and more neighbours; the pattern comes from
+    rdyhip_halo_plan_* (owner ranks carried by the mesh, or found by asking when it carries none)"""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from rdycore_amd import cases as CS
+        from rdycore_amd.halo import HaloExchange
+        from helpers import oracle_from_case, rel_linf
+        data = os.path.join(ROOT, "tests", "golden", "houston")
+        if kind == "houston":
+            case = CS.houston_refined_case(data, 2, "hilbert", rank=rank, world=world)
+            gc = CS.houston_refined_case(data, 2, "hilbert")
+            assert case.mesh.cell_owner_rank is not None
+        else:                                     # the C5 miniature: its generator knows only its own part (no owner ranks)
+            case = CS.c5_case(CS.c5_mesh(60, 50, rank, world), 60.0, 50.0)
+            gc = CS.c5_case(CS.c5_mesh(60, 50), 60.0, 50.0)
+            assert case.mesh.cell_owner_rank is None
+        mesh = case.mesh
+        truth = case.u_local.copy()
+        u = torch.tensor(case.u_local)
+        ghost = torch.tensor(mesh.cell_is_owned == 0)
+        u[ghost] = float("nan")
+        halo = HaloExchange(mesh, torch.device("cpu"))
+        halo.exchange(u)
+        assert torch.equal(u, torch.tensor(truth)), "ghost cells differ from their owners' values"
+        f = oracle_from_case(case).apply(case.dt, u.numpy())
+        fg = oracle_from_case(gc).apply(gc.dt, gc.u_local)
+        if kind == "houston":
+            key = {tuple(np.round(c[:2], 3)): i for i, c in enumerate(gc.mesh.cell_centroids)}
+            rows = np.array([key[tuple(np.round(c[:2], 3))] for c in mesh.cell_centroids[mesh.cell_owned_to_local]])
+        else:
+            g2row = {int(g): i for i, g in enumerate(gc.mesh.cell_global_ids)}
+            rows = np.array([g2row[int(g)] for g in mesh.cell_global_ids[mesh.cell_owned_to_local]])
+        q.put((rank, rel_linf(f, fg[rows]), len(halo.send_ids), len(halo.recv_ids), mesh.num_owned_cells, int(ghost.sum())))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind,world", [("houston", 8), ("c5", 3)])
+@pytest.mark.timeout(300)
+def test_rcb_ranks_through_the_halo_plan(kind, world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_rcb, args=(r, world, port, kind, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(240)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    res = sorted(q.get(timeout=5) for _ in range(world))
+    assert all(err < 1e-13 for _, err, *_ in res)
+    assert all(ns == nr and ns >= 1 for _, _, ns, nr, _, _ in res)       # the pattern is symmetric in its peers
+    if world == 8:
+        assert max(ns for _, _, ns, *_ in res) >= 3                      # ranks with three and more neighbours
+        sizes = [no for *_, no, _ in res]
+        assert max(sizes) - min(sizes) <= 1 and sum(sizes) == 2746 * 16

@@ -16,17 +16,25 @@ def _script(tmp_path, body):
 def test_ranks_get_the_rendezvous_environment_and_rank0_is_relayed(tmp_path):
     argv = _script(tmp_path, """
         import json, os
-        keys = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "HSA_ENABLE_IPC_MODE_LEGACY")
-        print(json.dumps({k: os.environ[k] for k in keys}), flush=True)
+        keys = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "HSA_ENABLE_IPC_MODE_LEGACY", "RDY_TEST_PASSTHROUGH")
+        print(json.dumps({k: os.environ.get(k) for k in keys}), flush=True)
     """)
     out = io.StringIO()
-    assert launch_ranks(3, argv, timeout=60, out=out) == 0
+    os.environ["RDY_TEST_PASSTHROUGH"] = "yes"
+    try:
+        assert launch_ranks(3, argv, timeout=60, out=out) == 0
+    finally:
+        del os.environ["RDY_TEST_PASSTHROUGH"]
     lines = [ln for ln in out.getvalue().splitlines() if ln.strip()]
     assert len(lines) == 1                       # only rank 0's stdout is relayed
     import json
     d = json.loads(lines[0])
     assert d["RANK"] == "0" and d["LOCAL_RANK"] == "0" and d["WORLD_SIZE"] == "3" and d["MASTER_ADDR"] == "127.0.0.1"
-    assert int(d["MASTER_PORT"]) > 0 and d["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert int(d["MASTER_PORT"]) > 0
+    # the caller's environment reaches the ranks unchanged; HSA_ENABLE_IPC_MODE_LEGACY (RCCL's intra-node transport depends
+    # on it) is passed through as it is -- the launcher invents no default for it
+    assert d["RDY_TEST_PASSTHROUGH"] == "yes" and d["HSA_ENABLE_IPC_MODE_LEGACY"] == os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")
+    assert "HSA_ENABLE_IPC_MODE_LEGACY" not in rank_environment(0, 2, 1, base={})
 
 
 def test_a_failing_rank_ends_the_others_and_sets_the_return_code(tmp_path):
