@@ -349,6 +349,7 @@ def run_rank(args, argv):
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
+    from rdycore_amd import _lib
     from rdycore_amd import cases as CS
     from rdycore_amd.halo import HaloExchange
 
@@ -606,7 +607,7 @@ def run_rank(args, argv):
         if world == 1 and args.emulate_world > 1:
             part = f"rank {args.emulate_rank} of rcb_{args.emulate_world} (ghost cells present, not exchanged)"
             if self_halo is not None:
-                part = (f"rank {args.emulate_rank} of strips_x{args.emulate_world}; every step is rdyhip_rhs_overlapped with a one-rank RCCL "
+                part = (f"rank {args.emulate_rank} of {'rcb_' if args.scaling == 'strong' else 'strips_x'}{args.emulate_world}; every step is rdyhip_rhs_overlapped with a one-rank RCCL "
                         f"communicator whose only peer is this rank ({self_halo[3]} cells = {self_halo[3] * 24} B sent to and received from itself)")
         friction = f"{args.source} friction"
         if args.workload == "c3":
@@ -670,6 +671,9 @@ def run_rank(args, argv):
                        # ncclCommCount of the communicator the library's exchange runs on: proof that RCCL spanned N ranks
                        "rccl_ranks": (halo.rccl_ranks() if halo is not None else (self_rccl_ranks if self_halo is not None else None)),
                        "hsa_enable_ipc_mode_legacy": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"),
+                       # 1: the exchange runs on the library's stream behind the interior tiles; 0: the in-order form of small parts
+                       "halo_overlapped": ((int(_lib.load().rdyhip_halo_overlaps(halo._halo)) if halo is not None and halo._halo is not None else None)
+                                           if self_halo is None else int(self_halo[0].rdyhip_halo_overlaps(self_halo[1]))),
                        "well_balancing": "hydrostatic_reconstruction" if args.hr else "none",
                        "spatial_order": ("second (MUSCL, %s limiter)" % args.limiter) if args.second_order else "first",
                        "halo_bytes_per_rank": halo.bytes_sent_per_exchange if halo else 0,

@@ -318,12 +318,17 @@ int rdyhip_unpack_rows(double *dst, int32_t ncomp, const int32_t *row_ids, int32
  * The tiles that need ghost data follow the unpack on the library's stream, beside the tail of the other tiles.
  * Second order: the state exchange hides behind the tiles that need no ghost data, then the ghost-adjacent gradients are
  * computed, exchanged (6 values per cell) and the remaining tiles follow.  The exchanges are ordered after everything
- * already enqueued on `stream`; when the call returns all work is enqueued and later work on `stream` is ordered after it. */
+ * already enqueued on `stream`; when the call returns all work is enqueued and later work on `stream` is ordered after it.
+ * Small parts: when a rank has fewer interior tiles than about six rounds of the persistent grid (~1.2 M cells), nothing
+ * is overlapped -- exchange, (gradients, their exchange,) ONE launch over all tiles, in order on `stream` -- because the
+ * interior phase is then shorter than the exchange chain and the two cross-stream dependencies cost more than they hide
+ * (profiles/r03_step_breakdown_360k.json).  rdyhip_halo_overlaps() says which form a halo uses; RDYHIP_OVERLAP=0 / 1 forces. */
 typedef struct RDyHipHalo_s *RDyHipHalo;
 typedef int (*RDyHipTransportFn)(void *ctx, const double *d_send, double *d_recv, int32_t ncomp, void *stream);
 int rdyhip_halo_create(RDyHipOperator op, void *nccl_comm, int32_t npeers, const int32_t *peers, const int32_t *send_counts,
                        const int32_t *send_cell_ids, const int32_t *recv_counts, const int32_t *recv_cell_ids, RDyHipHalo *halo);
 int rdyhip_halo_destroy(RDyHipHalo *halo);
+int32_t rdyhip_halo_overlaps(RDyHipHalo halo);
 int rdyhip_halo_set_transport(RDyHipHalo halo, RDyHipTransportFn fn, void *ctx);
 int rdyhip_halo_exchange(RDyHipHalo halo, double *rows, int32_t ncomp, void *stream);
 int rdyhip_rhs_overlapped(RDyHipOperator op, RDyHipHalo halo, double dt, double *u_local, double *f_global, void *stream);
@@ -391,14 +396,6 @@ int rdyhip_axpy_owned(RDyHipOperator op, double dt, const double *f_global, doub
  * (RDYHIP_PHASE_OVERWRITE is implied). */
 int rdyhip_euler_step(RDyHipOperator op, int32_t phase, int32_t flags, double dt, const double *u_local, double *u_local_out, double *f_global,
                       void *stream);
-
-/* ---- across a host-side gap (RDyAdvance returns, the driver writes output / talks to a coupler, calls RDyAdvance again)
- * After any idle moment the device runs its next few dozen launches 20-35 % slow (profiles/r02_launch_series.json).
- * rdyhip_keep_warm(op, 1), called when the host starts such a gap, parks ONE sleeping wave on a side stream of the
- * library's own (it polls a host flag, leaves at rdyhip_keep_warm(op, 0), at rdyhip_destroy, or after 250 ms at the
- * latest); the device then stays in its working power state.  Optional; costs one wave slot and nothing else.
- * tools/advance_pattern.py measures the loop with and without it. */
-int rdyhip_keep_warm(RDyHipOperator op, int32_t on);
 
 /* ---- introspection ----------------------------------------------------------
  * numbers describing the device layout, for DESIGN.md / bench.py */

@@ -88,6 +88,7 @@ SYMBOLS = {
     "rdyhip_euler_step": (C.c_int, [_H, C.c_int32, C.c_int32, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rdyhip_halo_create": (C.c_int, [_H, C.c_void_p, C.c_int32, c_int32_p, c_int32_p, c_int32_p, c_int32_p, c_int32_p, C.POINTER(C.c_void_p)]),
     "rdyhip_halo_destroy": (C.c_int, [C.POINTER(C.c_void_p)]),
+    "rdyhip_halo_overlaps": (C.c_int32, [C.c_void_p]),
     "rdyhip_halo_set_transport": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "rdyhip_halo_exchange": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "rdyhip_rhs_overlapped": (C.c_int, [_H, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -105,7 +106,6 @@ SYMBOLS = {
     "rdyhip_halo_plan_destroy": (C.c_int, [C.POINTER(C.c_void_p)]),
     "rdyhip_hilbert_cell_order": (C.c_int, [C.c_int32, c_double_p, C.c_int32, c_int32_p, c_int32_p]),
     "rdyhip_copy_owned_rows": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "rdyhip_keep_warm": (C.c_int, [_H, C.c_int32]),
     "rdyhip_probe_layout": (C.c_int, [C.POINTER(RDyHipConfig), C.POINTER(RDyHipMesh), C.c_int32, C.POINTER(RDyHipBoundary),
                                       C.POINTER(RDyHipLayoutInfo)]),
     "rdyhip_layout_info": (C.c_int, [_H, C.POINTER(RDyHipLayoutInfo)]),

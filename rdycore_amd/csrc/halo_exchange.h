@@ -19,6 +19,7 @@ struct RDyHipHalo_s {
   DevBuf<int32_t> d_send_ids, d_recv_ids;
   DevBuf<double>  d_send, d_recv;  // [cells][max_comp]
   int32_t         max_comp = 3;
+  bool            overlap = true;  // exchange hidden behind the interior tiles (large parts) or everything in order (small parts)
   hipStream_t     cs = nullptr;  // exchange stream
   // fork / join events: a small ring, one pair per step, so that steps still in flight never share an event (the host
   // runs several steps ahead of the device)
@@ -139,6 +140,20 @@ int overlapped(RDyHipOperator op, RDyHipHalo h, double dt, double *u, double *f,
     return launch_rhs(op, phase, 1, reset, dt, u, f, st, ready, u_out, conc && phase == RDYHIP_PHASE_INTERIOR ? 1 : 0);
   };
   int rc;
+  if (!h->overlap) {
+    // Small parts: the tiles that need no ghost data run for less time than the exchange chain (pack, transfer, unpack, halo
+    // tiles) takes, and the two cross-stream dependencies of the overlapped form cost more than they hide -- measured on
+    // a 360 000-cell rank (profiles/r03_step_breakdown_360k.json): 51.8 us per overlapped step against 14.0 us for the
+    // exchange plus 18.6 us for ONE launch over all tiles.  So: everything in order on the caller's stream.
+    rc = halo_exchange_on(h, u, 3, st);
+    if (!rc && op->muscl) {
+      // second order: the ghost-adjacent cells' gradients (fused form) or all of them (split form), then their exchange
+      rc = launch_gradients(op, op->muscl_fused ? RDYHIP_PHASE_HALO : RDYHIP_PHASE_ALL, u, st);
+      if (!rc) rc = halo_exchange_on(h, op->d_grad.p, 6, st);
+    }
+    if (!rc) rc = launch_rhs(op, RDYHIP_PHASE_ALL, 1, 1, dt, u, f, st, op->muscl, u_out, 0);
+    return rc;
+  }
   h->next_events();
   // fork: the exchange starts once everything already enqueued on the caller's stream (the update that produced u) is done
   HIP_TRY(hipEventRecord(h->ev_fork, st));
@@ -274,6 +289,15 @@ int rdyhip_halo_create(RDyHipOperator op, void *nccl_comm, int32_t npeers, const
       }
   }
   h->max_comp = op->muscl ? 6 : 3;
+  {
+    // overlap only where there is something to hide behind: at least RDYHIP_OVERLAP_MIN_ROUNDS (default 6) rounds of the
+    // persistent grid's worth of interior tiles (~7 us per round; the exchange chain is ~25-30 us).  RDYHIP_OVERLAP=0 / 1 forces.
+    const int pgrid    = std::max(8, op->muscl ? op->pgrid_muscl : op->pgrid);
+    int       min_rounds = 6;
+    if (const char *e = getenv("RDYHIP_OVERLAP_MIN_ROUNDS")) min_rounds = std::max(0, atoi(e));
+    h->overlap = op->use_tiled ? (int64_t)(op->ntiles - op->n_halo_tiles) >= (int64_t)min_rounds * pgrid : op->n_owned >= 1500000;
+    if (const char *e = getenv("RDYHIP_OVERLAP")) h->overlap = atoi(e) != 0;
+  }
   int rc      = h->d_send_ids.upload(std::vector<int32_t>(send_cell_ids, send_cell_ids + ns));
   if (!rc) rc = h->d_recv_ids.upload(std::vector<int32_t>(recv_cell_ids, recv_cell_ids + nr));
   if (!rc) rc = h->d_send.zeros((size_t)ns * h->max_comp);
@@ -318,6 +342,8 @@ int rdyhip_halo_destroy(RDyHipHalo *halo) {
   }
   return 0;
 }
+
+int32_t rdyhip_halo_overlaps(RDyHipHalo halo) { return halo && halo->overlap ? 1 : 0; }
 
 int rdyhip_halo_set_transport(RDyHipHalo halo, RDyHipTransportFn fn, void *ctx) {
   if (!halo) return fail(RDYHIP_ERR_USER, "null halo");

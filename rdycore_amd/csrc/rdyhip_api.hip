@@ -147,17 +147,8 @@ struct RDyHipOperator_s {
   DevBuf<int32_t> d_stage_ids;
 
   int64_t device_bytes = 0;
-  // rdyhip_keep_warm: a host-coherent flag, its device view, the side stream the waiting wave runs on
-  int        *kw_flag = nullptr, *kw_flag_dev = nullptr;
-  hipStream_t kw_stream = nullptr;
 
   ~RDyHipOperator_s() {
-    if (kw_flag) {
-      *(volatile int *)kw_flag = 0;
-      if (kw_stream) (void)hipStreamSynchronize(kw_stream);
-      (void)hipHostFree(kw_flag);
-    }
-    if (kw_stream) (void)hipStreamDestroy(kw_stream);
     d_o2l.release(); d_nbr.release(); d_pos.release(); d_halo_list.release(); d_btype.release(); d_bleft.release();
     d_bghost_list.release(); d_cn.release(); d_sn.release(); d_coef.release(); d_dzdx.release(); d_dzdy.release();
     d_mannings.release(); d_extsrc.release(); d_bvalues.release(); d_bflux.release();
@@ -1390,26 +1381,6 @@ int rdyhip_copy_owned_rows(RDyHipOperator op, const double *u_global, double *u_
   if (u_global == u_local) return fail(RDYHIP_ERR_USER, "rdyhip_copy_owned_rows in place needs owned cells numbered first");
   const int64_t n3 = 3 * (int64_t)op->n_owned;
   hipLaunchKernelGGL(copy_owned_rows_kernel, dim3((unsigned)((n3 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, op->n_owned, op->d_o2l.p, u_global, u_local);
-  HIP_TRY(hipGetLastError());
-  return 0;
-}
-
-int rdyhip_keep_warm(RDyHipOperator op, int32_t on) {
-  if (!op) return fail(RDYHIP_ERR_USER, "null operator");
-  if (!on) {
-    if (op->kw_flag) *(volatile int *)op->kw_flag = 0;  // the waiting wave sees it within microseconds and exits
-    return 0;
-  }
-  if (!op->kw_flag) {
-    HIP_TRY(hipHostMalloc((void **)&op->kw_flag, sizeof(int), hipHostMallocMapped | hipHostMallocCoherent));
-    *op->kw_flag = 0;
-    HIP_TRY(hipHostGetDevicePointer((void **)&op->kw_flag_dev, op->kw_flag, 0));
-    HIP_TRY(hipStreamCreateWithFlags(&op->kw_stream, hipStreamNonBlocking));
-  }
-  if (*(volatile int *)op->kw_flag) return 0;  // already waiting
-  *(volatile int *)op->kw_flag = 1;
-  // deadline: 250 ms (s_memrealtime counts at 100 MHz); a longer host gap simply lapses -- the host may call again
-  hipLaunchKernelGGL(keep_warm_kernel, dim3(1), dim3(64), 0, op->kw_stream, op->kw_flag_dev, 25000000LL);
   HIP_TRY(hipGetLastError());
   return 0;
 }

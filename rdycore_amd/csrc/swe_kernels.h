@@ -811,18 +811,6 @@ __global__ __launch_bounds__(1024) void courant_finalize_kernel(int nblk, const 
   }
 }
 
-// rdyhip_keep_warm: ONE wave that sleeps and polls a host-written flag until the host clears it or the deadline passes
-// (s_memrealtime ticks at 100 MHz) -- every path leaves the loop, so the grid always drains.  Keeps the device out of
-// its idle power state across a host-side gap between two batches of RHS launches.
-__global__ void keep_warm_kernel(const int *flag, long long max_ticks) {
-  if (threadIdx.x != 0) return;
-  const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();
-  while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) {
-    if ((long long)__builtin_amdgcn_s_memrealtime() - t0 > max_ticks) break;
-    __builtin_amdgcn_s_sleep(64);
-  }
-}
-
 // ResetOperatorDiagnostics (src/operator.c:772-784) on its own: clears every bucket
 __global__ void courant_reset_kernel(int nblk, double *__restrict__ blk_max, int32_t *__restrict__ blk_pos) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nblk; i += gridDim.x * blockDim.x) {

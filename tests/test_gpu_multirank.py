@@ -78,11 +78,14 @@ def _cases(kind, rank, world, second_order):
     return case, gc, ekey
 
 
-def _worker(rank, world, port, kernel, q, second_order=False, transport="torch", kind="strips"):
+def _worker(rank, world, port, kernel, q, second_order=False, transport="torch", kind="strips", overlap="1"):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    # these meshes are small: left to itself the library would run them in its in-order form (rdyhip_halo_overlaps);
+    # "1" forces the overlapped two-stream form the big meshes use, "0" the in-order one
+    os.environ["RDYHIP_OVERLAP"] = overlap
     if kernel:
         os.environ["RDYHIP_KERNEL"] = kernel
     import torch.distributed as dist
@@ -98,6 +101,9 @@ def _worker(rank, world, port, kernel, q, second_order=False, transport="torch",
         mesh = case.mesh
         op = CS.create_operator(case)
         halo = HaloExchange(mesh, dev, transport=transport, op=op)
+        if transport == "c":
+            from rdycore_amd import _lib
+            assert _lib.load().rdyhip_halo_overlaps(halo._halo) == int(overlap)
         u_np = case.u_local.copy()
         u_np[mesh.cell_is_owned == 0] = np.nan          # ghosts unknown until exchanged
         u = torch.tensor(u_np, dtype=torch.float64, device=dev)
@@ -174,7 +180,7 @@ def _worker(rank, world, port, kernel, q, second_order=False, transport="torch",
 
 
 def _run(world, args, join=240):
-    assert world <= 6, "at most six processes may use the GPU of a box together"
+    assert world <= 5, "at most six processes may use the GPU of a box together, and the test runner itself is one of them"
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -210,6 +216,18 @@ def test_three_ranks_one_gpu_second_order(rdyhip_kernel, transport):
 
 
 @pytest.mark.timeout(300)
+@pytest.mark.parametrize("second_order", [False, True])
+def test_three_ranks_one_gpu_in_order_form(rdyhip_kernel, second_order):
+    """the form small parts get (no overlap: exchange, gradients + their exchange, one launch over all tiles, in order on the
+    caller's stream) gives the same RHS, Euler step, RK4 steps, volume budget and Courant struct"""
+    if rdyhip_kernel == "cell" and second_order:
+        pytest.skip("second order is implemented by the tiled kernels")
+    for rank, err, cerr, ids_ok, nhalo_tiles, ntiles in _run(3, (rdyhip_kernel, second_order, "c", "strips", "0")):
+        assert err <= 1e-10, (rank, err)
+        assert cerr <= 1e-12 and ids_ok
+
+
+@pytest.mark.timeout(300)
 @pytest.mark.parametrize("kind", ["rcb_c5", "rcb_quads"])
 def test_three_rcb_ranks_one_gpu(rdyhip_kernel, kind):
     """RCB parts (rdycore_amd/partition.py) instead of strips: the C5 miniature (rough DEM, hydrostatic reconstruction, dry
@@ -224,13 +242,15 @@ def test_three_rcb_ranks_one_gpu(rdyhip_kernel, kind):
 
 @pytest.mark.timeout(600)
 @pytest.mark.parametrize("kind,second_order", [("strips", False), ("rcb_c5", False), ("rcb_quads", True), ("rcb_houston", False), ("rcb_houston", True)])
-def test_six_ranks_one_gpu(rdyhip_kernel, kind, second_order):
-    """the rehearsal of a full node as far as one device allows (six processes may share a card): strips with two inner
-    ranks' worth of neighbours, RCB-6 parts with three and more peers and uneven shapes, the second-order double exchange, RK4
-    (strips) -- every rank's RHS = the single-rank oracle's rows, the cross-rank Courant struct-max with its ids"""
+def test_five_ranks_one_gpu(rdyhip_kernel, kind, second_order):
+    """the rehearsal of a full node as far as one device allows (six processes may share a card, the test runner being one
+    of them): strips with three inner ranks, RCB-5 parts with three and more peers, uneven sizes and shapes, the second-order
+    double exchange, RK4 (strips) -- every rank's RHS = the single-rank oracle's rows, the cross-rank Courant struct-max
+    with its ids.  (Eight ranks: the same pattern discovery and exchange on the CPU, tests/test_halo_gloo.py,
+    tests/test_halo_plan_cpu.py.)"""
     if rdyhip_kernel == "cell":
-        pytest.skip("one kernel variant is enough for the six-rank rehearsal")
-    res = _run(6, (rdyhip_kernel, second_order, "c", kind), join=420)
+        pytest.skip("one kernel variant is enough for the five-rank rehearsal")
+    res = _run(5, (rdyhip_kernel, second_order, "c", kind), join=420)
     for rank, err, cerr, ids_ok, nhalo_tiles, ntiles in res:
         assert err <= 1e-10, (rank, err)
         assert cerr <= 1e-10 and ids_ok
@@ -300,8 +320,8 @@ def test_bench_self_launches_two_ranks(rdyhip_kernel):
     env.pop("WORLD_SIZE", None)
     env.pop("RANK", None)
     for extra, driver in (([], "torch"), (["--halo", "c"], "c"), (["--workload", "c5", "--nx", "160", "--ny", "160", "--halo", "c"], "c"),
-                          (["--gpus", "6", "--workload", "houston_refined", "--levels", "3", "--halo", "c"], "c")):
-        n = 6 if "6" in extra else 2
+                          (["--gpus", "5", "--workload", "houston_refined", "--levels", "3", "--halo", "c"], "c")):
+        n = 5 if "houston_refined" in extra else 2
         cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--nx", "200", "--ny", "200",
                "--condition-seconds", "0.2", "--watchdog-seconds", "150", "--launch-timeout", "200"] + extra
         out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)

@@ -8,9 +8,10 @@
 
 After ANY idle moment the device runs its next launches 5..40 at 20-35 % lower speed (profiles/r02_launch_series.json), so
 a loop with host gaps never reaches the back-to-back rate bench.py reports.  This tool measures the effective
-cell-updates/s of that pattern for several (N, gap) and, beside it, the same loop with the library's keep-warm option
-(rdyhip_keep_warm: a trickle of tiny launches on a side stream while the host is busy, so that the device does not drop
-its clocks) -- the mitigation, and its price.
+cell-updates/s of that pattern for several (N, gap).  (Round 3 also tried a keep-warm option inside the library -- one
+sleeping wave, or 16 / 64 workgroups streaming memory, on a side stream during the host's gap: no effect on the dip
+(profiles/r03_advance_pattern_keep_warm_modes.json), so it was removed again; the `keep_warm` rows only appear when a
+library that still exports rdyhip_keep_warm is loaded.)
 
 usage (GPU box): python tools/advance_pattern.py [--workload c3] > gpurun_out/advance_pattern.json"""
 import argparse
@@ -32,6 +33,7 @@ ap.add_argument("--levels", type=int, default=6)
 ap.add_argument("--intervals", type=int, default=12)
 ap.add_argument("--steps-per-interval", default="20,100,400")
 ap.add_argument("--gaps-ms", default="0,2,10,50")
+ap.add_argument("--keep-warm-modes", default="1", help="rdyhip_keep_warm arguments to try beside 0 (1: one sleeping wave; n > 1: n streaming workgroups)")
 ap.add_argument("--pair", action="store_true", help="RHS + axpy per step (what TSEULER does) instead of the fused Euler step")
 a = ap.parse_args()
 
@@ -84,13 +86,13 @@ def pattern(nsteps, gap_ms, keep_warm):
         advance(nsteps)
         t_dev += time.perf_counter() - t1
         if keep_warm:
-            _lib.check(lib.rdyhip_keep_warm(op._h, 1))
+            _lib.check(lib.rdyhip_keep_warm(op._h, int(keep_warm)))
         busy_wait(gap_ms)                             # the host's own work between two RDyAdvance calls
     wall = time.perf_counter() - t0
     if keep_warm:
         _lib.check(lib.rdyhip_keep_warm(op._h, 0))
     steps = a.intervals * nsteps
-    return {"steps_per_interval": nsteps, "gap_ms": gap_ms, "keep_warm": bool(keep_warm),
+    return {"steps_per_interval": nsteps, "gap_ms": gap_ms, "keep_warm": int(keep_warm),
             "ms_per_step_in_advance": round(t_dev / steps * 1e3, 5),
             "M_cell_updates_per_s_in_advance": round(n_owned * steps / t_dev / 1e6, 1),
             "M_cell_updates_per_s_wall": round(n_owned * steps / wall / 1e6, 1)}
@@ -112,7 +114,7 @@ out = {"workload": a.workload, "cells": n_owned, "step": "RHS + axpy (TSEULER)" 
 has_keep_warm = hasattr(lib, "rdyhip_keep_warm")
 for nsteps in map(int, a.steps_per_interval.split(",")):
     for gap in map(float, a.gaps_ms.split(",")):
-        for kw in ((0, 1) if (has_keep_warm and gap > 0) else (0,)):
+        for kw in ((0,) + tuple(int(x) for x in a.keep_warm_modes.split(",")) if (has_keep_warm and gap > 0) else (0,)):
             r = pattern(nsteps, gap, kw)
             r["vs_back_to_back"] = round(r["ms_per_step_in_advance"] / back_to_back, 4)
             out["rows"].append(r)

@@ -69,6 +69,8 @@ up, fp = int(u.data_ptr()), int(f.data_ptr())
 res = {"cells": mesh.num_owned_cells, "ghost_cells": int(n), "info": {k: op.layout_info()[k] for k in ("num_tiles", "num_halo_tiles", "persistent_grid")}}
 res["single_launch_rhs"] = timed(lambda: op.rhs_function(case.dt, u, f))
 res["overlapped_step"] = timed(lambda: _lib.check(lib.rdyhip_rhs_overlapped(op._h, hh, float(case.dt), up, fp, st)))
+res["halo_overlaps"] = int(lib.rdyhip_halo_overlaps(hh))
+res["in_order_exchange_then_single_launch"] = timed(lambda: (_lib.check(lib.rdyhip_halo_exchange(hh, up, 3, st)), op.rhs_function(case.dt, u, f)))
 res["phases_only_interior_then_halo"] = timed(lambda: (op.apply_phase(1, True, case.dt, u, f, reset_diagnostics=True), op.apply_phase(2, True, case.dt, u, f)))
 res["interior_phase_only"] = timed(lambda: op.apply_phase(1, True, case.dt, u, f, reset_diagnostics=True))
 res["halo_phase_only"] = timed(lambda: op.apply_phase(2, True, case.dt, u, f))
