@@ -287,6 +287,20 @@ def kernel_sha(second_order: bool = False) -> str:
     return h.hexdigest()[:16]
 
 
+def traffic_key(args) -> str:
+    """the key of a run's PMC entry in profiles/traffic.json (tools/make_traffic.py writes what this function names)"""
+    key = f"{args.workload}_{args.nx}x{args.ny}_{args.order}_{args.source}"
+    if args.hr and args.workload not in ("c5", "delaunay"):
+        key += "_hr"
+    if args.second_order:
+        key += "_second_order_" + args.limiter
+    if args.emulate_world > 1:
+        key += f"_rank{args.emulate_rank}of{args.emulate_world}"
+        if args.self_exchange:
+            key += "_self_exchange"       # bytes per STEP: the interior and the halo launch together
+    return key
+
+
 def load_traffic(workload_key: str, layout_bytes: int, second_order: bool = False):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic.json), only if they were
     collected on exactly these kernel sources AND this device layout (the layout is made by the host code in
@@ -639,10 +653,8 @@ def run_rank(args, argv):
                         f"{total_cells} cells in this run ({n_owned} on rank 0), {dry:.0%} of them dry, rain 1e-5 m/s, Manning 0.03, "
                         f"critical-outflow segment + reflecting walls, hydrostatic reconstruction, {friction}, dt = 0.05 s")
         traffic, traffic_src = (None, None)
-        if world == 1 and args.emulate_world <= 1:
-            traffic, traffic_src = load_traffic(f"{args.workload}_{args.nx}x{args.ny}_{args.order}_{args.source}" + ("_hr" if args.hr and args.workload not in ("c5", "delaunay") else "")
-                                                + ("_second_order_" + args.limiter if args.second_order else ""),
-                                                int(info["bytes_per_apply"]), args.second_order)
+        if world == 1:
+            traffic, traffic_src = load_traffic(traffic_key(args), int(info["bytes_per_apply"]), args.second_order)
         if args.second_order:
             kname = (("swe_rhs_muscl_fused_kernel<%d,%d>" if info["second_order_fused"] else "muscl_gradient_kernel<%d> + swe_rhs_muscl_kernel<.,%d>")
                      % (info["slots_per_cell"], 0 if args.source == "semi_implicit" else 1))

@@ -290,10 +290,13 @@ int rdyhip_halo_create(RDyHipOperator op, void *nccl_comm, int32_t npeers, const
   }
   h->max_comp = op->muscl ? 6 : 3;
   {
-    // overlap only where there is something to hide behind: at least RDYHIP_OVERLAP_MIN_ROUNDS (default 6) rounds of the
-    // persistent grid's worth of interior tiles (~7 us per round; the exchange chain is ~25-30 us).  RDYHIP_OVERLAP=0 / 1 forces.
+    // overlap only where there is something to hide behind: at least RDYHIP_OVERLAP_MIN_ROUNDS (default 12: ~2.4 M cells) rounds
+    // of the persistent grid's worth of interior tiles.  Measured with the exchange looped back on one device
+    // (tools/overlap_threshold.sh, profiles/r03_overlap_threshold.txt): in order / overlapped = 30 / 50 us at 0.36 M cells,
+    // 53 / 60 at 1.1 M, 81 / 83 at 2 M, 113 / 113 at 3 M, 143 / 142 at 4 M -- the overlapped form costs two cross-stream
+    // dependencies and ~3x the host time per step.  RDYHIP_OVERLAP=0 / 1 forces.
     const int pgrid    = std::max(8, op->muscl ? op->pgrid_muscl : op->pgrid);
-    int       min_rounds = 6;
+    int       min_rounds = 12;
     if (const char *e = getenv("RDYHIP_OVERLAP_MIN_ROUNDS")) min_rounds = std::max(0, atoi(e));
     h->overlap = op->use_tiled ? (int64_t)(op->ntiles - op->n_halo_tiles) >= (int64_t)min_rounds * pgrid : op->n_owned >= 1500000;
     if (const char *e = getenv("RDYHIP_OVERLAP")) h->overlap = atoi(e) != 0;

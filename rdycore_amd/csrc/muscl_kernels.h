@@ -68,14 +68,11 @@ struct MusclArgs {
 };
 constexpr uint16_t BN_NONE = 0xFFFF, BN_GLOBAL = 0xFFFE;
 
-// LDS layout of the second-order kernels: array-of-structs -- a cell's (h, hu, hv, centroid x, centroid y) are five
-// consecutive doubles, its gradient six (+ one of padding), an edge's (f0, f1, f2, amax) four -- so that every access to a
-// record is ONE address (slot x record size) plus immediate offsets the compiler folds into ds_read2_b64 / ds_write2_b64.
-// With one plane per component (the layout of swe_kernels.h) every plane's runtime offset costs an SGPR, and the kernel
-// ran out of them: phase 1 alone held 161 v_readlane_b32 of spilled plane offsets and 87 address adds.
-#define MSQ(k, j) sq[5 * (j) + (k)]
-#define MSG(k, j) sg[MUSCL_GS * (j) + (k)]
-#define MEF(c, e) ef[MUSCL_ES * (e) + (c)]
+// LDS layout of the second-order kernels.  Record layout (MusclAoS): a cell's (h, hu, hv, centroid x, centroid y) are five
+// consecutive doubles, its gradient six (+ one of padding), an edge's (f0, f1, f2, amax) four -- every access to a record
+// is ONE address (slot x record size) plus immediate offsets.  With one plane per component and RUN-TIME plane strides
+// every plane's offset cost an SGPR and the kernel ran out of them (round 2: 161 v_readlane_b32 of spilled plane offsets
+// and 87 address adds in phase 1 alone); compile-time strides (MusclSoA) have neither cost.
 // record strides in doubles (gradient: 6 values, edge flux: 4 values).  The gradient records are padded to 7: an odd
 // stride spreads consecutive records over all LDS banks (6 -> 7: -1.6 % on the 10 M-cell RHS; padding the flux records
 // to 5 as well changes nothing more)
@@ -86,6 +83,40 @@ constexpr uint16_t BN_NONE = 0xFFFF, BN_GLOBAL = 0xFFFE;
 #define RDYHIP_MUSCL_ES 4
 #endif
 constexpr int MUSCL_GS = RDYHIP_MUSCL_GS, MUSCL_ES = RDYHIP_MUSCL_ES;
+
+// Where value k of record j lives in LDS.  Two layouts behind the same kernels:
+//   MusclAoS        records of any count (sizes known at run time only): a record's values are consecutive doubles, so one
+//                   address per record and immediate offsets -- but hipcc fuses the 8-byte reads of a record into
+//                   ds_read2_b64, which the LDS serves at half the rate of ds_read_b64 (MI355X_MICROARCH.md, LDS table);
+//   MusclSoA<..>    one plane per value with COMPILE-TIME plane strides: the plane offsets are immediates as well (no
+//                   register, no address arithmetic) and every read is a full-rate ds_read_b64.  Chosen at create when the
+//                   mesh's tiles fit the fixed capacities (every mesh numbered with some locality does).
+struct MusclAoS {
+  static constexpr bool fixed = false;
+  static __device__ __forceinline__ int qidx(int k, int j) { return 5 * j + k; }
+  static __device__ __forceinline__ int gidx(int k, int j) { return MUSCL_GS * j + k; }
+  static __device__ __forceinline__ int eidx(int c, int e_) { return MUSCL_ES * e_ + c; }
+};
+template <int NQ, int NG, int NE>
+struct MusclSoA {
+  static constexpr bool fixed = true;
+  static constexpr int  nq = NQ, ng = NG, ne = NE;  // capacities: state records (own + both rings), gradient records (own + first ring), edges
+  static __device__ __forceinline__ int qidx(int k, int j) { return k * NQ + j; }
+  static __device__ __forceinline__ int gidx(int k, int j) { return k * NG + j; }
+  static __device__ __forceinline__ int eidx(int c, int e_) { return c * NE + e_; }
+  static constexpr size_t lds_bytes = sizeof(double) * (6 * (size_t)NG + 5 * (size_t)NQ) + sizeof(uint32_t) * (size_t)NE;
+};
+// triangles: 256 own + <= 104 first-ring cells, <= 264 ring cells in all, <= 512 edge records (two register rounds);
+// 40 128 B per workgroup: four workgroups per CU as with the record layout.  The edge fluxes (4 planes) overlay the
+// gradients (6 planes).  The plane strides are deliberately NOT multiples of 64 doubles: hipcc would otherwise fuse the
+// reads of two planes into ds_read2st64_b64, which is served like ds_read2_b64.
+using MusclSoATri = MusclSoA<520, 360, 520>;
+// quads / mixed meshes (three register rounds of edge records, a 16 x 16 block has 544): <= 112 first-ring cells, <= 168 ring
+// cells in all, <= 552 edge records; 36 832 B per workgroup
+using MusclSoAQuad = MusclSoA<424, 368, 552>;
+#define MSQ(k, j) sq[LAY::qidx((k), (j))]
+#define MSG(k, j) sg[LAY::gidx((k), (j))]
+#define MEF(c, e) ef[LAY::eidx((c), (e))]
 
 // Weighted least-squares gradient of a cell (PrecomputeLSGradCoeffs + ComputeLeastSquaresGradients,
 // src/operator_fluxes_ceed.c:884-1042) accumulated neighbour by neighbour: with d = centroid_n - centroid_c,
@@ -161,15 +192,16 @@ __device__ __forceinline__ double limit_slope(double extrap, double half_dq) {
 struct EdgeFlux {
   double f0, f1, f2, am;  // am: largest wave speed, -1 for a dry-dry edge (skipped, swe_petsc.c:184)
 };
+template <class LAY>
 __device__ __forceinline__ void store_edge_flux(const KernelArgs &a, double *ef, int e, const EdgeFlux &r) {
   MEF(0, e) = r.f0;
   MEF(1, e) = r.f1;
   MEF(2, e) = r.f2;
   MEF(3, e) = r.am;
 }
-template <int LIM>
+template <int LIM, class LAY>
 __device__ __forceinline__ EdgeFlux muscl_edge(const KernelArgs &a, const TileDesc &td, double dt, uint32_t lr, double cs, double2 mid,
-                                               const double *sq, int nq, const double *sg, int ng) {
+                                               const double *sq, const double *sg) {
   double cn, sn;
   edge_normal(lr, cs, cn, sn);
   const int jl = lr & EDGE_SLOT_MASK;
@@ -233,7 +265,7 @@ __device__ __forceinline__ int slot_edge(uint32_t r0, uint32_t r1, int s) {
 
 // Phase 2 of both second-order kernels: a cell's flux sum in the reference's edge order + the Courant number
 // (src/swe/swe_petsc.c:184-201); kf[s] = -+len/area of slot s.
-template <int S>
+template <int S, class LAY>
 __device__ __forceinline__ void muscl_cell_sum(const KernelArgs &a, uint32_t r0, uint32_t r1, const double (&kf)[S], const double *ef, double dt, int o,
                                                double &acc0, double &acc1, double &acc2, double &best,
                                                int &best_slot, int &best_o) {
@@ -300,12 +332,12 @@ __global__ __launch_bounds__(BLOCK) void muscl_gradient_kernel(const KernelArgs 
 template <int S, int SRC, bool OVW, int LIM>
 __global__ __launch_bounds__(TILE) void swe_rhs_muscl_kernel(const KernelArgs a, const MusclArgs g, const double dt, const double *__restrict__ u,
                                                               double *__restrict__ f) {
+  using LAY = MusclAoS;
   extern __shared__ double lds[];
   const int nside = TILE + a.hmax;
-  double   *sq    = lds;              // 5 planes of nside: h, hu, hv, centroid x, y
-  double   *sg    = lds + 5 * nside;  // 6 planes of nside: the gradient
-  double   *ef = lds + (5 + MUSCL_GS) * nside;  // 4 x emax: the edge fluxes
-  const int nq = nside, ng = nside;
+  double   *sq    = lds;              // nside records of 5: h, hu, hv, centroid x, y
+  double   *sg    = lds + 5 * nside;  // nside records of MUSCL_GS: the gradient
+  double   *ef = lds + (5 + MUSCL_GS) * nside;  // emax records of 4: the edge fluxes
   const int tid = threadIdx.x;
 
   // the tile sequence of this (persistent) workgroup: as in swe_rhs_tiled_kernel
@@ -363,7 +395,7 @@ __global__ __launch_bounds__(TILE) void swe_rhs_muscl_kernel(const KernelArgs a,
     // ---- phase 1: every edge of the tile once
     for (int e = tid; e < ne; e += TILE) {
       const double2 mid = *reinterpret_cast<const double2 *>(g.e_mid + 2 * ((int64_t)td.e_off + e));
-      store_edge_flux(a, ef, e, muscl_edge<LIM>(a, td, dt, a.e_lr[td.e_off + e], a.e_cs[td.e_off + e], mid, sq, nside, sg, nside));
+      store_edge_flux<LAY>(a, ef, e, muscl_edge<LIM, LAY>(a, td, dt, a.e_lr[td.e_off + e], a.e_cs[td.e_off + e], mid, sq, sg));
     }
     __syncthreads();
 
@@ -386,7 +418,7 @@ __global__ __launch_bounds__(TILE) void swe_rhs_muscl_kernel(const KernelArgs a,
       double kf[S];
 #pragma unroll
       for (int s = 0; s < S; ++s) kf[s] = a.coef[s * a.stride + o];
-      muscl_cell_sum<S>(a, r0, r1, kf, ef, dt, o, acc0, acc1, acc2, best, best_slot, best_o);
+      muscl_cell_sum<S, LAY>(a, r0, r1, kf, ef, dt, o, acc0, acc1, acc2, best, best_slot, best_o);
       const double      h = MSQ(0, tid), hu = MSQ(1, tid), hv = MSQ(2, tid);
       const RiemannSide self = riemann_side(h, hu, hv, a.tiny_h, a.h_anuga_sq);
       cell_epilogue<SRC>(a, o, dt, h, hu, hv, self.u, self.v, acc0, acc1, acc2, a.dzdx[o], a.dzdy[o], a.mannings[o], a.extsrc[3 * (int64_t)o + 0],
@@ -414,7 +446,7 @@ __global__ __launch_bounds__(TILE) void swe_rhs_muscl_kernel(const KernelArgs a,
 #else
 #define RDY_MUSCL_OCC
 #endif
-template <int S, int SRC, bool OVW, int LIM, bool EULER = false, bool EFO = false>
+template <int S, int SRC, bool OVW, int LIM, bool EULER = false, bool EFO = false, class LAY = MusclAoS>
 __global__ __launch_bounds__(TILE) RDY_MUSCL_OCC void swe_rhs_muscl_fused_kernel(const KernelArgs a, const MusclArgs g, const double dt, const double *__restrict__ u,
                                                                     double *__restrict__ f) {
   // LDS: gradients of own + first-ring cells | state of own + first-ring cells | a region that holds the second ring's
@@ -425,15 +457,25 @@ __global__ __launch_bounds__(TILE) RDY_MUSCL_OCC void swe_rhs_muscl_fused_kernel
   // workgroups share a CU's 160 KB --, otherwise that third region, grown to 4 emax doubles (45 KB on the same mesh:
   // three workgroups).
   extern __shared__ double lds[];
-  const int nq = TILE + g.hmax2;  // state + centroid records: own, first ring, second ring
+  static_assert(!LAY::fixed || EFO, "the fixed-capacity layout keeps the edge fluxes over the gradients");
   const int ng = TILE + a.hmax;   // gradient records: own, first ring
-  double   *sg = lds;             // [ng][MUSCL_GS]
-  double   *sq = lds + MUSCL_GS * ng;    // [nq][5]: h, hu, hv, centroid x, centroid y
-  // EFO: the edge fluxes take the place of the gradients (dead once every edge has been evaluated; the fluxes wait
-  // in registers for a barrier), else they follow the first ring's records, over the second ring and the edge records
-  double   *ef  = EFO ? sg : sq + 5 * ng;  // [emax][4]
-  const int ovl = EFO ? 5 * (g.hmax2 - a.hmax) + (a.emax + 1) / 2 : max(MUSCL_ES * a.emax, 5 * (g.hmax2 - a.hmax) + (a.emax + 1) / 2);
-  uint32_t *slr = reinterpret_cast<uint32_t *>(sq + 5 * ng + ovl) - ((a.emax + 1) / 2) * 2;  // [emax] the tile's edge records
+  double   *sg = lds;             // record layout: [ng][MUSCL_GS]; plane layout: 6 planes of LAY::ng
+  double   *sq;                   // state + centroid of own cells, first ring, second ring: h, hu, hv, centroid x, centroid y
+  double   *ef;                   // the edge fluxes: [emax][4] / 4 planes
+  uint32_t *slr;                  // [emax] the tile's edge records (read by the gradient phase only)
+  if constexpr (LAY::fixed) {
+    sq  = lds + 6 * LAY::ng;
+    ef  = sg;  // 4 x LAY::ne <= 6 x LAY::ng doubles
+    slr = reinterpret_cast<uint32_t *>(sq + 5 * LAY::nq);
+    static_assert(4 * LAY::ne <= 6 * LAY::ng, "the flux planes overlay the gradient planes");
+  } else {
+    sq = lds + MUSCL_GS * ng;
+    // EFO: the edge fluxes take the place of the gradients (dead once every edge has been evaluated; the fluxes wait
+    // in registers for a barrier), else they follow the first ring's records, over the second ring and the edge records
+    ef            = EFO ? sg : sq + 5 * ng;
+    const int ovl = EFO ? 5 * (g.hmax2 - a.hmax) + (a.emax + 1) / 2 : max(MUSCL_ES * a.emax, 5 * (g.hmax2 - a.hmax) + (a.emax + 1) / 2);
+    slr           = reinterpret_cast<uint32_t *>(sq + 5 * ng + ovl) - ((a.emax + 1) / 2) * 2;
+  }
   const int tid = threadIdx.x;
 
   int idx, step, hi;
@@ -620,20 +662,20 @@ __global__ __launch_bounds__(TILE) RDY_MUSCL_OCC void swe_rhs_muscl_fused_kernel
 
     // ---- phase 1: every edge of the tile once
     auto do_edge = [&](uint32_t lr, double cs, double2 mid) -> EdgeFlux {
-      return muscl_edge<LIM>(a, td, dt, lr, cs, mid, sq, nq, sg, ng);
+      return muscl_edge<LIM, LAY>(a, td, dt, lr, cs, mid, sq, sg);
     };
     // the two register-resident rounds one after the other (no per-value selects between the rounds' registers); the
     // scheduling barrier keeps the compiler from interleaving them, which would double the live registers
     EdgeFlux x0 = {0.0, 0.0, 0.0, -1.0}, x1 = x0;
     if (tid < ne) x0 = do_edge(lr0, cs0, md0);
-    if (!EFO && tid < ne) store_edge_flux(a, ef, tid, x0);
+    if (!EFO && tid < ne) store_edge_flux<LAY>(a, ef, tid, x0);
     __builtin_amdgcn_sched_barrier(0);
     if (tid + TILE < ne) x1 = do_edge(lr1, cs1, md1);
-    if (!EFO && tid + TILE < ne) store_edge_flux(a, ef, tid + TILE, x1);
+    if (!EFO && tid + TILE < ne) store_edge_flux<LAY>(a, ef, tid + TILE, x1);
     EdgeFlux x2 = {0.0, 0.0, 0.0, -1.0};
     if (!EFO) {
       for (int e = tid + 2 * TILE; e < ne; e += TILE)  // not slr: the fluxes overwrite it
-        store_edge_flux(a, ef, e, do_edge(a.e_lr[td.e_off + e], a.e_cs[td.e_off + e], *reinterpret_cast<const double2 *>(g.e_mid + 2 * ((int64_t)td.e_off + e))));
+        store_edge_flux<LAY>(a, ef, e, do_edge(a.e_lr[td.e_off + e], a.e_cs[td.e_off + e], *reinterpret_cast<const double2 *>(g.e_mid + 2 * ((int64_t)td.e_off + e))));
     } else if (S == 4) {
       // quads: a 16 x 16 block has 544 edge records; the third round loads its records here (EFO: emax <= 3 TILE)
       __builtin_amdgcn_sched_barrier(0);
@@ -657,9 +699,9 @@ __global__ __launch_bounds__(TILE) RDY_MUSCL_OCC void swe_rhs_muscl_fused_kernel
 #endif
     if (EFO) {
       __syncthreads();  // every edge has read its gradients: the fluxes may overwrite them
-      if (tid < ne) store_edge_flux(a, ef, tid, x0);
-      if (tid + TILE < ne) store_edge_flux(a, ef, tid + TILE, x1);
-      if (S == 4 && tid + 2 * TILE < ne) store_edge_flux(a, ef, tid + 2 * TILE, x2);
+      if (tid < ne) store_edge_flux<LAY>(a, ef, tid, x0);
+      if (tid + TILE < ne) store_edge_flux<LAY>(a, ef, tid + TILE, x1);
+      if (S == 4 && tid + 2 * TILE < ne) store_edge_flux<LAY>(a, ef, tid + 2 * TILE, x2);
     }
     __syncthreads();
 
@@ -672,7 +714,7 @@ __global__ __launch_bounds__(TILE) RDY_MUSCL_OCC void swe_rhs_muscl_fused_kernel
         acc1 = f[3 * (int64_t)o + 1];
         acc2 = f[3 * (int64_t)o + 2];
       }
-      muscl_cell_sum<S>(a, r0, r1, kf, ef, dt, o, acc0, acc1, acc2, best, best_slot, best_o);
+      muscl_cell_sum<S, LAY>(a, r0, r1, kf, ef, dt, o, acc0, acc1, acc2, best, best_slot, best_o);
       const RiemannSide self = riemann_side(h, hu, hv, a.tiny_h, a.h_anuga_sq);
       pu                     = self.u;
       pv_                    = self.v;

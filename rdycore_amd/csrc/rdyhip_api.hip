@@ -129,6 +129,7 @@ struct RDyHipOperator_s {
   bool             muscl = false;
   bool             muscl_fused = true;  // gradients formed in LDS by the flux kernel (RDYHIP_MUSCL=split: separate gradient launch)
   bool             muscl_efo   = false; // fused form: edge fluxes stored over the gradients (layout_build)
+  bool             muscl_soa   = false; // fused form: fixed-capacity plane layout in LDS (MusclSoATri)
   DevBuf<double>   d_grad, d_e_mid, d_cxy;
   DevBuf<int32_t>  d_hcells2, d_c_off;
   DevBuf<uint16_t> d_bn_idx;
@@ -217,7 +218,26 @@ MusclKernelFn muscl_fused_euler_fn_e(int S, int src, int limiter) {
     default: return muscl_fused_euler_fn_lim<LIMITER_MINMOD, EFO>(S, src);
   }
 }
-MusclKernelFn muscl_fused_euler_fn(int S, int src, int limiter, bool efo) {
+// the fixed-capacity plane layouts (MusclSoATri / MusclSoAQuad, muscl_kernels.h): edge fluxes over the gradients
+template <int S, class LAY, int LIM>
+MusclKernelFn muscl_soa_fn_lim(int src, bool ovw, bool euler) {
+  if (euler) return src ? swe_rhs_muscl_fused_kernel<S, 1, true, LIM, true, true, LAY> : swe_rhs_muscl_fused_kernel<S, 0, true, LIM, true, true, LAY>;
+  if (src) return ovw ? swe_rhs_muscl_fused_kernel<S, 1, true, LIM, false, true, LAY> : swe_rhs_muscl_fused_kernel<S, 1, false, LIM, false, true, LAY>;
+  return ovw ? swe_rhs_muscl_fused_kernel<S, 0, true, LIM, false, true, LAY> : swe_rhs_muscl_fused_kernel<S, 0, false, LIM, false, true, LAY>;
+}
+template <int S, class LAY>
+MusclKernelFn muscl_soa_fn_s(int src, bool ovw, bool euler, int limiter) {
+  switch (limiter) {
+    case RDYHIP_LIMITER_NONE: return muscl_soa_fn_lim<S, LAY, LIMITER_NONE>(src, ovw, euler);
+    case RDYHIP_LIMITER_VANLEER: return muscl_soa_fn_lim<S, LAY, LIMITER_VANLEER>(src, ovw, euler);
+    default: return muscl_soa_fn_lim<S, LAY, LIMITER_MINMOD>(src, ovw, euler);
+  }
+}
+MusclKernelFn muscl_soa_fn(int S, int src, bool ovw, bool euler, int limiter) {
+  return S == 3 ? muscl_soa_fn_s<3, MusclSoATri>(src, ovw, euler, limiter) : muscl_soa_fn_s<4, MusclSoAQuad>(src, ovw, euler, limiter);
+}
+MusclKernelFn muscl_fused_euler_fn(int S, int src, int limiter, bool efo, bool soa = false) {
+  if (soa) return muscl_soa_fn(S, src, true, true, limiter);
   return efo ? muscl_fused_euler_fn_e<true>(S, src, limiter) : muscl_fused_euler_fn_e<false>(S, src, limiter);
 }
 template <bool EFO>
@@ -228,7 +248,8 @@ MusclKernelFn muscl_fused_fn_e(int S, int src, bool ovw, int limiter) {
     default: return muscl_fused_fn_lim<LIMITER_MINMOD, EFO>(S, src, ovw);
   }
 }
-MusclKernelFn muscl_kernel_fn(int S, int src, bool ovw, int limiter, bool fused, bool efo) {
+MusclKernelFn muscl_kernel_fn(int S, int src, bool ovw, int limiter, bool fused, bool efo, bool soa = false) {
+  if (fused && soa) return muscl_soa_fn(S, src, ovw, false, limiter);
   if (fused) return efo ? muscl_fused_fn_e<true>(S, src, ovw, limiter) : muscl_fused_fn_e<false>(S, src, ovw, limiter);
   switch (limiter) {
     case RDYHIP_LIMITER_NONE: return muscl_kernel_fn_lim<LIMITER_NONE>(S, src, ovw);
@@ -387,8 +408,8 @@ int launch_rhs(RDyHipOperator op, int32_t phase, int32_t overwrite, int reset_di
       }
     }
     if (op->muscl) {
-      MusclKernelFn kfn = euler_fused ? muscl_fused_euler_fn(op->S, xq ? 1 : 0, op->config.limiter, op->muscl_efo)
-                                      : muscl_kernel_fn(op->S, xq ? 1 : 0, overwrite != 0, op->config.limiter, op->muscl_fused, op->muscl_efo);
+      MusclKernelFn kfn = euler_fused ? muscl_fused_euler_fn(op->S, xq ? 1 : 0, op->config.limiter, op->muscl_efo, op->muscl_soa)
+                                      : muscl_kernel_fn(op->S, xq ? 1 : 0, overwrite != 0, op->config.limiter, op->muscl_fused, op->muscl_efo, op->muscl_soa);
       hipLaunchKernelGGL(HIP_KERNEL_NAME(kfn), dim3(grid), dim3(TILE), op->lds_muscl, st, a, muscl_args(op), dt, u, f);
     } else if (euler_fused) {
       hipLaunchKernelGGL(HIP_KERNEL_NAME(tiled_euler_fn(op->S, xq ? 1 : 0, op->hr)), dim3(grid), dim3(TILE), op->lds_bytes, st, a, dt, u, f);
@@ -440,7 +461,7 @@ int launch_rhs(RDyHipOperator op, int32_t phase, int32_t overwrite, int reset_di
 struct HostLayout {
   int32_t nc = 0, no = 0, ne = 0, ni = 0, K = 0, S = 3, ntiles = 0, emax = 0, hmax = 0, hmax2 = 0;
   int64_t stride = 0;
-  bool    prefix = true, hr_on = false, muscl_on = false, muscl_fused = true, muscl_efo = false;
+  bool    prefix = true, hr_on = false, muscl_on = false, muscl_fused = true, muscl_efo = false, muscl_soa = false;
   size_t  lds_bytes = 0, lds_muscl = 0;
   std::vector<int32_t>  o2l, boff, nbr, pos, btype, bleft, bedge, bghost, halo, hcells, tile_bk, halo_tiles, hcells2, c_off;
   std::vector<double>   cn, sn, coef, bcn, bsn, e_cs, e_mid, dzdx, dzdy;
@@ -784,7 +805,13 @@ static int build_host_layout(const RDyHipConfig *config, const RDyHipMesh *mesh,
   const bool   muscl_efo = muscl_on && muscl_fused && emax <= (L.S == 3 ? 2 : 3) * TILE && MUSCL_ES * (size_t)emax <= MUSCL_GS * ((size_t)TILE + hmax) &&
                          !(eenv && atoi(eenv) == 0);
   const size_t ring2     = 5 * (size_t)(hmax2 - hmax) + ((size_t)emax + 1) / 2;
+  // plane layout with compile-time strides where the tiles fit its capacities (triangles).  RDYHIP_MUSCL_SOA=0: measurement knob
+  const char  *senv      = getenv("RDYHIP_MUSCL_SOA");
+  const bool   soa_fits  = L.S == 3 ? (TILE + hmax <= MusclSoATri::ng && TILE + hmax2 <= MusclSoATri::nq && emax <= MusclSoATri::ne)
+                                      : (TILE + hmax <= MusclSoAQuad::ng && TILE + hmax2 <= MusclSoAQuad::nq && emax <= MusclSoAQuad::ne);
+  const bool   muscl_soa = muscl_efo && soa_fits && !(senv && atoi(senv) == 0);
   const size_t lds_muscl = !muscl_on ? 0
+                           : muscl_soa ? (L.S == 3 ? MusclSoATri::lds_bytes : MusclSoAQuad::lds_bytes)
                            : sizeof(double) * ((5 + MUSCL_GS) * ((size_t)TILE + hmax) +
                                                (!muscl_fused ? MUSCL_ES * (size_t)emax : muscl_efo ? ring2 : std::max<size_t>(MUSCL_ES * (size_t)emax, ring2)));
   if (std::max(lds_bytes, lds_muscl) > 160 * 1024)
@@ -797,7 +824,7 @@ static int build_host_layout(const RDyHipConfig *config, const RDyHipMesh *mesh,
     dzdy[o] = mesh->cell_dz_dy[o2l[o]];
   }
 
-  L.hr_on = hr_on; L.muscl_fused = muscl_fused; L.muscl_efo = muscl_efo; L.lds_bytes = lds_bytes; L.lds_muscl = lds_muscl;
+  L.hr_on = hr_on; L.muscl_fused = muscl_fused; L.muscl_efo = muscl_efo; L.muscl_soa = muscl_soa; L.lds_bytes = lds_bytes; L.lds_muscl = lds_muscl;
   L.dzdx = std::move(dzdx); L.dzdy = std::move(dzdy);
   return 0;
 }
@@ -862,6 +889,7 @@ int rdyhip_create(const RDyHipConfig *config, const RDyHipMesh *mesh, int32_t nu
   op->muscl       = muscl_on;
   op->muscl_fused = muscl_fused;
   op->muscl_efo   = L.muscl_efo;
+  op->muscl_soa   = L.muscl_soa;
   op->hmax2       = hmax2;
   op->lds_muscl   = lds_muscl;
   if (lds_muscl > 64 * 1024) {
@@ -869,9 +897,9 @@ int rdyhip_create(const RDyHipConfig *config, const RDyHipMesh *mesh, int32_t nu
     bool      ok = true;
     for (int ovw = 0; ovw < 2; ++ovw)
       for (int src = 0; src < 2; ++src)
-        ok = ok && hipFuncSetAttribute((const void *)muscl_kernel_fn(S, src, ovw != 0, config->limiter, muscl_fused, L.muscl_efo),
+        ok = ok && hipFuncSetAttribute((const void *)muscl_kernel_fn(S, src, ovw != 0, config->limiter, muscl_fused, L.muscl_efo, L.muscl_soa),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, nb) == hipSuccess &&
-             (!muscl_fused || hipFuncSetAttribute((const void *)muscl_fused_euler_fn(S, src, config->limiter, L.muscl_efo),
+             (!muscl_fused || hipFuncSetAttribute((const void *)muscl_fused_euler_fn(S, src, config->limiter, L.muscl_efo, L.muscl_soa),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, nb) == hipSuccess);
     if (!ok) {
       delete op;
@@ -915,7 +943,7 @@ int rdyhip_create(const RDyHipConfig *config, const RDyHipMesh *mesh, int32_t nu
     if (muscl_on) {
       int qm = 0, per_cu_m = 2;
       const void *mfn =
-          (const void *)muscl_kernel_fn(S, config->source_method == RDYHIP_SOURCE_IMPLICIT_XQ2018 ? 1 : 0, true, config->limiter, muscl_fused, L.muscl_efo);
+          (const void *)muscl_kernel_fn(S, config->source_method == RDYHIP_SOURCE_IMPLICIT_XQ2018 ? 1 : 0, true, config->limiter, muscl_fused, L.muscl_efo, L.muscl_soa);
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&qm, mfn, TILE, lds_muscl) == hipSuccess && qm > 0) per_cu_m = qm;
       if (const char *e2 = getenv("RDYHIP_BLOCKS_PER_CU")) {
         if (atoi(e2) > 0) per_cu_m = atoi(e2);
@@ -1395,7 +1423,7 @@ int rdyhip_probe_layout(const RDyHipConfig *config, const RDyHipMesh *mesh, int3
   tmp.n_cells = L.nc; tmp.n_owned = L.no; tmp.S = L.S; tmp.K = L.K; tmp.n_halo = (int32_t)L.halo.size(); tmp.use_tiled = true;
   tmp.ntiles = L.ntiles; tmp.n_halo_tiles = (int32_t)L.halo_tiles.size(); tmp.emax = L.emax; tmp.hmax = L.hmax;
   tmp.nhalo_entries = (int64_t)L.hcells.size(); tmp.nrec = (int64_t)L.e_lr.size(); tmp.prefix = L.prefix; tmp.muscl = L.muscl_on;
-  tmp.muscl_fused = L.muscl_fused; tmp.muscl_efo = L.muscl_efo; tmp.hmax2 = L.hmax2; tmp.d_hcells2.n = L.hcells2.size(); tmp.lds_bytes = L.lds_bytes; tmp.lds_muscl = L.lds_muscl;
+  tmp.muscl_fused = L.muscl_fused; tmp.muscl_efo = L.muscl_efo; tmp.muscl_soa = L.muscl_soa; tmp.hmax2 = L.hmax2; tmp.d_hcells2.n = L.hcells2.size(); tmp.lds_bytes = L.lds_bytes; tmp.lds_muscl = L.lds_muscl;
   const int rc2 = rdyhip_layout_info(&tmp, info);
   tmp.d_hcells2.n = 0;
   return rc2;

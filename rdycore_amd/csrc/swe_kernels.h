@@ -552,7 +552,13 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
           fl              = bf.flux;
           wet             = bf.wet;
           store_boundary_flux(a, k, fl, dt);
-          if (HR && !wet) fl.f0 = fl.f1 = fl.f2 = 0.0;  // phase 2 of the HR variant adds every edge's flux
+          if (HR) {
+            if (!wet) fl.f0 = fl.f1 = fl.f2 = 0.0;  // phase 2 of the HR variant adds every edge's flux
+            // a boundary edge has no right cell, but phase 2 picks the side by the sign of the slot's coefficient: keep the
+            // right-hand copy defined too (never stale LDS of the previous tile, whatever the coefficient's sign bit says)
+            efr1[e] = fl.f1;
+            efr2[e] = fl.f2;
+          }
         }
         ef0[e] = fl.f0;
         ef1[e] = fl.f1;
@@ -597,7 +603,7 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
           const double k  = cur.coef[s];
           if (HR) {
             // a dry-dry edge (am == -1) carries zero Roe flux here but still its pressure correction
-            const bool left = k < 0.0;  // this cell is the edge's left (k < 0) or right cell
+            const bool left = __builtin_signbit(k);  // this cell is the edge's left (k = -len/area, -0.0 for a degenerate edge) or right cell
             acc0 += ef0[ref] * k;
             acc1 += (left ? ef1 : efr1)[ref] * k;
             acc2 += (left ? ef2 : efr2)[ref] * k;

@@ -308,6 +308,33 @@ def test_hydrostatic_reconstruction_parity(kind, source_method, rdyhip_kernel):
     assert rel_linf(f2, fr2) <= TOL
 
 
+def test_hydrostatic_reconstruction_with_zero_length_edges(rdyhip_kernel):
+    """edges of length zero (collapsed sides of a degenerate mesh: coefficient -0.0 on the left cell, +0.0 on the right)
+    among interior and boundary edges: the HR kernel picks a slot's side from the coefficient's SIGN BIT and keeps the
+    right-hand flux copy of boundary edges defined, so such a slot adds exactly 0 -- as in the oracle -- whatever the LDS
+    held before (two evaluations with a NaN-producing state in between)"""
+    if rdyhip_kernel == "cell":
+        pytest.skip("HR lives in the tiled kernel")
+    torch = _torch()
+    case = hr_case("tri", SOURCE_SEMI_IMPLICIT)
+    m = case.mesh
+    rng = np.random.default_rng(4)
+    zero = np.concatenate([rng.choice(m.edge_internal_ids, 40, replace=False), rng.choice(m.edge_boundary_ids, 12, replace=False)])
+    m.edge_lengths = m.edge_lengths.copy()
+    m.edge_lengths[zero] = 0.0
+    orc = oracle_from_case(case)
+    fr = orc.apply(case.dt, case.u_local)
+    op = CS.create_operator(case)
+    u = torch.tensor(case.u_local, dtype=torch.float64, device="cuda")
+    f = torch.empty((m.num_owned_cells, 3), dtype=torch.float64, device="cuda")
+    bad = u.clone()
+    bad[::7, 0] = float("nan")                      # leaves NaN fluxes behind in LDS
+    op.rhs_function(case.dt, bad, f)
+    op.rhs_function(case.dt, u, f)
+    torch.cuda.synchronize()
+    assert np.isfinite(fr).all() and rel_linf(f.cpu().numpy(), fr) <= TOL
+
+
 def test_hydrostatic_reconstruction_lake_at_rest(rdyhip_kernel):
     if rdyhip_kernel == "cell":
         pytest.skip("HR lives in the tiled kernel")

@@ -1,6 +1,8 @@
 """profiles/traffic.json entry from the PMC passes of tools/profile_gpu.sh.
 
-usage: python tools/make_traffic.py gpurun_out/prof_<tag>/summary.json <key> [source note]
+usage: python tools/make_traffic.py gpurun_out/prof_<tag>/summary.json <key> [source note] [launches per step]
+  (launches per step = 2 for the --self-exchange step, whose interior and halo launches are two launches of ONE kernel: the
+   entry then holds the bytes of a whole step = 2 x the mean over all launches)
   (the bench line printed during the traced run, gpurun_out/prof_<tag>/bench_trace.log, supplies the layout's byte count)
   key = <workload>_<nx>x<ny>_<order>_<source>[_hr]   (what bench.py looks up)
 
@@ -19,15 +21,18 @@ import bench  # noqa: E402
 
 def main():
     summ, key = sys.argv[1], sys.argv[2]
-    note = sys.argv[3] if len(sys.argv) > 3 else os.path.relpath(summ, ROOT)
+    note = sys.argv[3] if len(sys.argv) > 3 and sys.argv[3] else os.path.relpath(summ, ROOT)
+    per_step = int(sys.argv[4]) if len(sys.argv) > 4 else 1
     s = json.load(open(summ))
     raw = s["pmc_raw_KB"]
 
     def pick(sub, needle):
+        # the launches of the timed kernel are the many; a run also holds a few launches of its Euler variant
+        best = (None, None, -1)
         for k, v in raw.get(sub, {}).items():
-            if needle in k and v["mean"] is not None:
-                return k, v["mean"]
-        return None, None
+            if needle in k and v["mean"] is not None and v.get("n", 0) > best[2]:
+                best = (k, v["mean"], v.get("n", 0))
+        return best[0], best[1]
 
     kname, fetch = pick("pmc_fetch", "swe_rhs")
     _, write = pick("pmc_write", "swe_rhs")
@@ -35,7 +40,7 @@ def main():
     _, cal_w = pick("cal_write", "axpy_owned")
     if fetch is None or write is None:
         raise SystemExit("no FETCH_SIZE / WRITE_SIZE for the RHS kernel in " + summ)
-    rd, wr = fetch * 1024 * 2, write * 1024
+    rd, wr = fetch * 1024 * 2 * per_step, write * 1024 * per_step
     second = "second_order" in key
     layout = None
     log = os.path.join(os.path.dirname(summ), "bench_trace.log")
@@ -47,6 +52,8 @@ def main():
            "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr,
            "correction": "FETCH_SIZE x2 (gfx950 counts 128-B requests as 64 B, MI355X_MICROARCH.md HBM section); WRITE_SIZE as is",
            "source": note}
+    if per_step != 1:
+        ent["launches_per_step"] = per_step
     if cal_f is not None and cal_w is not None:
         ent["calibration"] = {"kernel": "rdyhip::axpy_owned_kernel, 10 M cells: 480.0 MB read / 240.0 MB written by construction",
                               "FETCH_SIZE_x2_MB": round(cal_f * 1024 * 2 / 1e6, 1), "WRITE_SIZE_MB": round(cal_w * 1024 / 1e6, 1)}
