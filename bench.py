@@ -708,7 +708,8 @@ def run_rank(args, argv):
                          "steady_state_frac": round(n_owned * alg / (period_median_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if period_median_ms else None,
                          "algorithmic_bytes_per_launch": int(n_owned * alg),
                          "layout_bytes_per_launch": int(info["bytes_per_apply"]),
-                         "persistent_workgroups": int(info["persistent_grid"]), "lds_bytes_per_workgroup": int(info["lds_bytes"])},
+                         "persistent_workgroups": int(info["persistent_grid"]), "lds_bytes_per_workgroup": int(info["lds_bytes"]),
+                         "lds_planes": "compile-time lengths" if info.get("lds_fixed_layout") else "lengths from the mesh"},
         }
         if quads:
             out["roofline"]["frac_176B_model"] = round(n_owned * ALG_BYTES_PER_CELL / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)

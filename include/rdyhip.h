@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RDYHIP_VERSION 106
+#define RDYHIP_VERSION 107
 
 /* error codes = PETSc's values */
 #define RDYHIP_SUCCESS 0
@@ -418,6 +418,8 @@ typedef struct {
   int32_t max_tile_ring2_cells; /* second order: largest first + second ring of a tile */
   int32_t persistent_grid;    /* workgroups of a full apply of the tiled kernel (resident workgroups per CU x CUs) */
   int32_t lds_bytes;          /* dynamic LDS per workgroup of that kernel */
+  int32_t lds_fixed_layout;   /* 1: that kernel's LDS planes have compile-time lengths (the mesh's tiles fit the fixed capacities:
+                                 plane offsets are instruction immediates); 0: lengths taken from the mesh (any numbering) */
 } RDyHipLayoutInfo;
 int rdyhip_layout_info(RDyHipOperator op, RDyHipLayoutInfo *info);
 /* the same numbers from the host-side layout pass alone (validation of the mesh, slot tables, tiles): no device is

@@ -49,7 +49,7 @@ class RDyHipLayoutInfo(C.Structure):
                 ("num_edge_records", C.c_int64), ("owned_is_prefix", C.c_int32),
                 ("device_bytes", C.c_int64), ("bytes_per_apply", C.c_int64),
                 ("second_order_fused", C.c_int32), ("max_tile_ring2_cells", C.c_int32),
-                ("persistent_grid", C.c_int32), ("lds_bytes", C.c_int32)]
+                ("persistent_grid", C.c_int32), ("lds_bytes", C.c_int32), ("lds_fixed_layout", C.c_int32)]
 
 
 # every symbol include/rdyhip.h declares: name -> (restype, argtypes)

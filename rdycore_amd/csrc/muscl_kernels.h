@@ -93,6 +93,7 @@ constexpr int MUSCL_GS = RDYHIP_MUSCL_GS, MUSCL_ES = RDYHIP_MUSCL_ES;
 //                   mesh's tiles fit the fixed capacities (every mesh numbered with some locality does).
 struct MusclAoS {
   static constexpr bool fixed = false;
+  static constexpr int  n3    = 0;
   static __device__ __forceinline__ int qidx(int k, int j) { return 5 * j + k; }
   static __device__ __forceinline__ int gidx(int k, int j) { return MUSCL_GS * j + k; }
   static __device__ __forceinline__ int eidx(int c, int e_) { return MUSCL_ES * e_ + c; }
@@ -104,7 +105,10 @@ struct MusclSoA {
   static __device__ __forceinline__ int qidx(int k, int j) { return k * NQ + j; }
   static __device__ __forceinline__ int gidx(int k, int j) { return k * NG + j; }
   static __device__ __forceinline__ int eidx(int c, int e_) { return c * NE + e_; }
-  static constexpr size_t lds_bytes = sizeof(double) * (6 * (size_t)NG + 5 * (size_t)NQ) + sizeof(uint32_t) * (size_t)NE;
+  // edge records beyond the two register rounds (quads: a 16 x 16 block has 544): their normal component and midpoint wait
+  // in LDS instead of being loaded inside the edge phase
+  static constexpr int n3 = NE > 2 * TILE ? NE - 2 * TILE : 0;
+  static constexpr size_t lds_bytes = sizeof(double) * (6 * (size_t)NG + 5 * (size_t)NQ + 3 * (size_t)n3) + sizeof(uint32_t) * (size_t)NE;
 };
 // triangles: 256 own + <= 104 first-ring cells, <= 264 ring cells in all, <= 512 edge records (two register rounds);
 // 40 128 B per workgroup: four workgroups per CU as with the record layout.  The edge fluxes (4 planes) overlay the
@@ -112,7 +116,7 @@ struct MusclSoA {
 // reads of two planes into ds_read2st64_b64, which is served like ds_read2_b64.
 using MusclSoATri = MusclSoA<520, 360, 520>;
 // quads / mixed meshes (three register rounds of edge records, a 16 x 16 block has 544): <= 112 first-ring cells, <= 168 ring
-// cells in all, <= 552 edge records; 36 832 B per workgroup
+// cells in all, <= 552 edge records; 37 792 B per workgroup
 using MusclSoAQuad = MusclSoA<424, 368, 552>;
 #define MSQ(k, j) sq[LAY::qidx((k), (j))]
 #define MSG(k, j) sg[LAY::gidx((k), (j))]
@@ -463,10 +467,13 @@ __global__ __launch_bounds__(TILE) RDY_MUSCL_OCC void swe_rhs_muscl_fused_kernel
   double   *sq;                   // state + centroid of own cells, first ring, second ring: h, hu, hv, centroid x, centroid y
   double   *ef;                   // the edge fluxes: [emax][4] / 4 planes
   uint32_t *slr;                  // [emax] the tile's edge records (read by the gradient phase only)
+  double   *e3 = nullptr;         // plane layout, third edge round: [3][n3] normal component, midpoint x, midpoint y
+  constexpr bool STAGE3 = LAY::fixed && S == 4 && LAY::n3 > 0;
   if constexpr (LAY::fixed) {
+    e3  = lds + 6 * LAY::ng + 5 * LAY::nq;
     sq  = lds + 6 * LAY::ng;
     ef  = sg;  // 4 x LAY::ne <= 6 x LAY::ng doubles
-    slr = reinterpret_cast<uint32_t *>(sq + 5 * LAY::nq);
+    slr = reinterpret_cast<uint32_t *>(sq + 5 * LAY::nq + 3 * LAY::n3);
     static_assert(4 * LAY::ne <= 6 * LAY::ng, "the flux planes overlay the gradient planes");
   } else {
     sq = lds + MUSCL_GS * ng;
@@ -575,8 +582,12 @@ __global__ __launch_bounds__(TILE) RDY_MUSCL_OCC void swe_rhs_muscl_fused_kernel
     uint2 bw = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);  // first-ring stencil of ring cell j = tid: the LDS slots of its neighbours
     if (tid < nh) bw = load_u2(g.bn_idx + 4 * ((int64_t)td.h_off + tid));
     uint32_t lr0 = 0, lr1 = 0;
-    double   cs0 = 0.0, cs1 = 0.0;
-    double2  md0 = make_double2(0.0, 0.0), md1 = md0;
+    double   cs0 = 0.0, cs1 = 0.0, cs3 = 0.0;
+    double2  md0 = make_double2(0.0, 0.0), md1 = md0, md3 = md0;
+    if (STAGE3 && tid + 2 * TILE < ne) {  // third round: staged through LDS (no global load inside the edge phase)
+      cs3 = RDY_MLD(&a.e_cs[td.e_off + 2 * TILE + tid]);
+      md3 = load_d2(g.e_mid + 2 * ((int64_t)td.e_off + 2 * TILE + tid));
+    }
     if (tid < ne) {
       lr0 = RDY_MLD(&a.e_lr[td.e_off + tid]);
       cs0 = RDY_MLD(&a.e_cs[td.e_off + tid]);
@@ -617,6 +628,11 @@ __global__ __launch_bounds__(TILE) RDY_MUSCL_OCC void swe_rhs_muscl_fused_kernel
     if (tid < ne) slr[tid] = lr0;
     if (tid + TILE < ne) slr[tid + TILE] = lr1;
     for (int e = tid + 2 * TILE; e < ne; e += TILE) slr[e] = a.e_lr[td.e_off + e];
+    if (STAGE3 && tid + 2 * TILE < ne) {
+      e3[tid]               = cs3;
+      e3[LAY::n3 + tid]     = md3.x;
+      e3[2 * LAY::n3 + tid] = md3.y;
+    }
     __syncthreads();
 
     // ---- phase G: least-squares gradients of own and first-ring cells -> LDS
@@ -680,7 +696,11 @@ __global__ __launch_bounds__(TILE) RDY_MUSCL_OCC void swe_rhs_muscl_fused_kernel
       // quads: a 16 x 16 block has 544 edge records; the third round loads its records here (EFO: emax <= 3 TILE)
       __builtin_amdgcn_sched_barrier(0);
       const int e = tid + 2 * TILE;
-      if (e < ne) x2 = do_edge(a.e_lr[td.e_off + e], a.e_cs[td.e_off + e], *reinterpret_cast<const double2 *>(g.e_mid + 2 * ((int64_t)td.e_off + e)));
+      if (STAGE3) {
+        if (e < ne) x2 = do_edge(slr[e], e3[tid], make_double2(e3[LAY::n3 + tid], e3[2 * LAY::n3 + tid]));
+      } else {
+        if (e < ne) x2 = do_edge(a.e_lr[td.e_off + e], a.e_cs[td.e_off + e], *reinterpret_cast<const double2 *>(g.e_mid + 2 * ((int64_t)td.e_off + e)));
+      }
     }
 #ifndef RDYHIP_MUSCL_EARLY_STREAMS
     // the per-cell streams of phase 2 are requested only here: held from the tile's top they would cost 18 registers

@@ -113,6 +113,7 @@ struct RDyHipOperator_s {
   // tiled kernel (swe_kernels.h)
   bool             use_tiled = true;
   bool             hr = false;   // hydrostatic reconstruction
+  bool             lds_fixed = false;  // first-order tiled kernel: compile-time LDS plane lengths (TILED_NS_* / TILED_NE_*)
   DevBuf<double>   d_zc_local;
   int32_t          ntiles = 0, n_halo_tiles = 0, emax = 0;
   int64_t          nrec = 0;
@@ -166,24 +167,34 @@ namespace {
 
 using TiledKernelFn = void (*)(const KernelArgs, const double, const double *, double *);
 
-// the instantiation of the tiled kernel for (slots per cell, source method, overwrite)
-template <bool HR>
+// the instantiation of the tiled kernel for (slots per cell, source method, overwrite, HR, fixed LDS plane lengths)
+template <bool HR, int NS3, int NE3, int NS4, int NE4>
 TiledKernelFn tiled_kernel_fn_hr(int S, int src, bool ovw) {
   if (S == 3) {
-    if (src) return ovw ? swe_rhs_tiled_kernel<3, 1, true, HR> : swe_rhs_tiled_kernel<3, 1, false, HR>;
-    return ovw ? swe_rhs_tiled_kernel<3, 0, true, HR> : swe_rhs_tiled_kernel<3, 0, false, HR>;
+    if (src) return ovw ? swe_rhs_tiled_kernel<3, 1, true, HR, false, NS3, NE3> : swe_rhs_tiled_kernel<3, 1, false, HR, false, NS3, NE3>;
+    return ovw ? swe_rhs_tiled_kernel<3, 0, true, HR, false, NS3, NE3> : swe_rhs_tiled_kernel<3, 0, false, HR, false, NS3, NE3>;
   }
-  if (src) return ovw ? swe_rhs_tiled_kernel<4, 1, true, HR> : swe_rhs_tiled_kernel<4, 1, false, HR>;
-  return ovw ? swe_rhs_tiled_kernel<4, 0, true, HR> : swe_rhs_tiled_kernel<4, 0, false, HR>;
+  if (src) return ovw ? swe_rhs_tiled_kernel<4, 1, true, HR, false, NS4, NE4> : swe_rhs_tiled_kernel<4, 1, false, HR, false, NS4, NE4>;
+  return ovw ? swe_rhs_tiled_kernel<4, 0, true, HR, false, NS4, NE4> : swe_rhs_tiled_kernel<4, 0, false, HR, false, NS4, NE4>;
 }
-TiledKernelFn tiled_kernel_fn(int S, int src, bool ovw, bool hr) { return hr ? tiled_kernel_fn_hr<true>(S, src, ovw) : tiled_kernel_fn_hr<false>(S, src, ovw); }
+TiledKernelFn tiled_kernel_fn(int S, int src, bool ovw, bool hr, bool fixed = false) {
+  if (fixed)
+    return hr ? tiled_kernel_fn_hr<true, TILED_NS_TRI, TILED_NE_TRI, TILED_NS_QUAD, TILED_NE_QUAD>(S, src, ovw)
+              : tiled_kernel_fn_hr<false, TILED_NS_TRI, TILED_NE_TRI, TILED_NS_QUAD, TILED_NE_QUAD>(S, src, ovw);
+  return hr ? tiled_kernel_fn_hr<true, 0, 0, 0, 0>(S, src, ovw) : tiled_kernel_fn_hr<false, 0, 0, 0, 0>(S, src, ovw);
+}
 // the instantiation with the forward-Euler update fused into the stores (rdyhip_euler_step)
-template <bool HR>
+template <bool HR, int NS3, int NE3, int NS4, int NE4>
 TiledKernelFn tiled_euler_fn_hr(int S, int src) {
-  if (S == 3) return src ? swe_rhs_tiled_kernel<3, 1, true, HR, true> : swe_rhs_tiled_kernel<3, 0, true, HR, true>;
-  return src ? swe_rhs_tiled_kernel<4, 1, true, HR, true> : swe_rhs_tiled_kernel<4, 0, true, HR, true>;
+  if (S == 3) return src ? swe_rhs_tiled_kernel<3, 1, true, HR, true, NS3, NE3> : swe_rhs_tiled_kernel<3, 0, true, HR, true, NS3, NE3>;
+  return src ? swe_rhs_tiled_kernel<4, 1, true, HR, true, NS4, NE4> : swe_rhs_tiled_kernel<4, 0, true, HR, true, NS4, NE4>;
 }
-TiledKernelFn tiled_euler_fn(int S, int src, bool hr) { return hr ? tiled_euler_fn_hr<true>(S, src) : tiled_euler_fn_hr<false>(S, src); }
+TiledKernelFn tiled_euler_fn(int S, int src, bool hr, bool fixed = false) {
+  if (fixed)
+    return hr ? tiled_euler_fn_hr<true, TILED_NS_TRI, TILED_NE_TRI, TILED_NS_QUAD, TILED_NE_QUAD>(S, src)
+              : tiled_euler_fn_hr<false, TILED_NS_TRI, TILED_NE_TRI, TILED_NS_QUAD, TILED_NE_QUAD>(S, src);
+  return hr ? tiled_euler_fn_hr<true, 0, 0, 0, 0>(S, src) : tiled_euler_fn_hr<false, 0, 0, 0, 0>(S, src);
+}
 
 using MusclKernelFn = void (*)(const KernelArgs, const MusclArgs, const double, const double *, double *);
 
@@ -412,10 +423,10 @@ int launch_rhs(RDyHipOperator op, int32_t phase, int32_t overwrite, int reset_di
                                       : muscl_kernel_fn(op->S, xq ? 1 : 0, overwrite != 0, op->config.limiter, op->muscl_fused, op->muscl_efo, op->muscl_soa);
       hipLaunchKernelGGL(HIP_KERNEL_NAME(kfn), dim3(grid), dim3(TILE), op->lds_muscl, st, a, muscl_args(op), dt, u, f);
     } else if (euler_fused) {
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(tiled_euler_fn(op->S, xq ? 1 : 0, op->hr)), dim3(grid), dim3(TILE), op->lds_bytes, st, a, dt, u, f);
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(tiled_euler_fn(op->S, xq ? 1 : 0, op->hr, op->lds_fixed)), dim3(grid), dim3(TILE), op->lds_bytes, st, a, dt, u, f);
     } else {
       const size_t lds = op->lds_bytes;
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(tiled_kernel_fn(op->S, xq ? 1 : 0, overwrite != 0, op->hr)), dim3(grid), dim3(TILE), lds, st, a, dt, u, f);
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(tiled_kernel_fn(op->S, xq ? 1 : 0, overwrite != 0, op->hr, op->lds_fixed)), dim3(grid), dim3(TILE), lds, st, a, dt, u, f);
     }
   } else {
     if (phase == RDYHIP_PHASE_HALO) {
@@ -461,7 +472,7 @@ int launch_rhs(RDyHipOperator op, int32_t phase, int32_t overwrite, int reset_di
 struct HostLayout {
   int32_t nc = 0, no = 0, ne = 0, ni = 0, K = 0, S = 3, ntiles = 0, emax = 0, hmax = 0, hmax2 = 0;
   int64_t stride = 0;
-  bool    prefix = true, hr_on = false, muscl_on = false, muscl_fused = true, muscl_efo = false, muscl_soa = false;
+  bool    prefix = true, hr_on = false, muscl_on = false, muscl_fused = true, muscl_efo = false, muscl_soa = false, lds_fixed = false;
   size_t  lds_bytes = 0, lds_muscl = 0;
   std::vector<int32_t>  o2l, boff, nbr, pos, btype, bleft, bedge, bghost, halo, hcells, tile_bk, halo_tiles, hcells2, c_off;
   std::vector<double>   cn, sn, coef, bcn, bsn, e_cs, e_mid, dzdx, dzdy;
@@ -795,7 +806,12 @@ static int build_host_layout(const RDyHipConfig *config, const RDyHipMesh *mesh,
   const bool    muscl_on = L.muscl_on;
   const auto   &o2l      = L.o2l;
   const bool   hr_on     = config->well_balancing == RDYHIP_WELL_BALANCING_HR;
-  const size_t lds_bytes = sizeof(double) * ((hr_on ? 6 : 5) * ((size_t)TILE + hmax) + 2 * (size_t)TILE + (hr_on ? 6 : 4) * (size_t)emax);
+  // first-order tiled kernel: compile-time plane lengths where the tiles fit them (RDYHIP_LDS_FIXED=0: measurement knob)
+  const char  *fenv      = getenv("RDYHIP_LDS_FIXED");
+  const int    ns_fix = L.S == 3 ? TILED_NS_TRI : TILED_NS_QUAD, ne_fix = L.S == 3 ? TILED_NE_TRI : TILED_NE_QUAD;
+  const bool   lds_fixed = TILE + hmax <= ns_fix && emax <= ne_fix && !(fenv && atoi(fenv) == 0);
+  const size_t ns_lds = lds_fixed ? (size_t)ns_fix : (size_t)TILE + hmax, ne_lds = lds_fixed ? (size_t)ne_fix : (size_t)emax;
+  const size_t lds_bytes = sizeof(double) * ((hr_on ? 6 : 5) * ns_lds + 2 * (size_t)TILE + (hr_on ? 6 : 4) * ne_lds);
   const char  *menv        = getenv("RDYHIP_MUSCL");
   const bool   muscl_fused = !(menv && strcmp(menv, "split") == 0);
   // second order, fused form: where the edge fluxes live (muscl_kernels.h) -- over the gradients when a tile's edges fit
@@ -824,7 +840,7 @@ static int build_host_layout(const RDyHipConfig *config, const RDyHipMesh *mesh,
     dzdy[o] = mesh->cell_dz_dy[o2l[o]];
   }
 
-  L.hr_on = hr_on; L.muscl_fused = muscl_fused; L.muscl_efo = muscl_efo; L.muscl_soa = muscl_soa; L.lds_bytes = lds_bytes; L.lds_muscl = lds_muscl;
+  L.hr_on = hr_on; L.muscl_fused = muscl_fused; L.muscl_efo = muscl_efo; L.muscl_soa = muscl_soa; L.lds_fixed = lds_fixed; L.lds_bytes = lds_bytes; L.lds_muscl = lds_muscl;
   L.dzdx = std::move(dzdx); L.dzdy = std::move(dzdy);
   return 0;
 }
@@ -872,6 +888,7 @@ int rdyhip_create(const RDyHipConfig *config, const RDyHipMesh *mesh, int32_t nu
   op->emax         = emax;
   op->hmax         = hmax;
   op->lds_bytes    = lds_bytes;
+  op->lds_fixed    = L.lds_fixed;
   if (lds_bytes > 64 * 1024) {
     // more than the default 64 KB of dynamic LDS (only for numberings with poor locality)
     const int nb = (int)lds_bytes;
@@ -879,8 +896,8 @@ int rdyhip_create(const RDyHipConfig *config, const RDyHipMesh *mesh, int32_t nu
     for (int ovw = 0; ovw < 2; ++ovw)
       for (int src = 0; src < 2; ++src)
         for (int sl = 3; sl <= 4; ++sl)
-          ok = ok && hipFuncSetAttribute((const void *)tiled_kernel_fn(sl, src, ovw != 0, hr_on), hipFuncAttributeMaxDynamicSharedMemorySize, nb) == hipSuccess &&
-               hipFuncSetAttribute((const void *)tiled_euler_fn(sl, src, hr_on), hipFuncAttributeMaxDynamicSharedMemorySize, nb) == hipSuccess;
+          ok = ok && hipFuncSetAttribute((const void *)tiled_kernel_fn(sl, src, ovw != 0, hr_on, L.lds_fixed), hipFuncAttributeMaxDynamicSharedMemorySize, nb) == hipSuccess &&
+               hipFuncSetAttribute((const void *)tiled_euler_fn(sl, src, hr_on, L.lds_fixed), hipFuncAttributeMaxDynamicSharedMemorySize, nb) == hipSuccess;
     if (!ok) {
       delete op;
       return fail(RDYHIP_ERR_LIB, "cannot reserve %d bytes of LDS per workgroup", nb);
@@ -934,7 +951,7 @@ int rdyhip_create(const RDyHipConfig *config, const RDyHipMesh *mesh, int32_t nu
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, op->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
     int q = 0;
-    const void *kfn = (const void *)tiled_kernel_fn(S, config->source_method == RDYHIP_SOURCE_IMPLICIT_XQ2018 ? 1 : 0, true, hr_on);
+    const void *kfn = (const void *)tiled_kernel_fn(S, config->source_method == RDYHIP_SOURCE_IMPLICIT_XQ2018 ? 1 : 0, true, hr_on, L.lds_fixed);
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, kfn, TILE, lds_bytes) == hipSuccess && q > 0) per_cu = q;
     if (const char *e2 = getenv("RDYHIP_BLOCKS_PER_CU")) {
       if (atoi(e2) > 0) per_cu = atoi(e2);
@@ -1423,7 +1440,7 @@ int rdyhip_probe_layout(const RDyHipConfig *config, const RDyHipMesh *mesh, int3
   tmp.n_cells = L.nc; tmp.n_owned = L.no; tmp.S = L.S; tmp.K = L.K; tmp.n_halo = (int32_t)L.halo.size(); tmp.use_tiled = true;
   tmp.ntiles = L.ntiles; tmp.n_halo_tiles = (int32_t)L.halo_tiles.size(); tmp.emax = L.emax; tmp.hmax = L.hmax;
   tmp.nhalo_entries = (int64_t)L.hcells.size(); tmp.nrec = (int64_t)L.e_lr.size(); tmp.prefix = L.prefix; tmp.muscl = L.muscl_on;
-  tmp.muscl_fused = L.muscl_fused; tmp.muscl_efo = L.muscl_efo; tmp.muscl_soa = L.muscl_soa; tmp.hmax2 = L.hmax2; tmp.d_hcells2.n = L.hcells2.size(); tmp.lds_bytes = L.lds_bytes; tmp.lds_muscl = L.lds_muscl;
+  tmp.muscl_fused = L.muscl_fused; tmp.muscl_efo = L.muscl_efo; tmp.muscl_soa = L.muscl_soa; tmp.hmax2 = L.hmax2; tmp.d_hcells2.n = L.hcells2.size(); tmp.lds_bytes = L.lds_bytes; tmp.lds_muscl = L.lds_muscl; tmp.lds_fixed = L.lds_fixed;
   const int rc2 = rdyhip_layout_info(&tmp, info);
   tmp.d_hcells2.n = 0;
   return rc2;
@@ -1449,6 +1466,7 @@ int rdyhip_layout_info(RDyHipOperator op, RDyHipLayoutInfo *info) {
   info->max_tile_ring2_cells = op->hmax2;
   info->persistent_grid      = op->muscl ? op->pgrid_muscl : op->pgrid;
   info->lds_bytes            = (int32_t)(op->muscl ? op->lds_muscl : op->lds_bytes);
+  info->lds_fixed_layout     = (op->muscl ? (op->muscl_fused && op->muscl_soa) : (op->use_tiled && op->lds_fixed)) ? 1 : 0;
   // u (own cell) 24 + slots S*(4+8+8+8) + dz 16 + n 8 + ext src 24 + F 24 + pv 24 (+4 for o2l)
   if (op->use_tiled) {
     // u 24 + slot refs 4 (8 for quads) + coef S*8 + dz 16 + n 8 + ext src 24 + F 24 + pv 24 (+4 for o2l) per cell;

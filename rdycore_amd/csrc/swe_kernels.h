@@ -339,7 +339,12 @@ __device__ __forceinline__ void load_streams(const KernelArgs &a, int o, bool ac
 //
 // EULER = the forward-Euler update fused into the store phase (what TSEULER's VecAXPY does after the RHS,
 // rdyhip_euler_step): the owned rows of a second state array receive u + dt F, F itself is stored only if f != nullptr.
-template <int S, int SRC, bool OVW, bool HR, bool EULER = false>
+// NS / NE > 0: the LDS planes have COMPILE-TIME lengths (NS side-data slots, NE edge slots: capacities the mesh's tiles were
+// checked against at create) -- every plane offset is then an instruction immediate instead of a register and an add.
+// 0: lengths from the mesh (a.hmax, a.emax), any numbering.  The lengths are not multiples of 64 doubles on purpose: hipcc
+// would fuse the reads of two planes into ds_read2st64_b64, which the LDS serves at half the rate of two ds_read_b64.
+constexpr int TILED_NS_TRI = 360, TILED_NE_TRI = 520, TILED_NS_QUAD = 368, TILED_NE_QUAD = 552;
+template <int S, int SRC, bool OVW, bool HR, bool EULER = false, int NS = 0, int NE = 0>
 __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(3, 3))) void swe_rhs_tiled_kernel(const KernelArgs a, const double dt, const double *__restrict__ u,
                                                               double *__restrict__ f) {
   // edge-record rounds held in registers: a 256-cell tile of a well-numbered triangle mesh has <= 2 x 256 edge records
@@ -347,13 +352,14 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
   // inside the flux phase.
   constexpr int NR = (S == 3) ? 2 : RDYHIP_QUAD_ROUNDS;
   extern __shared__ double lds[];
-  const int nside = TILE + a.hmax;
+  const int nside = NS > 0 ? NS : TILE + a.hmax;
+  const int nedge = NE > 0 ? NE : a.emax;
   double   *sd_h = lds, *sd_u = lds + nside, *sd_v = lds + 2 * nside, *sd_sq = lds + 3 * nside, *sd_c = lds + 4 * nside;
   double   *sd_hu = lds + 5 * nside, *sd_hv = sd_hu + TILE;
-  double   *ef0 = sd_hv + TILE, *ef1 = ef0 + a.emax, *ef2 = ef1 + a.emax, *eam = ef2 + a.emax;
+  double   *ef0 = sd_hv + TILE, *ef1 = ef0 + nedge, *ef2 = ef1 + nedge, *eam = ef2 + nedge;
   // HR only: bed elevation per slot; per edge the momentum flux as the RIGHT cell sees it (ef1 / ef2 then hold the left
   // cell's: the Roe flux plus each side's own pressure correction)
-  double   *sd_zc = eam + a.emax, *efr1 = sd_zc + nside, *efr2 = efr1 + a.emax;
+  double   *sd_zc = eam + nedge, *efr1 = sd_zc + nside, *efr2 = efr1 + nedge;
   const int tid = threadIdx.x;
 
   // ---- this workgroup's tile sequence.  Block ids are dealt round-robin to the

@@ -24,6 +24,8 @@ def test_tile_numbers_follow_the_cell_numbering():
     assert rec["rowmajor"] > 1.95 and rec["tiled"] < 1.65 and rec["hilbert"] < 1.68
     assert info["rowmajor"]["num_halo_entries"] > 4 * info["tiled"]["num_halo_entries"]
     assert info["tiled"]["lds_bytes"] < info["rowmajor"]["lds_bytes"] < 64 * 1024
+    # a numbering with locality fits the kernels' fixed LDS capacities (plane offsets become immediates), row-major does not
+    assert info["tiled"]["lds_fixed_layout"] == 1 and info["hilbert"]["lds_fixed_layout"] == 1 and info["rowmajor"]["lds_fixed_layout"] == 0
     # a random numbering: three records per cell (every edge cut), halo lists of hundreds of cells, > 64 KB of LDS
     rng = np.random.default_rng(0)
     xyz, conn, _, _ = M.structured_tri_connectivity(64, 48)
@@ -46,6 +48,7 @@ def test_quads_ghosts_and_second_order_tables():
     # second order: the fused kernel also stages a second ring; its halo tiles include tiles whose FIRST RING touches a ghost
     s = probe_layout(RDyFlowConfig(second_order=True), m)
     assert s["second_order_fused"] == 1 and s["max_tile_ring2_cells"] > s["max_tile_halo_cells"] and s["lds_bytes"] > i["lds_bytes"]
+    assert s["lds_fixed_layout"] == 1 and s["lds_bytes"] == 8 * (6 * 360 + 5 * 520 + 3 * 8) + 4 * 520       # MusclSoATri
     assert s["num_halo_tiles"] >= i["num_halo_tiles"]
     old = os.environ.get("RDYHIP_MUSCL")
     os.environ["RDYHIP_MUSCL"] = "split"
