@@ -543,6 +543,7 @@ __global__ __launch_bounds__(TILE) RDY_MUSCL_OCC void swe_rhs_muscl_fused_kernel
 
     // ---- the tile's load batch: everything the four phases read from global memory that does not depend on LDS.
     // hipcc waits with vmcnt(0) at the first use, so one batch = one exposed latency per tile.
+    __builtin_amdgcn_s_setprio(3);  // a wave that has reached its load batch issues it ahead of the waves that are computing (-0.7 %)
     const int hid = (pre_tile == tile) ? pre_hid : ring_id(td, nh, c0, nc2);
     double    q[3] = {0.0, 0.0, 0.0}, hq[3] = {0.0, 0.0, 0.0};
     double2   cxy = make_double2(0.0, 0.0), hcxy = make_double2(0.0, 0.0);
@@ -607,6 +608,7 @@ __global__ __launch_bounds__(TILE) RDY_MUSCL_OCC void swe_rhs_muscl_fused_kernel
       pre_hid            = ring_id(pd, pd.nh(), pc0, load_uniform(g.c_off, pre_tile + 1) - pc0);
     }
 
+    __builtin_amdgcn_s_setprio(0);
     // ---- phase 0: state + centroid of own cells, first ring, second ring; the tile's edge records -> LDS
 #pragma unroll
     for (int k = 0; k < 3; ++k) MSQ(k, tid) = q[k];

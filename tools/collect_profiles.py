@@ -1,0 +1,43 @@
+"""Copies what tools/profile_all.sh left under gpurun_out/prof_<round>_<tag>/ into profiles/ (kernel stats, the parsed PMC
+summary, the bench line printed under the tracer) and writes the variant's entry of profiles/traffic.json.
+usage: python tools/collect_profiles.py <round> [variant ...]"""
+import glob
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+ARGS = {
+    "c3": [], "hr": ["--hr"], "xq": ["--source", "implicit_xq2018"], "c2": ["--workload", "c2"], "quads": ["--workload", "dambreak_quads"],
+    "c5": ["--workload", "c5", "--emulate-world", "8", "--emulate-rank", "3"], "so": ["--second-order"],
+    "so_quads": ["--second-order", "--workload", "dambreak_quads"], "houston": ["--workload", "houston_refined"],
+    "houston_hr": ["--workload", "houston_refined", "--hr"], "houston_so": ["--workload", "houston_refined", "--second-order"],
+    "delaunay": ["--workload", "delaunay"], "self_exchange": ["--emulate-world", "3", "--emulate-rank", "1", "--self-exchange"],
+}
+rnd = sys.argv[1]
+tags = sys.argv[2:] or list(ARGS)
+for tag in tags:
+    d = os.path.join(ROOT, "gpurun_out", f"prof_{rnd}_{tag}")
+    summ = os.path.join(d, "summary.json")
+    if not os.path.exists(summ):
+        print(tag, ": no summary.json (not profiled yet)")
+        continue
+    ks = glob.glob(os.path.join(d, "trace", "**", "*kernel_stats.csv"), recursive=True)
+    if ks:
+        shutil.copy(ks[0], os.path.join(ROOT, "profiles", f"{rnd}_{tag}_kernel_stats.csv"))
+    shutil.copy(summ, os.path.join(ROOT, "profiles", f"{rnd}_{tag}_summary.json"))
+    log = os.path.join(d, "bench_trace.log")
+    if os.path.exists(log):
+        lines = [ln for ln in open(log) if ln.startswith("{")]
+        if lines:
+            open(os.path.join(ROOT, "profiles", f"{rnd}_{tag}_bench_under_rocprof.json"), "w").write(lines[-1])
+    key = bench.traffic_key(bench.parse(ARGS[tag]))
+    per_step = "2" if tag == "self_exchange" else "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_traffic.py"), summ, key, f"profiles/{rnd}_{tag}_summary.json", per_step],
+                       capture_output=True, text=True)
+    print(tag, key, "ok" if r.returncode == 0 else ("FAILED: " + r.stderr[-300:]))
