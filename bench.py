@@ -719,6 +719,8 @@ def run_rank(args, argv):
         if args.second_order:
             # the 176-B figure above keeps variants comparable; the second-order path's own model:
             b2 = ALG_BYTES_PER_CELL_SECOND_ORDER if info["second_order_fused"] else ALG_BYTES_PER_CELL_SECOND_ORDER_SPLIT
+            if quads:      # two edges per cell instead of 1.5: 192 + centroid 16 + midpoints 2 x 16 (+ the split form's extras)
+                b2 += ALG_BYTES_PER_CELL_QUADS - ALG_BYTES_PER_CELL + 8.0
             a2 = n_owned * b2 / (kern_ms * 1e-3) / 1e9
             out["roofline"]["second_order_model"] = {"bytes_per_cell_update": b2, "achieved": round(a2, 1),
                                                      "frac": round(a2 / HBM_PEAK_GBPS, 4)}

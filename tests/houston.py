@@ -26,10 +26,19 @@ def datasets():
     return rain, bc, rasters
 
 
-def oracle_run(mode: str, t_stop: float = T_STOP):
+def _case(levels: int, hr: bool):
+    """the reference's test mesh itself (levels = 0) or its refinement (the unstructured benchmark workload in small:
+    cases.houston_refined_case -- dt halves with every level, the coupling interval stays 60 s)"""
+    if levels == 0:
+        return CS.houston_case(DATA), DT
+    case = CS.houston_refined_case(DATA, levels, "hilbert", hr=hr, time=0.0)
+    return case, DT / 2 ** levels
+
+
+def oracle_run(mode: str, t_stop: float = T_STOP, levels: int = 0, hr: bool = False):
     from oracle import oracle as O
     from helpers import oracle_from_case
-    case = CS.houston_case(DATA)
+    case, dt0 = _case(levels, hr)
     mesh = case.mesh
     orc = oracle_from_case(case)
     rain, bc, rasters = datasets()
@@ -56,18 +65,18 @@ def oracle_run(mode: str, t_stop: float = T_STOP):
         # RDyAdvance: one coupling interval
         t_end = t + INTERVAL
         while t < t_end * (1.0 - 1e-14):
-            h = min(DT, t_end - t)
+            h = min(dt0, t_end - t)
             u = u + h * orc.apply(h, u)
             t += h
         wet_history.append(int((u[:, 0] > 1e-7).sum()))
     return case, u, orc, wet_history
 
 
-def device_run(mode: str, t_stop: float = T_STOP, fused: bool = True, second_order: bool = False):
+def device_run(mode: str, t_stop: float = T_STOP, fused: bool = True, second_order: bool = False, levels: int = 0, hr: bool = False):
     import torch
     from rdycore_amd import forcing as F
     from rdycore_amd.timestep import EulerStepper
-    case = CS.houston_case(DATA)
+    case, dt0 = _case(levels, hr)
     case.config.second_order = second_order
     mesh = case.mesh
     op = CS.create_operator(case)
@@ -88,6 +97,6 @@ def device_run(mode: str, t_stop: float = T_STOP, fused: bool = True, second_ord
         if ras is not None and ras.needs_next_file(st.time):
             ras.load_next(rasters[nfile])
             nfile += 1
-        st.advance(u, DT, INTERVAL)
+        st.advance(u, dt0, INTERVAL)
     torch.cuda.synchronize()
     return case, u.cpu().numpy(), op, st

@@ -26,6 +26,28 @@ def test_houston_time_loop_matches_the_oracle(mode, fused, rdyhip_kernel):
     assert rel_linf(op.external_sources.cpu().numpy(), orc.external_sources) == 0.0
 
 
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("hr", [False, True])
+def test_refined_houston_time_loop_matches_the_oracle(hr, rdyhip_kernel):
+    """the unstructured benchmark workload as a RUN, in small: the Houston mesh refined three times (175 744 triangles, Hilbert
+    order, 38 % of the cells dry at the start), the reference's rain and stage series re-applied every 60 s coupling interval
+    on the device, 48 fused Euler steps with wet / dry fronts moving over the real DEM -- against the same loop on the oracle,
+    with and without hydrostatic reconstruction"""
+    if rdyhip_kernel == "cell":
+        pytest.skip("one kernel variant is enough (HR lives in the tiled kernel)")
+    t_stop = 180.0
+    case, u_ref, orc, wet = houston.oracle_run("homogeneous", t_stop=t_stop, levels=3, hr=hr)
+    _, u, op, st = houston.device_run("homogeneous", t_stop=t_stop, levels=3, hr=hr)
+    assert st.step == 48 and abs(st.time - t_stop) < 1e-9
+    assert np.isfinite(u).all() and np.isfinite(u_ref).all()
+    h0 = case.u_local[:, 0]
+    assert ((h0 == 0) != (u_ref[:, 0] <= 1e-7)).sum() > 100          # the wet / dry front has moved over hundreds of cells
+    assert rel_linf(u, u_ref) <= 1e-10, rel_linf(u, u_ref)
+    b = case.mesh.boundary_by_name("bottom_wall")
+    assert rel_linf(op.boundary_fluxes(b, accumulated=True), orc.boundary_fluxes_accum[b]) <= 1e-10
+    assert rel_linf(op.external_sources.cpu().numpy(), orc.external_sources) == 0.0
+
+
 def test_houston_second_order(rdyhip_kernel):
     if rdyhip_kernel == "cell":
         pytest.skip("tiled kernels only")

@@ -18,6 +18,8 @@ ARGS = {
     "so_quads": ["--second-order", "--workload", "dambreak_quads"], "houston": ["--workload", "houston_refined"],
     "houston_hr": ["--workload", "houston_refined", "--hr"], "houston_so": ["--workload", "houston_refined", "--second-order"],
     "delaunay": ["--workload", "delaunay"], "self_exchange": ["--emulate-world", "3", "--emulate-rank", "1", "--self-exchange"],
+    "self_exchange_so": ["--emulate-world", "3", "--emulate-rank", "1", "--self-exchange", "--second-order"],
+    "houston_natural": ["--workload", "houston_refined", "--order", "natural"],
 }
 rnd = sys.argv[1]
 tags = sys.argv[2:] or list(ARGS)
@@ -37,7 +39,7 @@ for tag in tags:
         if lines:
             open(os.path.join(ROOT, "profiles", f"{rnd}_{tag}_bench_under_rocprof.json"), "w").write(lines[-1])
     key = bench.traffic_key(bench.parse(ARGS[tag]))
-    per_step = "2" if tag == "self_exchange" else "1"
+    per_step = "2" if tag.startswith("self_exchange") else "1"
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_traffic.py"), summ, key, f"profiles/{rnd}_{tag}_summary.json", per_step],
                        capture_output=True, text=True)
     print(tag, key, "ok" if r.returncode == 0 else ("FAILED: " + r.stderr[-300:]))

@@ -20,6 +20,8 @@ V[houston_hr]="--workload houston_refined --hr"
 V[houston_so]="--workload houston_refined --second-order"
 V[delaunay]="--workload delaunay"
 V[self_exchange]="--emulate-world 3 --emulate-rank 1 --self-exchange"
+V[self_exchange_so]="--emulate-world 3 --emulate-rank 1 --self-exchange --second-order"
+V[houston_natural]="--workload houston_refined --order natural"
 ORDER="${@:-c3 hr xq c2 quads c5 so so_quads houston houston_hr houston_so delaunay self_exchange}"
 cd /tmp
 echo "calibration"

@@ -1,0 +1,35 @@
+"""Markdown rows of DESIGN.md's results tables from the bench lines and rocprof summaries under profiles/.
+usage: python tools/results_table.py r03"""
+import csv
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r03"
+order = ["c3", "c3_200", "hr", "xq", "c2", "quads", "c5", "so", "so_quads", "houston", "houston_natural", "houston_hr", "houston_so", "delaunay",
+         "self_exchange", "self_exchange_so"]
+print("| variant | kernel | ms / step (unprofiled) | M cell-updates/s | frac of 8 TB/s (model B/cell) | PMC traffic vs algorithmic | rocprofv3 kernel avg (launches) |")
+print("|---|---|---|---|---|---|---|")
+for tag in order:
+    p = os.path.join(ROOT, "profiles", f"{rnd}_bench_{tag}.json")
+    if not os.path.exists(p):
+        continue
+    d = json.load(open(p))
+    r = d["roofline"]
+    alg = r["algorithmic_bytes_per_launch"]
+    tr = r.get("traffic")
+    ks = os.path.join(ROOT, "profiles", f"{rnd}_{tag.replace('c3_200', 'c3')}_kernel_stats.csv")
+    kavg = ""
+    if os.path.exists(ks):
+        rows = list(csv.DictReader(open(ks)))
+        top = max((x for x in rows if "swe_rhs" in x["Name"]), key=lambda x: int(x["Calls"]), default=None)
+        if top:
+            kavg = f"{float(top['AverageNs']) / 1e3:.1f} µs ({top['Calls']})"
+    frac = f"{r['frac']:.3f} ({int(r['algorithmic_bytes_per_cell'])})"
+    if "second_order_model" in r:
+        frac += f"; {r['second_order_model']['frac']:.3f} ({int(r['second_order_model']['bytes_per_cell_update'])})"
+    if "frac_176B_model" in r:
+        frac += f"; {r['frac_176B_model']:.3f} (176)"
+    print(f"| {tag} | `{r['kernel']}` | {d['ms_per_step']:.4f} | {d['value']:.0f} | {frac} | "
+          f"{(f'{tr / 1e9:.3f} GB = {tr / alg:.3f} ×') if tr else 'null: ' + str((r.get('traffic_source') or {}).get('status'))} | {kavg} |")
