@@ -101,6 +101,7 @@ int rdyhip_halo_plan_requests(RDyHipHaloPlan plan, const int32_t **request_count
 int rdyhip_halo_plan_finish(RDyHipHaloPlan plan, const int32_t *incoming_counts, const int64_t *incoming_keys, int32_t num_cells,
                             const int32_t *cell_is_owned, const int64_t *cell_keys) {
   if (!plan || !incoming_counts) return fail(RDYHIP_ERR_USER, "null argument");
+  plan->finished = false;  // a second call that fails must not leave the first call's lists readable
   if (num_cells < 0 || (num_cells > 0 && !cell_is_owned)) return fail(RDYHIP_ERR_USER, "bad cell list");
   const int32_t world = plan->world;
   int64_t       total = 0;
@@ -188,7 +189,9 @@ int rdyhip_hilbert_cell_order(int32_t num_cells, const double *xy, int32_t strid
   const double ext = std::max(std::max(hi[0] - lo[0], hi[1] - lo[1]), 1e-300);
   std::vector<std::pair<uint64_t, int32_t>> key((size_t)num_cells);
   for (int32_t c = 0; c < num_cells; ++c) {
-    const double   fx = (xy[(size_t)c * stride] - lo[0]) / ext * 65535.0, fy = (xy[(size_t)c * stride + 1] - lo[1]) / ext * 65535.0;
+    double fx = (xy[(size_t)c * stride] - lo[0]) / ext * 65535.0, fy = (xy[(size_t)c * stride + 1] - lo[1]) / ext * 65535.0;
+    if (!(fx == fx)) fx = 0.0;  // a NaN coordinate must not reach the integer conversion
+    if (!(fy == fy)) fy = 0.0;
     const uint32_t x = (uint32_t)std::min(65535.0, std::max(0.0, fx)), y = (uint32_t)std::min(65535.0, std::max(0.0, fy));
     // owned cells first (a contiguous prefix: the owned rows of a local vector are then one block), ghosts after them
     const uint64_t ghost = (cell_is_owned && !cell_is_owned[c]) ? (1ull << 40) : 0ull;

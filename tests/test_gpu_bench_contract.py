@@ -12,7 +12,9 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("extra", [[], ["--second-order"], ["--hr"], ["--workload", "dambreak_quads", "--nx", "160", "--ny", "80", "--cpu-sample", "80x40"],
                                    ["--workload", "c5", "--nx", "100", "--ny", "100", "--cpu-sample", "50x50", "--emulate-world", "4", "--emulate-rank", "1"],
-                                   ["--emulate-world", "3", "--emulate-rank", "1", "--self-exchange"]])
+                                   ["--emulate-world", "3", "--emulate-rank", "1", "--self-exchange"],
+                                   ["--workload", "houston_refined", "--levels", "2", "--cpu-sample", "1x0"],
+                                   ["--workload", "delaunay", "--nx", "90", "--cpu-sample", "40x40"]])
 def test_bench_line_has_the_contract_keys(extra, rdyhip_kernel):
     if rdyhip_kernel == "cell":
         pytest.skip("one kernel variant is enough")
@@ -27,10 +29,13 @@ def test_bench_line_has_the_contract_keys(extra, rdyhip_kernel):
               "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
     assert d["metric"].startswith("M cell-updates/s") and d["unit"] == "M cell-updates/s" and d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 2
-    strong = "dambreak_quads" in extra or "c5" in extra
+    strong = any(w in extra for w in ("dambreak_quads", "c5", "houston_refined", "delaunay"))
     assert d["higher_is_better"] is True and d["scaling"] == ("strong" if strong else "weak") and d["vs_baseline"] is None and d["dtype"] == "f64" and d["data"] == "synthetic"
     assert "untimed RHS launches" in d["config"]["conditioning"] and d["config"]["world_size"] == 1
     assert "workload" in d["config"] and "model" not in d["config"] and d["config"]["finite"] is True
+    if "houston_refined" in extra:      # the unstructured real-DEM workload: 2 746 x 4^2 triangles, wet / dry fronts, Hilbert order
+        assert d["config"]["cells_per_gpu"] == 2746 * 16 and d["config"]["cell_order"] == "hilbert" and "Houston1km" in d["config"]["workload"]
+        assert d["roofline"]["tile_edge_records_per_cell"] < 1.72 and d["roofline"]["halo_cells_per_tile"] < 70
     if "--self-exchange" in extra:      # the multi-rank step on one GPU: exchange looped back through a one-rank RCCL communicator
         assert "one-rank RCCL communicator" in d["config"]["partition"] and d["config"]["cells_per_gpu"] == 2 * 120 * 90
     r = d["roofline"]
