@@ -445,6 +445,18 @@ __global__ __launch_bounds__(TILE) void swe_rhs_muscl_kernel(const KernelArgs a,
 // take their gradient from `grad`, filled by the caller's exchange (their
 // stencil is not local).
 // ---------------------------------------------------------------------------
+// The per-cell streams become visible to phase 2 HERE and on every path: without this hipcc hoists their first uses (a
+// multiply by a constant) into the block that requests them -- the wave then waits for them before the barriers that were
+// meant to cover their latency -- and, the waits sitting inside `if (active)`, treats the registers as still pending after the
+// merge: a vmcnt(0) between the tile's first store and its second, i.e. a wait for the store itself.
+#ifndef RDYHIP_MUSCL_NO_ARRIVE
+#define RDY_STREAMS_ARRIVE()                                                                                                              \
+  do {                                                                                                                                    \
+    asm volatile("" ::"v"(dzx), "v"(dzy), "v"(nman), "v"(s0), "v"(s1), "v"(s2), "v"(kf[0]), "v"(kf[1]), "v"(kf[2]), "v"(kf[S - 1]) : "memory"); \
+  } while (0)
+#else
+#define RDY_STREAMS_ARRIVE() do { } while (0)
+#endif
 #ifdef RDYHIP_MUSCL_WAVES
 #define RDY_MUSCL_OCC __attribute__((amdgpu_waves_per_eu(RDYHIP_MUSCL_WAVES, RDYHIP_MUSCL_WAVES)))
 #else
@@ -530,238 +542,551 @@ __global__ __launch_bounds__(TILE) RDY_MUSCL_OCC void swe_rhs_muscl_fused_kernel
 
   double best      = 0.0;
   int    best_slot = -1, best_o = 0;
-  int    pre_tile = -1, pre_hid = -1;  // ring-cell id fetched one tile ahead (breaks the id -> state load chain)
-
-  for (; idx < hi; idx += step) {
-    const int      tile = tile_at(idx);
-    const TileDesc td = tile_desc(tile);
-    if (a.phase == RDYHIP_PHASE_INTERIOR && td.halo()) continue;  // wave-uniform
-    const int  ne = td.ne(), nh = td.nh();
-    const int  c0 = load_uniform(g.c_off, tile), nc2 = load_uniform(g.c_off, tile + 1) - c0;
-    const int  o      = tile * TILE + tid;
-    const bool active = o < a.n_owned;
-
-    // ---- the tile's load batch: everything the four phases read from global memory that does not depend on LDS.
-    // hipcc waits with vmcnt(0) at the first use, so one batch = one exposed latency per tile.
-    __builtin_amdgcn_s_setprio(3);  // a wave that has reached its load batch issues it ahead of the waves that are computing (-0.7 %)
-    const int hid = (pre_tile == tile) ? pre_hid : ring_id(td, nh, c0, nc2);
-    double    q[3] = {0.0, 0.0, 0.0}, hq[3] = {0.0, 0.0, 0.0};
-    double2   cxy = make_double2(0.0, 0.0), hcxy = make_double2(0.0, 0.0);
-    uint32_t  r0 = 0xFFFFFFFFu, r1 = 0xFFFFFFFFu;
-    double    kf[S];
-    double    dzx = 0.0, dzy = 0.0, nman = 0.0, s0 = 0.0, s1 = 0.0, s2 = 0.0;
-#pragma unroll
-    for (int s = 0; s < S; ++s) kf[s] = 0.0;
-    if (active) {
-      const int c = a.o2l ? a.o2l[o] : o;
-#pragma unroll
-      for (int k = 0; k < 3; ++k) q[k] = u[3 * (int64_t)c + k];
-      cxy = *reinterpret_cast<const double2 *>(g.cxy + 2 * (int64_t)c);
-      if (S == 3) {
-        r0 = RDY_MLD(&reinterpret_cast<const uint32_t *>(a.slot_ref)[o]);
-      } else {
-        const uint2 w = reinterpret_cast<const uint2 *>(a.slot_ref)[o];
-        r0            = w.x;
-        r1            = w.y;
+  if constexpr (S == 4) {
+    // Quads and mixed meshes: cross-tile software pipeline, as in the first-order kernel.  A tile's loads form three groups:
+    // CELLS (state + centroid of the own cell and of this thread's ring cell, the slot references), EDGES (the first-ring
+    // stencil, the edge records of the three rounds with their normal component and midpoint) and the per-cell STREAMS of
+    // phase 2.  Cells and edges of tile T+1 are requested right after phase 0's barrier of tile T (the ids they depend on --
+    // ring cell, own cell -- a tile before that) and are first touched before T's stores; the streams of T after its edge
+    // phase.  159 VGPRs, three workgroups per CU: 5.6 % faster than four workgroups without the pipeline on the reference's
+    // dam-break quads; on triangles (147 VGPRs against 107) the fourth workgroup is worth more than the pipeline, 2 - 3 %
+    // (profiles/r03_ab_muscl_pipeline.txt), so they keep the loop below.
+    // What makes it a pipeline is what is NOT between the request and the first use: (i) no global load on any path every wave
+    // takes -- hipcc answers a conditional load whose result is used after the merge with s_waitcnt vmcnt(0) AT THE MERGE,
+    // for every wave (the ghost gradients below wait inside their branch for that reason); (ii) no first use hoisted into
+    // the requesting block (opaque predicates and initial values, below); (iii) no register that is "pending" at the loop
+    // header (the ids are waited for explicitly).
+    auto next_valid = [&](int i) -> int {  // INTERIOR phase skips tiles with ghost-adjacent cells (wave-uniform)
+      if (a.phase == RDYHIP_PHASE_INTERIOR) {
+        while (i < hi && tile_desc(tile_at(i)).halo()) i += step;
       }
+      return i;
+    };
+    // Values a conditional load may leave untouched start from OPAQUE registers, not constants: with a constant on the other
+    // side hipcc folds the first operation on the loaded value into the loading block (phi(load, c) op k -> phi(load op k, c'))
+    // and the wave then waits for the load where it is requested.
+    double   zero = 0.0;
+    uint32_t ones = 0xFFFFFFFFu;
+    asm volatile("" : "+v"(zero), "+v"(ones));
+    double   q[3] = {zero, zero, zero}, hq[3] = {zero, zero, zero};
+    double2  cxy = make_double2(zero, zero), hcxy = make_double2(zero, zero);
+    uint32_t pr0 = ones, pr1 = ones;
+    struct EdgeRegs {
+      uint2    bw = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+      uint32_t lr0 = 0, lr1 = 0, lr2 = 0;
+      double   cs0 = 0.0, cs1 = 0.0, cs3 = 0.0;
+      double2  md0 = make_double2(0.0, 0.0), md1 = make_double2(0.0, 0.0), md3 = make_double2(0.0, 0.0);
+    };
+    EdgeRegs E;
+    // ids of the own cell (local numbering) and of the ring cell this thread stages for the tile at position i
+    auto tile_ids = [&](int i, int &c_, int &hid_) {
+      const int      t_  = tile_at(i);
+      const TileDesc d_  = tile_desc(t_);
+      const int      c0_ = load_uniform(g.c_off, t_);
+      hid_               = ring_id(d_, d_.nh(), c0_, load_uniform(g.c_off, t_ + 1) - c0_);
+      const int o_       = t_ * TILE + tid;
+      c_                 = (a.o2l && o_ < a.n_owned) ? a.o2l[o_] : o_;
+    };
+    auto issue_cells = [&](int t_, int c_, int hid_) {
+      const int o_ = t_ * TILE + tid;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) q[k] = zero;
+      cxy = make_double2(zero, zero);
+      pr0 = pr1 = ones;
+      // the predicates of the loads are opaque to the compiler: where it can prove one equal to the predicate of a later USE
+      // it hoists that use's first instructions into the loading block -- and the wave waits for the load right there
+      int nown = a.n_owned;
+      asm volatile("" : "+s"(nown));
+      if (o_ < nown) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) q[k] = u[3 * (int64_t)c_ + k];
+        cxy = *reinterpret_cast<const double2 *>(g.cxy + 2 * (int64_t)c_);
+        const uint2 w = reinterpret_cast<const uint2 *>(a.slot_ref)[o_];
+        pr0           = w.x;
+        pr1           = w.y;
+      }
+      if (hid_ >= 0) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) hq[k] = u[3 * (int64_t)hid_ + k];
+        hcxy = *reinterpret_cast<const double2 *>(g.cxy + 2 * (int64_t)hid_);
+      }
+    };
+    auto issue_edges = [&](const TileDesc &d_, EdgeRegs &R) {
+      int ne_ = d_.ne(), nh_ = d_.nh();
+      asm volatile("" : "+s"(ne_), "+s"(nh_));  // opaque predicates, as in issue_cells
+      R.bw = make_uint2(ones, ones);
+      if (tid < nh_) R.bw = load_u2(g.bn_idx + 4 * ((int64_t)d_.h_off + tid));
+      if (STAGE3 && tid + 2 * TILE < ne_) {  // third round: staged through LDS (no global load inside the edge phase)
+        R.lr2 = RDY_MLD(&a.e_lr[d_.e_off + 2 * TILE + tid]);
+        R.cs3 = RDY_MLD(&a.e_cs[d_.e_off + 2 * TILE + tid]);
+        R.md3 = load_d2(g.e_mid + 2 * ((int64_t)d_.e_off + 2 * TILE + tid));
+      }
+      if (tid < ne_) {
+        R.lr0 = RDY_MLD(&a.e_lr[d_.e_off + tid]);
+        R.cs0 = RDY_MLD(&a.e_cs[d_.e_off + tid]);
+        R.md0 = load_d2(g.e_mid + 2 * ((int64_t)d_.e_off + tid));
+      }
+      if (tid + TILE < ne_) {
+        R.lr1 = RDY_MLD(&a.e_lr[d_.e_off + TILE + tid]);
+        R.cs1 = RDY_MLD(&a.e_cs[d_.e_off + TILE + tid]);
+        R.md1 = load_d2(g.e_mid + 2 * ((int64_t)d_.e_off + TILE + tid));
+      }
+    };
+
+    idx = next_valid(idx);
+    if (idx < hi) {
+      int idx1 = next_valid(idx + step);
+      int c1 = 0, hid1 = -1;
+      {  // prologue: both groups of the first tile, the ids of the second
+        int c_, hid_;
+        tile_ids(idx, c_, hid_);
+        const int t_ = tile_at(idx);
+        issue_cells(t_, c_, hid_);
+        issue_edges(tile_desc(t_), E);
+        if (idx1 < hi) tile_ids(idx1, c1, hid1);
+        asm volatile("" ::"v"(hid1), "v"(c1));
+      }
+      while (true) {
+        const int      tile = tile_at(idx);
+        const TileDesc td = tile_desc(tile);
+        const int  ne = td.ne(), nh = td.nh();
+        const int  c0 = load_uniform(g.c_off, tile), nc2 = load_uniform(g.c_off, tile + 1) - c0;
+        const int  o      = tile * TILE + tid;
+        const bool active = o < a.n_owned;
+        int idx2 = hi, c2 = 0, hid2 = -1;
+        const uint32_t r0 = pr0, r1 = pr1;
+        auto pipe_cells = [&]() {  // the cells group of the next tile, the ids of the one after
+          if (idx1 < hi) {
+            idx2 = next_valid(idx1 + step);
+            if (idx2 < hi) tile_ids(idx2, c2, hid2);
+            issue_cells(tile_at(idx1), c1, hid1);
+          }
+        };
+        EdgeRegs N;
+        auto pipe_edges = [&]() {
+          if (idx1 < hi) issue_edges(tile_desc(tile_at(idx1)), N);
+        };
+
+        // ---- phase 0: state + centroid of own cells, first ring, second ring; the tile's edge records -> LDS
+#pragma unroll
+        for (int k = 0; k < 3; ++k) MSQ(k, tid) = q[k];
+        MSQ(3, tid) = cxy.x;
+        MSQ(4, tid) = cxy.y;
+        if (tid < nh + nc2) {
+#pragma unroll
+          for (int k = 0; k < 3; ++k) MSQ(k, TILE + tid) = hq[k];
+          MSQ(3, TILE + tid) = hcxy.x;
+          MSQ(4, TILE + tid) = hcxy.y;
+        }
+        for (int j = tid + TILE; j < nh + nc2; j += TILE) {  // only numberings with poor locality get here
+          const int hc = (j < nh) ? a.hcells[td.h_off + j] : g.hcells2[c0 + j - nh];
+#pragma unroll
+          for (int k = 0; k < 3; ++k) MSQ(k, TILE + j) = u[3 * (int64_t)hc + k];
+          MSQ(3, TILE + j) = g.cxy[2 * (int64_t)hc];
+          MSQ(4, TILE + j) = g.cxy[2 * (int64_t)hc + 1];
+        }
+        if (tid < ne) slr[tid] = E.lr0;
+        if (tid + TILE < ne) slr[tid + TILE] = E.lr1;
+        if (STAGE3) {
+          if (tid + 2 * TILE < ne) {
+            slr[tid + 2 * TILE]   = E.lr2;
+            e3[tid]               = E.cs3;
+            e3[LAY::n3 + tid]     = E.md3.x;
+            e3[2 * LAY::n3 + tid] = E.md3.y;
+          }
+        } else {
+          for (int e = tid + 2 * TILE; e < ne; e += TILE) slr[e] = a.e_lr[td.e_off + e];
+        }
+        const uint2 bwc = E.bw;
+        __syncthreads();
+        __builtin_amdgcn_s_setprio(3);
+        pipe_cells();
+        pipe_edges();
+        __builtin_amdgcn_s_setprio(0);
+
+        // ---- phase G: least-squares gradients of own and first-ring cells -> LDS
+        {
+          double gr[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+          if (active) {
+            int nb[S];
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+              nb[s]         = -1;
+              const int ref = slot_edge<S>(r0, r1, s);
+              if (ref < 0) continue;
+              const uint32_t lr = slr[ref];
+              if (lr & EDGE_BOUNDARY) continue;
+              const int jl = lr & EDGE_SLOT_MASK, jr = (lr >> EDGE_R_SHIFT) & EDGE_SLOT_MASK;
+              nb[s]        = (jl == tid) ? jr : jl;
+            }
+            lds_gradient(tid, nb, gr);
+          }
+#pragma unroll
+          for (int k = 0; k < 6; ++k) MSG(k, tid) = gr[k];
+          auto ring_gradient = [&](int j, uint2 w) {
+            const uint32_t ix[4] = {w.x & 0xFFFFu, w.x >> 16, w.y & 0xFFFFu, w.y >> 16};
+            double         hg[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+            if (ix[0] == BN_GLOBAL) {  // a ghost cell: its gradient was computed by its owner
+              const int hc = a.hcells[td.h_off + j];
+#pragma unroll
+              for (int k = 0; k < 6; ++k) hg[k] = g.grad[6 * (int64_t)hc + k];
+              // wait for them HERE: at the merge below hipcc would wait with vmcnt(0) in every wave, ghost or not, and with
+              // that for the next tile's groups
+              asm volatile("" ::"v"(hg[0]), "v"(hg[1]), "v"(hg[2]), "v"(hg[3]), "v"(hg[4]), "v"(hg[5]));
+            } else {
+              int nb[S];
+#pragma unroll
+              for (int s = 0; s < S; ++s) nb[s] = (ix[s] == BN_NONE) ? -1 : (int)ix[s];
+              lds_gradient(TILE + j, nb, hg);
+            }
+#pragma unroll
+            for (int k = 0; k < 6; ++k) MSG(k, TILE + j) = hg[k];
+          };
+          if (tid < nh) ring_gradient(tid, bwc);
+          for (int j = tid + TILE; j < nh; j += TILE)  // poor locality only
+            ring_gradient(j, reinterpret_cast<const uint2 *>(g.bn_idx)[(int64_t)td.h_off + j]);
+        }
+        __syncthreads();
+
+        // ---- phase 1: every edge of the tile once
+        auto do_edge = [&](uint32_t lr, double cs, double2 mid) -> EdgeFlux {
+          return muscl_edge<LIM, LAY>(a, td, dt, lr, cs, mid, sq, sg);
+        };
+        EdgeFlux x0 = {0.0, 0.0, 0.0, -1.0}, x1 = x0;
+        if (tid < ne) x0 = do_edge(E.lr0, E.cs0, E.md0);
+        if (!EFO && tid < ne) store_edge_flux<LAY>(a, ef, tid, x0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (tid + TILE < ne) x1 = do_edge(E.lr1, E.cs1, E.md1);
+        if (!EFO && tid + TILE < ne) store_edge_flux<LAY>(a, ef, tid + TILE, x1);
+        EdgeFlux x2 = {0.0, 0.0, 0.0, -1.0};
+        if (!EFO) {
+          for (int e = tid + 2 * TILE; e < ne; e += TILE)  // not slr: the fluxes overwrite it
+            store_edge_flux<LAY>(a, ef, e, do_edge(a.e_lr[td.e_off + e], a.e_cs[td.e_off + e], *reinterpret_cast<const double2 *>(g.e_mid + 2 * ((int64_t)td.e_off + e))));
+        } else if (S == 4) {
+          __builtin_amdgcn_sched_barrier(0);
+          const int e = tid + 2 * TILE;
+          if (STAGE3) {
+            if (e < ne) x2 = do_edge(slr[e], e3[tid], make_double2(e3[LAY::n3 + tid], e3[2 * LAY::n3 + tid]));
+          } else {
+            if (e < ne) x2 = do_edge(a.e_lr[td.e_off + e], a.e_cs[td.e_off + e], *reinterpret_cast<const double2 *>(g.e_mid + 2 * ((int64_t)td.e_off + e)));
+          }
+        }
+        // the per-cell streams of phase 2 (requested only here: 18 registers less through the edge phase), then the next
+        // tile's groups: phase 2 waits for the streams alone
+        double kf[S];
+        double dzx = 0.0, dzy = 0.0, nman = 0.0, s0 = 0.0, s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int s = 0; s < S; ++s) kf[s] = 0.0;
+        __builtin_amdgcn_s_setprio(3);
+        {
+          const int oc = active ? o : a.n_owned - 1;
+#pragma unroll
+          for (int s = 0; s < S; ++s) kf[s] = RDY_MLD(&a.coef[s * a.stride + oc]);
+          dzx  = RDY_MLD(&a.dzdx[oc]);
+          dzy  = RDY_MLD(&a.dzdy[oc]);
+          nman = RDY_MLD(&a.mannings[oc]);
+          s0   = RDY_MLD(&a.extsrc[3 * (int64_t)oc + 0]);
+          s1   = RDY_MLD(&a.extsrc[3 * (int64_t)oc + 1]);
+          s2   = RDY_MLD(&a.extsrc[3 * (int64_t)oc + 2]);
+        }
+        __builtin_amdgcn_s_setprio(0);
+        if (EFO) {
+          __syncthreads();  // every edge has read its gradients: the fluxes may overwrite them
+          if (tid < ne) store_edge_flux<LAY>(a, ef, tid, x0);
+          if (tid + TILE < ne) store_edge_flux<LAY>(a, ef, tid + TILE, x1);
+          if (S == 4 && tid + 2 * TILE < ne) store_edge_flux<LAY>(a, ef, tid + 2 * TILE, x2);
+        }
+        __syncthreads();
+
+        // ---- phase 2: per-cell sum in the reference's edge order, source terms, stores
+        RDY_STREAMS_ARRIVE();
+        double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, res[3] = {0.0, 0.0, 0.0}, pu = 0.0, pv_ = 0.0;
+        const double h = MSQ(0, tid), hu = MSQ(1, tid), hv = MSQ(2, tid);
+        if (active) {
+          if (!OVW) {
+            acc0 = f[3 * (int64_t)o + 0];
+            acc1 = f[3 * (int64_t)o + 1];
+            acc2 = f[3 * (int64_t)o + 2];
+          }
+          muscl_cell_sum<S, LAY>(a, r0, r1, kf, ef, dt, o, acc0, acc1, acc2, best, best_slot, best_o);
+          const RiemannSide self = riemann_side(h, hu, hv, a.tiny_h, a.h_anuga_sq);
+          pu                     = self.u;
+          pv_                    = self.v;
+          cell_results<SRC>(a, dt, h, hu, hv, acc0, acc1, acc2, dzx, dzy, nman, s0, s1, s2, res);
+        }
+        asm volatile("" ::"v"(hid2), "v"(c2));  // the ids are never "pending" at the loop header: hipcc would answer with vmcnt(0) at their use
+        // the tile's wait on the next tile's groups comes BEFORE its own stores are issued (vmcnt counts stores too)
+        asm volatile("" ::"v"(q[0]), "v"(q[1]), "v"(q[2]), "v"(cxy.x), "v"(cxy.y), "v"(hq[0]), "v"(hq[1]), "v"(hq[2]), "v"(hcxy.x), "v"(hcxy.y), "v"(pr0), "v"(pr1));
+        asm volatile("" ::"v"(N.bw.x), "v"(N.bw.y), "v"(N.lr0), "v"(N.lr1), "v"(N.cs0), "v"(N.cs1), "v"(N.md0.x), "v"(N.md0.y), "v"(N.md1.x), "v"(N.md1.y));
+        if (STAGE3) asm volatile("" ::"v"(N.lr2), "v"(N.cs3), "v"(N.md3.x), "v"(N.md3.y));
+        E = N;
+        __builtin_amdgcn_sched_barrier(0);
+        {  // whole-line stores of the [cell][3] rows (wave_store_rows3, swe_kernels.h); all 64 lanes take part
+          const int     lane  = tid & 63;
+          const int64_t base  = 3 * ((int64_t)o - lane);
+          const int     ncell = a.n_owned - (o - lane);
+          if (a.fdiv) wave_store_rows3(a.fdiv, base, lane, ncell, acc0, acc1, acc2);
+          if (!EULER || f) wave_store_rows3(f, base, lane, ncell, res[0], res[1], res[2]);
+          wave_store_rows3(a.pv, base, lane, ncell, h, pu, pv_);
+          if (EULER) {  // rdyhip_euler_step: the forward-Euler update rides on the stores, F only if asked for
+            const double n0 = h + dt * res[0], n1 = hu + dt * res[1], n2 = hv + dt * res[2];
+            if (!a.o2l) {
+              wave_store_rows3(a.u_out, base, lane, ncell, n0, n1, n2);
+            } else if (active) {
+              const int64_t c = a.o2l[o];
+              RDY_MST(&a.u_out[3 * c + 0], n0);
+              RDY_MST(&a.u_out[3 * c + 1], n1);
+              RDY_MST(&a.u_out[3 * c + 2], n2);
+            }
+          }
+        }
+        if (idx1 >= hi) break;
+        idx  = idx1;
+        idx1 = idx2;
+        c1   = c2;
+        hid1 = hid2;
+        __syncthreads();  // the LDS records are rewritten by the next tile
+      }
+    }
+
+  } else {
+    int    pre_tile = -1, pre_hid = -1;  // ring-cell id fetched one tile ahead (breaks the id -> state load chain)
+
+    for (; idx < hi; idx += step) {
+      const int      tile = tile_at(idx);
+      const TileDesc td = tile_desc(tile);
+      if (a.phase == RDYHIP_PHASE_INTERIOR && td.halo()) continue;  // wave-uniform
+      const int  ne = td.ne(), nh = td.nh();
+      const int  c0 = load_uniform(g.c_off, tile), nc2 = load_uniform(g.c_off, tile + 1) - c0;
+      const int  o      = tile * TILE + tid;
+      const bool active = o < a.n_owned;
+
+      // ---- the tile's load batch: everything the four phases read from global memory that does not depend on LDS.
+      // hipcc waits with vmcnt(0) at the first use, so one batch = one exposed latency per tile.
+      __builtin_amdgcn_s_setprio(3);  // a wave that has reached its load batch issues it ahead of the waves that are computing (-0.7 %)
+      const int hid = (pre_tile == tile) ? pre_hid : ring_id(td, nh, c0, nc2);
+      double    q[3] = {0.0, 0.0, 0.0}, hq[3] = {0.0, 0.0, 0.0};
+      double2   cxy = make_double2(0.0, 0.0), hcxy = make_double2(0.0, 0.0);
+      uint32_t  r0 = 0xFFFFFFFFu, r1 = 0xFFFFFFFFu;
+      double    kf[S];
+      double    dzx = 0.0, dzy = 0.0, nman = 0.0, s0 = 0.0, s1 = 0.0, s2 = 0.0;
+#pragma unroll
+      for (int s = 0; s < S; ++s) kf[s] = 0.0;
+      if (active) {
+        const int c = a.o2l ? a.o2l[o] : o;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) q[k] = u[3 * (int64_t)c + k];
+        cxy = *reinterpret_cast<const double2 *>(g.cxy + 2 * (int64_t)c);
+        if (S == 3) {
+          r0 = RDY_MLD(&reinterpret_cast<const uint32_t *>(a.slot_ref)[o]);
+        } else {
+          const uint2 w = reinterpret_cast<const uint2 *>(a.slot_ref)[o];
+          r0            = w.x;
+          r1            = w.y;
+        }
 #ifdef RDYHIP_MUSCL_EARLY_STREAMS
 #pragma unroll
-      for (int s = 0; s < S; ++s) kf[s] = RDY_MLD(&a.coef[s * a.stride + o]);
-      dzx  = RDY_MLD(&a.dzdx[o]);
-      dzy  = RDY_MLD(&a.dzdy[o]);
-      nman = RDY_MLD(&a.mannings[o]);
-      s0   = RDY_MLD(&a.extsrc[3 * (int64_t)o + 0]);
-      s1   = RDY_MLD(&a.extsrc[3 * (int64_t)o + 1]);
-      s2   = RDY_MLD(&a.extsrc[3 * (int64_t)o + 2]);
+        for (int s = 0; s < S; ++s) kf[s] = RDY_MLD(&a.coef[s * a.stride + o]);
+        dzx  = RDY_MLD(&a.dzdx[o]);
+        dzy  = RDY_MLD(&a.dzdy[o]);
+        nman = RDY_MLD(&a.mannings[o]);
+        s0   = RDY_MLD(&a.extsrc[3 * (int64_t)o + 0]);
+        s1   = RDY_MLD(&a.extsrc[3 * (int64_t)o + 1]);
+        s2   = RDY_MLD(&a.extsrc[3 * (int64_t)o + 2]);
 #endif
-    }
-    if (hid >= 0) {
-#pragma unroll
-      for (int k = 0; k < 3; ++k) hq[k] = u[3 * (int64_t)hid + k];
-      hcxy = *reinterpret_cast<const double2 *>(g.cxy + 2 * (int64_t)hid);
-    }
-    uint2 bw = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);  // first-ring stencil of ring cell j = tid: the LDS slots of its neighbours
-    if (tid < nh) bw = load_u2(g.bn_idx + 4 * ((int64_t)td.h_off + tid));
-    uint32_t lr0 = 0, lr1 = 0;
-    double   cs0 = 0.0, cs1 = 0.0, cs3 = 0.0;
-    double2  md0 = make_double2(0.0, 0.0), md1 = md0, md3 = md0;
-    if (STAGE3 && tid + 2 * TILE < ne) {  // third round: staged through LDS (no global load inside the edge phase)
-      cs3 = RDY_MLD(&a.e_cs[td.e_off + 2 * TILE + tid]);
-      md3 = load_d2(g.e_mid + 2 * ((int64_t)td.e_off + 2 * TILE + tid));
-    }
-    if (tid < ne) {
-      lr0 = RDY_MLD(&a.e_lr[td.e_off + tid]);
-      cs0 = RDY_MLD(&a.e_cs[td.e_off + tid]);
-      md0 = load_d2(g.e_mid + 2 * ((int64_t)td.e_off + tid));
-    }
-    if (tid + TILE < ne) {
-      lr1 = RDY_MLD(&a.e_lr[td.e_off + TILE + tid]);
-      cs1 = RDY_MLD(&a.e_cs[td.e_off + TILE + tid]);
-      md1 = load_d2(g.e_mid + 2 * ((int64_t)td.e_off + TILE + tid));
-    }
-    // the ring-cell id of the tile this workgroup takes next
-    pre_tile = -1;
-    if (idx + step < hi) {
-      pre_tile            = tile_at(idx + step);
-      const TileDesc pd  = tile_desc(pre_tile);
-      const int      pc0 = load_uniform(g.c_off, pre_tile);
-      pre_hid            = ring_id(pd, pd.nh(), pc0, load_uniform(g.c_off, pre_tile + 1) - pc0);
-    }
-
-    __builtin_amdgcn_s_setprio(0);
-    // ---- phase 0: state + centroid of own cells, first ring, second ring; the tile's edge records -> LDS
-#pragma unroll
-    for (int k = 0; k < 3; ++k) MSQ(k, tid) = q[k];
-    MSQ(3, tid) = cxy.x;
-    MSQ(4, tid) = cxy.y;
-    if (hid >= 0) {
-#pragma unroll
-      for (int k = 0; k < 3; ++k) MSQ(k, TILE + tid) = hq[k];
-      MSQ(3, TILE + tid) = hcxy.x;
-      MSQ(4, TILE + tid) = hcxy.y;
-    }
-    for (int j = tid + TILE; j < nh + nc2; j += TILE) {  // only numberings with poor locality get here
-      const int hc = (j < nh) ? a.hcells[td.h_off + j] : g.hcells2[c0 + j - nh];
-#pragma unroll
-      for (int k = 0; k < 3; ++k) MSQ(k, TILE + j) = u[3 * (int64_t)hc + k];
-      MSQ(3, TILE + j) = g.cxy[2 * (int64_t)hc];
-      MSQ(4, TILE + j) = g.cxy[2 * (int64_t)hc + 1];
-    }
-    if (tid < ne) slr[tid] = lr0;
-    if (tid + TILE < ne) slr[tid + TILE] = lr1;
-    for (int e = tid + 2 * TILE; e < ne; e += TILE) slr[e] = a.e_lr[td.e_off + e];
-    if (STAGE3 && tid + 2 * TILE < ne) {
-      e3[tid]               = cs3;
-      e3[LAY::n3 + tid]     = md3.x;
-      e3[2 * LAY::n3 + tid] = md3.y;
-    }
-    __syncthreads();
-
-    // ---- phase G: least-squares gradients of own and first-ring cells -> LDS
-    {
-      double gr[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-      if (active) {
-        int nb[S];
-#pragma unroll
-        for (int s = 0; s < S; ++s) {
-          nb[s]         = -1;
-          const int ref = slot_edge<S>(r0, r1, s);
-          if (ref < 0) continue;
-          const uint32_t lr = slr[ref];
-          if (lr & EDGE_BOUNDARY) continue;
-          const int jl = lr & EDGE_SLOT_MASK, jr = (lr >> EDGE_R_SHIFT) & EDGE_SLOT_MASK;
-          nb[s]        = (jl == tid) ? jr : jl;
-        }
-        lds_gradient(tid, nb, gr);
       }
+      if (hid >= 0) {
 #pragma unroll
-      for (int k = 0; k < 6; ++k) MSG(k, tid) = gr[k];
-      auto ring_gradient = [&](int j, uint2 w) {
-        const uint32_t ix[4] = {w.x & 0xFFFFu, w.x >> 16, w.y & 0xFFFFu, w.y >> 16};
-        double         hg[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-        if (ix[0] == BN_GLOBAL) {  // a ghost cell: its gradient was computed by its owner
-          const int hc = a.hcells[td.h_off + j];
+        for (int k = 0; k < 3; ++k) hq[k] = u[3 * (int64_t)hid + k];
+        hcxy = *reinterpret_cast<const double2 *>(g.cxy + 2 * (int64_t)hid);
+      }
+      uint2 bw = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);  // first-ring stencil of ring cell j = tid: the LDS slots of its neighbours
+      if (tid < nh) bw = load_u2(g.bn_idx + 4 * ((int64_t)td.h_off + tid));
+      uint32_t lr0 = 0, lr1 = 0;
+      double   cs0 = 0.0, cs1 = 0.0, cs3 = 0.0;
+      double2  md0 = make_double2(0.0, 0.0), md1 = md0, md3 = md0;
+      if (STAGE3 && tid + 2 * TILE < ne) {  // third round: staged through LDS (no global load inside the edge phase)
+        cs3 = RDY_MLD(&a.e_cs[td.e_off + 2 * TILE + tid]);
+        md3 = load_d2(g.e_mid + 2 * ((int64_t)td.e_off + 2 * TILE + tid));
+      }
+      if (tid < ne) {
+        lr0 = RDY_MLD(&a.e_lr[td.e_off + tid]);
+        cs0 = RDY_MLD(&a.e_cs[td.e_off + tid]);
+        md0 = load_d2(g.e_mid + 2 * ((int64_t)td.e_off + tid));
+      }
+      if (tid + TILE < ne) {
+        lr1 = RDY_MLD(&a.e_lr[td.e_off + TILE + tid]);
+        cs1 = RDY_MLD(&a.e_cs[td.e_off + TILE + tid]);
+        md1 = load_d2(g.e_mid + 2 * ((int64_t)td.e_off + TILE + tid));
+      }
+      // the ring-cell id of the tile this workgroup takes next
+      pre_tile = -1;
+      if (idx + step < hi) {
+        pre_tile            = tile_at(idx + step);
+        const TileDesc pd  = tile_desc(pre_tile);
+        const int      pc0 = load_uniform(g.c_off, pre_tile);
+        pre_hid            = ring_id(pd, pd.nh(), pc0, load_uniform(g.c_off, pre_tile + 1) - pc0);
+      }
+
+      __builtin_amdgcn_s_setprio(0);
+      // ---- phase 0: state + centroid of own cells, first ring, second ring; the tile's edge records -> LDS
 #pragma unroll
-          for (int k = 0; k < 6; ++k) hg[k] = g.grad[6 * (int64_t)hc + k];
-        } else {
+      for (int k = 0; k < 3; ++k) MSQ(k, tid) = q[k];
+      MSQ(3, tid) = cxy.x;
+      MSQ(4, tid) = cxy.y;
+      if (hid >= 0) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) MSQ(k, TILE + tid) = hq[k];
+        MSQ(3, TILE + tid) = hcxy.x;
+        MSQ(4, TILE + tid) = hcxy.y;
+      }
+      for (int j = tid + TILE; j < nh + nc2; j += TILE) {  // only numberings with poor locality get here
+        const int hc = (j < nh) ? a.hcells[td.h_off + j] : g.hcells2[c0 + j - nh];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) MSQ(k, TILE + j) = u[3 * (int64_t)hc + k];
+        MSQ(3, TILE + j) = g.cxy[2 * (int64_t)hc];
+        MSQ(4, TILE + j) = g.cxy[2 * (int64_t)hc + 1];
+      }
+      if (tid < ne) slr[tid] = lr0;
+      if (tid + TILE < ne) slr[tid + TILE] = lr1;
+      for (int e = tid + 2 * TILE; e < ne; e += TILE) slr[e] = a.e_lr[td.e_off + e];
+      if (STAGE3 && tid + 2 * TILE < ne) {
+        e3[tid]               = cs3;
+        e3[LAY::n3 + tid]     = md3.x;
+        e3[2 * LAY::n3 + tid] = md3.y;
+      }
+      __syncthreads();
+
+      // ---- phase G: least-squares gradients of own and first-ring cells -> LDS
+      {
+        double gr[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        if (active) {
           int nb[S];
 #pragma unroll
-          for (int s = 0; s < S; ++s) nb[s] = (ix[s] == BN_NONE) ? -1 : (int)ix[s];
-          lds_gradient(TILE + j, nb, hg);
+          for (int s = 0; s < S; ++s) {
+            nb[s]         = -1;
+            const int ref = slot_edge<S>(r0, r1, s);
+            if (ref < 0) continue;
+            const uint32_t lr = slr[ref];
+            if (lr & EDGE_BOUNDARY) continue;
+            const int jl = lr & EDGE_SLOT_MASK, jr = (lr >> EDGE_R_SHIFT) & EDGE_SLOT_MASK;
+            nb[s]        = (jl == tid) ? jr : jl;
+          }
+          lds_gradient(tid, nb, gr);
         }
 #pragma unroll
-        for (int k = 0; k < 6; ++k) MSG(k, TILE + j) = hg[k];
+        for (int k = 0; k < 6; ++k) MSG(k, tid) = gr[k];
+        auto ring_gradient = [&](int j, uint2 w) {
+          const uint32_t ix[4] = {w.x & 0xFFFFu, w.x >> 16, w.y & 0xFFFFu, w.y >> 16};
+          double         hg[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+          if (ix[0] == BN_GLOBAL) {  // a ghost cell: its gradient was computed by its owner
+            const int hc = a.hcells[td.h_off + j];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) hg[k] = g.grad[6 * (int64_t)hc + k];
+          } else {
+            int nb[S];
+#pragma unroll
+            for (int s = 0; s < S; ++s) nb[s] = (ix[s] == BN_NONE) ? -1 : (int)ix[s];
+            lds_gradient(TILE + j, nb, hg);
+          }
+#pragma unroll
+          for (int k = 0; k < 6; ++k) MSG(k, TILE + j) = hg[k];
+        };
+        if (tid < nh) ring_gradient(tid, bw);
+        for (int j = tid + TILE; j < nh; j += TILE)  // poor locality only
+          ring_gradient(j, reinterpret_cast<const uint2 *>(g.bn_idx)[(int64_t)td.h_off + j]);
+      }
+      __syncthreads();
+
+      // ---- phase 1: every edge of the tile once
+      auto do_edge = [&](uint32_t lr, double cs, double2 mid) -> EdgeFlux {
+        return muscl_edge<LIM, LAY>(a, td, dt, lr, cs, mid, sq, sg);
       };
-      if (tid < nh) ring_gradient(tid, bw);
-      for (int j = tid + TILE; j < nh; j += TILE)  // poor locality only
-        ring_gradient(j, reinterpret_cast<const uint2 *>(g.bn_idx)[(int64_t)td.h_off + j]);
-    }
-    __syncthreads();
-
-    // ---- phase 1: every edge of the tile once
-    auto do_edge = [&](uint32_t lr, double cs, double2 mid) -> EdgeFlux {
-      return muscl_edge<LIM, LAY>(a, td, dt, lr, cs, mid, sq, sg);
-    };
-    // the two register-resident rounds one after the other (no per-value selects between the rounds' registers); the
-    // scheduling barrier keeps the compiler from interleaving them, which would double the live registers
-    EdgeFlux x0 = {0.0, 0.0, 0.0, -1.0}, x1 = x0;
-    if (tid < ne) x0 = do_edge(lr0, cs0, md0);
-    if (!EFO && tid < ne) store_edge_flux<LAY>(a, ef, tid, x0);
-    __builtin_amdgcn_sched_barrier(0);
-    if (tid + TILE < ne) x1 = do_edge(lr1, cs1, md1);
-    if (!EFO && tid + TILE < ne) store_edge_flux<LAY>(a, ef, tid + TILE, x1);
-    EdgeFlux x2 = {0.0, 0.0, 0.0, -1.0};
-    if (!EFO) {
-      for (int e = tid + 2 * TILE; e < ne; e += TILE)  // not slr: the fluxes overwrite it
-        store_edge_flux<LAY>(a, ef, e, do_edge(a.e_lr[td.e_off + e], a.e_cs[td.e_off + e], *reinterpret_cast<const double2 *>(g.e_mid + 2 * ((int64_t)td.e_off + e))));
-    } else if (S == 4) {
-      // quads: a 16 x 16 block has 544 edge records; the third round loads its records here (EFO: emax <= 3 TILE)
+      // the two register-resident rounds one after the other (no per-value selects between the rounds' registers); the
+      // scheduling barrier keeps the compiler from interleaving them, which would double the live registers
+      EdgeFlux x0 = {0.0, 0.0, 0.0, -1.0}, x1 = x0;
+      if (tid < ne) x0 = do_edge(lr0, cs0, md0);
+      if (!EFO && tid < ne) store_edge_flux<LAY>(a, ef, tid, x0);
       __builtin_amdgcn_sched_barrier(0);
-      const int e = tid + 2 * TILE;
-      if (STAGE3) {
-        if (e < ne) x2 = do_edge(slr[e], e3[tid], make_double2(e3[LAY::n3 + tid], e3[2 * LAY::n3 + tid]));
-      } else {
-        if (e < ne) x2 = do_edge(a.e_lr[td.e_off + e], a.e_cs[td.e_off + e], *reinterpret_cast<const double2 *>(g.e_mid + 2 * ((int64_t)td.e_off + e)));
-      }
-    }
-#ifndef RDYHIP_MUSCL_EARLY_STREAMS
-    // the per-cell streams of phase 2 are requested only here: held from the tile's top they would cost 18 registers
-    // through the edge phase (129 instead of 111 VGPRs, three waves per SIMD instead of four); the barriers and the
-    // flux stores below cover most of their latency, the other resident workgroups the rest
-    if (active) {
-#pragma unroll
-      for (int s = 0; s < S; ++s) kf[s] = RDY_MLD(&a.coef[s * a.stride + o]);
-      dzx  = RDY_MLD(&a.dzdx[o]);
-      dzy  = RDY_MLD(&a.dzdy[o]);
-      nman = RDY_MLD(&a.mannings[o]);
-      s0   = RDY_MLD(&a.extsrc[3 * (int64_t)o + 0]);
-      s1   = RDY_MLD(&a.extsrc[3 * (int64_t)o + 1]);
-      s2   = RDY_MLD(&a.extsrc[3 * (int64_t)o + 2]);
-    }
-#endif
-    if (EFO) {
-      __syncthreads();  // every edge has read its gradients: the fluxes may overwrite them
-      if (tid < ne) store_edge_flux<LAY>(a, ef, tid, x0);
-      if (tid + TILE < ne) store_edge_flux<LAY>(a, ef, tid + TILE, x1);
-      if (S == 4 && tid + 2 * TILE < ne) store_edge_flux<LAY>(a, ef, tid + 2 * TILE, x2);
-    }
-    __syncthreads();
-
-    // ---- phase 2: per-cell sum in the reference's edge order, source terms, stores
-    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, res[3] = {0.0, 0.0, 0.0}, pu = 0.0, pv_ = 0.0;
-    const double h = MSQ(0, tid), hu = MSQ(1, tid), hv = MSQ(2, tid);
-    if (active) {
-      if (!OVW) {
-        acc0 = f[3 * (int64_t)o + 0];
-        acc1 = f[3 * (int64_t)o + 1];
-        acc2 = f[3 * (int64_t)o + 2];
-      }
-      muscl_cell_sum<S, LAY>(a, r0, r1, kf, ef, dt, o, acc0, acc1, acc2, best, best_slot, best_o);
-      const RiemannSide self = riemann_side(h, hu, hv, a.tiny_h, a.h_anuga_sq);
-      pu                     = self.u;
-      pv_                    = self.v;
-      cell_results<SRC>(a, dt, h, hu, hv, acc0, acc1, acc2, dzx, dzy, nman, s0, s1, s2, res);
-    }
-    {  // whole-line stores of the [cell][3] rows (wave_store_rows3, swe_kernels.h); all 64 lanes take part
-      const int     lane  = tid & 63;
-      const int64_t base  = 3 * ((int64_t)o - lane);
-      const int     ncell = a.n_owned - (o - lane);
-      if (a.fdiv) wave_store_rows3(a.fdiv, base, lane, ncell, acc0, acc1, acc2);
-      if (!EULER || f) wave_store_rows3(f, base, lane, ncell, res[0], res[1], res[2]);
-      wave_store_rows3(a.pv, base, lane, ncell, h, pu, pv_);
-      if (EULER) {  // rdyhip_euler_step: the forward-Euler update rides on the stores, F only if asked for
-        const double n0 = h + dt * res[0], n1 = hu + dt * res[1], n2 = hv + dt * res[2];
-        if (!a.o2l) {
-          wave_store_rows3(a.u_out, base, lane, ncell, n0, n1, n2);
-        } else if (active) {
-          const int64_t c = a.o2l[o];
-          RDY_MST(&a.u_out[3 * c + 0], n0);
-          RDY_MST(&a.u_out[3 * c + 1], n1);
-          RDY_MST(&a.u_out[3 * c + 2], n2);
+      if (tid + TILE < ne) x1 = do_edge(lr1, cs1, md1);
+      if (!EFO && tid + TILE < ne) store_edge_flux<LAY>(a, ef, tid + TILE, x1);
+      EdgeFlux x2 = {0.0, 0.0, 0.0, -1.0};
+      if (!EFO) {
+        for (int e = tid + 2 * TILE; e < ne; e += TILE)  // not slr: the fluxes overwrite it
+          store_edge_flux<LAY>(a, ef, e, do_edge(a.e_lr[td.e_off + e], a.e_cs[td.e_off + e], *reinterpret_cast<const double2 *>(g.e_mid + 2 * ((int64_t)td.e_off + e))));
+      } else if (S == 4) {
+        // quads: a 16 x 16 block has 544 edge records; the third round loads its records here (EFO: emax <= 3 TILE)
+        __builtin_amdgcn_sched_barrier(0);
+        const int e = tid + 2 * TILE;
+        if (STAGE3) {
+          if (e < ne) x2 = do_edge(slr[e], e3[tid], make_double2(e3[LAY::n3 + tid], e3[2 * LAY::n3 + tid]));
+        } else {
+          if (e < ne) x2 = do_edge(a.e_lr[td.e_off + e], a.e_cs[td.e_off + e], *reinterpret_cast<const double2 *>(g.e_mid + 2 * ((int64_t)td.e_off + e)));
         }
       }
+#ifndef RDYHIP_MUSCL_EARLY_STREAMS
+      // the per-cell streams of phase 2 are requested only here: held from the tile's top they would cost 18 registers
+      // through the edge phase (129 instead of 111 VGPRs, three waves per SIMD instead of four); the barriers and the
+      // flux stores below cover most of their latency, the other resident workgroups the rest
+      {  // unconditional (cells past the end read the last owned cell's, unused): a branch here costs register copies of
+         // loaded values at its merge, and with them a wait for the streams right where they are requested
+        const int oc = active ? o : a.n_owned - 1;
+#pragma unroll
+        for (int s = 0; s < S; ++s) kf[s] = RDY_MLD(&a.coef[s * a.stride + oc]);
+        dzx  = RDY_MLD(&a.dzdx[oc]);
+        dzy  = RDY_MLD(&a.dzdy[oc]);
+        nman = RDY_MLD(&a.mannings[oc]);
+        s0   = RDY_MLD(&a.extsrc[3 * (int64_t)oc + 0]);
+        s1   = RDY_MLD(&a.extsrc[3 * (int64_t)oc + 1]);
+        s2   = RDY_MLD(&a.extsrc[3 * (int64_t)oc + 2]);
+      }
+#endif
+      if (EFO) {
+        __syncthreads();  // every edge has read its gradients: the fluxes may overwrite them
+        if (tid < ne) store_edge_flux<LAY>(a, ef, tid, x0);
+        if (tid + TILE < ne) store_edge_flux<LAY>(a, ef, tid + TILE, x1);
+        if (S == 4 && tid + 2 * TILE < ne) store_edge_flux<LAY>(a, ef, tid + 2 * TILE, x2);
+      }
+      __syncthreads();
+
+      // ---- phase 2: per-cell sum in the reference's edge order, source terms, stores
+      RDY_STREAMS_ARRIVE();
+      double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, res[3] = {0.0, 0.0, 0.0}, pu = 0.0, pv_ = 0.0;
+      const double h = MSQ(0, tid), hu = MSQ(1, tid), hv = MSQ(2, tid);
+      if (active) {
+        if (!OVW) {
+          acc0 = f[3 * (int64_t)o + 0];
+          acc1 = f[3 * (int64_t)o + 1];
+          acc2 = f[3 * (int64_t)o + 2];
+        }
+        muscl_cell_sum<S, LAY>(a, r0, r1, kf, ef, dt, o, acc0, acc1, acc2, best, best_slot, best_o);
+        const RiemannSide self = riemann_side(h, hu, hv, a.tiny_h, a.h_anuga_sq);
+        pu                     = self.u;
+        pv_                    = self.v;
+        cell_results<SRC>(a, dt, h, hu, hv, acc0, acc1, acc2, dzx, dzy, nman, s0, s1, s2, res);
+      }
+      {  // whole-line stores of the [cell][3] rows (wave_store_rows3, swe_kernels.h); all 64 lanes take part
+        const int     lane  = tid & 63;
+        const int64_t base  = 3 * ((int64_t)o - lane);
+        const int     ncell = a.n_owned - (o - lane);
+        if (a.fdiv) wave_store_rows3(a.fdiv, base, lane, ncell, acc0, acc1, acc2);
+        if (!EULER || f) wave_store_rows3(f, base, lane, ncell, res[0], res[1], res[2]);
+        wave_store_rows3(a.pv, base, lane, ncell, h, pu, pv_);
+        if (EULER) {  // rdyhip_euler_step: the forward-Euler update rides on the stores, F only if asked for
+          const double n0 = h + dt * res[0], n1 = hu + dt * res[1], n2 = hv + dt * res[2];
+          if (!a.o2l) {
+            wave_store_rows3(a.u_out, base, lane, ncell, n0, n1, n2);
+          } else if (active) {
+            const int64_t c = a.o2l[o];
+            RDY_MST(&a.u_out[3 * c + 0], n0);
+            RDY_MST(&a.u_out[3 * c + 1], n1);
+            RDY_MST(&a.u_out[3 * c + 2], n2);
+          }
+        }
+      }
+      __syncthreads();  // the LDS records are rewritten by the next tile (dropping this barrier where the layout allows it gains nothing)
     }
-    __syncthreads();  // the LDS records are rewritten by the next tile (dropping this barrier where the layout allows it gains nothing)
+
   }
   block_courant_reduce<TILE>(a, best, best_slot, best_o);
 }
