@@ -443,7 +443,10 @@ __global__ __launch_bounds__(TILE) void swe_rhs_muscl_kernel(const KernelArgs a,
 // gradient array's write + read, the second read of the state and the streamed
 // least-squares coefficients / displacements.  First-ring cells that are ghosts
 // take their gradient from `grad`, filled by the caller's exchange (their
-// stencil is not local).
+// stencil is not local).  Two tile loops share the phases: triangles run four
+// workgroups per CU with each tile's loads in one batch at its top; quads and
+// mixed meshes three workgroups with the next tile's loads in flight while
+// this one is computed (profiles/r03_ab_muscl_pipeline.txt).
 // ---------------------------------------------------------------------------
 // The per-cell streams become visible to phase 2 HERE and on every path: without this hipcc hoists their first uses (a
 // multiply by a constant) into the block that requests them -- the wave then waits for them before the barriers that were
@@ -850,6 +853,8 @@ __global__ __launch_bounds__(TILE) RDY_MUSCL_OCC void swe_rhs_muscl_fused_kernel
     }
 
   } else {
+    // Triangles: four workgroups per CU (107 VGPRs), a tile's loads in ONE batch at its top; only the ring-cell id runs a
+    // tile ahead.
     int    pre_tile = -1, pre_hid = -1;  // ring-cell id fetched one tile ahead (breaks the id -> state load chain)
 
     for (; idx < hi; idx += step) {
@@ -864,10 +869,15 @@ __global__ __launch_bounds__(TILE) RDY_MUSCL_OCC void swe_rhs_muscl_fused_kernel
       // ---- the tile's load batch: everything the four phases read from global memory that does not depend on LDS.
       // hipcc waits with vmcnt(0) at the first use, so one batch = one exposed latency per tile.
       __builtin_amdgcn_s_setprio(3);  // a wave that has reached its load batch issues it ahead of the waves that are computing (-0.7 %)
-      const int hid = (pre_tile == tile) ? pre_hid : ring_id(td, nh, c0, nc2);
+      int hid = pre_hid;
+      if (pre_tile != tile) {  // a workgroup's first tile (or one after a skipped tile): the id was not fetched ahead.  Waited for INSIDE
+        hid = ring_id(td, nh, c0, nc2);  // the branch -- at the merge hipcc would wait with vmcnt(0) in every tile, between the own
+        asm volatile("" ::"v"(hid));     // cell's loads and the rest of the batch
+      }
       double    q[3] = {0.0, 0.0, 0.0}, hq[3] = {0.0, 0.0, 0.0};
       double2   cxy = make_double2(0.0, 0.0), hcxy = make_double2(0.0, 0.0);
-      uint32_t  r0 = 0xFFFFFFFFu, r1 = 0xFFFFFFFFu;
+      uint32_t  r0 = 0xFFFFFFFFu;
+      const uint32_t r1 = 0xFFFFFFFFu;  // triangles: three 10-bit slot references in r0
       double    kf[S];
       double    dzx = 0.0, dzy = 0.0, nman = 0.0, s0 = 0.0, s1 = 0.0, s2 = 0.0;
 #pragma unroll
@@ -877,23 +887,7 @@ __global__ __launch_bounds__(TILE) RDY_MUSCL_OCC void swe_rhs_muscl_fused_kernel
 #pragma unroll
         for (int k = 0; k < 3; ++k) q[k] = u[3 * (int64_t)c + k];
         cxy = *reinterpret_cast<const double2 *>(g.cxy + 2 * (int64_t)c);
-        if (S == 3) {
-          r0 = RDY_MLD(&reinterpret_cast<const uint32_t *>(a.slot_ref)[o]);
-        } else {
-          const uint2 w = reinterpret_cast<const uint2 *>(a.slot_ref)[o];
-          r0            = w.x;
-          r1            = w.y;
-        }
-#ifdef RDYHIP_MUSCL_EARLY_STREAMS
-#pragma unroll
-        for (int s = 0; s < S; ++s) kf[s] = RDY_MLD(&a.coef[s * a.stride + o]);
-        dzx  = RDY_MLD(&a.dzdx[o]);
-        dzy  = RDY_MLD(&a.dzdy[o]);
-        nman = RDY_MLD(&a.mannings[o]);
-        s0   = RDY_MLD(&a.extsrc[3 * (int64_t)o + 0]);
-        s1   = RDY_MLD(&a.extsrc[3 * (int64_t)o + 1]);
-        s2   = RDY_MLD(&a.extsrc[3 * (int64_t)o + 2]);
-#endif
+        r0 = RDY_MLD(&reinterpret_cast<const uint32_t *>(a.slot_ref)[o]);
       }
       if (hid >= 0) {
 #pragma unroll
@@ -903,12 +897,8 @@ __global__ __launch_bounds__(TILE) RDY_MUSCL_OCC void swe_rhs_muscl_fused_kernel
       uint2 bw = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);  // first-ring stencil of ring cell j = tid: the LDS slots of its neighbours
       if (tid < nh) bw = load_u2(g.bn_idx + 4 * ((int64_t)td.h_off + tid));
       uint32_t lr0 = 0, lr1 = 0;
-      double   cs0 = 0.0, cs1 = 0.0, cs3 = 0.0;
-      double2  md0 = make_double2(0.0, 0.0), md1 = md0, md3 = md0;
-      if (STAGE3 && tid + 2 * TILE < ne) {  // third round: staged through LDS (no global load inside the edge phase)
-        cs3 = RDY_MLD(&a.e_cs[td.e_off + 2 * TILE + tid]);
-        md3 = load_d2(g.e_mid + 2 * ((int64_t)td.e_off + 2 * TILE + tid));
-      }
+      double   cs0 = 0.0, cs1 = 0.0;
+      double2  md0 = make_double2(0.0, 0.0), md1 = md0;
       if (tid < ne) {
         lr0 = RDY_MLD(&a.e_lr[td.e_off + tid]);
         cs0 = RDY_MLD(&a.e_cs[td.e_off + tid]);
@@ -950,11 +940,6 @@ __global__ __launch_bounds__(TILE) RDY_MUSCL_OCC void swe_rhs_muscl_fused_kernel
       if (tid < ne) slr[tid] = lr0;
       if (tid + TILE < ne) slr[tid + TILE] = lr1;
       for (int e = tid + 2 * TILE; e < ne; e += TILE) slr[e] = a.e_lr[td.e_off + e];
-      if (STAGE3 && tid + 2 * TILE < ne) {
-        e3[tid]               = cs3;
-        e3[LAY::n3 + tid]     = md3.x;
-        e3[2 * LAY::n3 + tid] = md3.y;
-      }
       __syncthreads();
 
       // ---- phase G: least-squares gradients of own and first-ring cells -> LDS
@@ -1004,32 +989,9 @@ __global__ __launch_bounds__(TILE) RDY_MUSCL_OCC void swe_rhs_muscl_fused_kernel
       };
       // the two register-resident rounds one after the other (no per-value selects between the rounds' registers); the
       // scheduling barrier keeps the compiler from interleaving them, which would double the live registers
-      EdgeFlux x0 = {0.0, 0.0, 0.0, -1.0}, x1 = x0;
-      if (tid < ne) x0 = do_edge(lr0, cs0, md0);
-      if (!EFO && tid < ne) store_edge_flux<LAY>(a, ef, tid, x0);
-      __builtin_amdgcn_sched_barrier(0);
-      if (tid + TILE < ne) x1 = do_edge(lr1, cs1, md1);
-      if (!EFO && tid + TILE < ne) store_edge_flux<LAY>(a, ef, tid + TILE, x1);
-      EdgeFlux x2 = {0.0, 0.0, 0.0, -1.0};
-      if (!EFO) {
-        for (int e = tid + 2 * TILE; e < ne; e += TILE)  // not slr: the fluxes overwrite it
-          store_edge_flux<LAY>(a, ef, e, do_edge(a.e_lr[td.e_off + e], a.e_cs[td.e_off + e], *reinterpret_cast<const double2 *>(g.e_mid + 2 * ((int64_t)td.e_off + e))));
-      } else if (S == 4) {
-        // quads: a 16 x 16 block has 544 edge records; the third round loads its records here (EFO: emax <= 3 TILE)
-        __builtin_amdgcn_sched_barrier(0);
-        const int e = tid + 2 * TILE;
-        if (STAGE3) {
-          if (e < ne) x2 = do_edge(slr[e], e3[tid], make_double2(e3[LAY::n3 + tid], e3[2 * LAY::n3 + tid]));
-        } else {
-          if (e < ne) x2 = do_edge(a.e_lr[td.e_off + e], a.e_cs[td.e_off + e], *reinterpret_cast<const double2 *>(g.e_mid + 2 * ((int64_t)td.e_off + e)));
-        }
-      }
-#ifndef RDYHIP_MUSCL_EARLY_STREAMS
-      // the per-cell streams of phase 2 are requested only here: held from the tile's top they would cost 18 registers
-      // through the edge phase (129 instead of 111 VGPRs, three waves per SIMD instead of four); the barriers and the
-      // flux stores below cover most of their latency, the other resident workgroups the rest
-      {  // unconditional (cells past the end read the last owned cell's, unused): a branch here costs register copies of
-         // loaded values at its merge, and with them a wait for the streams right where they are requested
+      auto request_streams = [&]() {
+        // unconditional (cells past the end read the last owned cell's, unused): a branch here costs register copies of
+        // loaded values at its merge, and with them a wait for the streams right where they are requested
         const int oc = active ? o : a.n_owned - 1;
 #pragma unroll
         for (int s = 0; s < S; ++s) kf[s] = RDY_MLD(&a.coef[s * a.stride + oc]);
@@ -1039,18 +1001,32 @@ __global__ __launch_bounds__(TILE) RDY_MUSCL_OCC void swe_rhs_muscl_fused_kernel
         s0   = RDY_MLD(&a.extsrc[3 * (int64_t)oc + 0]);
         s1   = RDY_MLD(&a.extsrc[3 * (int64_t)oc + 1]);
         s2   = RDY_MLD(&a.extsrc[3 * (int64_t)oc + 2]);
+      };
+      EdgeFlux x0 = {0.0, 0.0, 0.0, -1.0}, x1 = x0;
+      if (tid < ne) x0 = do_edge(lr0, cs0, md0);
+      if (!EFO && tid < ne) store_edge_flux<LAY>(a, ef, tid, x0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (tid + TILE < ne) x1 = do_edge(lr1, cs1, md1);
+      if (!EFO && tid + TILE < ne) store_edge_flux<LAY>(a, ef, tid + TILE, x1);
+      if (!EFO) {
+        for (int e = tid + 2 * TILE; e < ne; e += TILE)  // not slr: the fluxes overwrite it
+          store_edge_flux<LAY>(a, ef, e, do_edge(a.e_lr[td.e_off + e], a.e_cs[td.e_off + e], *reinterpret_cast<const double2 *>(g.e_mid + 2 * ((int64_t)td.e_off + e))));
       }
-#endif
+      // the per-cell streams of phase 2 are requested only here: held from the tile's top they would cost 18 registers
+      // through the edge phase; the barriers and the flux stores below cover part of their latency, the other resident
+      // workgroups the rest (requested between the two edge rounds instead: 123 VGPRs, no gain --
+      // profiles/r03_ab_muscl_mid_streams.txt)
+      request_streams();
       if (EFO) {
         __syncthreads();  // every edge has read its gradients: the fluxes may overwrite them
         if (tid < ne) store_edge_flux<LAY>(a, ef, tid, x0);
         if (tid + TILE < ne) store_edge_flux<LAY>(a, ef, tid + TILE, x1);
-        if (S == 4 && tid + 2 * TILE < ne) store_edge_flux<LAY>(a, ef, tid + 2 * TILE, x2);
       }
       __syncthreads();
 
       // ---- phase 2: per-cell sum in the reference's edge order, source terms, stores
       RDY_STREAMS_ARRIVE();
+      asm volatile("" ::"v"(pre_hid));  // and the id fetched ahead is never "pending" at the loop header
       double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, res[3] = {0.0, 0.0, 0.0}, pu = 0.0, pv_ = 0.0;
       const double h = MSQ(0, tid), hu = MSQ(1, tid), hv = MSQ(2, tid);
       if (active) {
