@@ -853,71 +853,100 @@ __global__ __launch_bounds__(TILE) RDY_MUSCL_OCC void swe_rhs_muscl_fused_kernel
     }
 
   } else {
-    // Triangles: four workgroups per CU (107 VGPRs), a tile's loads in ONE batch at its top; only the ring-cell id runs a
-    // tile ahead.
-    int    pre_tile = -1, pre_hid = -1;  // ring-cell id fetched one tile ahead (breaks the id -> state load chain)
-
-    for (; idx < hi; idx += step) {
+    // Triangles: four workgroups per CU.  A tile's loads are ONE batch at its top -- except the CELLS group (state + centroid
+    // of the own cell and of this thread's ring cell), which for tile T+1 is requested right after phase 0's barrier of tile T,
+    // into the registers phase 0 has just emptied: 127 VGPRs instead of 107, still four waves, and every workgroup has
+    // requests in flight while it computes (-1.2 % on C3, -2.6 % on the refined Houston mesh: profiles/
+    // r03_ab_muscl_tri_prefetch.txt).  The XQ2018 source variant needs four registers more (131: it would lose the fourth
+    // workgroup) and requests its cells group with the rest of the batch.  The ids the group depends on (ring cell, own
+    // cell) run one tile further ahead.  Every rule of the quads' pipeline above applies to the loads in flight across phases.
+    constexpr bool PF = (SRC == 0) && LAY::fixed;  // the record layout (meshes without locality) would lose the fourth wave too: 130 - 137 VGPRs
+    auto next_valid = [&](int i) -> int {
+      if (a.phase == RDYHIP_PHASE_INTERIOR) {
+        while (i < hi && tile_desc(tile_at(i)).halo()) i += step;
+      }
+      return i;
+    };
+    double  q[3] = {0.0, 0.0, 0.0}, hq[3] = {0.0, 0.0, 0.0};  // their first use is a plain LDS store: nothing to fold into the loading block
+    double2 cxy = make_double2(0.0, 0.0), hcxy = make_double2(0.0, 0.0);
+    auto tile_ids = [&](int i, int &c_, int &hid_) {
+      const int      t_  = tile_at(i);
+      const TileDesc d_  = tile_desc(t_);
+      const int      c0_ = load_uniform(g.c_off, t_);
+      hid_               = ring_id(d_, d_.nh(), c0_, load_uniform(g.c_off, t_ + 1) - c0_);
+      const int o_       = t_ * TILE + tid;
+      c_                 = (a.o2l && o_ < a.n_owned) ? a.o2l[o_] : o_;
+    };
+    auto issue_cells = [&](int t_, int c_, int hid_) {
+      const int o_ = t_ * TILE + tid;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) q[k] = 0.0;
+      cxy = make_double2(0.0, 0.0);
+      int nown = a.n_owned;
+      asm volatile("" : "+s"(nown));
+      if (o_ < nown) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) q[k] = u[3 * (int64_t)c_ + k];
+        cxy = *reinterpret_cast<const double2 *>(g.cxy + 2 * (int64_t)c_);
+      }
+      if (hid_ >= 0) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) hq[k] = u[3 * (int64_t)hid_ + k];
+        hcxy = *reinterpret_cast<const double2 *>(g.cxy + 2 * (int64_t)hid_);
+      }
+    };
+    idx = next_valid(idx);
+    int idx1 = hi, c1 = 0, hid1 = -1;
+    if (idx < hi) {  // c1 / hid1: the ids of the tile whose cells group is requested next (PF: the next tile's, else this one's)
+      tile_ids(idx, c1, hid1);
+      asm volatile("" ::"v"(hid1), "v"(c1));
+      idx1 = next_valid(idx + step);
+      if (PF) {
+        issue_cells(tile_at(idx), c1, hid1);
+        c1   = 0;
+        hid1 = -1;
+        if (idx1 < hi) tile_ids(idx1, c1, hid1);
+        asm volatile("" ::"v"(hid1), "v"(c1));
+      }
+    }
+    while (idx < hi) {
       const int      tile = tile_at(idx);
       const TileDesc td = tile_desc(tile);
-      if (a.phase == RDYHIP_PHASE_INTERIOR && td.halo()) continue;  // wave-uniform
       const int  ne = td.ne(), nh = td.nh();
       const int  c0 = load_uniform(g.c_off, tile), nc2 = load_uniform(g.c_off, tile + 1) - c0;
       const int  o      = tile * TILE + tid;
       const bool active = o < a.n_owned;
+      const int  hid    = (tid < nh + nc2) ? 0 : -1;  // does this thread stage a ring cell
+      int idx2 = hi, c2 = 0, hid2 = -1;
 
-      // ---- the tile's load batch: everything the four phases read from global memory that does not depend on LDS.
-      // hipcc waits with vmcnt(0) at the first use, so one batch = one exposed latency per tile.
-      __builtin_amdgcn_s_setprio(3);  // a wave that has reached its load batch issues it ahead of the waves that are computing (-0.7 %)
-      int hid = pre_hid;
-      if (pre_tile != tile) {  // a workgroup's first tile (or one after a skipped tile): the id was not fetched ahead.  Waited for INSIDE
-        hid = ring_id(td, nh, c0, nc2);  // the branch -- at the merge hipcc would wait with vmcnt(0) in every tile, between the own
-        asm volatile("" ::"v"(hid));     // cell's loads and the rest of the batch
+      __builtin_amdgcn_s_setprio(3);
+      if (!PF) {
+        issue_cells(tile, c1, hid1);
+        if (idx1 < hi) {
+          tile_ids(idx1, c2, hid2);
+          idx2 = next_valid(idx1 + step);
+        }
       }
-      double    q[3] = {0.0, 0.0, 0.0}, hq[3] = {0.0, 0.0, 0.0};
-      double2   cxy = make_double2(0.0, 0.0), hcxy = make_double2(0.0, 0.0);
       uint32_t  r0 = 0xFFFFFFFFu;
-      const uint32_t r1 = 0xFFFFFFFFu;  // triangles: three 10-bit slot references in r0
+      const uint32_t r1 = 0xFFFFFFFFu;
       double    kf[S];
       double    dzx = 0.0, dzy = 0.0, nman = 0.0, s0 = 0.0, s1 = 0.0, s2 = 0.0;
 #pragma unroll
       for (int s = 0; s < S; ++s) kf[s] = 0.0;
-      if (active) {
-        const int c = a.o2l ? a.o2l[o] : o;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) q[k] = u[3 * (int64_t)c + k];
-        cxy = *reinterpret_cast<const double2 *>(g.cxy + 2 * (int64_t)c);
-        r0 = RDY_MLD(&reinterpret_cast<const uint32_t *>(a.slot_ref)[o]);
-      }
-      if (hid >= 0) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) hq[k] = u[3 * (int64_t)hid + k];
-        hcxy = *reinterpret_cast<const double2 *>(g.cxy + 2 * (int64_t)hid);
-      }
-      uint2 bw = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);  // first-ring stencil of ring cell j = tid: the LDS slots of its neighbours
+      // unconditional loads with clamped indices (a tile has edges; lanes past the end read the last record, unused): a
+      // lane-conditional load costs register copies of the loaded value at its merge -- and a wait in the middle of the batch
+      r0 = RDY_MLD(&reinterpret_cast<const uint32_t *>(a.slot_ref)[active ? o : a.n_owned - 1]);
+      uint32_t ones = 0xFFFFFFFFu;
+      asm volatile("" : "+v"(ones));
+      uint2 bw = make_uint2(ones, ones);
       if (tid < nh) bw = load_u2(g.bn_idx + 4 * ((int64_t)td.h_off + tid));
-      uint32_t lr0 = 0, lr1 = 0;
-      double   cs0 = 0.0, cs1 = 0.0;
-      double2  md0 = make_double2(0.0, 0.0), md1 = md0;
-      if (tid < ne) {
-        lr0 = RDY_MLD(&a.e_lr[td.e_off + tid]);
-        cs0 = RDY_MLD(&a.e_cs[td.e_off + tid]);
-        md0 = load_d2(g.e_mid + 2 * ((int64_t)td.e_off + tid));
-      }
-      if (tid + TILE < ne) {
-        lr1 = RDY_MLD(&a.e_lr[td.e_off + TILE + tid]);
-        cs1 = RDY_MLD(&a.e_cs[td.e_off + TILE + tid]);
-        md1 = load_d2(g.e_mid + 2 * ((int64_t)td.e_off + TILE + tid));
-      }
-      // the ring-cell id of the tile this workgroup takes next
-      pre_tile = -1;
-      if (idx + step < hi) {
-        pre_tile            = tile_at(idx + step);
-        const TileDesc pd  = tile_desc(pre_tile);
-        const int      pc0 = load_uniform(g.c_off, pre_tile);
-        pre_hid            = ring_id(pd, pd.nh(), pc0, load_uniform(g.c_off, pre_tile + 1) - pc0);
-      }
-
+      const int      e0 = td.e_off + min(tid, ne - 1), e1 = td.e_off + min(tid + TILE, ne - 1);
+      const uint32_t lr0 = RDY_MLD(&a.e_lr[e0]);
+      const double   cs0 = RDY_MLD(&a.e_cs[e0]);
+      const double2  md0 = load_d2(g.e_mid + 2 * (int64_t)e0);
+      const uint32_t lr1 = RDY_MLD(&a.e_lr[e1]);
+      const double   cs1 = RDY_MLD(&a.e_cs[e1]);
+      const double2  md1 = load_d2(g.e_mid + 2 * (int64_t)e1);
       __builtin_amdgcn_s_setprio(0);
       // ---- phase 0: state + centroid of own cells, first ring, second ring; the tile's edge records -> LDS
 #pragma unroll
@@ -940,7 +969,17 @@ __global__ __launch_bounds__(TILE) RDY_MUSCL_OCC void swe_rhs_muscl_fused_kernel
       if (tid < ne) slr[tid] = lr0;
       if (tid + TILE < ne) slr[tid + TILE] = lr1;
       for (int e = tid + 2 * TILE; e < ne; e += TILE) slr[e] = a.e_lr[td.e_off + e];
+      // the top batch has arrived on EVERY path before the next tile's cells are requested (the waits above sit inside
+      // lane-conditional branches; a register still "pending" on a skipped path costs a vmcnt(0) at its next use)
+      asm volatile("" ::"v"(r0), "v"(bw.x), "v"(bw.y), "v"(lr0), "v"(lr1), "v"(cs0), "v"(cs1), "v"(md0.x), "v"(md0.y), "v"(md1.x), "v"(md1.y));
       __syncthreads();
+      if (PF && idx1 < hi) {
+        __builtin_amdgcn_s_setprio(3);
+        idx2 = next_valid(idx1 + step);
+        if (idx2 < hi) tile_ids(idx2, c2, hid2);
+        issue_cells(tile_at(idx1), c1, hid1);
+        __builtin_amdgcn_s_setprio(0);
+      }
 
       // ---- phase G: least-squares gradients of own and first-ring cells -> LDS
       {
@@ -968,6 +1007,7 @@ __global__ __launch_bounds__(TILE) RDY_MUSCL_OCC void swe_rhs_muscl_fused_kernel
             const int hc = a.hcells[td.h_off + j];
 #pragma unroll
             for (int k = 0; k < 6; ++k) hg[k] = g.grad[6 * (int64_t)hc + k];
+            asm volatile("" ::"v"(hg[0]), "v"(hg[1]), "v"(hg[2]), "v"(hg[3]), "v"(hg[4]), "v"(hg[5]));  // waited for inside the branch, as in the quads' loop
           } else {
             int nb[S];
 #pragma unroll
@@ -1026,7 +1066,7 @@ __global__ __launch_bounds__(TILE) RDY_MUSCL_OCC void swe_rhs_muscl_fused_kernel
 
       // ---- phase 2: per-cell sum in the reference's edge order, source terms, stores
       RDY_STREAMS_ARRIVE();
-      asm volatile("" ::"v"(pre_hid));  // and the id fetched ahead is never "pending" at the loop header
+      asm volatile("" ::"v"(hid2), "v"(c2));
       double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, res[3] = {0.0, 0.0, 0.0}, pu = 0.0, pv_ = 0.0;
       const double h = MSQ(0, tid), hu = MSQ(1, tid), hv = MSQ(2, tid);
       if (active) {
@@ -1060,6 +1100,10 @@ __global__ __launch_bounds__(TILE) RDY_MUSCL_OCC void swe_rhs_muscl_fused_kernel
           }
         }
       }
+      idx  = idx1;
+      idx1 = idx2;
+      c1   = c2;
+      hid1 = hid2;
       __syncthreads();  // the LDS records are rewritten by the next tile (dropping this barrier where the layout allows it gains nothing)
     }
 
