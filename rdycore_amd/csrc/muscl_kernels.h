@@ -545,7 +545,7 @@ __global__ __launch_bounds__(TILE) RDY_MUSCL_OCC void swe_rhs_muscl_fused_kernel
 
   double best      = 0.0;
   int    best_slot = -1, best_o = 0;
-  if constexpr (S == 4) {
+  if constexpr (S == 4 && LAY::fixed) {
     // Quads and mixed meshes: cross-tile software pipeline, as in the first-order kernel.  A tile's loads form three groups:
     // CELLS (state + centroid of the own cell and of this thread's ring cell, the slot references), EDGES (the first-ring
     // stencil, the edge records of the three rounds with their normal component and midpoint) and the per-cell STREAMS of
@@ -553,7 +553,9 @@ __global__ __launch_bounds__(TILE) RDY_MUSCL_OCC void swe_rhs_muscl_fused_kernel
     // ring cell, own cell -- a tile before that) and are first touched before T's stores; the streams of T after its edge
     // phase.  159 VGPRs, three workgroups per CU: 5.6 % faster than four workgroups without the pipeline on the reference's
     // dam-break quads; on triangles (147 VGPRs against 107) the fourth workgroup is worth more than the pipeline, 2 - 3 %
-    // (profiles/r03_ab_muscl_pipeline.txt), so they keep the loop below.
+    // (profiles/r03_ab_muscl_pipeline.txt), so they keep the loop below -- as do quads in the record layout (meshes numbered
+    // without locality: their third edge round loads its records inside the edge phase, which no pipeline survives, and
+    // one instantiation would need 170 VGPRs).
     // What makes it a pipeline is what is NOT between the request and the first use: (i) no global load on any path every wave
     // takes -- hipcc answers a conditional load whose result is used after the merge with s_waitcnt vmcnt(0) AT THE MERGE,
     // for every wave (the ghost gradients below wait inside their branch for that reason); (ii) no first use hoisted into
@@ -853,7 +855,7 @@ __global__ __launch_bounds__(TILE) RDY_MUSCL_OCC void swe_rhs_muscl_fused_kernel
     }
 
   } else {
-    // Triangles: four workgroups per CU.  A tile's loads are ONE batch at its top -- except the CELLS group (state + centroid
+    // Triangles (and quads in the record layout): four workgroups per CU.  A tile's loads are ONE batch at its top -- except the CELLS group (state + centroid
     // of the own cell and of this thread's ring cell), which for tile T+1 is requested right after phase 0's barrier of tile T,
     // into the registers phase 0 has just emptied: 127 VGPRs instead of 107, still four waves, and every workgroup has
     // requests in flight while it computes (-1.2 % on C3, -2.6 % on the refined Houston mesh: profiles/
@@ -927,15 +929,20 @@ __global__ __launch_bounds__(TILE) RDY_MUSCL_OCC void swe_rhs_muscl_fused_kernel
           idx2 = next_valid(idx1 + step);
         }
       }
-      uint32_t  r0 = 0xFFFFFFFFu;
-      const uint32_t r1 = 0xFFFFFFFFu;
+      uint32_t  r0 = 0xFFFFFFFFu, r1 = 0xFFFFFFFFu;  // triangles: three 10-bit slot references in r0; quads: four 16-bit ones in r0, r1
       double    kf[S];
       double    dzx = 0.0, dzy = 0.0, nman = 0.0, s0 = 0.0, s1 = 0.0, s2 = 0.0;
 #pragma unroll
       for (int s = 0; s < S; ++s) kf[s] = 0.0;
       // unconditional loads with clamped indices (a tile has edges; lanes past the end read the last record, unused): a
       // lane-conditional load costs register copies of the loaded value at its merge -- and a wait in the middle of the batch
-      r0 = RDY_MLD(&reinterpret_cast<const uint32_t *>(a.slot_ref)[active ? o : a.n_owned - 1]);
+      if (S == 3) {
+        r0 = RDY_MLD(&reinterpret_cast<const uint32_t *>(a.slot_ref)[active ? o : a.n_owned - 1]);
+      } else {
+        const uint2 w = load_u2(reinterpret_cast<const uint2 *>(a.slot_ref) + (active ? o : a.n_owned - 1));
+        r0            = w.x;
+        r1            = w.y;
+      }
       uint32_t ones = 0xFFFFFFFFu;
       asm volatile("" : "+v"(ones));
       uint2 bw = make_uint2(ones, ones);
@@ -1048,9 +1055,14 @@ __global__ __launch_bounds__(TILE) RDY_MUSCL_OCC void swe_rhs_muscl_fused_kernel
       __builtin_amdgcn_sched_barrier(0);
       if (tid + TILE < ne) x1 = do_edge(lr1, cs1, md1);
       if (!EFO && tid + TILE < ne) store_edge_flux<LAY>(a, ef, tid + TILE, x1);
+      EdgeFlux x2 = {0.0, 0.0, 0.0, -1.0};
       if (!EFO) {
         for (int e = tid + 2 * TILE; e < ne; e += TILE)  // not slr: the fluxes overwrite it
           store_edge_flux<LAY>(a, ef, e, do_edge(a.e_lr[td.e_off + e], a.e_cs[td.e_off + e], *reinterpret_cast<const double2 *>(g.e_mid + 2 * ((int64_t)td.e_off + e))));
+      } else if (S == 4) {  // quads in the record layout: the third round (EFO: emax <= 3 TILE) loads its records here
+        __builtin_amdgcn_sched_barrier(0);
+        const int e = tid + 2 * TILE;
+        if (e < ne) x2 = do_edge(a.e_lr[td.e_off + e], a.e_cs[td.e_off + e], *reinterpret_cast<const double2 *>(g.e_mid + 2 * ((int64_t)td.e_off + e)));
       }
       // the per-cell streams of phase 2 are requested only here: held from the tile's top they would cost 18 registers
       // through the edge phase; the barriers and the flux stores below cover part of their latency, the other resident
@@ -1061,6 +1073,7 @@ __global__ __launch_bounds__(TILE) RDY_MUSCL_OCC void swe_rhs_muscl_fused_kernel
         __syncthreads();  // every edge has read its gradients: the fluxes may overwrite them
         if (tid < ne) store_edge_flux<LAY>(a, ef, tid, x0);
         if (tid + TILE < ne) store_edge_flux<LAY>(a, ef, tid + TILE, x1);
+        if (S == 4 && tid + 2 * TILE < ne) store_edge_flux<LAY>(a, ef, tid + 2 * TILE, x2);
       }
       __syncthreads();
 
