@@ -551,7 +551,7 @@ __global__ __launch_bounds__(TILE) RDY_MUSCL_OCC void swe_rhs_muscl_fused_kernel
     // stencil, the edge records of the three rounds with their normal component and midpoint) and the per-cell STREAMS of
     // phase 2.  Cells and edges of tile T+1 are requested right after phase 0's barrier of tile T (the ids they depend on --
     // ring cell, own cell -- a tile before that) and are first touched before T's stores; the streams of T after its edge
-    // phase.  159 VGPRs, three workgroups per CU: 5.6 % faster than four workgroups without the pipeline on the reference's
+    // phase.  160 - 165 VGPRs, three workgroups per CU: 5.6 % faster than four workgroups without the pipeline on the reference's
     // dam-break quads; on triangles (147 VGPRs against 107) the fourth workgroup is worth more than the pipeline, 2 - 3 %
     // (profiles/r03_ab_muscl_pipeline.txt), so they keep the loop below -- as do quads in the record layout (meshes numbered
     // without locality: their third edge round loads its records inside the edge phase, which no pipeline survives, and
