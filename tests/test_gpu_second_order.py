@@ -211,6 +211,23 @@ def test_full_size_parity_and_mass_balance(nx, ny):
     assert abs(lhs - rhs) <= 1e-9 * max(1.0, abs(rhs))
 
 
+def test_resident_workgroups_of_the_fused_kernels(muscl_mode):
+    """A register-count regression guard for the two tile loops of the fused kernel (csrc/muscl_kernels.h): triangles in the
+    plane layout must keep FOUR workgroups per CU (<= 128 VGPRs: the next tile's cells group in flight costs twenty), quads
+    run the cross-tile pipeline at THREE (<= 168)."""
+    if muscl_mode != "fused":
+        pytest.skip("the fused kernel's occupancy")
+    torch = _torch()
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    tri = second_order(CS.dam_break_case(M.structured_tri_mesh(64, 32, order="tiled"), 24.0))
+    quad = second_order(CS.dam_break_case(M.structured_quad_mesh(32, 64), 32.0))   # row-major, 32 wide: tiles of 32 x 8 quads fit the planes
+    for case, per_cu in ((tri, 4), (quad, 3)):
+        op = CS.create_operator(case)
+        info = op.layout_info()
+        assert info["second_order_fused"] == 1 and info["lds_fixed_layout"] == 1, info
+        assert info["persistent_grid"] == per_cu * cus, (info["persistent_grid"], per_cu, cus)
+
+
 # ---------------------------------------------------------------------------
 # edge cases: empty and ragged inputs
 # ---------------------------------------------------------------------------
