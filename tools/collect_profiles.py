@@ -20,6 +20,7 @@ ARGS = {
     "delaunay": ["--workload", "delaunay"], "self_exchange": ["--emulate-world", "3", "--emulate-rank", "1", "--self-exchange"],
     "self_exchange_so": ["--emulate-world", "3", "--emulate-rank", "1", "--self-exchange", "--second-order"],
     "houston_natural": ["--workload", "houston_refined", "--order", "natural"],
+    "houston_l7": ["--workload", "houston_refined", "--levels", "7"],
 }
 rnd = sys.argv[1]
 tags = sys.argv[2:] or list(ARGS)
