@@ -561,12 +561,25 @@ def run_rank(args, argv):
     u2 = torch.empty_like(u)
     u3 = u.clone()
 
+    # with a halo the two state arrays ping-pong as a time loop's do (dt = 0: the same work, the state stays put), so that the
+    # pack of each exchange can ride on the previous step's kernel (rdyhip_halo_fuse_pack) -- the chain a run of steps has
+    pack_fused = False
+    if halo is not None and halo._halo is not None:
+        pack_fused = halo.fuse_pack(True)
+    elif self_halo is not None:
+        pack_fused = self_halo[0].rdyhip_halo_fuse_pack(self_halo[1], 1) == 0
+    pp = [u, u2]
+    if halo is not None or self_halo is not None:
+        u2.copy_(u)
+
     def fused_step():
         if halo is not None:
-            halo.step_overlapped(op, case.dt, u, u2)
+            halo.step_overlapped(op, 0.0, pp[0], pp[1])
+            pp.reverse()
         elif self_halo is not None:
-            _lib.check(self_halo[0].rdyhip_euler_step_overlapped(op._h, self_halo[1], float(case.dt), int(u.data_ptr()), int(u2.data_ptr()), None,
+            _lib.check(self_halo[0].rdyhip_euler_step_overlapped(op._h, self_halo[1], 0.0, int(pp[0].data_ptr()), int(pp[1].data_ptr()), None,
                                                                  int(torch.cuda.current_stream().cuda_stream)))
+            pp.reverse()
         else:
             op.euler_step(case.dt, u, u2)
 
@@ -576,7 +589,11 @@ def run_rank(args, argv):
 
     ef, ep = timed(fused_step, 60), timed(pair_step, 60)
     euler = {"fused_ms_per_step": round(ef, 5), "rhs_plus_axpy_ms_per_step": round(ep, 5), "fused_steps_per_s": round(1e3 / ef, 1)}
-    del u2, u3
+    if halo is not None or self_halo is not None:
+        euler["pack_fused_into_kernel"] = bool(pack_fused)
+        if halo is not None:
+            halo.invalidate()
+    del u2, u3, pp
     step()   # leave F and the diagnostics of a plain RHS evaluation behind for the sanity checks below
 
     # sanity: the result is finite and the Courant diagnostic is alive (cross-rank struct-max, src/operator.c:705-751)
@@ -686,6 +703,9 @@ def run_rank(args, argv):
                        # 1: the exchange runs on the library's stream behind the interior tiles; 0: the in-order form of small parts
                        "halo_overlapped": ((int(_lib.load().rdyhip_halo_overlaps(halo._halo)) if halo is not None and halo._halo is not None else None)
                                            if self_halo is None else int(self_halo[0].rdyhip_halo_overlaps(self_halo[1]))),
+                       # 1: ncclRecv lands in u_local's ghost rows (ghosts numbered peer by peer in arrival order): no unpack launch
+                       "halo_direct_receive": (halo.direct_receive if halo is not None and halo._halo is not None else
+                                               (bool(self_halo[0].rdyhip_halo_direct_receive(self_halo[1])) if self_halo is not None else None)),
                        "well_balancing": "hydrostatic_reconstruction" if args.hr else "none",
                        "spatial_order": ("second (MUSCL, %s limiter)" % args.limiter) if args.second_order else "first",
                        "halo_bytes_per_rank": halo.bytes_sent_per_exchange if halo else 0,

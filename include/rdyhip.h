@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RDYHIP_VERSION 107
+#define RDYHIP_VERSION 108
 
 /* error codes = PETSc's values */
 #define RDYHIP_SUCCESS 0
@@ -81,8 +81,15 @@ typedef struct {
                             cell_centroids, edge_vertex_ids and vertex_points; not combinable with HR (src/operator.c:388-389) */
   int32_t limiter;       /* RDYHIP_LIMITER_* (config.numerics.limiter after the -no_limiter / -van_leer overrides,
                             src/swe/swe_petsc.c:357-367); read only if second_order */
-  int32_t reserved;
+  int32_t flags;         /* RDYHIP_CONFIG_* bits; 0 = defaults */
 } RDyHipConfig;
+
+/* RDyHipConfig.flags.
+ * CACHED_F_STORES: the tiled kernels store F with the default cache policy instead of the non-temporal hint.  For a host that
+ *   reads F straight back in a separate kernel -- PETSc's TSEULER: VecAXPY(U, dt, F) after every RHS (TSStep_Euler) -- the
+ *   hint costs ~6 % of the RHS + axpy pair, because F has then left the Infinity Cache (DESIGN.md section 7 note 6); a host
+ *   that takes the step through rdyhip_euler_step (F never stored) or lets F sit (RK stages summed later) leaves it clear. */
+#define RDYHIP_CONFIG_CACHED_F_STORES 1
 
 /* The RDyMesh arrays the SWE operators read (include/private/rdymeshimpl.h:26-202).
  * All host pointers, borrowed for the duration of rdyhip_create() only. */
@@ -236,6 +243,20 @@ int rdyhip_set_external_source(RDyHipOperator op, int32_t comp, int32_t n, const
  *   as used by RDySet{Regional,Domain}ManningsN (src/rdydata.c:506-539). */
 int rdyhip_set_mannings(RDyHipOperator op, int32_t n, const int32_t *owned_cell_ids, const double *values);
 
+/* The same three setters ordered on a stream instead of synchronising the device: launches enqueued on `stream` before the
+ * call see the old values, launches enqueued on it afterwards the new ones (applies running on OTHER streams are the
+ * caller's to order).  `values` / `owned_cell_ids` are host arrays and may be reused as soon as the call returns: they are
+ * copied into pinned staging memory of the operator, travel to the device on the operator's own copy stream beside whatever
+ * `stream` is executing, and only the last step -- a scatter launch or a device-to-device copy -- is ordered on `stream`.
+ * Nothing blocks and nothing drains the device: with a fixed time step RDyAdvance needs no synchronisation at all
+ * (src/rdyadvance.c:303-305), and a drained device runs its next ~40 launches 20-30 % slow (profiles/r02_launch_series.json).
+ * rdyhip_refresh_field replaces a whole input field (RDYHIP_FIELD_EXTERNAL_SOURCES [owned][3], RDYHIP_FIELD_MANNINGS [owned])
+ * from a host or a device array -- what an adapter does when a PETSc Vec of the Operator changed (src/operator.c:91-96). */
+int rdyhip_set_boundary_values_on(RDyHipOperator op, int32_t boundary, int32_t comp_offset, int32_t num_comp, int32_t num_edges,
+                                  const double *values, void *stream);
+int rdyhip_set_external_source_on(RDyHipOperator op, int32_t comp, int32_t n, const int32_t *owned_cell_ids, const double *values, void *stream);
+int rdyhip_set_mannings_on(RDyHipOperator op, int32_t n, const int32_t *owned_cell_ids, const double *values, void *stream);
+
 /* ---- forcing ingestion on the device -----------------------------------------
  * The per-step fill loops of RDyApplyForcing (src/forcing/rdyforcing.c:688-770)
  * with the dataset, the data->mesh map and the region's cell list resident in
@@ -272,6 +293,7 @@ int rdyhip_forcing_nearest_map(int32_t n, const double *d_xc, const double *d_yc
  * kernel can write the external source on the GPU, an output routine can read
  * primitive_variables (read by src/rdyadvance.c's averaging monitors). */
 int rdyhip_field_ptr(RDyHipOperator op, RDyHipField field, double **device_ptr, int64_t *num_values);
+int rdyhip_refresh_field(RDyHipOperator op, RDyHipField field, const double *values, int64_t num_values, int32_t values_on_device, void *stream);
 /* keep Operator.flux_divergence (one extra [owned][3] store per apply); off by default */
 int rdyhip_enable_flux_divergence(RDyHipOperator op, int32_t enable);
 
@@ -322,13 +344,31 @@ int rdyhip_unpack_rows(double *dst, int32_t ncomp, const int32_t *row_ids, int32
  * Small parts: when a rank has fewer interior tiles than about twelve rounds of the persistent grid (~2.4 M cells), nothing
  * is overlapped -- exchange, (gradients, their exchange,) ONE launch over all tiles, in order on `stream` -- because the
  * interior phase is then shorter than the exchange chain and the two cross-stream dependencies cost more than they hide
- * (profiles/r03_step_breakdown_360k.json, profiles/r03_overlap_threshold.txt).  rdyhip_halo_overlaps() says which form a halo uses; RDYHIP_OVERLAP=0 / 1 forces. */
+ * (profiles/r03_step_breakdown_360k.json, profiles/r03_overlap_threshold.txt).  rdyhip_halo_overlaps() says which form a halo uses; RDYHIP_OVERLAP=0 / 1 forces.
+ *
+ * Two ways to shorten the exchange chain of a small part (a 0.36 M-cell rank's kernel runs 17 us; a pack and an unpack launch
+ * cost 3.5 us each):
+ *   direct receive   when the ghost cells this rank receives are one run of consecutive local rows in arrival order -- peer
+ *                    by peer, a peer's cells in the agreed order, which is how rdyhip_local_cell_order numbers them -- the
+ *                    transfer lands in the caller's array itself (ncclRecv into u_local's ghost rows): no receive buffer, no
+ *                    unpack launch.  Detected at rdyhip_halo_create; rdyhip_halo_direct_receive() says whether it applies.
+ *   fused pack       rdyhip_halo_fuse_pack(halo, 1): the Euler-step kernels (first order and HR) also store the new state of
+ *                    the cells other ranks need into the send buffer as they store u_local_out, so that the NEXT
+ *                    rdyhip_euler_step_overlapped, called with that array as its u_local, starts with the transfer: no pack
+ *                    launch.  The promise the caller makes: between two such steps it does not write the owned rows of that
+ *                    array itself -- or calls rdyhip_halo_invalidate() if it did (a host that sets the state, a restart).  A
+ *                    step whose u_local is any other array packs as before.  One halo per operator can hold the fused pack.
+ * With both, a step of rdyhip_euler_step_overlapped is the transfer and ONE kernel launch. */
 typedef struct RDyHipHalo_s *RDyHipHalo;
 typedef int (*RDyHipTransportFn)(void *ctx, const double *d_send, double *d_recv, int32_t ncomp, void *stream);
 int rdyhip_halo_create(RDyHipOperator op, void *nccl_comm, int32_t npeers, const int32_t *peers, const int32_t *send_counts,
                        const int32_t *send_cell_ids, const int32_t *recv_counts, const int32_t *recv_cell_ids, RDyHipHalo *halo);
 int rdyhip_halo_destroy(RDyHipHalo *halo);
 int32_t rdyhip_halo_overlaps(RDyHipHalo halo);
+int32_t rdyhip_halo_direct_receive(RDyHipHalo halo);
+int rdyhip_halo_fuse_pack(RDyHipHalo halo, int32_t enable);
+int32_t rdyhip_halo_pack_fused(RDyHipHalo halo);
+int rdyhip_halo_invalidate(RDyHipHalo halo);
 int rdyhip_halo_set_transport(RDyHipHalo halo, RDyHipTransportFn fn, void *ctx);
 int rdyhip_halo_exchange(RDyHipHalo halo, double *rows, int32_t ncomp, void *stream);
 int rdyhip_rhs_overlapped(RDyHipOperator op, RDyHipHalo halo, double dt, double *u_local, double *f_global, void *stream);
@@ -368,6 +408,11 @@ int32_t rdyhip_rccl_version(void);
  *        through the centroids xy[c*stride + 0..1].  The tiles of the operator are runs of 256 consecutive owned cells, so
  *        this is the numbering a host should give its local cells before it builds RDyMesh (DMPlexPermute; DESIGN.md
  *        section 7 note 7 has the measurements: row-major -18 %, random order 3x slower than a curve order).
+ *   rdyhip_local_cell_order(..., cell_owner_rank, cell_keys, perm): the same for the owned cells; the GHOST cells are grouped by
+ *        owner rank (cell_owner_rank[c], read for ghosts only) and sorted by cell_keys[c] inside a group -- the key the plan is
+ *        given for them (a global cell id; or the owner's local id, which is known once the owners have renumbered: a second
+ *        pass over the ghosts only).  rdyhip_halo_plan_* then lists every peer's ghosts as consecutive rows in arrival order,
+ *        and rdyhip_halo_create receives in place (direct receive, above).
  *   rdyhip_copy_owned_rows(op, u_global, u_local, stream): u_local[owned cell o] = u_global[o] -- the local half of
  *        DMGlobalToLocal (device pointers; one contiguous copy when the owned cells are numbered first) */
 typedef struct RDyHipHaloPlan_s *RDyHipHaloPlan;
@@ -380,6 +425,8 @@ int rdyhip_halo_plan_get(RDyHipHaloPlan plan, int32_t *npeers, const int32_t **p
                          const int32_t **recv_counts, const int32_t **recv_cell_ids);
 int rdyhip_halo_plan_destroy(RDyHipHaloPlan *plan);
 int rdyhip_hilbert_cell_order(int32_t num_cells, const double *xy, int32_t stride, const int32_t *cell_is_owned, int32_t *perm);
+int rdyhip_local_cell_order(int32_t num_cells, const double *xy, int32_t stride, const int32_t *cell_is_owned, const int32_t *cell_owner_rank,
+                            const int64_t *cell_keys, int32_t *perm);
 int rdyhip_copy_owned_rows(RDyHipOperator op, const double *u_global, double *u_local, void *stream);
 
 /* ---- explicit update kept on the device (what TSEULER does between RHS calls)

@@ -19,7 +19,7 @@ c_int64_p = C.POINTER(C.c_int64)
 class RDyHipConfig(C.Structure):
     _fields_ = [("tiny_h", C.c_double), ("h_anuga_regular", C.c_double), ("xq2018_threshold", C.c_double),
                 ("source_method", C.c_int32), ("riemann", C.c_int32), ("well_balancing", C.c_int32), ("second_order", C.c_int32),
-                ("limiter", C.c_int32), ("reserved", C.c_int32)]
+                ("limiter", C.c_int32), ("flags", C.c_int32)]
 
 
 class RDyHipMesh(C.Structure):
@@ -68,6 +68,10 @@ SYMBOLS = {
     "rdyhip_reset_boundary_fluxes_accum": (C.c_int, [_H]),
     "rdyhip_set_external_source": (C.c_int, [_H, C.c_int32, C.c_int32, c_int32_p, c_double_p]),
     "rdyhip_set_mannings": (C.c_int, [_H, C.c_int32, c_int32_p, c_double_p]),
+    "rdyhip_set_boundary_values_on": (C.c_int, [_H, C.c_int32, C.c_int32, C.c_int32, C.c_int32, c_double_p, C.c_void_p]),
+    "rdyhip_set_external_source_on": (C.c_int, [_H, C.c_int32, C.c_int32, c_int32_p, c_double_p, C.c_void_p]),
+    "rdyhip_set_mannings_on": (C.c_int, [_H, C.c_int32, c_int32_p, c_double_p, C.c_void_p]),
+    "rdyhip_refresh_field": (C.c_int, [_H, C.c_int, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),
     "rdyhip_forcing_fill_source": (C.c_int, [_H, C.c_int32, C.c_int32, C.c_void_p, C.c_double, C.c_void_p]),
     "rdyhip_forcing_gather_source": (C.c_int, [_H, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
                                                C.c_double, C.c_void_p]),
@@ -89,6 +93,10 @@ SYMBOLS = {
     "rdyhip_halo_create": (C.c_int, [_H, C.c_void_p, C.c_int32, c_int32_p, c_int32_p, c_int32_p, c_int32_p, c_int32_p, C.POINTER(C.c_void_p)]),
     "rdyhip_halo_destroy": (C.c_int, [C.POINTER(C.c_void_p)]),
     "rdyhip_halo_overlaps": (C.c_int32, [C.c_void_p]),
+    "rdyhip_halo_direct_receive": (C.c_int32, [C.c_void_p]),
+    "rdyhip_halo_fuse_pack": (C.c_int, [C.c_void_p, C.c_int32]),
+    "rdyhip_halo_pack_fused": (C.c_int32, [C.c_void_p]),
+    "rdyhip_halo_invalidate": (C.c_int, [C.c_void_p]),
     "rdyhip_halo_set_transport": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "rdyhip_halo_exchange": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "rdyhip_rhs_overlapped": (C.c_int, [_H, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -105,6 +113,7 @@ SYMBOLS = {
                                        C.POINTER(c_int32_p), C.POINTER(c_int32_p)]),
     "rdyhip_halo_plan_destroy": (C.c_int, [C.POINTER(C.c_void_p)]),
     "rdyhip_hilbert_cell_order": (C.c_int, [C.c_int32, c_double_p, C.c_int32, c_int32_p, c_int32_p]),
+    "rdyhip_local_cell_order": (C.c_int, [C.c_int32, c_double_p, C.c_int32, c_int32_p, c_int32_p, c_int64_p, c_int32_p]),
     "rdyhip_copy_owned_rows": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rdyhip_probe_layout": (C.c_int, [C.POINTER(RDyHipConfig), C.POINTER(RDyHipMesh), C.c_int32, C.POINTER(RDyHipBoundary),
                                       C.POINTER(RDyHipLayoutInfo)]),

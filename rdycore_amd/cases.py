@@ -359,7 +359,7 @@ def _extract_with_vertex_ids(xyz, conn, owned, classifier, project_2d, nvg, part
     caller (parent lookup, boundary tags in global vertex ids)"""
     from . import mesh as M
     conn4 = np.concatenate([conn, -np.ones((conn.shape[0], 1), conn.dtype)], axis=1) if conn.shape[1] == 3 else conn
-    # the same selection extract_local_mesh makes (owned first, then the edge-adjacent ghosts in source order)
+    # the vertices extract_local_mesh keeps: those of the owned cells and of their edge-adjacent ghosts
     nv = xyz.shape[0]
     a = np.concatenate([conn[:, 0], conn[:, 1], conn[:, 2]]).astype(np.int64)
     b = np.concatenate([conn[:, 1], conn[:, 2], conn[:, 0]]).astype(np.int64)
@@ -372,16 +372,14 @@ def _extract_with_vertex_ids(xyz, conn, owned, classifier, project_2d, nvg, part
     keep = owned.copy()
     keep[c2[owned[c1]]] = True
     keep[c1[owned[c2]]] = True
-    sel = np.concatenate([np.nonzero(owned)[0], np.nonzero(keep & ~owned)[0]])
-    used = np.unique(conn[sel])
+    used = np.unique(conn[keep])
 
     def wrapped(mesh):
         mesh._vertex_global_ids = used
         return classifier(mesh)
     lm = M.extract_local_mesh(xyz, conn4, owned, boundary_classifier=wrapped, project_2d=project_2d,
                               vertex_global_ids=np.arange(nv, dtype=np.int64), num_vertices_global=nvg, cell_parts=parts)
-    lm._cell_sel = sel
-    assert lm.num_cells == sel.size
+    assert lm.num_cells == lm._cell_sel.size      # the selection (source cell of each local cell) extract_local_mesh made
     return lm
 
 

@@ -19,6 +19,15 @@ struct RDyHipHalo_s {
   DevBuf<int32_t> d_send_ids, d_recv_ids;
   DevBuf<double>  d_send, d_recv;  // [cells][max_comp]
   int32_t         max_comp = 3;
+  // every ghost this rank receives is one of a run of consecutive local rows, in arrival order (peer by peer, the agreed
+  // order inside a peer: rdyhip_local_cell_order): the transfer lands in the caller's array itself, no unpack launch
+  int32_t         recv_base = -1;  // first row of that run, or -1: receive into d_recv and unpack
+  // rdyhip_halo_fuse_pack: the Euler-step kernels store the rows of their send-flagged cells into d_send as they store
+  // u_out (per-tile send lists, swe_kernels.h), so the next step's exchange needs no pack launch either
+  bool            fused_pack = false;
+  const double   *packed_state = nullptr;  // the state array whose send rows d_send holds ([cells][3]), or nullptr
+  DevBuf<int32_t>  d_send_tile_off;        // [ntiles + 1]
+  DevBuf<uint32_t> d_send_ent;             // cell-in-tile | send row << 8, sorted by tile
   bool            overlap = true;  // exchange hidden behind the interior tiles (large parts) or everything in order (small parts)
   hipStream_t     cs = nullptr;  // exchange stream
   // fork / join events: a small ring, one pair per step, so that steps still in flight never share an event (the host
@@ -33,7 +42,7 @@ struct RDyHipHalo_s {
     ++step;
   }
   ~RDyHipHalo_s() {
-    d_send_ids.release(); d_recv_ids.release(); d_send.release(); d_recv.release();
+    d_send_ids.release(); d_recv_ids.release(); d_send.release(); d_recv.release(); d_send_tile_off.release(); d_send_ent.release();
     for (int i = 0; i < NEV; ++i) {
       if (ev_fork_ring[i]) (void)hipEventDestroy(ev_fork_ring[i]);
       if (ev_join_ring[i]) (void)hipEventDestroy(ev_join_ring[i]);
@@ -43,6 +52,13 @@ struct RDyHipHalo_s {
 };
 
 namespace {
+
+void halo_forget_packed_state(RDyHipHalo_s *h) { h->packed_state = nullptr; }
+// the operator is being destroyed before its halo: the send lists die with it
+void halo_operator_gone(RDyHipHalo_s *h) {
+  h->fused_pack   = false;
+  h->packed_state = nullptr;
+}
 
 #define NCCL_TRY(expr)                                                                                 \
   do {                                                                                                 \
@@ -60,15 +76,18 @@ int halo_pack(RDyHipHalo h, const double *rows, int32_t ncomp, hipStream_t s) {
   const int32_t ns = h->send_off.back();
   if (ns == 0) return 0;
   const int64_t tot = (int64_t)ns * ncomp;
+  h->packed_state = nullptr;  // d_send is overwritten
   hipLaunchKernelGGL(pack_rows_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, ns, ncomp, rows, h->d_send_ids.p, h->d_send.p);
   HIP_TRY(hipGetLastError());
   return 0;
 }
-int halo_transfer(RDyHipHalo h, int32_t ncomp, hipStream_t s) {
+// `rows`: the array being updated ([num_cells][ncomp]); with recv_base >= 0 the ghost rows themselves are the receive buffer
+int halo_transfer(RDyHipHalo h, double *rows, int32_t ncomp, hipStream_t s) {
   const int32_t np = (int32_t)h->peers.size();
   if (h->send_off[np] == 0 && h->recv_off[np] == 0) return 0;
+  double *recv = h->recv_base >= 0 ? rows + (size_t)h->recv_base * ncomp : h->d_recv.p;
   if (h->transport) {
-    const int rc = h->transport(h->transport_ctx, h->d_send.p, h->d_recv.p, ncomp, (void *)s);
+    const int rc = h->transport(h->transport_ctx, h->d_send.p, recv, ncomp, (void *)s);
     if (rc) return fail(RDYHIP_ERR_LIB, "the halo transport callback returned %d", rc);
     return 0;
   }
@@ -85,7 +104,7 @@ int halo_transfer(RDyHipHalo h, int32_t ncomp, hipStream_t s) {
       what = "ncclSend";
     }
     if (cnt_r && r == ncclSuccess) {
-      r    = ncclRecv(h->d_recv.p + (size_t)h->recv_off[i] * ncomp, cnt_r, ncclDouble, h->peers[i], h->comm, s);
+      r    = ncclRecv(recv + (size_t)h->recv_off[i] * ncomp, cnt_r, ncclDouble, h->peers[i], h->comm, s);
       what = "ncclRecv";
     }
   }
@@ -98,7 +117,7 @@ int halo_transfer(RDyHipHalo h, int32_t ncomp, hipStream_t s) {
 }
 int halo_unpack(RDyHipHalo h, double *rows, int32_t ncomp, hipStream_t s) {
   const int32_t nr = h->recv_off.back();
-  if (nr == 0) return 0;
+  if (nr == 0 || h->recv_base >= 0) return 0;  // received in place
   const int64_t tot = (int64_t)nr * ncomp;
   hipLaunchKernelGGL(unpack_rows_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, nr, ncomp, rows, h->d_recv_ids.p, h->d_recv.p);
   HIP_TRY(hipGetLastError());
@@ -107,9 +126,22 @@ int halo_unpack(RDyHipHalo h, double *rows, int32_t ncomp, hipStream_t s) {
 int halo_exchange_on(RDyHipHalo h, double *rows, int32_t ncomp, hipStream_t s) {
   int rc = halo_check(h, rows, ncomp);
   if (!rc) rc = halo_pack(h, rows, ncomp, s);
-  if (!rc) rc = halo_transfer(h, ncomp, s);
+  if (!rc) rc = halo_transfer(h, rows, ncomp, s);
   if (!rc) rc = halo_unpack(h, rows, ncomp, s);
   return rc;
+}
+
+// the pack of the STATE at the head of a step: skipped when the previous Euler step's kernel has already stored exactly
+// these rows into d_send (rdyhip_halo_fuse_pack)
+int halo_pack_state(RDyHipHalo h, const double *u, hipStream_t s) {
+  if (h->fused_pack && h->packed_state == u && u) return 0;
+  return halo_pack(h, u, 3, s);
+}
+// what d_send holds once the launches of a step are enqueued: the send rows of u_out if the fused Euler kernel of a
+// first-order operator has just stored them (every send cell is ghost-adjacent, i.e. in a tile of the HALO phase, which
+// runs after this step's transfer has read d_send), nothing the next step could use otherwise
+void halo_note_step(RDyHipOperator op, RDyHipHalo h, const double *u_out) {
+  h->packed_state = (h->fused_pack && op->fused_halo == h && u_out && op->use_tiled && !op->muscl) ? u_out : nullptr;
 }
 
 // OperatorRHSFunction (u_out == nullptr) or one forward-Euler step (u_out != nullptr) with the ghost update of u
@@ -145,13 +177,16 @@ int overlapped(RDyHipOperator op, RDyHipHalo h, double dt, double *u, double *f,
     // tiles) takes, and the two cross-stream dependencies of the overlapped form cost more than they hide -- measured on
     // a 360 000-cell rank (profiles/r03_step_breakdown_360k.json): 51.8 us per overlapped step against 14.0 us for the
     // exchange plus 18.6 us for ONE launch over all tiles.  So: everything in order on the caller's stream.
-    rc = halo_exchange_on(h, u, 3, st);
+    rc = halo_pack_state(h, u, st);
+    if (!rc) rc = halo_transfer(h, u, 3, st);
+    if (!rc) rc = halo_unpack(h, u, 3, st);
     if (!rc && op->muscl) {
       // second order: the ghost-adjacent cells' gradients (fused form) or all of them (split form), then their exchange
       rc = launch_gradients(op, op->muscl_fused ? RDYHIP_PHASE_HALO : RDYHIP_PHASE_ALL, u, st);
       if (!rc) rc = halo_exchange_on(h, op->d_grad.p, 6, st);
     }
     if (!rc) rc = launch_rhs(op, RDYHIP_PHASE_ALL, 1, 1, dt, u, f, st, op->muscl, u_out, 0);
+    halo_note_step(op, h, rc ? nullptr : u_out);
     return rc;
   }
   h->next_events();
@@ -180,16 +215,17 @@ int overlapped(RDyHipOperator op, RDyHipHalo h, double dt, double *u, double *f,
     // RCCL (asynchronous): the whole exchange is enqueued first, the interior tiles right behind it on the other stream.
     // A transport callback may block the host: there the interior tiles are enqueued before it is called, so that it
     // blocks while the device already works.
-    rc = halo_pack(h, u, 3, h->cs);
+    rc = halo_pack_state(h, u, h->cs);
     if (!rc && h->transport) rc = part(RDYHIP_PHASE_INTERIOR, 1, false);
-    if (!rc) rc = halo_transfer(h, 3, h->cs);
+    if (!rc) rc = halo_transfer(h, u, 3, h->cs);
     if (!rc) rc = halo_unpack(h, u, 3, h->cs);
     if (!rc && !h->transport) rc = part(RDYHIP_PHASE_INTERIOR, 1, false);
     if (!rc && conc) rc = part(RDYHIP_PHASE_HALO, 0, false);
     if (rc) return bail(rc);
     rc = join();
-    if (rc) return rc;
-    return conc ? 0 : part(RDYHIP_PHASE_HALO, 0, false);
+    if (!rc && !conc) rc = part(RDYHIP_PHASE_HALO, 0, false);
+    halo_note_step(op, h, rc ? nullptr : u_out);
+    return rc;
   }
   // ApplyInteriorFlux2R (src/swe/swe_petsc.c:98-213) needs two exchanges: the state, then the gradients of the ghost
   // cells (CommunicateCellGradients).  No reverse exchange: every rank evaluates all edges of its owned cells.
@@ -197,9 +233,9 @@ int overlapped(RDyHipOperator op, RDyHipHalo h, double dt, double *u, double *f,
     // tiles whose cells and first ring touch no ghost need nothing from other ranks and hide BOTH exchanges: the state,
     // then -- still on the exchange stream -- the gradients of the ghost-adjacent owned cells (the only ones that go
     // through memory; the interior tiles neither read nor write that array) and their exchange
-    rc = halo_pack(h, u, 3, h->cs);
+    rc = halo_pack_state(h, u, h->cs);
     if (!rc && h->transport) rc = part(RDYHIP_PHASE_INTERIOR, 1, true);
-    if (!rc) rc = halo_transfer(h, 3, h->cs);
+    if (!rc) rc = halo_transfer(h, u, 3, h->cs);
     if (!rc) rc = halo_unpack(h, u, 3, h->cs);
     if (!rc && !h->transport) rc = part(RDYHIP_PHASE_INTERIOR, 1, true);
     if (!rc) rc = launch_gradients(op, RDYHIP_PHASE_HALO, u, h->cs);
@@ -212,9 +248,9 @@ int overlapped(RDyHipOperator op, RDyHipHalo h, double dt, double *u, double *f,
   }
   // split kernels: the gradients of the cells without ghost neighbours hide the state exchange, the fluxes of the tiles
   // without ghost-adjacent cells (which read owned gradient rows only) hide the gradient exchange
-  rc = halo_pack(h, u, 3, h->cs);
+  rc = halo_pack_state(h, u, h->cs);
   if (!rc && h->transport) rc = launch_gradients(op, RDYHIP_PHASE_INTERIOR, u, st);
-  if (!rc) rc = halo_transfer(h, 3, h->cs);
+  if (!rc) rc = halo_transfer(h, u, 3, h->cs);
   if (!rc) rc = halo_unpack(h, u, 3, h->cs);
   if (!rc && !h->transport) rc = launch_gradients(op, RDYHIP_PHASE_INTERIOR, u, st);
   if (rc) return bail(rc);
@@ -227,7 +263,7 @@ int overlapped(RDyHipOperator op, RDyHipHalo h, double dt, double *u, double *f,
   if (rc) return rc;
   rc = halo_pack(h, op->d_grad.p, 6, h->cs);
   if (!rc && h->transport) rc = part(RDYHIP_PHASE_INTERIOR, 1, true);
-  if (!rc) rc = halo_transfer(h, 6, h->cs);
+  if (!rc) rc = halo_transfer(h, op->d_grad.p, 6, h->cs);
   if (!rc) rc = halo_unpack(h, op->d_grad.p, 6, h->cs);
   if (!rc && !h->transport) rc = part(RDYHIP_PHASE_INTERIOR, 1, true);
   if (rc) return bail(rc);
@@ -290,6 +326,13 @@ int rdyhip_halo_create(RDyHipOperator op, void *nccl_comm, int32_t npeers, const
   }
   h->max_comp = op->muscl ? 6 : 3;
   {
+    // ghosts numbered peer by peer in arrival order (rdyhip_local_cell_order): receive in place.  RDYHIP_DIRECT_RECV=0: measurement knob
+    bool run = nr > 0;
+    for (int32_t i = 1; i < nr && run; ++i) run = recv_cell_ids[i] == recv_cell_ids[0] + i;
+    const char *e = getenv("RDYHIP_DIRECT_RECV");
+    if (run && !(e && atoi(e) == 0)) h->recv_base = recv_cell_ids[0];
+  }
+  {
     // overlap only where there is something to hide behind: at least RDYHIP_OVERLAP_MIN_ROUNDS (default 12: ~2.4 M cells) rounds
     // of the persistent grid's worth of interior tiles.  Measured with the exchange looped back on one device
     // (tools/overlap_threshold.sh, profiles/r03_overlap_threshold.txt): in order / overlapped = 30 / 50 us at 0.36 M cells,
@@ -336,10 +379,88 @@ int rdyhip_halo_create(RDyHipOperator op, void *nccl_comm, int32_t npeers, const
   return 0;
 }
 
+// attaches (or detaches) the halo's per-tile send lists to its operator: the tile descriptors' send flag and the three
+// ColdArgs fields the Euler-step kernels read them through
+static int halo_attach_send_lists(RDyHipHalo h, bool on) {
+  RDyHipOperator op = h->op;
+  HIP_TRY(hipDeviceSynchronize());  // launches in flight read the descriptors
+  std::vector<TileDesc> tiles((size_t)op->ntiles + 1);
+  HIP_TRY(hipMemcpy(tiles.data(), op->d_tiles.p, tiles.size() * sizeof(TileDesc), hipMemcpyDeviceToHost));
+  for (auto &t : tiles) t.cnt &= ~TILE_SEND_FLAG;
+  if (on) {
+    const int32_t ns = h->send_off.back();
+    std::vector<int32_t> ids((size_t)ns);
+    if (ns) HIP_TRY(hipMemcpy(ids.data(), h->d_send_ids.p, sizeof(int32_t) * (size_t)ns, hipMemcpyDeviceToHost));
+    if ((int64_t)ns >= (1 << 24)) return fail(RDYHIP_ERR_ARG_SIZ, "%d send cells do not fit the 24-bit row of a send entry", ns);
+    std::vector<std::pair<int32_t, uint32_t>> ent((size_t)ns);  // (tile, cell-in-tile | row << 8)
+    for (int32_t i = 0; i < ns; ++i) {
+      const int32_t c = ids[i];
+      const int32_t o = op->prefix ? c : (c < (int32_t)op->h_l2o.size() ? op->h_l2o[c] : -1);
+      if (o < 0 || o >= op->n_owned) return fail(RDYHIP_ERR_USER, "send cell %d is not an owned cell", c);
+      ent[i] = std::make_pair(o / TILE, (uint32_t)(o % TILE) | ((uint32_t)i << 8));
+    }
+    std::sort(ent.begin(), ent.end());
+    std::vector<int32_t>  off((size_t)op->ntiles + 1, 0);
+    std::vector<uint32_t> packed((size_t)ns);
+    for (int32_t i = 0; i < ns; ++i) {
+      off[(size_t)ent[i].first + 1]++;
+      packed[i] = ent[i].second;
+      tiles[(size_t)ent[i].first].cnt |= TILE_SEND_FLAG;
+    }
+    for (int32_t t = 0; t < op->ntiles; ++t) off[(size_t)t + 1] += off[t];
+    h->d_send_tile_off.release();
+    h->d_send_ent.release();
+    int rc = h->d_send_tile_off.upload(off);
+    if (!rc) rc = h->d_send_ent.upload(packed);
+    if (rc) return rc;
+  }
+  ColdArgs c;
+  HIP_TRY(hipMemcpy(&c, op->d_cold.p, sizeof(c), hipMemcpyDeviceToHost));
+  c.send_off = on ? h->d_send_tile_off.p : nullptr;
+  c.send_ent = on ? h->d_send_ent.p : nullptr;
+  c.send_buf = on ? h->d_send.p : nullptr;
+  HIP_TRY(hipMemcpy(op->d_cold.p, &c, sizeof(c), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(op->d_tiles.p, tiles.data(), tiles.size() * sizeof(TileDesc), hipMemcpyHostToDevice));
+  op->fused_halo = on ? h : nullptr;
+  return 0;
+}
+
+int rdyhip_halo_fuse_pack(RDyHipHalo halo, int32_t enable) {
+  if (!halo) return fail(RDYHIP_ERR_USER, "null halo");
+  RDyHipOperator op = halo->op;
+  halo->packed_state = nullptr;
+  if (!enable) {
+    if (halo->fused_pack && op->fused_halo == halo) {
+      const int rc = halo_attach_send_lists(halo, false);
+      if (rc) return rc;
+    }
+    halo->fused_pack = false;
+    return 0;
+  }
+  if (halo->fused_pack) return 0;
+  if (!op->use_tiled || op->muscl)
+    return fail(RDYHIP_ERR_USER, "the fused pack rides on the first-order / HR tiled Euler-step kernels (not RDYHIP_KERNEL=cell, not second_order)");
+  if (op->fused_halo && op->fused_halo != halo) return fail(RDYHIP_ERR_USER, "another halo of this operator already has the fused pack");
+  const int rc = halo_attach_send_lists(halo, true);
+  if (rc) return rc;
+  halo->fused_pack = true;
+  return 0;
+}
+
+int rdyhip_halo_invalidate(RDyHipHalo halo) {
+  if (!halo) return fail(RDYHIP_ERR_USER, "null halo");
+  halo->packed_state = nullptr;
+  return 0;
+}
+
+int32_t rdyhip_halo_direct_receive(RDyHipHalo halo) { return halo && halo->recv_base >= 0 ? 1 : 0; }
+int32_t rdyhip_halo_pack_fused(RDyHipHalo halo) { return halo && halo->fused_pack ? 1 : 0; }
+
 int rdyhip_halo_destroy(RDyHipHalo *halo) {
   if (!halo) return fail(RDYHIP_ERR_USER, "null argument to rdyhip_halo_destroy");
   if (*halo) {
     (void)hipDeviceSynchronize();
+    if ((*halo)->fused_pack && (*halo)->op->fused_halo == *halo) (void)halo_attach_send_lists(*halo, false);
     delete *halo;
     *halo = nullptr;
   }

@@ -176,10 +176,17 @@ int rdyhip_halo_plan_destroy(RDyHipHaloPlan *plan) {
   return 0;
 }
 
-int rdyhip_hilbert_cell_order(int32_t num_cells, const double *xy, int32_t stride, const int32_t *cell_is_owned, int32_t *perm) {
+// perm[new] = old: owned cells first along a Hilbert curve through their centroids; the ghost cells after them -- along the
+// curve as well (cell_owner_rank == NULL), or grouped by owner rank and ascending key inside a group (the order in which
+// rdyhip_halo_plan_* lists a peer's cells on both sides: every peer's ghosts are then ONE run of consecutive rows in the order
+// they arrive, and rdyhip_halo_create receives straight into the local vector, with no unpack launch)
+static int local_cell_order(int32_t num_cells, const double *xy, int32_t stride, const int32_t *cell_is_owned, const int32_t *cell_owner_rank,
+                            const int64_t *cell_keys, int32_t *perm) {
   if (num_cells < 0 || stride < 2) return fail(RDYHIP_ERR_ARG_SIZ, "bad size");
   if (num_cells == 0) return 0;
   if (!xy || !perm) return fail(RDYHIP_ERR_USER, "null argument");
+  if ((cell_owner_rank != nullptr) != (cell_keys != nullptr)) return fail(RDYHIP_ERR_USER, "cell_owner_rank and cell_keys go together");
+  if (cell_owner_rank && !cell_is_owned) return fail(RDYHIP_ERR_USER, "ghost ordering needs cell_is_owned");
   double lo[2] = {xy[0], xy[1]}, hi[2] = {xy[0], xy[1]};
   for (int32_t c = 1; c < num_cells; ++c)
     for (int k = 0; k < 2; ++k) {
@@ -187,19 +194,38 @@ int rdyhip_hilbert_cell_order(int32_t num_cells, const double *xy, int32_t strid
       hi[k] = std::max(hi[k], xy[(size_t)c * stride + k]);
     }
   const double ext = std::max(std::max(hi[0] - lo[0], hi[1] - lo[1]), 1e-300);
-  std::vector<std::pair<uint64_t, int32_t>> key((size_t)num_cells);
+  struct Key {
+    uint64_t a, b;  // owned: (0, Hilbert index); ghost: (1 + owner rank, key) or (1, Hilbert index)
+    int32_t  c;
+    bool operator<(const Key &o) const { return a != o.a ? a < o.a : (b != o.b ? b < o.b : c < o.c); }
+  };
+  std::vector<Key> key((size_t)num_cells);
   for (int32_t c = 0; c < num_cells; ++c) {
+    const bool ghost = cell_is_owned && !cell_is_owned[c];
+    if (ghost && cell_owner_rank) {
+      if (cell_owner_rank[c] < 0) return fail(RDYHIP_ERR_ARG_OUTOFRANGE, "ghost cell %d: negative owner rank", c);
+      key[c] = Key{1ull + (uint64_t)cell_owner_rank[c], (uint64_t)cell_keys[c] ^ (1ull << 63), c};  // signed order of the keys
+      continue;
+    }
     double fx = (xy[(size_t)c * stride] - lo[0]) / ext * 65535.0, fy = (xy[(size_t)c * stride + 1] - lo[1]) / ext * 65535.0;
     if (!(fx == fx)) fx = 0.0;  // a NaN coordinate must not reach the integer conversion
     if (!(fy == fy)) fy = 0.0;
     const uint32_t x = (uint32_t)std::min(65535.0, std::max(0.0, fx)), y = (uint32_t)std::min(65535.0, std::max(0.0, fy));
     // owned cells first (a contiguous prefix: the owned rows of a local vector are then one block), ghosts after them
-    const uint64_t ghost = (cell_is_owned && !cell_is_owned[c]) ? (1ull << 40) : 0ull;
-    key[c]               = std::make_pair(ghost | hilbert_d(x, y), c);
+    key[c] = Key{ghost ? 1ull : 0ull, hilbert_d(x, y), c};
   }
   std::sort(key.begin(), key.end());  // ties (coincident lattice points) fall back to the old cell id: deterministic
-  for (int32_t i = 0; i < num_cells; ++i) perm[i] = key[i].second;
+  for (int32_t i = 0; i < num_cells; ++i) perm[i] = key[i].c;
   return 0;
+}
+
+int rdyhip_hilbert_cell_order(int32_t num_cells, const double *xy, int32_t stride, const int32_t *cell_is_owned, int32_t *perm) {
+  return local_cell_order(num_cells, xy, stride, cell_is_owned, nullptr, nullptr, perm);
+}
+
+int rdyhip_local_cell_order(int32_t num_cells, const double *xy, int32_t stride, const int32_t *cell_is_owned, const int32_t *cell_owner_rank,
+                            const int64_t *cell_keys, int32_t *perm) {
+  return local_cell_order(num_cells, xy, stride, cell_is_owned, cell_owner_rank, cell_keys, perm);
 }
 
 }  // extern "C"

@@ -28,6 +28,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "rdyhip.h"
@@ -91,8 +92,40 @@ struct DevBuf {
 
 }  // namespace
 
+// Staging of the stream-ordered setters (rdyhip_set_*_on): a small ring of slots, each a pinned host buffer + a device
+// buffer + an event.  The caller's array is copied into the pinned buffer before the call returns (the caller may reuse it
+// at once, as with the reference's setters, which copy into a Vec); the host -> device copy then runs on the operator's own
+// copy stream, beside whatever the caller's stream is executing, and only the final scatter into the operator's field is
+// ordered on the caller's stream.  A slot is reused once the work that read it has finished (its event).
+struct StageRing {
+  static constexpr int N = 4;
+  struct Slot {
+    void      *h = nullptr, *d = nullptr;
+    size_t     cap = 0;
+    hipEvent_t copied = nullptr, done = nullptr;
+    bool       used = false;
+  } slot[N];
+  int         next = 0;
+  hipStream_t copy = nullptr;
+  void release() {
+    for (auto &s : slot) {
+      if (s.h) (void)hipHostFree(s.h);
+      if (s.d) (void)hipFree(s.d);
+      if (s.copied) (void)hipEventDestroy(s.copied);
+      if (s.done) (void)hipEventDestroy(s.done);
+      s = Slot{};
+    }
+    if (copy) (void)hipStreamDestroy(copy);
+    copy = nullptr;
+  }
+};
+
+struct RDyHipHalo_s;
 struct RDyHipOperator_s {
+  StageRing stage;
   RDyHipConfig config;
+  RDyHipHalo_s *fused_halo = nullptr;  // the halo whose send lists are attached to the tile descriptors (rdyhip_halo_fuse_pack)
+  std::vector<int32_t> h_l2o;          // local -> owned cell id, kept only when the owned cells are not a prefix
   int          device = 0;
   int32_t      n_cells = 0, n_owned = 0, S = 3, K = 0, n_internal = 0;
   int64_t      stride = 0;
@@ -160,12 +193,16 @@ struct RDyHipOperator_s {
     d_e_cs.release(); d_slot_ref.release(); d_slot_ref3.release(); d_zc_local.release();
     d_grad.release(); d_e_mid.release(); d_cxy.release(); d_hcells2.release(); d_c_off.release();
     d_bn_idx.release();
+    stage.release();
   }
 };
 
 namespace {
 
 using TiledKernelFn = void (*)(const KernelArgs, const double, const double *, double *);
+
+void halo_forget_packed_state(RDyHipHalo_s *h);   // halo_exchange.h
+void halo_operator_gone(RDyHipHalo_s *h);
 
 // the instantiation of the tiled kernel for (slots per cell, source method, overwrite, HR, fixed LDS plane lengths)
 template <bool HR, int NS3, int NE3, int NS4, int NE4>
@@ -321,6 +358,9 @@ int launch_gradients(RDyHipOperator op, int32_t phase, const double *u, hipStrea
 int launch_rhs(RDyHipOperator op, int32_t phase, int32_t overwrite, int reset_diag, double dt, const double *u, double *f, hipStream_t st,
                bool gradients_ready = false, double *u_out = nullptr, int bucket_half = 0) {
   if (!op) return fail(RDYHIP_ERR_USER, "null operator");
+  // an Euler-step launch rewrites the attached halo's send buffer (tiles flagged TILE_SEND_FLAG): whatever it held is gone
+  // (rdyhip_euler_step_overlapped notes the new content itself once its launches are enqueued)
+  if (u_out && op->fused_halo) halo_forget_packed_state(op->fused_halo);
   // rdyhip_euler_step: the first-order / HR tiled kernel has the update fused into its stores (F optional); the
   // other kernels evaluate F (into a scratch vector if the caller wants none) and a separate update follows
   const bool euler_fused = u_out && op->use_tiled && (!op->muscl || op->muscl_fused);
@@ -372,6 +412,7 @@ int launch_rhs(RDyHipOperator op, int32_t phase, int32_t overwrite, int reset_di
   a.xq_thresh  = op->config.xq2018_threshold;
   a.overwrite  = overwrite ? 1 : 0;
   a.phase      = phase;
+  a.f_cached   = (op->config.flags & RDYHIP_CONFIG_CACHED_F_STORES) ? 1 : 0;
 
   a.tiles    = op->d_tiles.p;
   a.e_lr     = op->d_e_lr.p;
@@ -1068,6 +1109,7 @@ int rdyhip_create(const RDyHipConfig *config, const RDyHipMesh *mesh, int32_t nu
   op->h_edge_cells.assign(mesh->edge_cell_ids, mesh->edge_cell_ids + 2 * (size_t)ne);
   op->h_bedge = bedge;
   op->h_boff  = boff;
+  if (!prefix) op->h_l2o.assign(mesh->cell_local_to_owned, mesh->cell_local_to_owned + nc);
   if (mesh->cell_global_ids) op->h_cell_gid.assign(mesh->cell_global_ids, mesh->cell_global_ids + nc);
   if (mesh->edge_global_ids) op->h_edge_gid.assign(mesh->edge_global_ids, mesh->edge_global_ids + ne);
 
@@ -1085,6 +1127,7 @@ int rdyhip_destroy(RDyHipOperator *op) {
   if (!op) return fail(RDYHIP_ERR_USER, "null argument to rdyhip_destroy");
   if (*op) {
     (void)hipDeviceSynchronize();
+    if ((*op)->fused_halo) halo_operator_gone((*op)->fused_halo);
     delete *op;
     *op = nullptr;
   }
@@ -1209,6 +1252,148 @@ int rdyhip_set_external_source(RDyHipOperator op, int32_t comp, int32_t n, const
 int rdyhip_set_mannings(RDyHipOperator op, int32_t n, const int32_t *owned_cell_ids, const double *values) {
   if (!op) return fail(RDYHIP_ERR_USER, "null operator");
   return scatter_component(op, op->d_mannings.p, 1, 0, n, owned_cell_ids, values);
+}
+
+// ---- the stream-ordered forms: no device-wide synchronisation, no blocking copy ---------------------------------------
+// A slot of the staging ring with room for `bytes`, free to be written by the host (the work that read it last is through).
+static int stage_acquire(RDyHipOperator op, size_t bytes, StageRing::Slot **out) {
+  StageRing &r = op->stage;
+  if (!r.copy) HIP_TRY(hipStreamCreateWithFlags(&r.copy, hipStreamNonBlocking));
+  StageRing::Slot &s = r.slot[r.next];
+  r.next = (r.next + 1) % StageRing::N;
+  if (!s.copied) {
+    HIP_TRY(hipEventCreateWithFlags(&s.copied, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+  }
+  if (s.used) HIP_TRY(hipEventSynchronize(s.done));
+  s.used = false;
+  if (s.cap < bytes) {
+    if (s.h) HIP_TRY(hipHostFree(s.h));
+    if (s.d) HIP_TRY(hipFree(s.d));
+    s.h = s.d = nullptr;
+    s.cap = 0;
+    const size_t cap = std::max<size_t>(bytes + bytes / 4, 4096);
+    HIP_TRY(hipHostMalloc(&s.h, cap, hipHostMallocDefault));
+    HIP_TRY(hipMalloc(&s.d, cap));
+    s.cap = cap;
+  }
+  *out = &s;
+  return 0;
+}
+// host -> pinned (a few threads for large arrays: one core copies ~10 GB/s, which at 8 B per cell is as long as 25 RHS
+// evaluations of that many cells)
+static void stage_memcpy(void *dst, const void *src, size_t bytes) {
+  constexpr size_t CHUNK = 8u << 20;
+  const int nt = (int)std::min<size_t>(4, bytes / CHUNK);
+  if (nt <= 1) {
+    memcpy(dst, src, bytes);
+    return;
+  }
+  std::vector<std::thread> th;
+  const size_t per = ((bytes / nt) + 63) & ~(size_t)63;
+  for (int t = 0; t < nt; ++t) {
+    const size_t off = (size_t)t * per, len = t == nt - 1 ? bytes - off : per;
+    th.emplace_back([=] { memcpy((char *)dst + off, (const char *)src + off, len); });
+  }
+  for (auto &t : th) t.join();
+}
+// values (and ids) -> slot: pinned now, device on the copy stream; `st` then waits for that copy
+static int stage_upload(RDyHipOperator op, StageRing::Slot *s, size_t bytes, hipStream_t st) {
+  HIP_TRY(hipMemcpyAsync(s->d, s->h, bytes, hipMemcpyHostToDevice, op->stage.copy));
+  HIP_TRY(hipEventRecord(s->copied, op->stage.copy));
+  HIP_TRY(hipStreamWaitEvent(st, s->copied, 0));
+  return 0;
+}
+static int stage_release(StageRing::Slot *s, hipStream_t st) {
+  HIP_TRY(hipEventRecord(s->done, st));
+  s->used = true;
+  return 0;
+}
+
+static int scatter_component_on(RDyHipOperator op, double *dst, int ncomp, int comp, int32_t n, const int32_t *ids, const double *values, hipStream_t st) {
+  if (n < 0 || n > op->n_owned) return fail(RDYHIP_ERR_ARG_SIZ, "n (%d) exceeds the number of owned cells (%d)", n, op->n_owned);
+  if (n == 0) return 0;
+  if (!values) return fail(RDYHIP_ERR_USER, "null values");
+  if (ids) {
+    for (int32_t i = 0; i < n; ++i)
+      if (ids[i] < 0 || ids[i] >= op->n_owned) return fail(RDYHIP_ERR_ARG_OUTOFRANGE, "owned cell id %d out of range", ids[i]);
+  }
+  const size_t vbytes = sizeof(double) * (size_t)n, ibytes = ids ? sizeof(int32_t) * (size_t)n : 0;
+  StageRing::Slot *s;
+  int rc = stage_acquire(op, vbytes + ibytes, &s);
+  if (rc) return rc;
+  stage_memcpy(s->h, values, vbytes);
+  if (ids) stage_memcpy((char *)s->h + vbytes, ids, ibytes);
+  rc = stage_upload(op, s, vbytes + ibytes, st);
+  if (rc) return rc;
+  const int32_t *dids = ids ? (const int32_t *)((const char *)s->d + vbytes) : nullptr;
+  hipLaunchKernelGGL(scatter_component_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, dids, (const double *)s->d, dst, ncomp, comp);
+  HIP_TRY(hipGetLastError());
+  return stage_release(s, st);
+}
+
+int rdyhip_set_external_source_on(RDyHipOperator op, int32_t comp, int32_t n, const int32_t *owned_cell_ids, const double *values, void *stream) {
+  if (!op) return fail(RDYHIP_ERR_USER, "null operator");
+  if (comp < 0 || comp > 2) return fail(RDYHIP_ERR_USER, "bad source component %d", comp);
+  return scatter_component_on(op, op->d_extsrc.p, 3, comp, n, owned_cell_ids, values, (hipStream_t)stream);
+}
+
+int rdyhip_set_mannings_on(RDyHipOperator op, int32_t n, const int32_t *owned_cell_ids, const double *values, void *stream) {
+  if (!op) return fail(RDYHIP_ERR_USER, "null operator");
+  return scatter_component_on(op, op->d_mannings.p, 1, 0, n, owned_cell_ids, values, (hipStream_t)stream);
+}
+
+int rdyhip_set_boundary_values_on(RDyHipOperator op, int32_t boundary, int32_t comp_offset, int32_t num_comp, int32_t num_edges, const double *values,
+                                  void *stream) {
+  if (!op) return fail(RDYHIP_ERR_USER, "null operator");
+  if (boundary < 0 || boundary + 1 >= (int32_t)op->h_boff.size()) return fail(RDYHIP_ERR_USER, "Invalid boundary index %d", boundary);
+  const int32_t n = op->h_boff[boundary + 1] - op->h_boff[boundary];
+  if (n != num_edges) return fail(RDYHIP_ERR_USER, "num_edges (%d) does not match boundary.num_edges (%d)", num_edges, n);
+  if (comp_offset < 0 || num_comp < 0 || comp_offset + num_comp > 3) return fail(RDYHIP_ERR_USER, "bad component range [%d,%d)", comp_offset, comp_offset + num_comp);
+  if (n == 0 || num_comp == 0) return 0;
+  if (!values) return fail(RDYHIP_ERR_USER, "null values");
+  hipStream_t      st = (hipStream_t)stream;
+  const size_t     bytes = sizeof(double) * (size_t)num_comp * (size_t)n;
+  StageRing::Slot *s;
+  int rc = stage_acquire(op, bytes, &s);
+  if (rc) return rc;
+  stage_memcpy(s->h, values, bytes);
+  rc = stage_upload(op, s, bytes, st);
+  if (rc) return rc;
+  double *dst = op->d_bvalues.p + 3 * (size_t)op->h_boff[boundary];
+  if (comp_offset == 0 && num_comp == 3) {
+    HIP_TRY(hipMemcpyAsync(dst, s->d, bytes, hipMemcpyDeviceToDevice, st));
+  } else {
+    HIP_TRY(hipMemcpy2DAsync(dst + comp_offset, 3 * sizeof(double), s->d, num_comp * sizeof(double), num_comp * sizeof(double), n, hipMemcpyDeviceToDevice, st));
+  }
+  return stage_release(s, st);
+}
+
+int rdyhip_refresh_field(RDyHipOperator op, RDyHipField field, const double *values, int64_t num_values, int32_t values_on_device, void *stream) {
+  if (!op) return fail(RDYHIP_ERR_USER, "null operator");
+  double *dst = nullptr;
+  int64_t n   = 0;
+  if (field != RDYHIP_FIELD_EXTERNAL_SOURCES && field != RDYHIP_FIELD_MANNINGS)
+    return fail(RDYHIP_ERR_USER, "rdyhip_refresh_field: only the operator's input fields (external sources, Manning n) can be written");
+  int rc = rdyhip_field_ptr(op, field, &dst, &n);
+  if (rc) return rc;
+  if (num_values != n) return fail(RDYHIP_ERR_ARG_SIZ, "%lld values for a device field of %lld", (long long)num_values, (long long)n);
+  if (n == 0) return 0;
+  if (!values) return fail(RDYHIP_ERR_USER, "null values");
+  hipStream_t  st = (hipStream_t)stream;
+  const size_t bytes = sizeof(double) * (size_t)n;
+  if (values_on_device) {
+    HIP_TRY(hipMemcpyAsync(dst, values, bytes, hipMemcpyDeviceToDevice, st));
+    return 0;
+  }
+  StageRing::Slot *s;
+  rc = stage_acquire(op, bytes, &s);
+  if (rc) return rc;
+  stage_memcpy(s->h, values, bytes);
+  rc = stage_upload(op, s, bytes, st);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(dst, s->d, bytes, hipMemcpyDeviceToDevice, st));
+  return stage_release(s, st);
 }
 
 // ---- device-side forcing ingestion (forcing_kernels.h) -------------------------------------------------

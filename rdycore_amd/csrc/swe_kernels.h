@@ -80,6 +80,11 @@ struct ColdArgs {
   const int32_t *tile_bk;    // boundary-edge ids k of each tile's boundary edges
   double        *blk_max;    // [2 * maxgrid] the Courant diagnostic, one running (max, first position) bucket per workgroup slot;
   int32_t       *blk_pos;    //               merged by courant_finalize_kernel only when the host asks (rdyhip_update_diagnostics)
+  // the pack of the next ghost update fused into the Euler-step kernels' stores (rdyhip_halo_fuse_pack): tiles flagged
+  // TILE_SEND_FLAG also store the new state of their send cells into the halo's send buffer
+  const int32_t  *send_off;  // [ntiles + 1] first send entry of each tile
+  const uint32_t *send_ent;  // cell-in-tile (bits 0-7) | row of the send buffer (bits 8-31), sorted by tile
+  double         *send_buf;  // [send cells][3]
 };
 
 struct KernelArgs {
@@ -103,6 +108,7 @@ struct KernelArgs {
   int32_t        phase;      // RDYHIP_PHASE_*
   int32_t        overwrite;  // 1: f = rhs, 0: f += rhs
   int32_t        xcd_chunks; // >0: blocks are dealt to XCDs in contiguous chunks of this many tiles
+  int32_t        f_cached;   // 1: F is stored with the default cache policy (RDYHIP_CONFIG_CACHED_F_STORES: a separate update reads it back)
   // ---- tiled kernel only
   const struct TileDesc *tiles;  // [ntiles+1]
   const uint32_t *e_lr;      // [nrec] packed LDS slots of the edge's cells
@@ -184,12 +190,19 @@ __device__ __forceinline__ void cell_results(const KernelArgs &a, double dt, dou
 }
 // Stores one [cell][3] row per lane of a full wave, transposed so that the wave writes its 192 consecutive doubles
 // with three unit-stride instructions.  `base`: index of the wave's first double; lanes >= ncell hold no cell.
-__device__ __forceinline__ void wave_store_rows3(double *__restrict__ arr, int64_t base, int lane, int ncell, double v0, double v1, double v2) {
+// `cached` (wave-uniform): store with the default cache policy instead of the non-temporal hint -- F when a separate update
+// kernel reads it straight back (TSEULER's VecAXPY: RDYHIP_CONFIG_CACHED_F_STORES)
+__device__ __forceinline__ void wave_store_rows3(double *__restrict__ arr, int64_t base, int lane, int ncell, double v0, double v1, double v2,
+                                                 bool cached = false) {
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     const int    e = 64 * k + lane, src = e / 3, comp = e - 3 * src;
     const double s0 = __shfl(v0, src, 64), s1 = __shfl(v1, src, 64), s2 = __shfl(v2, src, 64);
-    if (src < ncell) RDY_ST(&arr[base + e], comp == 0 ? s0 : (comp == 1 ? s1 : s2));
+    const double v  = comp == 0 ? s0 : (comp == 1 ? s1 : s2);
+    if (src < ncell) {
+      if (cached) arr[base + e] = v;
+      else RDY_ST(&arr[base + e], v);
+    }
   }
 }
 
@@ -281,12 +294,38 @@ struct TileDesc {  // 16 B, one per tile (+1 sentinel): everything about a tile 
   int32_t  e_off;  // first edge record
   int32_t  h_off;  // first halo-cell entry
   int32_t  b_off;  // first boundary-edge entry
-  uint32_t cnt;    // edge records (bits 0-10) | halo cells (bits 11-21) | bit 31: a tile cell has a ghost neighbour
+  uint32_t cnt;    // edge records (bits 0-10) | halo cells (bits 11-21) | bit 30: a tile cell is sent to another rank (set while a
+                   // halo with the fused pack is attached) | bit 31: a tile cell has a ghost neighbour
   __host__ __device__ int  ne() const { return (int)(cnt & 0x7FFu); }
   __host__ __device__ int  nh() const { return (int)((cnt >> 11) & 0x7FFu); }
   __host__ __device__ bool halo() const { return (cnt >> 31) != 0; }
+  __host__ __device__ bool send() const { return ((cnt >> 30) & 1u) != 0; }
 };
 constexpr uint32_t TILE_HALO_FLAG = 1u << 31;
+constexpr uint32_t TILE_SEND_FLAG = 1u << 30;
+
+// The fused pack: the lanes of a wave hand the new state of the tile's send cells to the send buffer.  Every wave scans the
+// tile's (short) entry list 64 entries at a time and takes the entries whose cell it holds; the values come from the owning
+// lane through a wave shuffle, so there is no LDS traffic and no barrier.  Runs only in tiles flagged TILE_SEND_FLAG.
+__device__ __forceinline__ void wave_store_send_rows(const KernelArgs &a, int tile, int tid, double n0, double n1, double n2) {
+  const int32_t  *soff = RDY_COLD(a, send_off);
+  const int       s0 = load_uniform(soff, tile), s1 = load_uniform(soff, tile + 1);
+  const uint32_t *sent = RDY_COLD(a, send_ent);
+  double         *sbuf = RDY_COLD(a, send_buf);
+  const int       lane = tid & 63, wave = tid >> 6;
+  for (int base = s0; base < s1; base += 64) {
+    const int      i   = base + lane;
+    const uint32_t ent = i < s1 ? sent[i] : 0u;
+    const int      j   = (int)(ent & 0xFFu);
+    const double   v0 = __shfl(n0, j & 63, 64), v1 = __shfl(n1, j & 63, 64), v2 = __shfl(n2, j & 63, 64);
+    if (i < s1 && (j >> 6) == wave) {
+      const int64_t row = (int64_t)(ent >> 8);
+      sbuf[3 * row + 0] = v0;
+      sbuf[3 * row + 1] = v1;
+      sbuf[3 * row + 2] = v2;
+    }
+  }
+}
 
 // per-cell streams consumed in phase 2 (slot references, flux coefficients,
 // bed slopes, Manning n, external source)
@@ -650,6 +689,8 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
       asm volatile("" ::"v"(nxt.r0), "v"(nxt.r1), "v"(nxt.coef[0]), "v"(nxt.coef[1]), "v"(nxt.coef[2]), "v"(nxt.coef[S - 1]), "v"(nxt.dzdx),
                    "v"(nxt.dzdy), "v"(nxt.nman), "v"(nxt.s0), "v"(nxt.s1), "v"(nxt.s2));
       // rotate the pipeline registers, store
+      const bool send_tile = EULER && td.send();  // wave-uniform
+      const int  tile_cur  = tile;
       idx = idx1; tile = tile1; td = td1;
       idx1 = idx2; tile1 = tile2; td1 = td2; hid1 = hid2; c1 = c2;
       lr0 = nlr0; lr1 = nlr1; cs0 = ncs0; cs1 = ncs1;
@@ -664,7 +705,7 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
         const int     lane  = tid & 63;
         const int64_t base  = 3 * ((int64_t)o - lane);
         const int     ncell = a.n_owned - (o - lane);
-        if (!EULER || f) wave_store_rows3(f, base, lane, ncell, out[0], out[1], out[2]);
+        if (!EULER || f) wave_store_rows3(f, base, lane, ncell, out[0], out[1], out[2], a.f_cached != 0);
         wave_store_rows3(a.pv, base, lane, ncell, out[3], out[4], out[5]);
         if (a.fdiv) wave_store_rows3(a.fdiv, base, lane, ncell, acc_fdiv[0], acc_fdiv[1], acc_fdiv[2]);
         if (EULER) {
@@ -677,6 +718,7 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
             RDY_ST(&a.u_out[3 * c + 1], n1);
             RDY_ST(&a.u_out[3 * c + 2], n2);
           }
+          if (send_tile) wave_store_send_rows(a, tile_cur, tid, n0, n1, n2);
         }
       }
       if (last) break;

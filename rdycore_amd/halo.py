@@ -121,6 +121,36 @@ class HaloExchange:
             self.destroy()
             raise RuntimeError(f"rdyhip_halo_create failed on some rank (this rank: {err!r})")
 
+    # -- the two shortcuts of the exchange chain (include/rdyhip.h: direct receive, fused pack) -----------------
+    @property
+    def direct_receive(self) -> bool:
+        """the transfer lands in the local array's ghost rows themselves (ghosts numbered peer by peer in arrival order,
+        mesh.extract_local_mesh / rdyhip_local_cell_order): no unpack launch"""
+        from . import _lib
+        return self._halo is not None and bool(_lib.load().rdyhip_halo_direct_receive(self._halo))
+
+    def fuse_pack(self, enable: bool = True) -> bool:
+        """rdyhip_halo_fuse_pack: the Euler-step kernels store their send cells' new state into the send buffer, so the next
+        `step_overlapped` on that array starts with the transfer.  The caller must not write the owned rows of the array
+        between two steps itself, or call `invalidate()`.  Returns whether the fused pack is on (first-order tiled kernels)."""
+        from . import _lib
+        if self._halo is None:
+            return False
+        lib = _lib.load()
+        if enable:
+            rc = lib.rdyhip_halo_fuse_pack(self._halo, 1)
+            if rc:                              # second order / cell-centric kernel: not available, the pack launch stays
+                return False
+        else:
+            _lib.check(lib.rdyhip_halo_fuse_pack(self._halo, 0))
+        return bool(lib.rdyhip_halo_pack_fused(self._halo))
+
+    def invalidate(self):
+        """the state array was written by somebody else since the last step: the next step packs again"""
+        from . import _lib
+        if self._halo is not None:
+            _lib.check(_lib.load().rdyhip_halo_invalidate(self._halo))
+
     def rccl_ranks(self) -> Optional[int]:
         """ncclCommCount of the library's own communicator (None when the bytes do not travel over RCCL)"""
         if self._comm is None:

@@ -589,10 +589,15 @@ def extract_local_mesh(xyz: np.ndarray, conn: np.ndarray, owned_mask: np.ndarray
     DMPlexDistributeOverlap(dm, 1, ...), src/rdydm.c:145-157, under edge
     adjacency, which is all a first-order flux needs).
 
-    `ghosts="tail"` numbers ghosts after the owned cells; "interleaved" keeps
-    the source order (owned and ghost cells mixed, as a DMPlex local numbering
-    may be).  `cell_parts` (the owner rank of every source cell) is carried onto
-    the local mesh as `cell_owner_rank`.
+    `ghosts="tail"` numbers ghosts after the owned cells -- grouped by owner rank
+    and ascending global id inside a group when `cell_parts` is given (what
+    rdyhip_local_cell_order does for a C host: every peer's ghosts are then
+    consecutive rows in the order the halo plan lists them, and the exchange
+    receives in place), in source order otherwise ("tail_source" forces that);
+    "interleaved" keeps the source order (owned and ghost cells mixed, as a
+    DMPlex local numbering may be).  `cell_parts` (the owner rank of every
+    source cell) is carried onto the local mesh as `cell_owner_rank`.  The
+    selection (source cell of each local cell) is left on the mesh as `_cell_sel`.
     """
     conn = np.asarray(conn)
     if conn.shape[1] == 3:
@@ -617,8 +622,12 @@ def extract_local_mesh(xyz: np.ndarray, conn: np.ndarray, owned_mask: np.ndarray
     keep = owned_mask.copy()
     keep[c2[owned_mask[c1]]] = True
     keep[c1[owned_mask[c2]]] = True
-    if ghosts == "tail":
-        sel = np.concatenate([np.nonzero(owned_mask)[0], np.nonzero(keep & ~owned_mask)[0]])
+    gids = np.arange(nc, dtype=np.int64) if cell_global_ids is None else np.asarray(cell_global_ids)
+    if ghosts in ("tail", "tail_source"):
+        gsel = np.nonzero(keep & ~owned_mask)[0]
+        if cell_parts is not None and ghosts == "tail":
+            gsel = gsel[np.lexsort((gids[gsel], np.asarray(cell_parts)[gsel]))]     # by owner, then by global id
+        sel = np.concatenate([np.nonzero(owned_mask)[0], gsel])
     elif ghosts == "interleaved":
         sel = np.nonzero(keep)[0]
     else:
@@ -628,7 +637,6 @@ def extract_local_mesh(xyz: np.ndarray, conn: np.ndarray, owned_mask: np.ndarray
     remap = -np.ones(nv, dtype=np.int64)
     remap[used] = np.arange(used.size)
     sub_conn = np.where(sub_conn >= 0, remap[np.maximum(sub_conn, 0)], -1).astype(np.int32)
-    gids = np.arange(nc, dtype=np.int64) if cell_global_ids is None else np.asarray(cell_global_ids)
     vg = used if vertex_global_ids is None else np.asarray(vertex_global_ids)[used]
     lm = build_mesh(xyz[used], sub_conn, is_owned=owned_mask[sel].astype(np.int32),
                     cell_global_ids=gids[sel],
@@ -637,6 +645,7 @@ def extract_local_mesh(xyz: np.ndarray, conn: np.ndarray, owned_mask: np.ndarray
                     vertex_global_ids=vg, num_vertices_global=num_vertices_global if num_vertices_global is not None else nv)
     if cell_parts is not None:
         lm.cell_owner_rank = np.ascontiguousarray(np.asarray(cell_parts)[sel], dtype=np.int32)
+    lm._cell_sel = sel
     return lm
 
 

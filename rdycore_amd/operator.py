@@ -42,6 +42,7 @@ class RDyFlowConfig:
     well_balancing: int = WELL_BALANCING_NONE
     second_order: bool = False        # numerics.second_order: MUSCL reconstruction (src/swe/swe_petsc.c:98-213)
     limiter: int = LIMITER_MINMOD     # numerics.limiter
+    cached_f_stores: bool = False     # RDYHIP_CONFIG_CACHED_F_STORES: F is read back by a separate update kernel (TSEULER's VecAXPY)
 
 
 @dataclasses.dataclass
@@ -110,7 +111,7 @@ def _abi_arguments(config: "RDyFlowConfig", mesh: RDyMesh, condition_types: Opti
         barr[i].condition_type = int(condition_types[i])
     cfg = _lib.RDyHipConfig(config.tiny_h, config.h_anuga_regular, config.xq2018_threshold,
                             int(config.source_method), int(config.riemann), int(config.well_balancing),
-                            1 if config.second_order else 0, int(config.limiter), 0)
+                            1 if config.second_order else 0, int(config.limiter), 1 if getattr(config, "cached_f_stores", False) else 0)
     return cfg, m, nb, barr, list(condition_types), keep
 
 
@@ -210,12 +211,17 @@ class Operator:
         return self._field(4, 6)
 
     # -- SetOperatorBoundaryValues (src/operator.c:1045-1061) --------------
-    def set_boundary_values(self, boundary: int, values, comp_offset: int = 0):
+    def set_boundary_values(self, boundary: int, values, comp_offset: int = 0, ordered: bool = False):
         """values[e, c] for component comp_offset+c of boundary edge e (RDySetFlowDirichletBoundaryValues,
-        src/rdydata.c:88-106)."""
+        src/rdydata.c:88-106).  `ordered`: the stream-ordered form (rdyhip_set_boundary_values_on, current stream) -- no
+        device synchronisation, no blocking copy; the default synchronises as the legacy entry point does."""
         v = np.ascontiguousarray(values, dtype=np.float64)
         if v.ndim == 1:
             v = v.reshape(-1, 1)
+        if ordered:
+            _lib.check(_lib.load().rdyhip_set_boundary_values_on(self._h, int(boundary), int(comp_offset), int(v.shape[1]),
+                                                                int(v.shape[0]), v.ctypes.data_as(_lib.c_double_p), _stream()))
+            return
         _lib.check(_lib.load().rdyhip_set_boundary_values(self._h, int(boundary), int(comp_offset), int(v.shape[1]),
                                                          int(v.shape[0]), v.ctypes.data_as(_lib.c_double_p)))
 
@@ -231,34 +237,58 @@ class Operator:
         _lib.check(_lib.load().rdyhip_reset_boundary_fluxes_accum(self._h))
 
     # -- external sources (RDySet{Regional,Domain}{Water,XMomentum,YMomentum}Source, src/rdydata.c:225-366)
-    def set_domain_external_source(self, comp: int, values):
+    def set_domain_external_source(self, comp: int, values, ordered: bool = False):
         v = np.ascontiguousarray(values, dtype=np.float64).ravel()
         if v.size != self.mesh.num_owned_cells:
             raise RDyHipError(60, f"size ({v.size}) does not match the number of owned cells ({self.mesh.num_owned_cells})")
+        if ordered:
+            _lib.check(_lib.load().rdyhip_set_external_source_on(self._h, int(comp), int(v.size), None, v.ctypes.data_as(_lib.c_double_p), _stream()))
+            return
         _lib.check(_lib.load().rdyhip_set_external_source(self._h, int(comp), int(v.size), None, v.ctypes.data_as(_lib.c_double_p)))
 
-    def set_regional_external_source(self, owned_cell_ids, comp: int, values):
+    def set_regional_external_source(self, owned_cell_ids, comp: int, values, ordered: bool = False):
         ids = np.ascontiguousarray(owned_cell_ids, dtype=np.int32).ravel()
         v = np.ascontiguousarray(values, dtype=np.float64).ravel()
         if v.size != ids.size:
             raise RDyHipError(60, f"size ({v.size}) does not match the region size ({ids.size})")
+        if ordered:
+            _lib.check(_lib.load().rdyhip_set_external_source_on(self._h, int(comp), int(v.size), ids.ctypes.data_as(_lib.c_int32_p),
+                                                                v.ctypes.data_as(_lib.c_double_p), _stream()))
+            return
         _lib.check(_lib.load().rdyhip_set_external_source(self._h, int(comp), int(v.size), ids.ctypes.data_as(_lib.c_int32_p),
                                                          v.ctypes.data_as(_lib.c_double_p)))
 
     # -- Manning's n (RDySet{Regional,Domain}ManningsN, src/rdydata.c:506-539)
-    def set_domain_mannings_n(self, values):
+    def set_domain_mannings_n(self, values, ordered: bool = False):
         v = np.ascontiguousarray(values, dtype=np.float64).ravel()
         if v.size != self.mesh.num_owned_cells:
             raise RDyHipError(60, f"size ({v.size}) does not match the number of owned cells ({self.mesh.num_owned_cells})")
+        if ordered:
+            _lib.check(_lib.load().rdyhip_set_mannings_on(self._h, int(v.size), None, v.ctypes.data_as(_lib.c_double_p), _stream()))
+            return
         _lib.check(_lib.load().rdyhip_set_mannings(self._h, int(v.size), None, v.ctypes.data_as(_lib.c_double_p)))
 
-    def set_regional_mannings_n(self, owned_cell_ids, values):
+    def set_regional_mannings_n(self, owned_cell_ids, values, ordered: bool = False):
         ids = np.ascontiguousarray(owned_cell_ids, dtype=np.int32).ravel()
         v = np.ascontiguousarray(values, dtype=np.float64).ravel()
         if v.size != ids.size:
             raise RDyHipError(60, f"size ({v.size}) does not match the region size ({ids.size})")
+        if ordered:
+            _lib.check(_lib.load().rdyhip_set_mannings_on(self._h, int(v.size), ids.ctypes.data_as(_lib.c_int32_p),
+                                                         v.ctypes.data_as(_lib.c_double_p), _stream()))
+            return
         _lib.check(_lib.load().rdyhip_set_mannings(self._h, int(v.size), ids.ctypes.data_as(_lib.c_int32_p),
                                                   v.ctypes.data_as(_lib.c_double_p)))
+
+    def refresh_field(self, field: int, values):
+        """rdyhip_refresh_field: a whole input field (1: external sources [owned,3]; 2: Manning n [owned]) from a host array or a
+        device tensor, ordered on the current stream"""
+        if isinstance(values, torch.Tensor) and values.is_cuda:
+            t = values.contiguous()
+            _lib.check(_lib.load().rdyhip_refresh_field(self._h, int(field), _ptr(t), int(t.numel()), 1, _stream()))
+            return
+        v = np.ascontiguousarray(values, dtype=np.float64).ravel()
+        _lib.check(_lib.load().rdyhip_refresh_field(self._h, int(field), v.ctypes.data, int(v.size), 0, _stream()))
 
     # -- device-resident fields ------------------------------------------------
     def _field(self, field: int, ncomp: int) -> torch.Tensor:

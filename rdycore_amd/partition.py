@@ -96,10 +96,9 @@ def partition_mesh(xyz: np.ndarray, conn: np.ndarray, nparts: int, rank: int, bo
     if parts is None:
         nv = (conn >= 0).sum(axis=1)
         cent = np.where((conn >= 0)[:, :, None], xyz[np.maximum(conn, 0), :2], 0.0).sum(axis=1) / nv[:, None]
-        owned = rcb_owned_mask(cent, nparts, rank)
-    else:
-        owned = np.asarray(parts) == rank
-    return M.extract_local_mesh(xyz, conn, owned, boundary_classifier=boundary_classifier, project_2d=project_2d)
+        parts = rcb_partition(cent, nparts)
+    owned = np.asarray(parts) == rank
+    return M.extract_local_mesh(xyz, conn, owned, boundary_classifier=boundary_classifier, project_2d=project_2d, cell_parts=parts)
 
 
 def owned_cell_boundaries(namer: Optional[Callable[[np.ndarray, np.ndarray], np.ndarray]] = None, names=("domain_boundary",)):
@@ -181,7 +180,10 @@ def partitioned_structured_mesh(kind: str, nxg: int, nyg: int, d, rank: int, wor
             k = keep(qi, qj)
             qi, qj = qi[k], qj[k]
         pts = np.stack([(qi + 0.5) * d[0], (qj + 0.5) * d[1]], axis=1)
-        mine = rcb_owned_mask(pts, world, rank)
+        # every square's part, not only this rank's branch: the owners of the ghost cells order them (by owner, then by
+        # global id) so that the exchange receives in place (mesh.extract_local_mesh, rdyhip_local_cell_order)
+        sq_part = rcb_partition(pts, world)
+        mine = sq_part == rank
         del pts
         oi, oj = qi[mine], qj[mine]
         if oi.size == 0:
@@ -190,7 +192,10 @@ def partitioned_structured_mesh(kind: str, nxg: int, nyg: int, d, rank: int, wor
         j0, j1 = max(int(oj.min()) - 1, 0), min(int(oj.max()) + 2, nyg)
         owned_sq = np.zeros((j1 - j0, i1 - i0), dtype=bool)
         owned_sq[oj - j0, oi - i0] = True
-        del qi, qj, oi, oj, mine
+        inb = (qi >= i0) & (qi < i1) & (qj >= j0) & (qj < j1)
+        part_sq = np.full((j1 - j0, i1 - i0), -1, dtype=np.int32)      # squares removed from the domain keep -1
+        part_sq[qj[inb] - j0, qi[inb] - i0] = sq_part[inb]
+        del qi, qj, oi, oj, mine, sq_part, inb
     xyz, conn, cqi, cqj, t = _block_connectivity(kind, i0, i1, j0, j1, d, order, tile)
     bi, bj = np.meshgrid(np.arange(i1 - i0 + 1, dtype=np.int64), np.arange(j1 - j0 + 1, dtype=np.int64), indexing="xy")
     vgid = (bj.ravel() + j0) * (nxg + 1) + bi.ravel() + i0      # vertex (i, j) of the global (nxg+1) x (nyg+1) lattice
@@ -220,4 +225,4 @@ def partitioned_structured_mesh(kind: str, nxg: int, nyg: int, d, rank: int, wor
     owned = owned_sq[cqj - j0, cqi - i0]
     return M.extract_local_mesh(xyz, conn, owned, cell_global_ids=gids, num_cells_global=nglobal,
                                 boundary_classifier=boundary_classifier, project_2d=project_2d,
-                                vertex_global_ids=vgid, num_vertices_global=nvg)
+                                vertex_global_ids=vgid, num_vertices_global=nvg, cell_parts=part_sq[cqj - j0, cqi - i0])

@@ -73,6 +73,10 @@ class EulerStepper:
         self.fused = fused
         self._u2 = None
         self.halo = halo
+        # the stepper owns the two state arrays of the fused Euler step between the steps of one advance(): the pack of each
+        # exchange can ride on the previous step's kernel (rdyhip_halo_fuse_pack); advance() invalidates at its start
+        if halo is not None and fused and temporal == "euler" and getattr(halo, "_halo", None) is not None:
+            halo.fuse_pack(True)
         self.adaptive = adaptive
         self.time = 0.0
         self.step = 0
@@ -105,6 +109,8 @@ class EulerStepper:
         if self.forcing is not None:
             self.forcing.apply(self.time)
         self.op.reset_diagnostics()
+        if self.halo is not None and getattr(self.halo, "_halo", None) is not None:
+            self.halo.invalidate()          # the caller may have written u_local since the last interval
         cur = u_local
         if self.fused and (self._u2 is None or self._u2.shape != u_local.shape):
             self._u2 = torch.empty_like(u_local)

@@ -453,3 +453,88 @@ def test_c5_rank_3_of_8_full_size(rdyhip_kernel):
     case = CS.c5_case(mesh, 5000.0, 5000.0)
     op = _check_whole_rhs_against_oracle(case)
     op.destroy()
+
+
+@pytest.mark.timeout(1500)
+@pytest.mark.parametrize("variant", ["hr", "second_order"])
+def test_houston_refined_45M(variant, rdyhip_kernel):
+    """BASELINE.json configs[4] at its own scale: the reference's Houston1km real-DEM mesh refined SEVEN times = 44,990,464
+    triangles, 38 % of them dry (wet / dry fronts along every slope), rain + Dirichlet stage from the reference's series --
+    with hydrostatic reconstruction (ApplyInteriorFluxHR, src/swe/swe_petsc.c:1000-1161: configs[4]'s kernel) and, second
+    variant, the MUSCL path (ApplyInteriorFlux2R, 98-213) -- the whole RHS against the oracle, all 45 M cells"""
+    if rdyhip_kernel == "cell":
+        pytest.skip("one kernel variant is enough at this size")
+    case = CS.houston_refined_case(os.path.join(ROOT, "tests", "golden", "houston"), 7, "hilbert", hr=(variant == "hr"))
+    assert case.mesh.num_cells == 2746 * 4 ** 7
+    if variant == "second_order":
+        case.config.second_order = True
+    else:
+        assert case.config.well_balancing == 2
+    dry = (case.u_local[:, 0] == 0).mean()
+    assert 0.2 < dry < 0.6
+    op = _check_whole_rhs_against_oracle(case, ids=(variant == "hr"))
+    info = op.layout_info()
+    assert info["lds_fixed_layout"] == 1 and info["num_edge_records"] / case.mesh.num_cells < 1.70
+    op.destroy()
+
+
+@pytest.mark.timeout(900)
+def test_c3_strip_rank_with_ghosts_full_size(rdyhip_kernel):
+    """BASELINE.json configs[3] as one rank sees it: rank 1 of 3 of the weak-scaled strips -- 10 M owned cells, a ghost column on
+    both sides (2 x 2000 cells numbered peer by peer after the owned ones) -- the whole RHS against the oracle on the same local
+    mesh, the INTERIOR + HALO phases the overlapped step is made of = the single launch, and the step of the C ABI itself
+    (rdyhip_rhs_overlapped, ghost rows refreshed in place by a looped-back exchange) = the plain RHS"""
+    if rdyhip_kernel == "cell":
+        pytest.skip("one kernel variant is enough at this size")
+    torch = _torch()
+    import ctypes as C
+    from rdycore_amd import _lib
+    K = 2 * np.pi / 200.0
+    mesh = M.strip_partition_tri_mesh(2500, 2000, 1, 3, 1.0, zfunc=CS.mms_bathymetry(K=K), order="tiled")
+    assert mesh.num_owned_cells == 10_000_000 and mesh.num_cells == 10_004_000
+    assert np.array_equal(mesh.cell_owner_rank[mesh.num_owned_cells:], np.repeat([0, 2], 2000))      # ghosts: peer by peer
+    case = CS.friction_slope_case(mesh, 7500.0, 2000.0, dt=1e-3, K=K)
+    op = _check_whole_rhs_against_oracle(case)
+    info = op.layout_info()
+    assert 0 < info["num_halo_tiles"] < 0.03 * info["num_tiles"]
+    u = torch.tensor(case.u_local, dtype=torch.float64, device="cuda")
+    f = torch.empty((mesh.num_owned_cells, 3), dtype=torch.float64, device="cuda")
+    f2 = torch.full_like(f, -1.0)
+    op.rhs_function(case.dt, u, f)
+    op.apply_phase(1, True, case.dt, u, f2, reset_diagnostics=True)
+    op.apply_phase(2, True, case.dt, u, f2)
+    torch.cuda.synchronize()
+    assert torch.equal(f, f2)
+    # the multi-rank step itself, its exchange looped back through a one-rank RCCL communicator (as bench.py --self-exchange):
+    # the ghost-adjacent owned cells travel to the ghost rows, in place, behind the interior tiles; the result must be the
+    # plain RHS of the state that exchange leaves behind
+    lib = _lib.load()
+    uid = C.create_string_buffer(128)
+    _lib.check(lib.rdyhip_comm_unique_id(uid))
+    comm = C.c_void_p()
+    _lib.check(lib.rdyhip_comm_init_rank(1, 0, uid.raw, C.byref(comm)))
+    ghost = np.ascontiguousarray(np.arange(mesh.num_owned_cells, mesh.num_cells, dtype=np.int32))
+    gset = np.zeros(mesh.num_cells, dtype=bool)
+    gset[ghost] = True
+    cl, cr = mesh.edge_cell_ids[0::2], mesh.edge_cell_ids[1::2]
+    cut = (cr >= 0) & (gset[cl] != gset[np.maximum(cr, 0)])
+    sendc = np.unique(np.where(gset[cl[cut]], cr[cut], cl[cut])).astype(np.int32)
+    n = min(sendc.size, ghost.size)
+    i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+    p = lambda a: a.ctypes.data_as(_lib.c_int32_p)
+    h = C.c_void_p()
+    _lib.check(lib.rdyhip_halo_create(op._h, comm, 1, p(i32([0])), p(i32([n])), p(i32(sendc[:n])), p(i32([n])), p(i32(ghost[:n])), C.byref(h)))
+    assert lib.rdyhip_halo_overlaps(h) == 1 and lib.rdyhip_halo_direct_receive(h) == 1
+    st = int(torch.cuda.current_stream().cuda_stream)
+    w = u.clone()
+    _lib.check(lib.rdyhip_rhs_overlapped(op._h, h, case.dt, int(w.data_ptr()), int(f.data_ptr()), st))
+    torch.cuda.synchronize()
+    expect = u.clone()
+    expect[mesh.num_owned_cells:mesh.num_owned_cells + n] = u[torch.as_tensor(sendc[:n].astype(np.int64), device="cuda")]
+    assert torch.equal(w, expect)
+    op.rhs_function(case.dt, expect, f2)
+    torch.cuda.synchronize()
+    assert torch.equal(f, f2)
+    _lib.check(lib.rdyhip_halo_destroy(C.byref(h)))
+    _lib.check(lib.rdyhip_comm_destroy(comm))
+    op.destroy()

@@ -118,6 +118,28 @@ def _worker(rank, world, port, kernel, q, second_order=False, transport="torch",
         torch.cuda.synchronize()
         own = torch.as_tensor(mesh.cell_owned_to_local, device=dev).long()
         assert torch.allclose(u2[own], u[own] + case.dt * f, rtol=0, atol=1e-13), "fused Euler step differs from RHS + axpy"
+        if transport == "c":
+            # the two shortcuts of the exchange chain (include/rdyhip.h).  Direct receive: these meshes number their ghosts peer
+            # by peer in arrival order, so every exchange above already landed in the ghost rows themselves (no unpack launch).
+            # Fused pack: inside one advance() the pack of each exchange rides on the previous step's kernel -- the same five
+            # steps with the pack launches back give the same bits.
+            from rdycore_amd import _lib
+            from rdycore_amd.timestep import EulerStepper
+            lib = _lib.load()
+            assert halo.direct_receive
+            if not second_order and kernel != "cell":
+                ua = torch.tensor(case.u_local, dtype=torch.float64, device=dev)
+                uc = ua.clone()
+                dts = 0.1 * case.dt
+                EulerStepper(op, halo=halo).advance(ua, dts, 5 * dts)
+                assert lib.rdyhip_halo_pack_fused(halo._halo) == 1
+                stepper = EulerStepper(op, halo=halo)
+                assert halo.fuse_pack(False) is False
+                stepper.advance(uc, dts, 5 * dts)
+                torch.cuda.synchronize()
+                assert bool(torch.isfinite(ua[own]).all()) and torch.equal(ua, uc), "fused pack changes the trajectory"
+            else:
+                assert halo.fuse_pack(True) is False         # second order / the cell-centric kernel keep their pack launch
         # the plain (not overlapped) ghost update of a fresh array
         u3 = torch.tensor(u_np, dtype=torch.float64, device=dev)
         halo.exchange(u3)
@@ -303,6 +325,30 @@ def test_rccl_self_exchange_one_rank(rdyhip_kernel):
     op.rhs_function(case.dt, expect, f2)
     torch.cuda.synchronize()
     assert torch.equal(w, expect) and torch.equal(f1, f2)
+    # rows 2000.. are consecutive: the transfer above landed in the array itself (direct receive).  The fused pack over RCCL:
+    # four ping-pong Euler steps whose packs ride on the kernels = the same steps with a pack launch each
+    assert lib.rdyhip_halo_direct_receive(h) == 1 and lib.rdyhip_halo_pack_fused(h) == 0
+    res = []
+    for fuse in (1, 0):
+        _lib.check(lib.rdyhip_halo_fuse_pack(h, fuse))
+        assert lib.rdyhip_halo_pack_fused(h) == fuse
+        a, b = expect.clone(), torch.empty_like(expect)
+        for _ in range(4):
+            _lib.check(lib.rdyhip_euler_step_overlapped(op._h, h, 0.1 * case.dt, int(a.data_ptr()), int(b.data_ptr()), None, st))
+            a, b = b, a
+        torch.cuda.synchronize()
+        res.append(a.clone())
+    assert bool(torch.isfinite(res[0]).all()) and torch.equal(res[0], res[1])
+    # a state written behind the library's back must be announced: without rdyhip_halo_invalidate the stale send rows travel
+    _lib.check(lib.rdyhip_halo_fuse_pack(h, 1))
+    a, b = expect.clone(), torch.empty_like(expect)
+    _lib.check(lib.rdyhip_euler_step_overlapped(op._h, h, 0.0, int(a.data_ptr()), int(b.data_ptr()), None, st))   # dt = 0: b = a on the owned rows
+    torch.cuda.synchronize()
+    b[0:n] += 1.0                                             # the host edits the cells that are sent
+    _lib.check(lib.rdyhip_halo_invalidate(h))
+    _lib.check(lib.rdyhip_euler_step_overlapped(op._h, h, 0.0, int(b.data_ptr()), int(a.data_ptr()), None, st))
+    torch.cuda.synchronize()
+    assert torch.equal(b[2000:2000 + n], b[0:n])              # the exchange of the second step carried the edited rows
     _lib.check(lib.rdyhip_halo_destroy(C.byref(h)))
     _lib.check(lib.rdyhip_comm_destroy(comm))
     op.destroy()

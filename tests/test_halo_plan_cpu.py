@@ -98,6 +98,41 @@ def test_rcb_parts_of_the_refined_houston_mesh(world, keys_are_local_ids):
     assert max(len(p[0]) for p in res) >= min(3, world - 1)        # ranks with three and more neighbours
 
 
+@pytest.mark.parametrize("world", [5, 8])
+def test_ghosts_numbered_by_owner_are_received_in_place(world):
+    """the contiguous-ghost plan: a mesh whose ghost cells are numbered peer by peer, ascending key inside a peer
+    (mesh.extract_local_mesh with owner ranks; rdyhip_local_cell_order for a C host) gets receive lists that are ONE run of
+    consecutive rows -- what lets rdyhip_halo_create receive in place (no unpack launch)"""
+    import os
+    data = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "houston")
+    meshes = [CS.houston_refined_mesh(data, 1, "hilbert", rank=r, world=world)[0] for r in range(world)]
+    res = _plan_all(meshes, False)
+    _check_pattern(meshes, res)
+    for m, (peers, sc, send, rc, recv) in zip(meshes, res):
+        assert np.array_equal(recv, np.arange(m.num_owned_cells, m.num_cells))
+    # the same numbering from the C routine, starting from ghosts in arbitrary order
+    lib = _lib.load()
+    m = meshes[world // 2]
+    rng = np.random.default_rng(world)
+    shuffle = np.concatenate([rng.permutation(m.num_owned_cells), m.num_owned_cells + rng.permutation(m.num_cells - m.num_owned_cells)])
+    owned, owner, gid = _i32(m.cell_is_owned[shuffle]), _i32(m.cell_owner_rank[shuffle]), _i64(m.cell_global_ids[shuffle])
+    xy = np.ascontiguousarray(m.cell_centroids[shuffle])
+    perm = np.empty(m.num_cells, dtype=np.int32)
+    _lib.check(lib.rdyhip_local_cell_order(m.num_cells, xy.ctypes.data_as(_lib.c_double_p), 3, pi(owned), pi(owner), pl(gid), pi(perm)))
+    assert np.array_equal(np.sort(perm), np.arange(m.num_cells))
+    no = m.num_owned_cells
+    assert owned[perm[:no]].all() and not owned[perm[no:]].any()
+    assert np.array_equal(gid[perm[no:]], m.cell_global_ids[no:])        # ghosts: by owner, then by key -- the mesh's own order
+    hil = np.empty(m.num_cells, dtype=np.int32)
+    _lib.check(lib.rdyhip_hilbert_cell_order(m.num_cells, xy.ctypes.data_as(_lib.c_double_p), 3, pi(owned), pi(hil)))
+    assert np.array_equal(perm[:no], hil[:no])                            # owned cells: along the curve, as before
+    # argument errors: owners and keys go together, and need the owned flags
+    assert lib.rdyhip_local_cell_order(m.num_cells, xy.ctypes.data_as(_lib.c_double_p), 3, pi(owned), pi(owner), None, pi(perm)) == 83
+    assert lib.rdyhip_local_cell_order(m.num_cells, xy.ctypes.data_as(_lib.c_double_p), 3, None, pi(owner), pl(gid), pi(perm)) == 83
+    owner[np.nonzero(owned == 0)[0][0]] = -3
+    assert lib.rdyhip_local_cell_order(m.num_cells, xy.ctypes.data_as(_lib.c_double_p), 3, pi(owned), pi(owner), pl(gid), pi(perm)) == 63
+
+
 def test_strips_and_an_empty_halo_rank():
     meshes = [M.strip_partition_tri_mesh(6, 5, r, 3) for r in range(3)]
     res = _plan_all(meshes, False)
