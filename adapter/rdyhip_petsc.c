@@ -40,6 +40,12 @@
  *                             update over RCCL on the library's stream + ResetOperatorDiagnostics + ApplyOperator, interior tiles
  *                             meanwhile (1130-1139 in one call); second order included (state and gradient exchanges inside)
  *
+ *   TSRDyHipEuler ("rdyhip_euler")   a TS type that takes the WHOLE forward-Euler step in the native kernel: TSStep = ghost update over
+ *                             RCCL + rdyhip_euler_step_overlapped on two ping-pong local arrays (F is never stored, no separate
+ *                             VecAXPY: 0.32 instead of 0.44 ms per 10 M-cell step); the solution Vec is placed on the owned rows of the
+ *                             array that holds the current state (VecHIPPlaceArray), so monitors and output read it as ever.
+ *                             Selected in InitSolver when -rdy_hip_native and temporal: euler (src/rdysetup.c:1183-1185).
+ *
  * plus four small hooks the patch in INTEGRATION.md section 2 wires in: RDyHipResetDiagnostics, RDyHipUpdateDiagnostics
  * (called by UpdateOperatorDiagnostics before its MPI_Allreduce, src/operator.c:867-883), RDyHipSyncBoundaryFluxes (called by
  * ExtractOperatorBoundaryFluxes before it reads boundary_fluxes_accum, src/operator.c:1069-1086) and
@@ -49,8 +55,11 @@
  * as they are (VecGetArrayReadAndMemType, the pattern of src/operator.c:563-573); host Vecs are staged through device
  * scratch (correct, slow -- meant for checking the backend against the PETSc one on a workstation).
  *
- * Streams: every launch goes on the stream of PETSc's current device context (PetscDeviceContextGetStreamHandle), i.e.
- * it is ordered with PETSc's own Vec kernels (VecAXPY of TSEULER, VecZeroEntries) without a device synchronisation.
+ * Streams: every launch AND every copy goes on the stream of PETSc's current device context (PetscDeviceContextGetStreamHandle),
+ * i.e. it is ordered with PETSc's own Vec kernels (VecAXPY of TSEULER, VecZeroEntries) without a device synchronisation.  The
+ * per-advance refresh of rain, Dirichlet values and Manning n is stream-ordered too (rdyhip_refresh_field,
+ * rdyhip_set_boundary_values_on: pinned staging, the library's copy stream): with a fixed time step nothing in RDyAdvance
+ * drains the device (a drained MI355X runs its next ~40 launches 20-30 % slow).
  *
  * Parallel runs: through the plain PetscOperator seam (ApplyHipSource after PETSc's DMGlobalToLocal) only FIRST order
  * is possible -- a second-order apply on a mesh with ghost cells needs the ghost gradients exchanged between its two
@@ -67,6 +76,7 @@
 
 #include <hip/hip_runtime_api.h>
 #include <petsc.h>
+#include <petsc/private/tsimpl.h>
 #include <private/rdycoreimpl.h>
 #include <private/rdyoperatorimpl.h>
 #include <private/rdysweimpl.h>
@@ -283,38 +293,38 @@ static PetscErrorCode CreateShared(RDyConfig *config, RDyMesh *mesh, PetscInt nu
   PetscFunctionReturn(PETSC_SUCCESS);
 }
 
-// copies a (host or device) Vec's array over a device array of the operator if the Vec changed since the last copy
-static PetscErrorCode RefreshField(Vec v, PetscObjectState *seen, double *d_dst, int64_t nvalues) {
+// the stream PETSc's own device kernels run on (the current device context's), so that our launches are ordered with them
+static PetscErrorCode PetscHipStream(hipStream_t *stream) {
+  PetscFunctionBegin;
+  PetscDeviceContext dctx;
+  void              *handle = NULL;
+  PetscCall(PetscDeviceContextGetCurrentContext(&dctx));
+  PetscCall(PetscDeviceContextGetStreamHandle(dctx, &handle));  // for a HIP context: a pointer to its hipStream_t
+  PetscCheck(handle, PETSC_COMM_SELF, PETSC_ERR_SUP, "PETSc's current device context has no HIP stream (a host context?): run with -dm_vec_type hip");
+  *stream = *(hipStream_t *)handle;
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+// replaces an input field of the operator by a (host or device) Vec's array if the Vec changed since the last refresh: ordered
+// on PETSc's stream (launches already enqueued there still see the old values), nothing blocks, nothing drains the device
+static PetscErrorCode RefreshField(RDyHipShared *s, Vec v, PetscObjectState *seen, RDyHipField field, hipStream_t stream) {
   PetscFunctionBegin;
   PetscObjectState st;
   PetscCall(PetscObjectStateGet((PetscObject)v, &st));
   if (st == *seen) PetscFunctionReturn(PETSC_SUCCESS);
   PetscInt n;
   PetscCall(VecGetLocalSize(v, &n));
-  PetscCheck((int64_t)n == nvalues, PETSC_COMM_SELF, PETSC_ERR_ARG_SIZ, "Vec of %" PetscInt_FMT " values for a device field of %lld", n, (long long)nvalues);
   const PetscScalar *a;
   PetscMemType       mt;
   PetscCall(VecGetArrayReadAndMemType(v, &a, &mt));
-  HipCall(hipDeviceSynchronize());  // an RHS in flight may still read the field
-  HipCall(hipMemcpy(d_dst, a, sizeof(double) * (size_t)n, PetscMemTypeDevice(mt) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+  RDyHipCall(rdyhip_refresh_field(s->handle, field, a, (int64_t)n, PetscMemTypeDevice(mt) ? 1 : 0, (void *)stream));  // checks n against the field
   PetscCall(VecRestoreArrayReadAndMemType(v, &a));
   *seen = st;
   PetscFunctionReturn(PETSC_SUCCESS);
 }
 
-// the stream PETSc's own device kernels run on (the current device context's), so that our launches are ordered with them
-static PetscErrorCode PetscHipStream(hipStream_t *stream) {
-  PetscFunctionBegin;
-  PetscDeviceContext dctx;
-  void              *handle;
-  PetscCall(PetscDeviceContextGetCurrentContext(&dctx));
-  PetscCall(PetscDeviceContextGetStreamHandle(dctx, &handle));  // for a HIP context: a pointer to its hipStream_t
-  *stream = *(hipStream_t *)handle;
-  PetscFunctionReturn(PETSC_SUCCESS);
-}
-
 // the Dirichlet values the host changed since the last apply (SetOperatorBoundaryValues writes the Vecs, src/operator.c:1045-1061)
-static PetscErrorCode RefreshBoundaryValues(RDyHipShared *s) {
+static PetscErrorCode RefreshBoundaryValues(RDyHipShared *s, hipStream_t stream) {
   PetscFunctionBegin;
   for (PetscInt b = 0; b < s->num_boundaries; ++b) {
     PetscObjectState st;
@@ -322,7 +332,7 @@ static PetscErrorCode RefreshBoundaryValues(RDyHipShared *s) {
     if (st == s->boundary_values_state[b] || s->boundary_num_edges[b] == 0) continue;
     const PetscScalar *a;
     PetscCall(VecGetArrayRead(s->boundary_values[b], &a));  // VECSEQ in the PETSc backend (operator.c:47-75): a host array [edge][3]
-    RDyHipCall(rdyhip_set_boundary_values(s->handle, (int32_t)b, 0, 3, (int32_t)s->boundary_num_edges[b], a));
+    RDyHipCall(rdyhip_set_boundary_values_on(s->handle, (int32_t)b, 0, 3, (int32_t)s->boundary_num_edges[b], a, (void *)stream));  // staged: `a` is free again on return
     PetscCall(VecRestoreArrayRead(s->boundary_values[b], &a));
     s->boundary_values_state[b] = st;
   }
@@ -330,14 +340,10 @@ static PetscErrorCode RefreshBoundaryValues(RDyHipShared *s) {
 }
 
 // external sources / Manning n: whole-array copies when the Vecs changed (their layouts are the device fields', operator.c:91-96)
-static PetscErrorCode RefreshCellFields(RDyHipShared *s) {
+static PetscErrorCode RefreshCellFields(RDyHipShared *s, hipStream_t stream) {
   PetscFunctionBegin;
-  double *d_ext, *d_man;
-  int64_t n_ext, n_man;
-  RDyHipCall(rdyhip_field_ptr(s->handle, RDYHIP_FIELD_EXTERNAL_SOURCES, &d_ext, &n_ext));
-  RDyHipCall(rdyhip_field_ptr(s->handle, RDYHIP_FIELD_MANNINGS, &d_man, &n_man));
-  PetscCall(RefreshField(s->external_sources, &s->external_sources_state, d_ext, n_ext));
-  PetscCall(RefreshField(s->material_properties, &s->material_properties_state, d_man, n_man));
+  PetscCall(RefreshField(s, s->external_sources, &s->external_sources_state, RDYHIP_FIELD_EXTERNAL_SOURCES, stream));
+  PetscCall(RefreshField(s, s->material_properties, &s->material_properties_state, RDYHIP_FIELD_MANNINGS, stream));
   PetscFunctionReturn(PETSC_SUCCESS);
 }
 
@@ -347,7 +353,10 @@ static PetscErrorCode RefreshCellFields(RDyHipShared *s) {
 static PetscErrorCode ApplyHipFlux(void *context, PetscOperatorFields fields, PetscReal dt, Vec u_local, Vec f_global) {
   PetscFunctionBegin;
   RDyHipShared *s = context;
-  PetscCall(RefreshBoundaryValues(s));
+  (void)fields; (void)dt; (void)u_local; (void)f_global;  // the launch itself is ApplyHipSource's
+  hipStream_t stream;
+  PetscCall(PetscHipStream(&stream));
+  PetscCall(RefreshBoundaryValues(s, stream));
   PetscFunctionReturn(PETSC_SUCCESS);
 }
 
@@ -376,13 +385,14 @@ PetscErrorCode CreateHipSWEFluxOperator(RDyConfig *config, RDyMesh *mesh, MPI_Co
 static PetscErrorCode ApplyHipSource(void *context, PetscOperatorFields fields, PetscReal dt, Vec u_local, Vec f_global) {
   PetscFunctionBegin;
   RDyHipShared *s = context;
-  PetscCall(RefreshCellFields(s));
+  (void)fields;
+  hipStream_t stream;
+  PetscCall(PetscHipStream(&stream));
+  PetscCall(RefreshCellFields(s, stream));
   // second order on a partitioned mesh needs the ghost gradients exchanged between the two phases of the apply: that is
   // OperatorRHSFunctionHip's job (the library would refuse this call with "needs RDYHIP_PHASE_GRADIENTS_READY")
   PetscCheck(!(s->second_order && s->mesh->num_cells > s->mesh->num_owned_cells), PETSC_COMM_WORLD, PETSC_ERR_SUP,
              "second_order on several ranks: install OperatorRHSFunctionHip (RDyHipCreateHaloFromDM) instead of the plain PetscOperator path");
-  hipStream_t stream;
-  PetscCall(PetscHipStream(&stream));
 
   const PetscScalar *u;
   PetscScalar       *f;
@@ -399,11 +409,12 @@ static PetscErrorCode ApplyHipSource(void *context, PetscOperatorFields fields, 
   } else {
     if (!s->d_u) HipCall(hipMalloc((void **)&s->d_u, sizeof(double) * (size_t)(nu > 0 ? nu : 1)));
     if (!s->d_f) HipCall(hipMalloc((void **)&s->d_f, sizeof(double) * (size_t)(nf > 0 ? nf : 1)));
-    HipCall(hipMemcpy(s->d_u, u, sizeof(double) * (size_t)nu, PetscMemTypeDevice(mu) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
-    HipCall(hipMemcpy(s->d_f, f, sizeof(double) * (size_t)nf, PetscMemTypeDevice(mf) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+    // every copy on the same stream as the launch: ordered after PETSc's producers of the arrays and before the kernel
+    HipCall(hipMemcpyAsync(s->d_u, u, sizeof(double) * (size_t)nu, PetscMemTypeDevice(mu) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, stream));
+    HipCall(hipMemcpyAsync(s->d_f, f, sizeof(double) * (size_t)nf, PetscMemTypeDevice(mf) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, stream));
     RDyHipCall(rdyhip_apply(s->handle, dt, s->d_u, s->d_f, (void *)stream));
-    HipCall(hipStreamSynchronize(stream));
-    HipCall(hipMemcpy(f, s->d_f, sizeof(double) * (size_t)nf, PetscMemTypeDevice(mf) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost));
+    HipCall(hipMemcpyAsync(f, s->d_f, sizeof(double) * (size_t)nf, PetscMemTypeDevice(mf) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, stream));
+    HipCall(hipStreamSynchronize(stream));  // the host arrays are PETSc's again on return
   }
   PetscCall(VecRestoreArrayAndMemType(f_global, &f));
   PetscCall(VecRestoreArrayReadAndMemType(u_local, &u));
@@ -432,43 +443,15 @@ PetscErrorCode CreateHipSWESourceOperator(RDyConfig *config, RDyMesh *mesh, Vec 
 // the multi-rank binding: local cell numbering, the ghost exchange from the DM's point SF, the overlapped RHS function
 //-------------------------------------------------------------------------------------------------
 
-// Renumbers the LOCAL cells of a distributed (and overlapped) DMPlex: owned cells first, ghosts after, each group along a
-// Hilbert curve through the cell centroids.  Call between DMPlexDistributeOverlap and everything that reads point numbers
-// (labels made afterwards, RDyMeshCreateFromDM, the sections).  Edges and vertices keep their numbers.
-PetscErrorCode RDyHipPermuteLocalCells(DM *dm) {
+// DMPlexPermute of the cells [c_start, c_end) by perm[new cell] = old cell (the other points keep their numbers).  Collective:
+// DMPlexPermute remaps the point SF's remote indices with a PetscSFBcast, so EVERY rank must call it -- a rank without cells
+// with the identity -- or the others' remote indices go stale (or the broadcast hangs).
+static PetscErrorCode PermuteCells(DM *dm, PetscInt c_start, PetscInt nc, const int32_t *perm) {
   PetscFunctionBegin;
-  PetscInt c_start, c_end, p_start, p_end;
-  PetscCall(DMPlexGetHeightStratum(*dm, 0, &c_start, &c_end));
+  PetscInt p_start, p_end;
   PetscCall(DMPlexGetChart(*dm, &p_start, &p_end));
-  const PetscInt nc = c_end - c_start;
-  if (nc == 0) PetscFunctionReturn(PETSC_SUCCESS);
-
-  // which cells are ghosts: the leaves of the point SF (points owned by another rank)
-  int32_t *is_owned, *perm;
-  double  *xy;
-  PetscCall(PetscMalloc3(nc, &is_owned, nc, &perm, 2 * nc, &xy));
-  for (PetscInt c = 0; c < nc; ++c) is_owned[c] = 1;
-  PetscSF            sf;
-  PetscInt           nroots, nleaves;
-  const PetscInt    *ilocal;
-  const PetscSFNode *iremote;
-  PetscCall(DMGetPointSF(*dm, &sf));
-  PetscCall(PetscSFGetGraph(sf, &nroots, &nleaves, &ilocal, &iremote));
-  for (PetscInt i = 0; i < (nroots >= 0 ? nleaves : 0); ++i) {
-    const PetscInt p = ilocal ? ilocal[i] : i;
-    if (p >= c_start && p < c_end) is_owned[p - c_start] = 0;
-  }
-  for (PetscInt c = c_start; c < c_end; ++c) {
-    PetscReal area, centroid[3], normal[3];
-    PetscCall(DMPlexComputeCellGeometryFVM(*dm, c, &area, centroid, normal));
-    xy[2 * (c - c_start)]     = centroid[0];
-    xy[2 * (c - c_start) + 1] = centroid[1];
-  }
-  RDyHipCall(rdyhip_hilbert_cell_order((int32_t)nc, xy, 2, is_owned, perm));  // perm[new cell] = old cell
-
-  // DMPlexPermute wants perm[old point] = new point, over the whole chart
-  PetscInt *new_of_old;
-  PetscCall(PetscMalloc1(p_end - p_start, &new_of_old));
+  PetscInt *new_of_old;  // DMPlexPermute wants perm[old point] = new point, over the whole chart
+  PetscCall(PetscMalloc1(p_end - p_start > 0 ? p_end - p_start : 1, &new_of_old));
   for (PetscInt p = p_start; p < p_end; ++p) new_of_old[p - p_start] = p;
   for (PetscInt i = 0; i < nc; ++i) new_of_old[c_start + perm[i] - p_start] = c_start + i;
   IS is;
@@ -476,9 +459,72 @@ PetscErrorCode RDyHipPermuteLocalCells(DM *dm) {
   PetscCall(ISCreateGeneral(PETSC_COMM_SELF, p_end - p_start, new_of_old, PETSC_OWN_POINTER, &is));
   PetscCall(DMPlexPermute(*dm, is, &pdm));  // carries coordinates, labels, the local section and the point SF along
   PetscCall(ISDestroy(&is));
-  PetscCall(PetscFree3(is_owned, perm, xy));
   PetscCall(DMDestroy(dm));
   *dm = pdm;
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+// which local cells are ghosts (leaves of the point SF), their owner ranks and the owners' point numbers for them
+static PetscErrorCode GhostCells(DM dm, PetscInt c_start, PetscInt c_end, int32_t *is_owned, int32_t *owner, int64_t *key) {
+  PetscFunctionBegin;
+  PetscSF            sf;
+  PetscInt           nroots, nleaves;
+  const PetscInt    *ilocal;
+  const PetscSFNode *iremote;
+  for (PetscInt c = 0; c < c_end - c_start; ++c) {
+    is_owned[c] = 1;
+    owner[c]    = -1;
+    key[c]      = -1;
+  }
+  PetscCall(DMGetPointSF(dm, &sf));
+  PetscCall(PetscSFGetGraph(sf, &nroots, &nleaves, &ilocal, &iremote));
+  for (PetscInt i = 0; i < (nroots >= 0 ? nleaves : 0); ++i) {
+    const PetscInt p = ilocal ? ilocal[i] : i;
+    if (p < c_start || p >= c_end) continue;
+    is_owned[p - c_start] = 0;
+    owner[p - c_start]    = (int32_t)iremote[i].rank;
+    key[p - c_start]      = (int64_t)iremote[i].index;
+  }
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+// Renumbers the LOCAL cells of a distributed (and overlapped) DMPlex in two collective passes.  Call between
+// DMPlexDistributeOverlap and everything that reads point numbers (labels made afterwards, RDyMeshCreateFromDM, the sections).
+//   pass 1  owned cells first, along a Hilbert curve through the centroids (the operator's tiles are runs of 256 consecutive
+//           owned cells); the ghosts after them in any order.  DMPlexPermute remaps the SF: every ghost's remote index is now
+//           its owner's NEW number for it.
+//   pass 2  the ghosts alone, grouped by owner rank and ascending remote index inside a group -- the order in which
+//           rdyhip_halo_plan_* lists them on both sides, so that every peer's ghosts are consecutive rows in arrival order and
+//           the exchange receives straight into u_local (rdyhip_halo_direct_receive; no unpack launch).  Owned cells keep the
+//           numbers of pass 1, so nobody's remote indices move.
+PetscErrorCode RDyHipPermuteLocalCells(DM *dm) {
+  PetscFunctionBegin;
+  for (int pass = 1; pass <= 2; ++pass) {
+    PetscInt c_start, c_end;
+    PetscCall(DMPlexGetHeightStratum(*dm, 0, &c_start, &c_end));
+    const PetscInt nc = c_end - c_start;
+    int32_t       *is_owned, *owner, *perm;
+    int64_t       *key;
+    double        *xy;
+    PetscCall(PetscMalloc3(nc > 0 ? nc : 1, &is_owned, nc > 0 ? nc : 1, &owner, nc > 0 ? nc : 1, &perm));
+    PetscCall(PetscMalloc1(nc > 0 ? nc : 1, &key));
+    PetscCall(PetscMalloc1(nc > 0 ? 2 * nc : 1, &xy));
+    PetscCall(GhostCells(*dm, c_start, c_end, is_owned, owner, key));
+    for (PetscInt c = c_start; c < c_end; ++c) {
+      PetscReal area, centroid[3], normal[3];
+      PetscCall(DMPlexComputeCellGeometryFVM(*dm, c, &area, centroid, normal));
+      xy[2 * (c - c_start)]     = centroid[0];
+      xy[2 * (c - c_start) + 1] = centroid[1];
+    }
+    // perm[new cell] = old cell.  Pass 2 runs on the numbering of pass 1: its owned prefix is already in curve order (the sort
+    // is stable in the old cell id for equal keys and the Hilbert keys are unchanged), only the ghosts move.
+    if (pass == 1) RDyHipCall(rdyhip_hilbert_cell_order((int32_t)nc, xy, 2, is_owned, perm));
+    else RDyHipCall(rdyhip_local_cell_order((int32_t)nc, xy, 2, is_owned, owner, key, perm));
+    PetscCall(PermuteCells(dm, c_start, nc, perm));  // every rank, also with nc == 0
+    PetscCall(PetscFree3(is_owned, owner, perm));
+    PetscCall(PetscFree(key));
+    PetscCall(PetscFree(xy));
+  }
   PetscFunctionReturn(PETSC_SUCCESS);
 }
 
@@ -562,6 +608,28 @@ PetscErrorCode RDyHipCreateHaloFromDM(DM dm, RDyMesh *mesh) {
   RDyHipCall(rdyhip_comm_init_rank((int32_t)size, (int32_t)rank, id, &s->nccl_comm));
   RDyHipCall(rdyhip_halo_create(s->handle, s->nccl_comm, npeers, peers, send_counts, send_cells, recv_counts, recv_cells, &s->halo));
 
+  // Cross-check of the whole chain (SF remap under DMPlexPermute, plan, communicator, exchange) with one exchange at setup:
+  // every owned cell carries its global id, every ghost row must come back holding the id RDyMesh has for that ghost.  The
+  // plan's own checks only catch requests for cells that are not owned; a request for the WRONG owned cell would be silent.
+  {
+    const PetscInt nloc = mesh->num_cells;
+    double        *h_ids, *d_ids;
+    PetscCall(PetscMalloc1(nloc > 0 ? 3 * nloc : 1, &h_ids));
+    for (PetscInt c = 0; c < nloc; ++c)
+      for (int k = 0; k < 3; ++k) h_ids[3 * c + k] = mesh->cells.is_owned[c] ? (double)mesh->cells.global_ids[c] : -1.0;
+    HipCall(hipMalloc((void **)&d_ids, sizeof(double) * (size_t)(nloc > 0 ? 3 * nloc : 1)));
+    HipCall(hipMemcpy(d_ids, h_ids, sizeof(double) * 3 * (size_t)nloc, hipMemcpyHostToDevice));
+    RDyHipCall(rdyhip_halo_exchange(s->halo, d_ids, 3, NULL));
+    HipCall(hipStreamSynchronize(NULL));
+    HipCall(hipMemcpy(h_ids, d_ids, sizeof(double) * 3 * (size_t)nloc, hipMemcpyDeviceToHost));
+    HipCall(hipFree(d_ids));
+    PetscInt bad = 0;
+    for (PetscInt c = 0; c < nloc; ++c)
+      if (!mesh->cells.is_owned[c] && h_ids[3 * c] != (double)mesh->cells.global_ids[c]) ++bad;
+    PetscCall(PetscFree(h_ids));
+    PetscCheck(bad == 0, PETSC_COMM_SELF, PETSC_ERR_PLIB, "%" PetscInt_FMT " ghost cells received another cell's data in the setup exchange: the point SF and RDyMesh disagree", bad);
+  }
+
   RDyHipCall(rdyhip_halo_plan_destroy(&plan));
   PetscCall(PetscFree(owned));
   PetscCall(PetscFree(in_keys));
@@ -584,8 +652,10 @@ PetscErrorCode OperatorRHSFunctionHip(TS ts, PetscReal t, Vec U, Vec F, void *ct
   PetscCall(TSGetTimeStep(ts, &dt));
 
   // what the two PetscOperators' apply functions do before the launch: inputs the host changed since the last RHS
-  PetscCall(RefreshBoundaryValues(s));
-  PetscCall(RefreshCellFields(s));
+  hipStream_t stream;
+  PetscCall(PetscHipStream(&stream));
+  PetscCall(RefreshBoundaryValues(s, stream));
+  PetscCall(RefreshCellFields(s, stream));
 
   const PetscScalar *u;
   PetscScalar       *ul, *f;
@@ -595,8 +665,6 @@ PetscErrorCode OperatorRHSFunctionHip(TS ts, PetscReal t, Vec U, Vec F, void *ct
   PetscCall(VecGetArrayWriteAndMemType(F, &f, &mf));
   PetscCheck(PetscMemTypeDevice(mu) && PetscMemTypeDevice(ml) && PetscMemTypeDevice(mf), rdy->comm, PETSC_ERR_SUP,
              "OperatorRHSFunctionHip needs device Vecs (-dm_vec_type hip); host Vecs go through the PetscOperator path");
-  hipStream_t stream;
-  PetscCall(PetscHipStream(&stream));
   // DMGlobalToLocal, local half: the owned rows of u_local (one contiguous copy after RDyHipPermuteLocalCells) ...
   RDyHipCall(rdyhip_copy_owned_rows(s->handle, u, ul, (void *)stream));
   if (s->halo) {
@@ -622,6 +690,140 @@ PetscErrorCode OperatorRHSFunctionHip(TS ts, PetscReal t, Vec U, Vec F, void *ct
     RDyLogDebug(rdy, "[%" PetscInt_FMT "] Time = %f [%s] Max courant number %g", stepnum, ConvertTimeFromSeconds(time, rdy->config.time.unit),
                 TimeUnitAsString(rdy->config.time.unit), diagnostics.courant_number.max_courant_num);
   }
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+//-------------------------------------------------------------------------------------------------
+// TSRDyHipEuler: forward Euler with the update fused into the RHS kernel (rdyhip_euler_step_overlapped)
+//-------------------------------------------------------------------------------------------------
+// TSEULER evaluates F = RHS(U) and then U += dt F with a separate VecAXPY (TSStep_Euler): 0.44 ms per 10 M-cell step, of which
+// the axpy pass and the F store are 0.12.  This TS type hands the whole step to the native kernel: two local arrays ([num_cells][3],
+// owned rows first) ping-pong, the kernel reads one and writes the owned rows of the other, the ghost rows of the input are
+// refreshed over RCCL at the start of each step, F never exists.  The TS's solution Vec (rdy->u_global, TSSetSolution) does not get
+// copied either: it is PLACED on the owned rows of whichever array holds the current state (VecHIPPlaceArray), so monitors,
+// output and RDyGet* read the current solution as ever, and whatever the host writes into it (initial conditions, a restart,
+// RDySet*) lands in that array -- noticed through the Vec's PetscObjectState, which makes the next step pack its send cells
+// again (rdyhip_halo_invalidate).  Needs device Vecs (-dm_vec_type hip) and owned cells numbered first
+// (RDyHipPermuteLocalCells).  Registered as "rdyhip_euler"; InitSolver selects it instead of TSEULER.
+typedef struct {
+  RDy              rdy;
+  double          *d_state[2];  // the two local arrays
+  int              cur;         // which one holds the current state
+  PetscBool        placed;      // vec_sol's array is d_state[cur]
+  PetscObjectState seen;        // vec_sol's state after our last step
+} TS_RDyHipEuler;
+
+static PetscErrorCode TSSetUp_RDyHipEuler(TS ts) {
+  PetscFunctionBegin;
+  TS_RDyHipEuler *e = (TS_RDyHipEuler *)ts->data;
+  PetscCall(TSGetApplicationContext(ts, &e->rdy));
+  PetscCheck(e->rdy, PETSC_COMM_WORLD, PETSC_ERR_ORDER, "TSRDyHipEuler needs the RDy as application context (TSSetApplicationContext, src/rdysetup.c:1198)");
+  RDyHipShared *s = FindShared(&e->rdy->mesh);
+  PetscCheck(s, e->rdy->comm, PETSC_ERR_ORDER, "no native operator for this RDy (CreateOperator with -rdy_hip_native first)");
+  PetscCheck(s->halo || e->rdy->mesh.num_cells == e->rdy->mesh.num_owned_cells, e->rdy->comm, PETSC_ERR_ORDER,
+             "the mesh has ghost cells: call RDyHipCreateHaloFromDM after CreateOperator");
+  const size_t bytes = sizeof(double) * 3 * (size_t)(e->rdy->mesh.num_cells > 0 ? e->rdy->mesh.num_cells : 1);
+  for (int k = 0; k < 2; ++k)
+    if (!e->d_state[k]) {
+      HipCall(hipMalloc((void **)&e->d_state[k], bytes));
+      HipCall(hipMemset(e->d_state[k], 0, bytes));
+    }
+  if (s->halo) RDyHipCall(rdyhip_halo_fuse_pack(s->halo, 1));  // first order / HR: the pack rides on the step kernel (second order keeps its launch)
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+static PetscErrorCode TSStep_RDyHipEuler(TS ts) {
+  PetscFunctionBegin;
+  TS_RDyHipEuler *e   = (TS_RDyHipEuler *)ts->data;
+  RDy             rdy = e->rdy;
+  RDyHipShared   *s   = FindShared(&rdy->mesh);
+  Vec             U   = ts->vec_sol;
+  hipStream_t     stream;
+  PetscCall(PetscHipStream(&stream));
+  PetscCall(TSPreStage(ts, ts->ptime));
+  PetscCall(RefreshBoundaryValues(s, stream));
+  PetscCall(RefreshCellFields(s, stream));
+
+  PetscObjectState st;
+  PetscCall(PetscObjectStateGet((PetscObject)U, &st));
+  if (!e->placed) {
+    // first step (or after a reset): the state is in U's own array -> owned rows of d_state[cur]
+    const PetscScalar *u;
+    PetscMemType       mu;
+    PetscCall(VecGetArrayReadAndMemType(U, &u, &mu));
+    PetscCheck(PetscMemTypeDevice(mu), rdy->comm, PETSC_ERR_SUP, "TSRDyHipEuler needs device Vecs (-dm_vec_type hip)");
+    RDyHipCall(rdyhip_copy_owned_rows(s->handle, u, e->d_state[e->cur], (void *)stream));
+    PetscCall(VecRestoreArrayReadAndMemType(U, &u));
+    if (s->halo) RDyHipCall(rdyhip_halo_invalidate(s->halo));
+  } else if (st != e->seen) {
+    // somebody wrote the solution since our last step: it went straight into d_state[cur] (U is placed there), but the send
+    // rows the last kernel packed are stale
+    if (s->halo) RDyHipCall(rdyhip_halo_invalidate(s->halo));
+  }
+  double *in = e->d_state[e->cur], *out = e->d_state[1 - e->cur];
+  if (s->halo) RDyHipCall(rdyhip_euler_step_overlapped(s->handle, s->halo, ts->time_step, in, out, NULL, (void *)stream));
+  else RDyHipCall(rdyhip_euler_step(s->handle, RDYHIP_PHASE_ALL, RDYHIP_PHASE_RESET_DIAGNOSTICS, ts->time_step, in, out, NULL, (void *)stream));
+  // the solution Vec now IS the owned rows of `out` (owned cells are numbered first: one contiguous block of 3 * no values)
+  if (e->placed) PetscCall(VecHIPResetArray(U));
+  PetscCall(VecHIPPlaceArray(U, out));
+  e->placed = PETSC_TRUE;
+  e->cur    = 1 - e->cur;
+  PetscCall(PetscObjectStateIncrease((PetscObject)U));
+  PetscCall(PetscObjectStateGet((PetscObject)U, &e->seen));
+  ts->ptime += ts->time_step;
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+static PetscErrorCode TSReset_RDyHipEuler(TS ts) {
+  PetscFunctionBegin;
+  TS_RDyHipEuler *e = (TS_RDyHipEuler *)ts->data;
+  if (e->placed && ts->vec_sol) {
+    // give U its own array back, holding the current state
+    hipStream_t stream;
+    PetscCall(PetscHipStream(&stream));
+    const double *cur = e->d_state[e->cur];
+    PetscCall(VecHIPResetArray(ts->vec_sol));
+    PetscScalar *u;
+    PetscMemType mu;
+    PetscInt     n;
+    PetscCall(VecGetLocalSize(ts->vec_sol, &n));
+    PetscCall(VecGetArrayWriteAndMemType(ts->vec_sol, &u, &mu));
+    HipCall(hipMemcpyAsync(u, cur, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, stream));
+    HipCall(hipStreamSynchronize(stream));
+    PetscCall(VecRestoreArrayWriteAndMemType(ts->vec_sol, &u));
+    e->placed = PETSC_FALSE;
+  }
+  for (int k = 0; k < 2; ++k) {
+    if (e->d_state[k]) HipCall(hipFree(e->d_state[k]));
+    e->d_state[k] = NULL;
+  }
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+static PetscErrorCode TSDestroy_RDyHipEuler(TS ts) {
+  PetscFunctionBegin;
+  PetscCall(TSReset_RDyHipEuler(ts));
+  PetscCall(PetscFree(ts->data));
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+static PetscErrorCode TSCreate_RDyHipEuler(TS ts) {
+  PetscFunctionBegin;
+  TS_RDyHipEuler *e;
+  PetscCall(PetscNew(&e));
+  ts->data         = (void *)e;
+  ts->ops->setup   = TSSetUp_RDyHipEuler;
+  ts->ops->step    = TSStep_RDyHipEuler;
+  ts->ops->reset   = TSReset_RDyHipEuler;
+  ts->ops->destroy = TSDestroy_RDyHipEuler;
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+// once, before InitSolver: TSRegister makes "rdyhip_euler" a TSType; InitSolver then does TSSetType(rdy->ts, "rdyhip_euler")
+// instead of TSEULER when the native backend is on, the rest of InitSolver unchanged
+PetscErrorCode RDyHipRegisterTS(void) {
+  PetscFunctionBegin;
+  PetscCall(TSRegister("rdyhip_euler", TSCreate_RDyHipEuler));
   PetscFunctionReturn(PETSC_SUCCESS);
 }
 

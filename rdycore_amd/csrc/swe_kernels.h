@@ -382,6 +382,14 @@ __device__ __forceinline__ void load_streams(const KernelArgs &a, int o, bool ac
 // checked against at create) -- every plane offset is then an instruction immediate instead of a register and an add.
 // 0: lengths from the mesh (a.hmax, a.emax), any numbering.  The lengths are not multiples of 64 doubles on purpose: hipcc
 // would fuse the reads of two planes into ds_read2st64_b64, which the LDS serves at half the rate of two ds_read_b64.
+// HR kernels stage the velocities with the HR operator's wet test, "h > tiny_h" (swe_petsc.c:1061-1064), instead of
+// ComputeRiemannVelocities' "h < tiny_h => 0" (62): the edge phase then needs no per-edge selects.  The two rules differ only
+// at h == tiny_h exactly, where the boundary edges and the primitive variables (which keep the other rule) recompute.
+__device__ __forceinline__ void hr_velocity_rule(RiemannSide &s, double tiny_h) {
+  const bool wet = s.h > tiny_h;
+  s.u            = wet ? s.u : 0.0;
+  s.v            = wet ? s.v : 0.0;
+}
 constexpr int TILED_NS_TRI = 360, TILED_NE_TRI = 520, TILED_NS_QUAD = 368, TILED_NE_QUAD = 552;
 template <int S, int SRC, bool OVW, bool HR, bool EULER = false, int NS = 0, int NE = 0>
 __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(3, 3))) void swe_rhs_tiled_kernel(const KernelArgs a, const double dt, const double *__restrict__ u,
@@ -390,6 +398,11 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
   // (1.6 per cell), a quad tile up to 3 x 256 (a 16 x 16 block: 544).  Records beyond that (poor numberings) are loaded
   // inside the flux phase.
   constexpr int NR = (S == 3) ? 2 : RDYHIP_QUAD_ROUNDS;
+#ifdef RDYHIP_HR_V1
+  constexpr bool HR_STAGED_VEL = false;
+#else
+  constexpr bool HR_STAGED_VEL = HR;
+#endif
   extern __shared__ double lds[];
   const int nside = NS > 0 ? NS : TILE + a.hmax;
   const int nedge = NE > 0 ? NE : a.emax;
@@ -484,18 +497,21 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
         RiemannSide self;
         self.h = self.u = self.v = self.sqh = self.c = 0.0;
         if (active) self = riemann_side(pu0, pu1, pu2, a.tiny_h, a.h_anuga_sq);
+        if (HR_STAGED_VEL) hr_velocity_rule(self, a.tiny_h);
         sd_h[tid] = self.h; sd_u[tid] = self.u; sd_v[tid] = self.v; sd_sq[tid] = self.sqh; sd_c[tid] = self.c;
         sd_hu[tid] = pu1;
         sd_hv[tid] = pu2;
         if (HR) sd_zc[tid] = pz;
         if (tid < nh) {
-          const RiemannSide hs = riemann_side(ph0, ph1, ph2, a.tiny_h, a.h_anuga_sq);
+          RiemannSide hs = riemann_side(ph0, ph1, ph2, a.tiny_h, a.h_anuga_sq);
+          if (HR_STAGED_VEL) hr_velocity_rule(hs, a.tiny_h);
           sd_h[TILE + tid] = hs.h; sd_u[TILE + tid] = hs.u; sd_v[TILE + tid] = hs.v; sd_sq[TILE + tid] = hs.sqh; sd_c[TILE + tid] = hs.c;
           if (HR) sd_zc[TILE + tid] = phz;
         }
         for (int j = tid + TILE; j < nh; j += TILE) {  // only numberings with poor locality get here
           const int         hc = a.hcells[td.h_off + j];
-          const RiemannSide hs = riemann_side(u[3 * (int64_t)hc + 0], u[3 * (int64_t)hc + 1], u[3 * (int64_t)hc + 2], a.tiny_h, a.h_anuga_sq);
+          RiemannSide hs = riemann_side(u[3 * (int64_t)hc + 0], u[3 * (int64_t)hc + 1], u[3 * (int64_t)hc + 2], a.tiny_h, a.h_anuga_sq);
+          if (HR_STAGED_VEL) hr_velocity_rule(hs, a.tiny_h);
           sd_h[TILE + j] = hs.h; sd_u[TILE + j] = hs.u; sd_v[TILE + j] = hs.v; sd_sq[TILE + j] = hs.sqh; sd_c[TILE + j] = hs.c;
           if (HR) sd_zc[TILE + j] = a.zc_local[hc];
         }
@@ -568,12 +584,25 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
             RiemannSide  Lr, Rr;
             Lr.h   = fmax(0.0, (L.h + zl) - z_max);
             Rr.h   = fmax(0.0, (R.h + zr) - z_max);
+#ifdef RDYHIP_HR_V1
             Lr.u   = (L.h > a.tiny_h) ? L.u : 0.0;
             Lr.v   = (L.h > a.tiny_h) ? L.v : 0.0;
             Rr.u   = (R.h > a.tiny_h) ? R.u : 0.0;
             Rr.v   = (R.h > a.tiny_h) ? R.v : 0.0;
             Lr.sqh = rdy_sqrt(Lr.h);
             Rr.sqh = rdy_sqrt(Rr.h);
+#else
+            // the staged velocities already follow the HR operator's rule (hr_velocity_rule, phase 0)
+            Lr.u = L.u; Lr.v = L.v; Rr.u = R.u; Rr.v = R.v;
+            // Only the side with the LOWER bed changes its depth; the other one keeps (h + z) - z, i.e. its own depth up to one
+            // rounding of the sum, and its staged square root stands in for the root of that value (relative difference
+            // <= ulp(h + z) / (4 h): ~1e-13 for 1 cm of water over a bed at 50 m).  One square root
+            // per edge instead of two.
+            const bool   l_high = zl >= zr;
+            const double sx     = rdy_sqrt(l_high ? Rr.h : Lr.h);
+            Lr.sqh = l_high ? L.sqh : sx;
+            Rr.sqh = l_high ? sx : R.sqh;
+#endif
             Lr.c   = SQRT_GRAVITY * Lr.sqh;
             Rr.c   = SQRT_GRAVITY * Rr.sqh;
             fl     = roe_flux(Lr, Rr, sn, cn);
@@ -593,6 +622,13 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
         } else {
           // boundary edges: HR is a no-op (operator_fluxes_petsc.c:57-58); their cell is the left one
           const int    k  = RDY_COLD(a, tile_bk)[td.b_off + ((lr >> EDGE_R_SHIFT) & EDGE_SLOT_MASK)];
+          if (HR_STAGED_VEL && L.h == a.tiny_h) {
+            // the staged velocities carry the HR operator's "h > tiny_h" rule, ApplyBoundaryFlux wants ComputeRiemannVelocities'
+            // "h < tiny_h => 0" (swe_petsc.c:62): they differ at equality only (the left cell of a boundary edge is a tile cell)
+            const RiemannSide s = riemann_side(L.h, sd_hu[jl], sd_hv[jl], a.tiny_h, a.h_anuga_sq);
+            L.u = s.u;
+            L.v = s.v;
+          }
           BoundaryFlux bf = boundary_flux(RDY_COLD(a, btype)[k], true, L, RDY_COLD(a, bvalues) + 3 * (int64_t)k, sn, cn, a.tiny_h, a.h_anuga_sq);
           fl              = bf.flux;
           wet             = bf.wet;
@@ -674,6 +710,11 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
         out[3] = sd_h[tid];
         out[4] = sd_u[tid];
         out[5] = sd_v[tid];
+        if (HR_STAGED_VEL && out[3] == a.tiny_h) {  // primitive variables: zero BELOW tiny_h (swe_petsc.c:788-791), see hr_velocity_rule
+          const RiemannSide s = riemann_side(out[3], sd_hu[tid], sd_hv[tid], a.tiny_h, a.h_anuga_sq);
+          out[4] = s.u;
+          out[5] = s.v;
+        }
         if (EULER) {
           own_hu = sd_hu[tid];
           own_hv = sd_hv[tid];

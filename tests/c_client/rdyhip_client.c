@@ -13,7 +13,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 
-#include "rdyhip.h"
+#include "case_io.h"
 
 #define CHECK(call)                                                                      \
   do {                                                                                   \
@@ -32,59 +32,17 @@
     }                                                                                    \
   } while (0)
 
-static void *rd(FILE *f, size_t n, size_t sz) {
-  void *p = malloc(n * sz > 0 ? n * sz : 1);
-  if (n && fread(p, sz, n, f) != n) {
-    fprintf(stderr, "short read\n");
-    exit(4);
-  }
-  return p;
-}
-
 int main(int argc, char **argv) {
   if (argc < 2) return 1;
-  FILE *f = fopen(argv[1], "rb");
-  if (!f) return 1;
-  int32_t hdr[8]; /* num_cells, num_owned, num_edges, num_internal, num_boundaries, source_method, overwrite, reserved */
-  if (fread(hdr, sizeof(int32_t), 8, f) != 8) return 4;
-  double scal[4]; /* tiny_h, h_anuga, xq2018_threshold, dt */
-  if (fread(scal, sizeof(double), 4, f) != 4) return 4;
-  const int32_t nc = hdr[0], no = hdr[1], ne = hdr[2], ni = hdr[3], nb = hdr[4];
-
-  RDyHipMesh m = {0};
-  m.num_cells = nc; m.num_owned_cells = no; m.num_edges = ne; m.num_internal_edges = ni;
-  m.cell_is_owned       = rd(f, nc, 4);
-  m.cell_local_to_owned = rd(f, nc, 4);
-  m.cell_global_ids     = rd(f, nc, 8);
-  m.cell_areas          = rd(f, nc, 8);
-  m.cell_dz_dx          = rd(f, nc, 8);
-  m.cell_dz_dy          = rd(f, nc, 8);
-  m.edge_cell_ids       = rd(f, 2 * (size_t)ne, 4);
-  m.edge_internal_ids   = rd(f, ni, 4);
-  m.edge_global_ids     = rd(f, ne, 8);
-  m.edge_lengths        = rd(f, ne, 8);
-  m.edge_cn             = rd(f, ne, 8);
-  m.edge_sn             = rd(f, ne, 8);
-
-  RDyHipBoundary *b      = calloc(nb > 0 ? nb : 1, sizeof(*b));
-  double        **bvals  = calloc(nb > 0 ? nb : 1, sizeof(double *));
-  for (int i = 0; i < nb; ++i) {
-    int32_t bh[2]; /* num_edges, condition type */
-    if (fread(bh, 4, 2, f) != 2) return 4;
-    b[i].num_edges      = bh[0];
-    b[i].condition_type = bh[1];
-    b[i].edge_ids       = rd(f, bh[0], 4);
-    bvals[i]            = rd(f, 3 * (size_t)bh[0], 8);
-  }
-  double *mannings = rd(f, no, 8);
-  double *extsrc   = rd(f, 3 * (size_t)no, 8); /* [comp][owned] */
-  double *u        = rd(f, 3 * (size_t)nc, 8);
-  double *f_in     = rd(f, 3 * (size_t)no, 8);
-  double *f_exp    = rd(f, 3 * (size_t)no, 8);
-  double *pv_exp   = rd(f, 3 * (size_t)no, 8);
-  double  courant_exp;
-  if (fread(&courant_exp, 8, 1, f) != 1) return 4;
-  fclose(f);
+  CaseFile cf;
+  if (case_read(argv[1], &cf)) return 1;
+  const int32_t *hdr = cf.hdr;
+  const double  *scal = cf.scal;
+  const int32_t  nc = hdr[0], no = hdr[1], nb = hdr[4];
+  RDyHipMesh      m = cf.mesh;
+  RDyHipBoundary *b = cf.boundaries;
+  double **bvals = cf.bvals, *mannings = cf.mannings, *extsrc = cf.extsrc, *u = cf.u, *f_in = cf.f_in, *f_exp = cf.f_exp, *pv_exp = cf.pv_exp;
+  const double courant_exp = cf.courant_exp;
 
   RDyHipConfig cfg = {scal[0], scal[1], scal[2], hdr[5], RDYHIP_RIEMANN_ROE};
   RDyHipOperator op = NULL;

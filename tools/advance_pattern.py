@@ -35,6 +35,14 @@ ap.add_argument("--steps-per-interval", default="20,100,400")
 ap.add_argument("--gaps-ms", default="0,2,10,50")
 ap.add_argument("--keep-warm-modes", default="1", help="rdyhip_keep_warm arguments to try beside 0 (1: one sleeping wave; n > 1: n streaming workgroups)")
 ap.add_argument("--pair", action="store_true", help="RHS + axpy per step (what TSEULER does) instead of the fused Euler step")
+ap.add_argument("--refresh", default="device", choices=["device", "setter", "setter_sync"],
+                help="how the rain source is refreshed at the start of every interval: device = rdyhip_forcing_fill_source (one small launch); "
+                     "setter = RDySetDomainWaterSource's path, a host array of one value per owned cell through the stream-ordered "
+                     "rdyhip_set_external_source_on; setter_sync = the same through the synchronising legacy setter")
+ap.add_argument("--fixed-dt", action="store_true",
+                help="time.adaptive.enable off (the reference's default, src/rdyadvance.c:303-305): no Courant read-back, i.e. nothing in an "
+                     "interval synchronises; the host only waits at the very end")
+ap.add_argument("--region-fraction", type=float, default=1.0, help="setter: the refreshed region as a fraction of the owned cells")
 a = ap.parse_args()
 
 args = bench.parse(["--no-cpu-baseline", "--workload", a.workload, "--levels", str(a.levels)])
@@ -52,10 +60,20 @@ f = torch.empty((n_owned, 3), dtype=torch.float64, device="cuda")
 st = int(torch.cuda.current_stream().cuda_stream)
 
 
+n_region = max(1, int(round(a.region_fraction * n_owned)))
+rain = np.full(n_region, 1e-5)
+region_ids = None if n_region == n_owned else np.arange(n_region, dtype=np.int32)
+
+
 def advance(nsteps):
     """one RDyAdvance: forcing refill, nsteps explicit steps with dt = 0 (the state stays put: every interval does the
     same work), diagnostics read-back"""
-    _lib.check(lib.rdyhip_forcing_fill_source(op._h, 0, n_owned, None, 1e-5, st))
+    if a.refresh == "device":
+        _lib.check(lib.rdyhip_forcing_fill_source(op._h, 0, n_owned, None, 1e-5, st))
+    elif region_ids is None:
+        op.set_domain_external_source(0, rain, ordered=(a.refresh == "setter"))
+    else:
+        op.set_regional_external_source(region_ids, 0, rain, ordered=(a.refresh == "setter"))
     cur, nxt = u, u2
     for _ in range(nsteps):
         if a.pair:
@@ -64,6 +82,8 @@ def advance(nsteps):
         else:
             op.euler_step(0.0, cur, nxt)
             cur, nxt = nxt, cur
+    if a.fixed_dt:
+        return 0.0
     op.update_diagnostics()          # hipStreamSynchronize + 16 bytes D2H
     return op.get_diagnostics().max_courant_num
 
@@ -88,6 +108,8 @@ def pattern(nsteps, gap_ms, keep_warm):
         if keep_warm:
             _lib.check(lib.rdyhip_keep_warm(op._h, int(keep_warm)))
         busy_wait(gap_ms)                             # the host's own work between two RDyAdvance calls
+    torch.cuda.synchronize()                          # fixed dt: the only wait of the whole pattern
+    t_dev = t_dev if not a.fixed_dt else time.perf_counter() - t0
     wall = time.perf_counter() - t0
     if keep_warm:
         _lib.check(lib.rdyhip_keep_warm(op._h, 0))
@@ -109,6 +131,7 @@ e1.record()
 torch.cuda.synchronize()
 back_to_back = e0.elapsed_time(e1) / 400
 out = {"workload": a.workload, "cells": n_owned, "step": "RHS + axpy (TSEULER)" if a.pair else "fused Euler step (rdyhip_euler_step)",
+       "refresh": a.refresh, "refreshed_cells": n_region, "fixed_dt": bool(a.fixed_dt),
        "back_to_back_ms_per_step": round(back_to_back, 5), "back_to_back_M_cell_updates_per_s": round(n_owned / back_to_back / 1e3, 1),
        "intervals": a.intervals, "rows": []}
 has_keep_warm = hasattr(lib, "rdyhip_keep_warm")
