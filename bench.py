@@ -82,6 +82,9 @@ def parse(argv=None):
                         "setup leaves it in; disclosed in config.conditioning)")
     p.add_argument("--halo", default=None, choices=["torch", "c"],
                    help="N > 1: who drives the exchange -- torch.distributed P2P from Python, or the C ABI's RCCL path (default: c with nccl)")
+    p.add_argument("--inject-fault", default="none", choices=["none", "exchange"],
+                   help="test hook of the N > 1 self-check: 'exchange' makes the last rank expect a wrong ghost value, so that the run must end "
+                        "with the one-line {\"error\": ...} and a non-zero exit code (tests/test_gpu_multirank.py)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-cpu-all-cores", action="store_true", help="skip the all-host-cores CPU figure (the 1-core cpu_baseline stays)")
     p.add_argument("--no-order-study", action="store_true", help="skip the row-major / Hilbert numbering figures (c3, N = 1 only)")
@@ -358,6 +361,7 @@ def run_rank(args, argv):
     dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("NCCL_DEBUG", "WARN")      # RCCL's warnings land in stderr (fd 1 points there): kept with the run's log
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -367,6 +371,31 @@ def run_rank(args, argv):
     from rdycore_amd import cases as CS
     from rdycore_amd.halo import HaloExchange
 
+    def all_ranks_ok(ok: bool) -> bool:
+        if world == 1:
+            return ok
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item())
+
+    def abort_run(what: str, mine: str = ""):
+        """first contact with N > 1 devices must not end in a silent hang or a plausible-looking number: every rank reports,
+        rank 0 prints ONE line {"error": ...} instead of the bench line, everybody exits non-zero"""
+        print(f"bench.py rank {rank}: {what} {mine}", file=sys.stderr)
+        notes = [None] * world
+        if world > 1:
+            dist.all_gather_object(notes, mine)
+        else:
+            notes = [mine]
+        if rank == 0:
+            os.write(real_stdout, (json.dumps({"error": what, "per_rank": notes, "n_gpus": world, "metric": "M cell-updates/s (SWE RHS eval)",
+                                               "value": None}) + "\n").encode())
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        sys.exit(3)
+
+    stages = {}
     t0 = time.time()
     if world == 1 and args.emulate_world > 1:
         sav = args.scaling
@@ -377,7 +406,10 @@ def run_rank(args, argv):
     else:
         case = build_case(args, rank, world)
     mesh = case.mesh
+    stages["mesh_and_state_s"] = round(time.time() - t0, 2)
+    t1 = time.time()
     op = CS.create_operator(case)
+    stages["operator_create_s"] = round(time.time() - t1, 2)
     halo_mode = args.halo or ("c" if backend == "nccl" else "torch")
     halo, halo_note = None, None
     if world > 1:
@@ -396,6 +428,12 @@ def run_rank(args, argv):
                 halo.destroy()
             halo = HaloExchange(mesh, dev, transport="torch", op=op)
             halo_note = f"fell back from the C-side RCCL exchange to torch.distributed P2P: {halo_note}"
+        stages.update({k: round(v, 3) for k, v in halo.timings.items()})
+        # the library's communicator must span every rank of this run (a silent single-rank communicator would make each
+        # rank exchange with itself and still print a plausible line)
+        spans = halo.rccl_ranks()
+        if not all_ranks_ok(not (halo.transport == "c" and backend == "nccl" and halo_note is None and spans != world)):
+            abort_run("the library's RCCL communicator does not span the run", f"ncclCommCount = {spans}, world = {world}")
     self_halo, self_rccl_ranks = None, None
     if args.self_exchange:
         if world != 1 or args.emulate_world < 2:
@@ -429,6 +467,35 @@ def run_rank(args, argv):
     f = torch.empty((mesh.num_owned_cells, 3), dtype=torch.float64, device=dev)
     setup_s = time.time() - t0
     n_owned = mesh.num_owned_cells
+
+    # ---- exchange self-check before anything is timed (N > 1): the analytic state of every LOCAL cell, ghosts included, is known
+    # on this rank (build_case fills all local cells), so what the neighbours send can be checked bit for bit -- first the plain
+    # ghost update, then the whole multi-rank step
+    if halo is not None:
+        truth = u.clone()
+        ghost_rows = torch.as_tensor(np.nonzero(mesh.cell_is_owned == 0)[0], device=dev)
+        if args.inject_fault == "exchange" and rank == world - 1 and ghost_rows.numel():
+            truth[ghost_rows[:1]] += 1.0
+        mine = ""
+        try:
+            for name, fn in (("exchange", lambda: halo.exchange(u)), ("overlapped step", lambda: halo.rhs_overlapped(op, case.dt, u, f))):
+                u[ghost_rows] = float("nan")
+                torch.cuda.synchronize()
+                t1 = time.time()
+                fn()
+                torch.cuda.synchronize()
+                stages[f"first_{name.replace(' ', '_')}_s"] = round(time.time() - t1, 3)
+                bad = int((~(u == truth).all(dim=1)).sum().item())
+                if bad and not mine:        # no early exit: every rank takes part in both exchanges, whatever it found
+                    mine = f"{bad} of {int(ghost_rows.numel())} ghost cells differ from their owners' values after the first {name}"
+            if not mine and not bool(torch.isfinite(f).all().item()):
+                mine = "non-finite RHS after the first overlapped step"
+        except Exception as exc:
+            mine = f"exception in the exchange self-check: {exc!r}"
+        if not all_ranks_ok(not mine):
+            abort_run("exchange self-check failed", mine)
+        u.copy_(truth)
+        del truth
 
     def step():
         if halo is not None:
@@ -606,6 +673,17 @@ def run_rank(args, argv):
         dist.all_reduce(fin, op=dist.ReduceOp.MIN)
         finite = bool(fin.item())
 
+    # what every rank did (rank 0's line carries all of them): the form of the step, direct receive, cells, ghosts
+    mine_info = {"rank": rank, "cells": n_owned, "ghost_cells": int(mesh.num_cells - n_owned),
+                 "halo_overlapped": (int(_lib.load().rdyhip_halo_overlaps(halo._halo)) if halo is not None and halo._halo is not None else None),
+                 "direct_receive": (bool(halo.direct_receive) if halo is not None and halo._halo is not None else None),
+                 "peers": (len(halo._plan_peers) if halo is not None else 0), "device": dev_index}
+    per_rank = [None] * world
+    if world > 1:
+        dist.all_gather_object(per_rank, mine_info)
+    else:
+        per_rank = [mine_info]
+
     order_study = None
     if rank == 0 and world == 1 and args.workload == "c3" and not args.no_order_study and args.emulate_world <= 1 \
             and not args.second_order and not args.hr:
@@ -712,7 +790,7 @@ def run_rank(args, argv):
                        "halo_exchange_alone_ms": round(halo_ms, 5) if halo_ms is not None else None,
                        "conditioning": (f"{n_cond} untimed RHS launches ({args.condition_seconds:g} s) before --warmup"
                                         if n_cond else "none"),
-                       "setup_seconds": round(setup_s, 1), "max_courant": cd.max_courant_num,
+                       "setup_seconds": round(setup_s, 1), "setup_stages": stages, "per_rank": per_rank, "max_courant": cd.max_courant_num,
                        "max_courant_edge": cd.global_edge_id, "max_courant_cell": cd.global_cell_id, "finite": finite},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4),

@@ -689,6 +689,10 @@ static int layout_build_tiles(const RDyHipMesh *mesh, HostLayout &L) {
   int32_t               hmax2 = 0;
   std::vector<uint16_t> slot_ref((size_t)no * 4, SLOT_EMPTY);
   int32_t               emax = 0, hmax = 0;
+  // RDYHIP_EDGE_SORT: order of a tile's edge records -- 0: the reference's loop position (the edge numbering); 1: by the LDS
+  // slot of the left cell, then of the right one; 2: by the smaller of the two slots, then the larger
+  int edge_sort = 0;
+  if (const char *es = getenv("RDYHIP_EDGE_SORT")) edge_sort = atoi(es);
   {
     e_lr.reserve((size_t)no * 2);
     e_cs.reserve((size_t)no * 2);
@@ -772,6 +776,40 @@ static int layout_build_tiles(const RDyHipMesh *mesh, HostLayout &L) {
           e_lr.push_back(lr);
         }
         slot_ref[(size_t)(it.second >> 2) * 4 + (it.second & 3)] = (uint16_t)local;
+      }
+      if (edge_sort && local + 1 > 1) {
+        // The order of a tile's records is free (a cell finds its edges through slot_ref, and sums them in slot = loop order):
+        // sorted by the LDS slot of the left cell, the 32 lanes of a ds_read_b64 group read ~20 consecutive slots of every
+        // left-side plane (duplicates broadcast) -- conflict-free -- instead of slots scattered like the edge numbering.
+        const int32_t n_rec = local + 1;
+        const size_t  r0    = (size_t)tiles[t].e_off;
+        std::vector<int32_t> order((size_t)n_rec), inv((size_t)n_rec);
+        for (int32_t i = 0; i < n_rec; ++i) order[i] = i;
+        auto key = [&](int32_t i) -> uint32_t {
+          const uint32_t lr = e_lr[r0 + i];
+          const uint32_t jl = lr & EDGE_SLOT_MASK, jr = (lr & EDGE_BOUNDARY) ? 0x7FFu : ((lr >> EDGE_R_SHIFT) & EDGE_SLOT_MASK);
+          return edge_sort == 2 ? ((std::min(jl, jr) << 11) | std::max(jl, jr)) : ((jl << 11) | jr);
+        };
+        std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return key(x) < key(y); });
+        std::vector<uint32_t> lr2((size_t)n_rec);
+        std::vector<double>   cs2((size_t)n_rec), mid2(muscl_on ? 2 * (size_t)n_rec : 0);
+        for (int32_t i = 0; i < n_rec; ++i) {
+          inv[order[i]] = i;
+          lr2[i]        = e_lr[r0 + order[i]];
+          cs2[i]        = e_cs[r0 + order[i]];
+          if (muscl_on) {
+            mid2[2 * (size_t)i]     = e_mid[2 * (r0 + order[i])];
+            mid2[2 * (size_t)i + 1] = e_mid[2 * (r0 + order[i]) + 1];
+          }
+        }
+        std::copy(lr2.begin(), lr2.end(), e_lr.begin() + r0);
+        std::copy(cs2.begin(), cs2.end(), e_cs.begin() + r0);
+        if (muscl_on) std::copy(mid2.begin(), mid2.end(), e_mid.begin() + 2 * r0);
+        for (int32_t j = 0; j < cntc; ++j)
+          for (int32_t sl = 0; sl < 4; ++sl) {
+            uint16_t &ref = slot_ref[(size_t)(base + j) * 4 + sl];
+            if (ref != SLOT_EMPTY) ref = (uint16_t)inv[ref];
+          }
       }
       if (muscl_on) {
         // fused second-order kernel: the stencil of every first-ring cell (LDS slots of its neighbours) and the tile's

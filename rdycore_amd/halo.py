@@ -54,12 +54,18 @@ class HaloExchange:
         self.recv_ids: Dict[int, torch.Tensor] = {}   # peer -> local ids of ghost cells to fill
         self.send_buf: Dict[int, torch.Tensor] = {}
         self.recv_buf: Dict[int, torch.Tensor] = {}
+        self.timings: Dict[str, float] = {}          # wall seconds per setup stage (bench.py reports them per run)
+        import time as _time
+        t0 = _time.perf_counter()
         self._setup()
+        self.timings["plan_s"] = _time.perf_counter() - t0
         # default priority, like the compute stream: ordering work between streams of different priorities costs 0.25 ms of
         # host time per step on this runtime (csrc/halo_exchange.h)
         self.comm_stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
         if transport == "c" and self.world > 1:
+            t0 = _time.perf_counter()
             self._create_c_halo(op)
+            self.timings["c_halo_total_s"] = _time.perf_counter() - t0
 
     # -- the exchange behind the C ABI (include/rdyhip.h: rdyhip_halo_create) ------------------------------
     def _all_ok(self, ok: bool) -> bool:
@@ -96,11 +102,14 @@ class HaloExchange:
             dist.broadcast_object_list(box, src=0, group=self.group)
             if box[0] is None:
                 raise RuntimeError(f"rank 0 could not draw an RCCL unique id: {err!r}")
+            import time as _time
+            t0 = _time.perf_counter()
             try:
                 _lib.check(lib.rdyhip_comm_init_rank(self.world, self.rank, box[0], C.byref(comm)))
                 self._comm = comm
             except Exception as exc:
                 err = exc
+            self.timings["rccl_comm_init_s"] = _time.perf_counter() - t0
             if not self._all_ok(err is None):
                 self.destroy()
                 raise RuntimeError(f"ncclCommInitRank failed on some rank (this rank: {err!r})")

@@ -133,7 +133,7 @@ def test_c_host_runs_rdyadvance_on_ex2b(tmp_path, adaptive):
         cmax = orc.diagnostics()[0]
     assert steps == n and (n >= 1000 if not adaptive else n > 100)
     assert abs(dt_c - dt) <= 1e-12 * dt and abs(t_c - t) <= 1e-12 * t
-    assert np.abs(u[:, 1]).max() > 1.0                   # the dam has broken
+    assert np.abs(u[:, 0] - case.u_local[:, 0]).max() > 0.5          # the dam has broken: the pools have levelled
     from helpers import rel_linf
     assert rel_linf(u_c, u) <= 1e-9
 
@@ -141,13 +141,14 @@ def test_c_host_runs_rdyadvance_on_ex2b(tmp_path, adaptive):
 @pytest.mark.gpu
 @pytest.mark.timeout(300)
 @pytest.mark.parametrize("kind,overlap", [("strips", "0"), ("strips", "1"), ("rcb_c5", "0")])
-def test_c_multi_rank_host(tmp_path, kind, overlap):
+def test_c_multi_rank_host(tmp_path, kind, overlap, rdyhip_kernel):
     """the multi-rank path from C alone (tests/c_client/rdyhip_mr_client.c: three forked ranks, pipes for the plan's all-to-all
     and for the exchange through rdyhip_halo_set_transport): rdyhip_copy_owned_rows + rdyhip_rhs_overlapped as
     OperatorRHSFunctionHip calls them = the single-rank oracle's rows, ghost rows bit for bit, the Courant struct-max,
     fused-pack Euler steps = RHS + axpy.  Strips (first order, both forms of the step) and RCB parts of the C5 miniature (HR)."""
+    if rdyhip_kernel == "cell" and kind == "rcb_c5":
+        pytest.skip("hydrostatic reconstruction is implemented by the tiled kernel")
     build.build_native()
-    from rdycore_amd import partition as P
     world = 3
     if kind == "strips":
         nxp, ny, K = 40, 48, 2 * np.pi / 37
@@ -181,4 +182,5 @@ def test_c_multi_rank_host(tmp_path, kind, overlap):
     print(run.stdout, run.stderr)
     assert run.returncode == 0, (run.returncode, run.stdout, run.stderr)
     assert run.stdout.count("direct receive 1") == world and run.stdout.count(f"overlapped form {overlap}") == world
-    assert "courant ok" in run.stdout and run.stdout.count("fused pack 1") == world
+    # the fused pack rides on the tiled Euler-step kernels; the cell-centric kernel keeps its pack launch
+    assert "courant ok" in run.stdout and run.stdout.count(f"fused pack {0 if rdyhip_kernel == 'cell' else 1}") == world

@@ -380,6 +380,21 @@ def test_bench_self_launches_two_ranks(rdyhip_kernel):
         assert d["scaling"] == ("strong" if ("c5" in extra or "houston_refined" in extra) else "weak") and d["value"] > 0
         assert d["config"]["halo_driver"] == driver and d["config"]["halo_bytes_per_rank"] > 0
         assert d["config"]["max_courant"] > 0 and d["config"]["max_courant_cell"] >= 0
+        # first-contact evidence: what every rank did, how long each setup stage took, the self-check ran (its two stages are timed)
+        pr = d["config"]["per_rank"]
+        assert [r["rank"] for r in pr] == list(range(n)) and all(r["cells"] > 0 and r["ghost_cells"] > 0 and r["peers"] >= 1 for r in pr)
+        if driver == "c":
+            assert all(r["direct_receive"] is True and r["halo_overlapped"] in (0, 1) for r in pr)
+        st = d["config"]["setup_stages"]
+        assert {"mesh_and_state_s", "operator_create_s", "plan_s", "first_exchange_s", "first_overlapped_step_s"} <= set(st)
+    # the self-check's failure path: one rank expects a wrong ghost value -> ONE line {"error": ...}, exit code 3, no hang
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--steps", "5", "--warmup", "2", "--nx", "120", "--ny", "100",
+           "--condition-seconds", "0", "--watchdog-seconds", "150", "--launch-timeout", "200", "--halo", "c", "--inject-fault", "exchange"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert out.returncode != 0
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and "exchange self-check failed" in json.loads(lines[0])["error"], (out.stdout, out.stderr[-2000:])
+    assert "ghost cells differ" in json.loads(lines[0])["per_rank"][2]
 
 
 @pytest.mark.timeout(600)

@@ -223,6 +223,92 @@ def test_setters_regional_and_components():
     assert rel_linf(op.flux_divergence.cpu().numpy(), orc.flux_divergence) <= TOL
 
 
+def test_stream_ordered_setters():
+    """rdyhip_set_*_on / rdyhip_refresh_field (no device synchronisation, pinned staging, the operator's copy stream): the fields
+    end up as the synchronising setters leave them; a launch enqueued BEFORE the call still sees the old values, one enqueued
+    after it the new ones; the host array is free again when the call returns; more refreshes in flight than staging slots"""
+    torch = _torch()
+    K = 2 * np.pi / 31
+    mesh = M.structured_tri_mesh(40, 30, 1.0, zfunc=CS.mms_bathymetry(K=K))
+    case = CS.friction_slope_case(mesh, 40.0, 30.0, dt=1e-2, K=K)
+    op, ref = CS.create_operator(case), CS.create_operator(case)
+    no = mesh.num_owned_cells
+    rng = np.random.default_rng(11)
+    ids = np.sort(rng.choice(no, size=no // 3, replace=False)).astype(np.int32)
+    s = torch.cuda.Stream()
+    u = torch.tensor(case.u_local, dtype=torch.float64, device="cuda")
+    f_old, f_new, f_ref = (torch.empty((no, 3), dtype=torch.float64, device="cuda") for _ in range(3))
+    torch.cuda.synchronize()
+    with torch.cuda.stream(s):
+        op.rhs_function(case.dt, u, f_old)                       # enqueued before the refresh: the old inputs
+        for rep in range(7):                                     # 7 x 4 staged arrays through a ring of 4 slots
+            scratch = rng.random(no)
+            op.set_domain_external_source(0, scratch, ordered=True)
+            scratch[:] = np.nan                                  # free again: the call has copied it
+            vals = rng.random(ids.size)
+            op.set_regional_external_source(ids, 1, vals, ordered=True)
+            man = 0.02 + 0.01 * rng.random(no)
+            op.set_domain_mannings_n(man, ordered=True)
+            b = mesh.boundary_by_name("left") if any(bd.name == "left" for bd in mesh.boundaries) else 0
+            bv = np.abs(rng.normal(size=(mesh.boundaries[b].num_edges, 3))) + 0.5
+            op.set_boundary_values(b, bv[:, :2], ordered=True)
+            op.set_boundary_values(b, bv[:, 2], comp_offset=2, ordered=True)
+        op.rhs_function(case.dt, u, f_new)
+    # the same final inputs through the synchronising setters on a second operator
+    src0 = rng.random(no)
+    ref.set_domain_external_source(0, src0)
+    op.set_domain_external_source(0, src0, ordered=False)        # the legacy call orders itself against everything
+    ref.set_regional_external_source(ids, 1, vals)
+    ref.set_domain_mannings_n(man)
+    ref.set_boundary_values(b, bv)
+    s.synchronize()
+    for name in ("external_sources", "mannings_n"):
+        assert torch.equal(getattr(op, name), getattr(ref, name)), name
+    ref.rhs_function(case.dt, u, f_ref)
+    with torch.cuda.stream(s):
+        op.rhs_function(case.dt, u, f_new)
+    torch.cuda.synchronize()
+    assert torch.equal(f_new, f_ref)
+    orc = oracle_from_case(case)
+    assert rel_linf(f_old.cpu().numpy(), orc.apply(case.dt, case.u_local)) <= TOL       # untouched by the refreshes behind it
+    # whole-field refresh from a host array and from a device tensor
+    ext = rng.random((no, 3))
+    op.refresh_field(1, ext)
+    op.refresh_field(2, torch.tensor(man[::-1].copy(), device="cuda"))
+    torch.cuda.synchronize()
+    assert np.array_equal(op.external_sources.cpu().numpy(), ext) and np.array_equal(op.mannings_n.cpu().numpy(), man[::-1])
+    from rdycore_amd.operator import RDyHipError
+    with pytest.raises(RDyHipError):
+        op.refresh_field(1, ext[:-1])                            # size is checked against the field
+    with pytest.raises(RDyHipError):
+        op.refresh_field(0, ext)                                 # outputs cannot be written
+    with pytest.raises(RDyHipError):
+        op.set_regional_external_source(np.array([no], dtype=np.int32), 0, np.zeros(1), ordered=True)
+    op.destroy(); ref.destroy()
+
+
+def test_cached_f_stores_option_changes_nothing_but_the_cache_policy():
+    """RDYHIP_CONFIG_CACHED_F_STORES (for hosts whose TSEULER reads F straight back): same bits"""
+    torch = _torch()
+    import copy
+    K = 2 * np.pi / 31
+    mesh = M.structured_tri_mesh(40, 30, 1.0, zfunc=CS.mms_bathymetry(K=K))
+    case = CS.friction_slope_case(mesh, 40.0, 30.0, dt=1e-2, K=K)
+    case2 = copy.copy(case)
+    case2.config = copy.copy(case.config)
+    case2.config.cached_f_stores = True
+    u = torch.tensor(case.u_local, dtype=torch.float64, device="cuda")
+    out = []
+    for c in (case, case2):
+        op = CS.create_operator(c)
+        f = torch.empty((mesh.num_owned_cells, 3), dtype=torch.float64, device="cuda")
+        op.rhs_function(c.dt, u, f)
+        torch.cuda.synchronize()
+        out.append(f)
+        op.destroy()
+    assert torch.equal(out[0], out[1])
+
+
 def test_error_behaviour():
     from rdycore_amd.operator import Operator, RDyFlowConfig, RDyHipError
     torch = _torch()

@@ -17,6 +17,8 @@ V[houston_hr]="--workload houston_refined --hr --no-cpu-all-cores"
 V[houston_natural]="--workload houston_refined --order natural --no-cpu-baseline"
 V[houston_so]="--workload houston_refined --second-order --no-cpu-all-cores"
 V[houston_l7]="--workload houston_refined --levels 7 --no-cpu-all-cores"
+V[houston_l7_so]="--workload houston_refined --levels 7 --second-order --no-cpu-all-cores"
+V[houston_l7_hr]="--workload houston_refined --levels 7 --hr --no-cpu-all-cores"
 V[delaunay]="--workload delaunay --no-cpu-all-cores"
 V[self_exchange]="--emulate-world 3 --emulate-rank 1 --self-exchange --no-cpu-baseline"
 V[self_exchange_so]="--emulate-world 3 --emulate-rank 1 --self-exchange --second-order --no-cpu-baseline"

@@ -21,6 +21,8 @@ ARGS = {
     "self_exchange_so": ["--emulate-world", "3", "--emulate-rank", "1", "--self-exchange", "--second-order"],
     "houston_natural": ["--workload", "houston_refined", "--order", "natural"],
     "houston_l7": ["--workload", "houston_refined", "--levels", "7"],
+    "houston_l7_so": ["--workload", "houston_refined", "--levels", "7", "--second-order"],
+    "houston_l7_hr": ["--workload", "houston_refined", "--levels", "7", "--hr"],
 }
 rnd = sys.argv[1]
 tags = sys.argv[2:] or list(ARGS)
@@ -35,12 +37,24 @@ for tag in tags:
         shutil.copy(ks[0], os.path.join(ROOT, "profiles", f"{rnd}_{tag}_kernel_stats.csv"))
     shutil.copy(summ, os.path.join(ROOT, "profiles", f"{rnd}_{tag}_summary.json"))
     log = os.path.join(d, "bench_trace.log")
+    line = None
     if os.path.exists(log):
         lines = [ln for ln in open(log) if ln.startswith("{")]
         if lines:
             open(os.path.join(ROOT, "profiles", f"{rnd}_{tag}_bench_under_rocprof.json"), "w").write(lines[-1])
+            line = json.loads(lines[-1])
     key = bench.traffic_key(bench.parse(ARGS[tag]))
-    per_step = "2" if tag.startswith("self_exchange") else "1"
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_traffic.py"), summ, key, f"profiles/{rnd}_{tag}_summary.json", per_step],
+    # launches of the RHS kernel per STEP: two (interior + halo tiles) only where the traced run really used the overlapped form
+    # of the multi-rank step (config.halo_overlapped); the in-order form of small parts is one launch.  Second order: the
+    # ghost-adjacent cells' gradient launch belongs to the step as well.
+    per_step, extra = "1", ""
+    if tag.startswith("self_exchange"):
+        if line is None:
+            print(tag, ": no bench line under the tracer, cannot tell the form of the step -- skipped")
+            continue
+        per_step = "2" if line["config"].get("halo_overlapped") else "1"
+        if "second" in line["config"].get("spatial_order", ""):
+            extra = "muscl_gradient_kernel"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_traffic.py"), summ, key, f"profiles/{rnd}_{tag}_summary.json", per_step, extra],
                        capture_output=True, text=True)
     print(tag, key, "ok" if r.returncode == 0 else ("FAILED: " + r.stderr[-300:]))

@@ -1,8 +1,9 @@
 """profiles/traffic.json entry from the PMC passes of tools/profile_gpu.sh.
 
-usage: python tools/make_traffic.py gpurun_out/prof_<tag>/summary.json <key> [source note] [launches per step]
+usage: python tools/make_traffic.py gpurun_out/prof_<tag>/summary.json <key> [source note] [launches per step] [extra kernel]
   (launches per step = 2 for the --self-exchange step, whose interior and halo launches are two launches of ONE kernel: the
-   entry then holds the bytes of a whole step = 2 x the mean over all launches)
+   entry then holds the bytes of a whole step = 2 x the mean over all launches; extra kernel: a kernel launched once per step
+   beside the RHS kernel whose bytes belong to the step -- the second-order step's muscl_gradient_kernel)
   (the bench line printed during the traced run, gpurun_out/prof_<tag>/bench_trace.log, supplies the layout's byte count)
   key = <workload>_<nx>x<ny>_<order>_<source>[_hr]   (what bench.py looks up)
 
@@ -22,7 +23,8 @@ import bench  # noqa: E402
 def main():
     summ, key = sys.argv[1], sys.argv[2]
     note = sys.argv[3] if len(sys.argv) > 3 and sys.argv[3] else os.path.relpath(summ, ROOT)
-    per_step = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+    per_step = int(sys.argv[4]) if len(sys.argv) > 4 and sys.argv[4] else 1
+    extra = sys.argv[5] if len(sys.argv) > 5 else ""
     s = json.load(open(summ))
     raw = s["pmc_raw_KB"]
 
@@ -41,6 +43,14 @@ def main():
     if fetch is None or write is None:
         raise SystemExit("no FETCH_SIZE / WRITE_SIZE for the RHS kernel in " + summ)
     rd, wr = fetch * 1024 * 2 * per_step, write * 1024 * per_step
+    extra_ent = None
+    if extra:
+        ek, ef = pick("pmc_fetch", extra)
+        _, ew = pick("pmc_write", extra)
+        if ef is None or ew is None:
+            raise SystemExit(f"no FETCH_SIZE / WRITE_SIZE for {extra} in " + summ)
+        rd, wr = rd + ef * 1024 * 2, wr + ew * 1024
+        extra_ent = {"kernel": ek, "FETCH_SIZE_KB_raw": ef, "WRITE_SIZE_KB_raw": ew, "launches_per_step": 1}
     second = "second_order" in key
     layout = None
     log = os.path.join(os.path.dirname(summ), "bench_trace.log")
@@ -54,6 +64,8 @@ def main():
            "source": note}
     if per_step != 1:
         ent["launches_per_step"] = per_step
+    if extra_ent:
+        ent["also_in_the_step"] = extra_ent
     if cal_f is not None and cal_w is not None:
         ent["calibration"] = {"kernel": "rdyhip::axpy_owned_kernel, 10 M cells: 480.0 MB read / 240.0 MB written by construction",
                               "FETCH_SIZE_x2_MB": round(cal_f * 1024 * 2 / 1e6, 1), "WRITE_SIZE_MB": round(cal_w * 1024 / 1e6, 1)}

@@ -23,6 +23,8 @@ V[self_exchange]="--emulate-world 3 --emulate-rank 1 --self-exchange"
 V[self_exchange_so]="--emulate-world 3 --emulate-rank 1 --self-exchange --second-order"
 V[houston_natural]="--workload houston_refined --order natural"
 V[houston_l7]="--workload houston_refined --levels 7"
+V[houston_l7_so]="--workload houston_refined --levels 7 --second-order"
+V[houston_l7_hr]="--workload houston_refined --levels 7 --hr"
 ORDER="${@:-c3 hr xq c2 quads c5 so so_quads houston houston_hr houston_so delaunay self_exchange}"
 cd /tmp
 echo "calibration"
