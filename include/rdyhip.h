@@ -341,8 +341,8 @@ int rdyhip_unpack_rows(double *dst, int32_t ncomp, const int32_t *row_ids, int32
  * Second order: the state exchange hides behind the tiles that need no ghost data, then the ghost-adjacent gradients are
  * computed, exchanged (6 values per cell) and the remaining tiles follow.  The exchanges are ordered after everything
  * already enqueued on `stream`; when the call returns all work is enqueued and later work on `stream` is ordered after it.
- * Small parts: when a rank has fewer interior tiles than about six rounds of the persistent grid (~1.2 M cells first order,
- * ~1.6 M second order on triangles), nothing is overlapped -- exchange, (gradients, their exchange,) ONE launch over all tiles, in order on `stream` -- because the
+ * Small parts: when a rank has fewer interior tiles than about twelve rounds of the persistent grid (~2.4 M cells first order,
+ * ~3.1 M second order on triangles), nothing is overlapped -- exchange, (gradients, their exchange,) ONE launch over all tiles, in order on `stream` -- because the
  * interior phase is then shorter than the exchange chain and the two cross-stream dependencies cost more than they hide
  * (profiles/r03_step_breakdown_360k.json, profiles/r03_overlap_threshold.txt).  rdyhip_halo_overlaps() says which form a halo uses; RDYHIP_OVERLAP=0 / 1 forces.
  *

@@ -124,6 +124,7 @@ SYMBOLS = {
 TRANSPORT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p)
 
 _LIB = None
+ABI_VERSION = 108     # RDYHIP_VERSION of include/rdyhip.h this binding was written against
 
 
 class RDyHipError(RuntimeError):
@@ -154,15 +155,25 @@ def load(build_if_missing: bool = False):
                 f"{path} not found: the HIP extension is required (run `python -m rdycore_amd.build` or "
                 "__graft_entry__.build()); there is no CPU fallback for the operator")
     lib = C.CDLL(path)
+    missing = []
     for name, (res, args) in SYMBOLS.items():
         try:
             fn = getattr(lib, name)  # AttributeError if the .so does not export it
         except AttributeError:
             if "RDYHIP_LIB" in os.environ:   # A/B timing of an older build of the same ABI: later additions are absent
+                missing.append(name)
                 continue
             raise
         fn.restype = res
         fn.argtypes = args
+    if "RDYHIP_LIB" in os.environ:
+        # another build of the library was asked for: say what it is, so that an ABI mismatch shows up here and not later as an
+        # AttributeError or a call through default-int ctypes signatures
+        import sys
+        have = int(lib.rdyhip_version()) if hasattr(lib, "rdyhip_version") else -1
+        if missing or have != ABI_VERSION:
+            print(f"rdycore_amd: RDYHIP_LIB={path}: library version {have}, this binding expects {ABI_VERSION}; "
+                  f"symbols it lacks: {', '.join(missing) if missing else 'none'}", file=sys.stderr)
     _LIB = lib
     return lib
 

@@ -334,17 +334,21 @@ int rdyhip_halo_create(RDyHipOperator op, void *nccl_comm, int32_t npeers, const
   }
   {
     // Overlap only where there is something to hide behind: at least RDYHIP_OVERLAP_MIN_ROUNDS rounds of the persistent grid's
-    // worth of interior tiles -- default 6: ~1.2 M cells first order (768 workgroups x 256 cells), ~1.6 M second order on
-    // triangles (1 024 workgroups), ~1.2 M second order on quads (768).  The only measurement behind it is ONE device with the
-    // exchange looped back (tools/overlap_threshold.sh, profiles/r03_overlap_threshold.txt): in order / overlapped = 30 / 50 us
-    // at 0.36 M cells, 53 / 60 at 1.1 M, 81 / 83 at 2 M, 113 / 113 at 3 M -- the overlapped form costs two cross-stream
-    // dependencies and ~3x the host time per step, and its gain is the exchange time, which a real xGMI hop makes LONGER than
-    // the loop-back's 14 us.  Round 3 put the switch at 12 rounds (2.4 M cells), where the two forms tie on the loop-back; it
-    // now sits at 6, where the in-order form's measured advantage starts to exceed ~10 %, so that parts between 1.2 and 2.4 M
-    // cells take the form that a longer exchange favours (cost on the loop-back: <= 2 %).  No multi-GPU sweep exists yet;
-    // RDYHIP_OVERLAP=0 / 1 forces a form, RDYHIP_OVERLAP_MIN_ROUNDS moves the switch.
+    // worth of interior tiles -- default 12: ~2.4 M cells first order (768 workgroups x 256 cells), ~3.1 M second order on
+    // triangles (1 024 workgroups), ~2.4 M second order on quads (768).  What is known, all of it from ONE device with the
+    // exchange looped back through a one-rank RCCL communicator:
+    //   * the overlapped form costs the kernel + 16-24 us per step at every size measured (two cross-stream event dependencies,
+    //     ~3x the host time): RCB parts of 1.4 M cells 81-88 us for a 59 us kernel, 2.9 M cells 127-130 for 108
+    //     (profiles/r04_small_parts.txt, with RDYHIP_OVERLAP_MIN_ROUNDS=6); strips: 50 vs 17 us at 0.36 M, 83 vs 73 at 2 M,
+    //     113 vs 104 at 3 M, 329 vs 318 at 10 M (profiles/r03_overlap_threshold.txt);
+    //   * the in-order form costs the kernel + the exchange itself: 10-12 us looped back with the direct receive (one pack
+    //     launch + RCCL), ~7.5 us with the fused pack as well.
+    // So the overlapped form pays only where a real xGMI exchange takes longer than ~20 us, and either choice moves a part of
+    // >= 2.4 M cells (kernel >= 90 us) by a few per cent at most.  Round 4 tried the switch at 6 rounds (the advisor's point: a
+    // real exchange is longer than the loop-back's) and measured 1.4 M-cell parts 15 % slower for it; it is back at 12 until a
+    // sweep on two real GPUs exists.  RDYHIP_OVERLAP=0 / 1 forces a form, RDYHIP_OVERLAP_MIN_ROUNDS moves the switch.
     const int pgrid    = std::max(8, op->muscl ? op->pgrid_muscl : op->pgrid);
-    int       min_rounds = 6;
+    int       min_rounds = 12;
     if (const char *e = getenv("RDYHIP_OVERLAP_MIN_ROUNDS")) min_rounds = std::max(0, atoi(e));
     h->overlap = op->use_tiled ? (int64_t)(op->ntiles - op->n_halo_tiles) >= (int64_t)min_rounds * pgrid : op->n_owned >= 1500000;
     if (const char *e = getenv("RDYHIP_OVERLAP")) h->overlap = atoi(e) != 0;

@@ -9,7 +9,9 @@ the cell gradients (6 doubles per cell, CommunicateCellGradients,
 src/operator_fluxes_ceed.c:1058-1107); its reverse ADD exchange is avoided by
 evaluating cut edges on both ranks (csrc/muscl_kernels.h).
 
-One process per GPU.  Two drivers of the same exchange pattern:
+One process per GPU.  The pattern itself (who needs which cells) is planned by rdyhip_halo_plan_* behind the C ABI for BOTH
+drivers below, so HaloExchange needs librdyhip.so even for the pure torch / gloo transport (the plan functions touch no
+device: the CPU tests use them as they are).  Two drivers of the same exchange pattern:
 
   * transport="c" (what a C host gets, and the default of bench.py on RCCL): the whole overlapped step is ONE call into
     librdyhip.so -- rdyhip_rhs_overlapped / rdyhip_euler_step_overlapped (csrc/halo_exchange.h): pack, ncclSend / ncclRecv in
