@@ -722,6 +722,10 @@ static PetscErrorCode TSSetUp_RDyHipEuler(TS ts) {
   PetscCheck(s, e->rdy->comm, PETSC_ERR_ORDER, "no native operator for this RDy (CreateOperator with -rdy_hip_native first)");
   PetscCheck(s->halo || e->rdy->mesh.num_cells == e->rdy->mesh.num_owned_cells, e->rdy->comm, PETSC_ERR_ORDER,
              "the mesh has ghost cells: call RDyHipCreateHaloFromDM after CreateOperator");
+  // the solution Vec is placed on the first 3 * num_owned_cells values of a local array: the owned cells must be numbered first
+  RDyHipLayoutInfo info;
+  RDyHipCall(rdyhip_layout_info(s->handle, &info));
+  PetscCheck(info.owned_is_prefix, e->rdy->comm, PETSC_ERR_ORDER, "TSRDyHipEuler needs the owned cells numbered before the ghosts: call RDyHipPermuteLocalCells in CreateDM");
   const size_t bytes = sizeof(double) * 3 * (size_t)(e->rdy->mesh.num_cells > 0 ? e->rdy->mesh.num_cells : 1);
   for (int k = 0; k < 2; ++k)
     if (!e->d_state[k]) {

@@ -88,7 +88,9 @@ typedef struct {
  * CACHED_F_STORES: the tiled kernels store F with the default cache policy instead of the non-temporal hint.  For a host that
  *   reads F straight back in a separate kernel -- PETSc's TSEULER: VecAXPY(U, dt, F) after every RHS (TSStep_Euler) -- the
  *   hint costs ~6 % of the RHS + axpy pair, because F has then left the Infinity Cache (DESIGN.md section 7 note 6); a host
- *   that takes the step through rdyhip_euler_step (F never stored) or lets F sit (RK stages summed later) leaves it clear. */
+ *   that takes the step through rdyhip_euler_step (F never stored) or lets F sit (RK stages summed later) leaves it clear.
+ *   Honoured by the first-order and HR tiled kernels on meshes whose tiles fit the fixed LDS layout (every numbering with
+ *   locality: RDyHipLayoutInfo.lds_fixed_layout); the second-order kernels and the run-time-length layout keep the hint. */
 #define RDYHIP_CONFIG_CACHED_F_STORES 1
 
 /* The RDyMesh arrays the SWE operators read (include/private/rdymeshimpl.h:26-202).

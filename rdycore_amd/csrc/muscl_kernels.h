@@ -831,7 +831,7 @@ __global__ __launch_bounds__(TILE) RDY_MUSCL_OCC void swe_rhs_muscl_fused_kernel
           const int64_t base  = 3 * ((int64_t)o - lane);
           const int     ncell = a.n_owned - (o - lane);
           if (a.fdiv) wave_store_rows3(a.fdiv, base, lane, ncell, acc0, acc1, acc2);
-          if (!EULER || f) wave_store_rows3(f, base, lane, ncell, res[0], res[1], res[2], a.f_cached != 0);
+          if (!EULER || f) wave_store_rows3(f, base, lane, ncell, res[0], res[1], res[2]);
           wave_store_rows3(a.pv, base, lane, ncell, h, pu, pv_);
           if (EULER) {  // rdyhip_euler_step: the forward-Euler update rides on the stores, F only if asked for
             const double n0 = h + dt * res[0], n1 = hu + dt * res[1], n2 = hv + dt * res[2];
@@ -1099,7 +1099,7 @@ __global__ __launch_bounds__(TILE) RDY_MUSCL_OCC void swe_rhs_muscl_fused_kernel
         const int64_t base  = 3 * ((int64_t)o - lane);
         const int     ncell = a.n_owned - (o - lane);
         if (a.fdiv) wave_store_rows3(a.fdiv, base, lane, ncell, acc0, acc1, acc2);
-        if (!EULER || f) wave_store_rows3(f, base, lane, ncell, res[0], res[1], res[2], a.f_cached != 0);
+        if (!EULER || f) wave_store_rows3(f, base, lane, ncell, res[0], res[1], res[2]);
         wave_store_rows3(a.pv, base, lane, ncell, h, pu, pv_);
         if (EULER) {  // rdyhip_euler_step: the forward-Euler update rides on the stores, F only if asked for
           const double n0 = h + dt * res[0], n1 = hu + dt * res[1], n2 = hv + dt * res[2];

@@ -214,7 +214,18 @@ TiledKernelFn tiled_kernel_fn_hr(int S, int src, bool ovw) {
   if (src) return ovw ? swe_rhs_tiled_kernel<4, 1, true, HR, false, NS4, NE4> : swe_rhs_tiled_kernel<4, 1, false, HR, false, NS4, NE4>;
   return ovw ? swe_rhs_tiled_kernel<4, 0, true, HR, false, NS4, NE4> : swe_rhs_tiled_kernel<4, 0, false, HR, false, NS4, NE4>;
 }
-TiledKernelFn tiled_kernel_fn(int S, int src, bool ovw, bool hr, bool fixed = false) {
+// F stored without the non-temporal hint (RDYHIP_CONFIG_CACHED_F_STORES): the fixed LDS layout's instantiations only
+template <bool HR>
+TiledKernelFn tiled_kernel_fn_cached(int S, int src, bool ovw) {
+  if (S == 3) {
+    if (src) return ovw ? swe_rhs_tiled_kernel<3, 1, true, HR, false, TILED_NS_TRI, TILED_NE_TRI, false> : swe_rhs_tiled_kernel<3, 1, false, HR, false, TILED_NS_TRI, TILED_NE_TRI, false>;
+    return ovw ? swe_rhs_tiled_kernel<3, 0, true, HR, false, TILED_NS_TRI, TILED_NE_TRI, false> : swe_rhs_tiled_kernel<3, 0, false, HR, false, TILED_NS_TRI, TILED_NE_TRI, false>;
+  }
+  if (src) return ovw ? swe_rhs_tiled_kernel<4, 1, true, HR, false, TILED_NS_QUAD, TILED_NE_QUAD, false> : swe_rhs_tiled_kernel<4, 1, false, HR, false, TILED_NS_QUAD, TILED_NE_QUAD, false>;
+  return ovw ? swe_rhs_tiled_kernel<4, 0, true, HR, false, TILED_NS_QUAD, TILED_NE_QUAD, false> : swe_rhs_tiled_kernel<4, 0, false, HR, false, TILED_NS_QUAD, TILED_NE_QUAD, false>;
+}
+TiledKernelFn tiled_kernel_fn(int S, int src, bool ovw, bool hr, bool fixed = false, bool cached_f = false) {
+  if (fixed && cached_f) return hr ? tiled_kernel_fn_cached<true>(S, src, ovw) : tiled_kernel_fn_cached<false>(S, src, ovw);
   if (fixed)
     return hr ? tiled_kernel_fn_hr<true, TILED_NS_TRI, TILED_NE_TRI, TILED_NS_QUAD, TILED_NE_QUAD>(S, src, ovw)
               : tiled_kernel_fn_hr<false, TILED_NS_TRI, TILED_NE_TRI, TILED_NS_QUAD, TILED_NE_QUAD>(S, src, ovw);
@@ -412,7 +423,6 @@ int launch_rhs(RDyHipOperator op, int32_t phase, int32_t overwrite, int reset_di
   a.xq_thresh  = op->config.xq2018_threshold;
   a.overwrite  = overwrite ? 1 : 0;
   a.phase      = phase;
-  a.f_cached   = (op->config.flags & RDYHIP_CONFIG_CACHED_F_STORES) ? 1 : 0;
 
   a.tiles    = op->d_tiles.p;
   a.e_lr     = op->d_e_lr.p;
@@ -467,7 +477,8 @@ int launch_rhs(RDyHipOperator op, int32_t phase, int32_t overwrite, int reset_di
       hipLaunchKernelGGL(HIP_KERNEL_NAME(tiled_euler_fn(op->S, xq ? 1 : 0, op->hr, op->lds_fixed)), dim3(grid), dim3(TILE), op->lds_bytes, st, a, dt, u, f);
     } else {
       const size_t lds = op->lds_bytes;
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(tiled_kernel_fn(op->S, xq ? 1 : 0, overwrite != 0, op->hr, op->lds_fixed)), dim3(grid), dim3(TILE), lds, st, a, dt, u, f);
+      const bool cached_f = (op->config.flags & RDYHIP_CONFIG_CACHED_F_STORES) != 0;
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(tiled_kernel_fn(op->S, xq ? 1 : 0, overwrite != 0, op->hr, op->lds_fixed, cached_f)), dim3(grid), dim3(TILE), lds, st, a, dt, u, f);
     }
   } else {
     if (phase == RDYHIP_PHASE_HALO) {

@@ -108,7 +108,6 @@ struct KernelArgs {
   int32_t        phase;      // RDYHIP_PHASE_*
   int32_t        overwrite;  // 1: f = rhs, 0: f += rhs
   int32_t        xcd_chunks; // >0: blocks are dealt to XCDs in contiguous chunks of this many tiles
-  int32_t        f_cached;   // 1: F is stored with the default cache policy (RDYHIP_CONFIG_CACHED_F_STORES: a separate update reads it back)
   // ---- tiled kernel only
   const struct TileDesc *tiles;  // [ntiles+1]
   const uint32_t *e_lr;      // [nrec] packed LDS slots of the edge's cells
@@ -190,18 +189,21 @@ __device__ __forceinline__ void cell_results(const KernelArgs &a, double dt, dou
 }
 // Stores one [cell][3] row per lane of a full wave, transposed so that the wave writes its 192 consecutive doubles
 // with three unit-stride instructions.  `base`: index of the wave's first double; lanes >= ncell hold no cell.
-// `cached` (wave-uniform): store with the default cache policy instead of the non-temporal hint -- F when a separate update
-// kernel reads it straight back (TSEULER's VecAXPY: RDYHIP_CONFIG_CACHED_F_STORES)
-__device__ __forceinline__ void wave_store_rows3(double *__restrict__ arr, int64_t base, int lane, int ncell, double v0, double v1, double v2,
-                                                 bool cached = false) {
+// NT = false: store with the default cache policy instead of the non-temporal hint -- F when a separate update kernel reads it
+// straight back (TSEULER's VecAXPY: RDYHIP_CONFIG_CACHED_F_STORES).  A COMPILE-TIME choice on purpose: round 4 first made it a
+// wave-uniform run-time branch around the store, and the optimiser sank the two arms (same value, same address) into ONE store
+// whose metadata is the intersection of the two -- the hint was dropped from every F / pv / u_out store of every kernel, first
+// order -6 %, and nothing but a same-box A/B against the previous round's library showed it (tests/test_isa_cpu.py now counts
+// the hinted stores of every RHS kernel in the built library).
+template <bool NT = true>
+__device__ __forceinline__ void wave_store_rows3(double *__restrict__ arr, int64_t base, int lane, int ncell, double v0, double v1, double v2) {
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     const int    e = 64 * k + lane, src = e / 3, comp = e - 3 * src;
     const double s0 = __shfl(v0, src, 64), s1 = __shfl(v1, src, 64), s2 = __shfl(v2, src, 64);
-    const double v  = comp == 0 ? s0 : (comp == 1 ? s1 : s2);
     if (src < ncell) {
-      if (cached) arr[base + e] = v;
-      else RDY_ST(&arr[base + e], v);
+      if (NT) RDY_ST(&arr[base + e], comp == 0 ? s0 : (comp == 1 ? s1 : s2));
+      else arr[base + e] = comp == 0 ? s0 : (comp == 1 ? s1 : s2);
     }
   }
 }
@@ -391,7 +393,8 @@ __device__ __forceinline__ void hr_velocity_rule(RiemannSide &s, double tiny_h) 
   s.v            = wet ? s.v : 0.0;
 }
 constexpr int TILED_NS_TRI = 360, TILED_NE_TRI = 520, TILED_NS_QUAD = 368, TILED_NE_QUAD = 552;
-template <int S, int SRC, bool OVW, bool HR, bool EULER = false, int NS = 0, int NE = 0>
+// FNT = false: F is stored without the non-temporal hint (RDYHIP_CONFIG_CACHED_F_STORES; instantiated for the fixed LDS layout only)
+template <int S, int SRC, bool OVW, bool HR, bool EULER = false, int NS = 0, int NE = 0, bool FNT = true>
 __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(3, 3))) void swe_rhs_tiled_kernel(const KernelArgs a, const double dt, const double *__restrict__ u,
                                                               double *__restrict__ f) {
   // edge-record rounds held in registers: a 256-cell tile of a well-numbered triangle mesh has <= 2 x 256 edge records
@@ -746,7 +749,7 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
         const int     lane  = tid & 63;
         const int64_t base  = 3 * ((int64_t)o - lane);
         const int     ncell = a.n_owned - (o - lane);
-        if (!EULER || f) wave_store_rows3(f, base, lane, ncell, out[0], out[1], out[2], a.f_cached != 0);
+        if (!EULER || f) wave_store_rows3<FNT>(f, base, lane, ncell, out[0], out[1], out[2]);
         wave_store_rows3(a.pv, base, lane, ncell, out[3], out[4], out[5]);
         if (a.fdiv) wave_store_rows3(a.fdiv, base, lane, ncell, acc_fdiv[0], acc_fdiv[1], acc_fdiv[2]);
         if (EULER) {

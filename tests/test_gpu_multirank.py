@@ -430,3 +430,58 @@ def test_three_rcb_ranks_one_gpu_second_order_quads(rdyhip_kernel):
         assert err <= 1e-10, (rank, err)
         assert cerr <= 1e-10 and ids_ok
         assert 0 < nhalo_tiles < ntiles
+
+
+def test_fused_pack_lifetime_and_argument_errors(rdyhip_kernel):
+    """rdyhip_halo_fuse_pack: one halo per operator holds it, second order and the cell-centric kernel refuse it, a halo without
+    peers may hold it (empty lists), and a halo that outlives its operator is destroyed without touching freed state"""
+    import ctypes as C
+    from rdycore_amd import _lib
+    from rdycore_amd import cases as CS
+    from rdycore_amd import mesh as M
+    lib = _lib.load()
+    torch.cuda.set_device(0)
+    K = 2 * np.pi / 37
+    mesh = M.structured_tri_mesh(48, 40, 1.0, zfunc=CS.mms_bathymetry(K=K), order="tiled", tile=8)
+    case = CS.friction_slope_case(mesh, 48.0, 40.0, dt=1e-2, K=K)
+    i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+    p = lambda a: a.ctypes.data_as(_lib.c_int32_p)
+
+    def make_halo(op, n):
+        h = C.c_void_p()
+        send, recv = i32(np.arange(0, n)), i32(np.arange(2000, 2000 + n))
+        _lib.check(lib.rdyhip_halo_create(op._h, None, 1 if n else 0, p(i32([0])), p(i32([n])), p(send), p(i32([n])), p(recv), C.byref(h)))
+        return h
+
+    op = CS.create_operator(case)
+    h1, h2, h0 = make_halo(op, 300), make_halo(op, 200), make_halo(op, 0)
+    if rdyhip_kernel == "cell":
+        assert lib.rdyhip_halo_fuse_pack(h1, 1) == 83 and b"tiled" in lib.rdyhip_last_error()
+    else:
+        assert lib.rdyhip_halo_fuse_pack(h1, 1) == 0 and lib.rdyhip_halo_pack_fused(h1) == 1
+        assert lib.rdyhip_halo_fuse_pack(h1, 1) == 0                                   # idempotent
+        assert lib.rdyhip_halo_fuse_pack(h2, 1) == 83 and b"another halo" in lib.rdyhip_last_error()
+        assert lib.rdyhip_halo_fuse_pack(h1, 0) == 0 and lib.rdyhip_halo_pack_fused(h1) == 0
+        assert lib.rdyhip_halo_fuse_pack(h0, 1) == 0                                   # no peers: empty send lists
+        # an Euler step with the (empty) lists attached is the plain step
+        u = torch.tensor(case.u_local, dtype=torch.float64, device="cuda:0")
+        a, b = torch.empty_like(u), torch.empty_like(u)
+        st = int(torch.cuda.current_stream().cuda_stream)
+        _lib.check(lib.rdyhip_euler_step_overlapped(op._h, h0, case.dt, int(u.data_ptr()), int(a.data_ptr()), None, st))
+        op.euler_step(case.dt, u, b)
+        torch.cuda.synchronize()
+        assert torch.equal(a[:mesh.num_owned_cells], b[:mesh.num_owned_cells])
+        assert lib.rdyhip_halo_fuse_pack(h0, 0) == 0 and lib.rdyhip_halo_fuse_pack(h2, 1) == 0
+    assert lib.rdyhip_halo_invalidate(None) == 83 and lib.rdyhip_halo_fuse_pack(None, 1) == 83
+    _lib.check(lib.rdyhip_halo_destroy(C.byref(h1)))
+    _lib.check(lib.rdyhip_halo_destroy(C.byref(h0)))
+    op.destroy()                                       # h2 (holding the fused pack on the tiled kernel) outlives its operator
+    _lib.check(lib.rdyhip_halo_destroy(C.byref(h2)))
+    # second order keeps its pack launch
+    case.config.second_order = True
+    if rdyhip_kernel != "cell":
+        op2 = CS.create_operator(case)
+        h = make_halo(op2, 100)
+        assert lib.rdyhip_halo_fuse_pack(h, 1) == 83 and b"second_order" in lib.rdyhip_last_error()
+        _lib.check(lib.rdyhip_halo_destroy(C.byref(h)))
+        op2.destroy()
