@@ -305,12 +305,14 @@ def traffic_key(args) -> str:
 
 
 def load_traffic(workload_key: str, layout_bytes: int, second_order: bool = False):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic.json), only if they were
-    collected on exactly these kernel sources AND this device layout (the layout is made by the host code in
-    rdyhip_api.hip: its byte count per launch is compared); a stale entry is reported as such, never silently."""
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic.json), only if they were collected on
+    exactly this MACHINE CODE of the measured kernel(s) -- the entry names the kernel and holds the hash of its bytes in the
+    library the profiled run loaded; the library this run loads must have the same bytes (rdycore_amd/codeobj.py) -- AND this
+    device layout (made by the host code in rdyhip_api.hip: its byte count per launch is compared); a stale or unverifiable
+    entry is reported as such, never silently."""
+    from rdycore_amd import build as _build, codeobj
     path = os.path.join(ROOT, "profiles", "traffic.json")
-    sha = kernel_sha(second_order)
-    src = {"source": "profiles/traffic.json", "key": workload_key, "kernel_sha": sha}
+    src = {"source": "profiles/traffic.json", "key": workload_key, "kernel_source_sha": kernel_sha(second_order)}
     try:
         with open(path) as fh:
             t = json.load(fh)
@@ -321,12 +323,22 @@ def load_traffic(workload_key: str, layout_bytes: int, second_order: bool = Fals
     if not ent:
         src["status"] = "no PMC passes for this workload"
         return None, src
-    if ent.get("kernel_sha") != sha or int(ent.get("layout_bytes_per_launch", -1)) != int(layout_bytes):
-        src["status"] = (f"STALE: measured on kernel_sha {ent.get('kernel_sha')} / layout {ent.get('layout_bytes_per_launch')} B, "
-                         f"current: {sha} / {layout_bytes} B -- rerun tools/profile_gpu.sh")
+    measured = [(ent.get("kernel"), ent.get("code_sha"))]
+    if ent.get("also_in_the_step"):
+        measured.append((ent["also_in_the_step"].get("kernel"), ent["also_in_the_step"].get("code_sha")))
+    try:
+        now = [codeobj.kernel_sha(_build.lib_path(), k) for k, _ in measured]
+    except Exception as exc:
+        src["status"] = f"cannot verify the code of the measured kernel: {exc!r}"
+        print(f"bench.py: profiles/traffic.json[{workload_key}]: {src['status']}; roofline.traffic = null", file=sys.stderr)
+        return None, src
+    src["kernel"], src["code_sha"] = measured[0][0], now[0]
+    if [m[1] for m in measured] != now or int(ent.get("layout_bytes_per_launch", -1)) != int(layout_bytes):
+        src["status"] = (f"STALE: measured on code {[m[1] for m in measured]} / layout {ent.get('layout_bytes_per_launch')} B, "
+                         f"current: {now} / {layout_bytes} B -- rerun tools/profile_gpu.sh")
         print(f"bench.py: profiles/traffic.json[{workload_key}] is stale; roofline.traffic = null", file=sys.stderr)
         return None, src
-    src["status"] = "measured on this kernel source"
+    src["status"] = "measured on this machine code of the kernel"
     return ent.get("hbm_bytes_per_launch"), src
 
 
@@ -658,6 +670,8 @@ def run_rank(args, argv):
     euler = {"fused_ms_per_step": round(ef, 5), "rhs_plus_axpy_ms_per_step": round(ep, 5), "fused_steps_per_s": round(1e3 / ef, 1)}
     if halo is not None or self_halo is not None:
         euler["pack_fused_into_kernel"] = bool(pack_fused)
+        # the next step's transfer starts when this step's launch has stored its last send row (include/rdyhip.h, "signalled form")
+        euler["signalled_form"] = bool(halo.signalled) if halo is not None else bool(self_halo[0].rdyhip_halo_signalled(self_halo[1]))
         if halo is not None:
             halo.invalidate()
     del u2, u3, pp

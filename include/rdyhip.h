@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RDYHIP_VERSION 108
+#define RDYHIP_VERSION 109
 
 /* error codes = PETSc's values */
 #define RDYHIP_SUCCESS 0
@@ -360,7 +360,17 @@ int rdyhip_unpack_rows(double *dst, int32_t ncomp, const int32_t *row_ids, int32
  *                    launch.  The promise the caller makes: between two such steps it does not write the owned rows of that
  *                    array itself -- or calls rdyhip_halo_invalidate() if it did (a host that sets the state, a restart).  A
  *                    step whose u_local is any other array packs as before.  One halo per operator can hold the fused pack.
- * With both, a step of rdyhip_euler_step_overlapped is the transfer and ONE kernel launch. */
+ * With both, a step of rdyhip_euler_step_overlapped is the transfer and ONE kernel launch.
+ * Such a step runs in order at every size (transfer, launch: there is no pack left to hide, and launch + 8-10 us beats the two-stream
+ * form's launch + 14 us up to the largest part measured); RDYHIP_OVERLAP=1 forces the two-stream form, a transport callback keeps it.
+ *   signalled form   opt-in, RDYHIP_SIGNALLED=1 at rdyhip_halo_fuse_pack: RCCL halos with the fused pack, on devices whose streams
+ *                    can wait for a word in memory (hipDeviceAttributeCanUseStreamWaitValue; rdyhip_halo_signalled() says whether
+ *                    it is in use).  The launch of step n runs its send-flagged tiles first and, when the last send row is in
+ *                    memory, advances a counter in signal memory; the exchange stream waits for THAT (hipStreamWaitValue64), not
+ *                    for the launch, so the transfer of step n + 1 runs beside the rest of step n's launch.  Looped back on one
+ *                    device it equals the in-order form to +-3 % from 1.4 M cells per rank on and loses below;
+ *                    it is there for transfers that take longer than a loop-back.  Never used under rocprofv3's counter collection
+ *                    (ROCPROF_COUNTER_COLLECTION=1 in the environment), whose dispatch serialiser stalls on the wait packet. */
 typedef struct RDyHipHalo_s *RDyHipHalo;
 typedef int (*RDyHipTransportFn)(void *ctx, const double *d_send, double *d_recv, int32_t ncomp, void *stream);
 int rdyhip_halo_create(RDyHipOperator op, void *nccl_comm, int32_t npeers, const int32_t *peers, const int32_t *send_counts,
@@ -370,6 +380,7 @@ int32_t rdyhip_halo_overlaps(RDyHipHalo halo);
 int32_t rdyhip_halo_direct_receive(RDyHipHalo halo);
 int rdyhip_halo_fuse_pack(RDyHipHalo halo, int32_t enable);
 int32_t rdyhip_halo_pack_fused(RDyHipHalo halo);
+int32_t rdyhip_halo_signalled(RDyHipHalo halo);
 int rdyhip_halo_invalidate(RDyHipHalo halo);
 int rdyhip_halo_set_transport(RDyHipHalo halo, RDyHipTransportFn fn, void *ctx);
 int rdyhip_halo_exchange(RDyHipHalo halo, double *rows, int32_t ncomp, void *stream);

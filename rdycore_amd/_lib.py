@@ -96,6 +96,7 @@ SYMBOLS = {
     "rdyhip_halo_direct_receive": (C.c_int32, [C.c_void_p]),
     "rdyhip_halo_fuse_pack": (C.c_int, [C.c_void_p, C.c_int32]),
     "rdyhip_halo_pack_fused": (C.c_int32, [C.c_void_p]),
+    "rdyhip_halo_signalled": (C.c_int32, [C.c_void_p]),
     "rdyhip_halo_invalidate": (C.c_int, [C.c_void_p]),
     "rdyhip_halo_set_transport": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "rdyhip_halo_exchange": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
@@ -124,7 +125,7 @@ SYMBOLS = {
 TRANSPORT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p)
 
 _LIB = None
-ABI_VERSION = 108     # RDYHIP_VERSION of include/rdyhip.h this binding was written against
+ABI_VERSION = 109     # RDYHIP_VERSION of include/rdyhip.h this binding was written against
 
 
 class RDyHipError(RuntimeError):

@@ -26,9 +26,18 @@ struct RDyHipHalo_s {
   // u_out (per-tile send lists, swe_kernels.h), so the next step's exchange needs no pack launch either
   bool            fused_pack = false;
   const double   *packed_state = nullptr;  // the state array whose send rows d_send holds ([cells][3]), or nullptr
+  // The signalled form of a fused-pack Euler step (RCCL halos on devices with hipStreamWaitValue64): the launch that stores
+  // the send rows tells the exchange stream when the last of them is in memory (wave_signal_send_rows, swe_kernels.h), so the
+  // NEXT step's transfer runs while that launch is still busy with the tiles no other rank needs
+  uint64_t        *signal = nullptr;       // signal memory (hipMallocSignalMemory): launches that have stored all their send rows
+  uint64_t         packed_epoch = 0;       // the value of *signal that says packed_state's rows are in d_send
+  int32_t          n_send_tiles = 0;
+  DevBuf<uint32_t> d_send_done;            // [1] the running launch's count of send waves
+  DevBuf<uint64_t> d_send_epoch;           // [1] the device's copy of *signal
   DevBuf<int32_t>  d_send_tile_off;        // [ntiles + 1]
   DevBuf<uint32_t> d_send_ent;             // cell-in-tile | send row << 8, sorted by tile
   bool            overlap = true;  // exchange hidden behind the interior tiles (large parts) or everything in order (small parts)
+  bool            overlap_forced = false;  // RDYHIP_OVERLAP was set at create
   hipStream_t     cs = nullptr;  // exchange stream
   // fork / join events: a small ring, one pair per step, so that steps still in flight never share an event (the host
   // runs several steps ahead of the device)
@@ -43,6 +52,8 @@ struct RDyHipHalo_s {
   }
   ~RDyHipHalo_s() {
     d_send_ids.release(); d_recv_ids.release(); d_send.release(); d_recv.release(); d_send_tile_off.release(); d_send_ent.release();
+    d_send_done.release(); d_send_epoch.release();
+    if (signal) (void)hipFree(signal);
     for (int i = 0; i < NEV; ++i) {
       if (ev_fork_ring[i]) (void)hipEventDestroy(ev_fork_ring[i]);
       if (ev_join_ring[i]) (void)hipEventDestroy(ev_join_ring[i]);
@@ -142,6 +153,7 @@ int halo_pack_state(RDyHipHalo h, const double *u, hipStream_t s) {
 // runs after this step's transfer has read d_send), nothing the next step could use otherwise
 void halo_note_step(RDyHipOperator op, RDyHipHalo h, const double *u_out) {
   h->packed_state = (h->fused_pack && op->fused_halo == h && u_out && op->use_tiled && !op->muscl) ? u_out : nullptr;
+  h->packed_epoch = op->send_epoch;  // the launch just enqueued is the one that stores them
 }
 
 // OperatorRHSFunction (u_out == nullptr) or one forward-Euler step (u_out != nullptr) with the ghost update of u
@@ -172,7 +184,37 @@ int overlapped(RDyHipOperator op, RDyHipHalo h, double dt, double *u, double *f,
     return launch_rhs(op, phase, 1, reset, dt, u, f, st, ready, u_out, conc && phase == RDYHIP_PHASE_INTERIOR ? 1 : 0);
   };
   int rc;
-  if (!h->overlap) {
+  // Fused-pack Euler steps over RCCL, where a stream can wait for a word in memory: the signalled form.
+  //   exchange stream:  [wait until the launch of step n - 1 has stored its last send row]  transfer (, unpack)  -> event
+  //   caller's stream:  [wait for that event]  ONE launch over all tiles, the send-flagged tiles of every XCD chunk first
+  // The transfer of step n thus runs beside the rest of step n - 1's launch and the caller's stream finds its event signalled
+  // (profiles/r04_wait_value_probe.txt: 3 us from the store to the waiting stream's next kernel).  Opt-in: RDYHIP_SIGNALLED=1.
+  // The first step of a run (d_send does not hold u's rows yet) packs with a launch, ordered after the caller's stream.
+  if (h->signal && h->fused_pack && op->fused_halo == h && u_out && !op->muscl && op->use_tiled && !h->transport && op->send_signalling) {
+    h->next_events();
+    if (h->packed_state == u) {
+      HIP_TRY(hipStreamWaitValue64(h->cs, h->signal, h->packed_epoch, hipStreamWaitValueGte, ~0ull));
+    } else {
+      HIP_TRY(hipEventRecord(h->ev_fork, st));
+      HIP_TRY(hipStreamWaitEvent(h->cs, h->ev_fork, 0));
+    }
+    rc = halo_pack_state(h, u, h->cs);  // nothing to do when d_send already holds u's rows
+    if (!rc) rc = halo_transfer(h, u, 3, h->cs);
+    if (!rc) rc = halo_unpack(h, u, 3, h->cs);
+    // (an error leaves the exchange stream joined back all the same: later work on the caller's stream stays ordered behind it)
+    hipError_t e = hipEventRecord(h->ev_join, h->cs);
+    if (e == hipSuccess) e = hipStreamWaitEvent(st, h->ev_join, 0);
+    if (!rc && e != hipSuccess) rc = fail(RDYHIP_ERR_LIB, "joining the exchange stream failed: %s", hipGetErrorString(e));
+    if (!rc) rc = launch_rhs(op, RDYHIP_PHASE_ALL, 1, 1, dt, u, f, st, false, u_out, 0, true);
+    halo_note_step(op, h, rc ? nullptr : u_out);
+    return rc;
+  }
+  // A fused-pack Euler step over RCCL is the transfer and one launch: in order that is launch + 8-10 us at every size measured
+  // (0.36 - 2.9 M cells per rank), the two-stream form launch + 14 us or more (profiles/r04_small_parts.txt) -- there is no pack
+  // to hide any more, and the second launch of the ghost-adjacent tiles finds no free workgroup slot until the first one ends.
+  // (A transport callback may block the host: it keeps the two-stream form, whose interior launch is enqueued first.)
+  const bool fused_euler = h->fused_pack && op->fused_halo == h && u_out && !op->muscl && op->use_tiled && !h->transport;
+  if (!h->overlap || (fused_euler && !h->overlap_forced)) {
     // Small parts: the tiles that need no ghost data run for less time than the exchange chain (pack, transfer, unpack, halo
     // tiles) takes, and the two cross-stream dependencies of the overlapped form cost more than they hide -- measured on
     // a 360 000-cell rank (profiles/r03_step_breakdown_360k.json): 51.8 us per overlapped step against 14.0 us for the
@@ -351,7 +393,10 @@ int rdyhip_halo_create(RDyHipOperator op, void *nccl_comm, int32_t npeers, const
     int       min_rounds = 12;
     if (const char *e = getenv("RDYHIP_OVERLAP_MIN_ROUNDS")) min_rounds = std::max(0, atoi(e));
     h->overlap = op->use_tiled ? (int64_t)(op->ntiles - op->n_halo_tiles) >= (int64_t)min_rounds * pgrid : op->n_owned >= 1500000;
-    if (const char *e = getenv("RDYHIP_OVERLAP")) h->overlap = atoi(e) != 0;
+    if (const char *e = getenv("RDYHIP_OVERLAP")) {
+      h->overlap        = atoi(e) != 0;
+      h->overlap_forced = true;
+    }
   }
   int rc      = h->d_send_ids.upload(std::vector<int32_t>(send_cell_ids, send_cell_ids + ns));
   if (!rc) rc = h->d_recv_ids.upload(std::vector<int32_t>(recv_cell_ids, recv_cell_ids + nr));
@@ -396,6 +441,7 @@ static int halo_attach_send_lists(RDyHipHalo h, bool on) {
   std::vector<TileDesc> tiles((size_t)op->ntiles + 1);
   HIP_TRY(hipMemcpy(tiles.data(), op->d_tiles.p, tiles.size() * sizeof(TileDesc), hipMemcpyDeviceToHost));
   for (auto &t : tiles) t.cnt &= ~TILE_SEND_FLAG;
+  bool signalling = false;
   if (on) {
     const int32_t ns = h->send_off.back();
     std::vector<int32_t> ids((size_t)ns);
@@ -422,12 +468,70 @@ static int halo_attach_send_lists(RDyHipHalo h, bool on) {
     int rc = h->d_send_tile_off.upload(off);
     if (!rc) rc = h->d_send_ent.upload(packed);
     if (rc) return rc;
+    // the signalled form (overlapped(), above): RCCL halos on a device whose streams can wait for a word in memory
+    // (RDYHIP_SIGNALLED=0: the forms without it, for A/B timing)
+    h->n_send_tiles = 0;
+    for (int32_t t = 0; t < op->ntiles; ++t) h->n_send_tiles += (tiles[(size_t)t].cnt & TILE_SEND_FLAG) ? 1 : 0;
+    int can = 0;
+    (void)hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, op->device);
+    const char *senv = getenv("RDYHIP_SIGNALLED");
+    // Opt-in (RDYHIP_SIGNALLED=1): on one device, with the transfer looped back, it is within +-3 % of the in-order form at
+    // 1.4 - 2.9 M cells per rank (better on the unstructured part, worse on quads) and loses below ~0.8 M, where the launch is
+    // over before the chain it is meant to hide (profiles/r04_small_parts.txt); what a real xGMI hop -- a longer transfer to
+    // hide -- makes of it cannot be measured on this pool.  Never under rocprofv3's counter collection (it exports
+    // ROCPROF_COUNTER_COLLECTION=1 to the profiled process): its dispatch serialiser does not let the wait packet through --
+    // every PMC pass of the looped-back multi-rank step hung at its first signalled step, while plain kernel tracing runs it
+    // fine (profiles/RESULTS_LOG.md section 11).
+    const char *pmc = getenv("ROCPROF_COUNTER_COLLECTION");
+    const bool  counters = pmc && atoi(pmc) != 0;
+    signalling = can && h->comm && h->n_send_tiles > 0 && senv && atoi(senv) != 0 && !counters;
+    if (signalling) {
+      // the early transfer writes the receive rows of an array the running launch is still storing owned rows of: they must
+      // be ghost rows, which no launch writes (always so for a real partition; a synthetic pattern keeps the other forms)
+      const int32_t nr = h->recv_off.back();
+      std::vector<int32_t> rid((size_t)nr);
+      if (nr) HIP_TRY(hipMemcpy(rid.data(), h->d_recv_ids.p, sizeof(int32_t) * (size_t)nr, hipMemcpyDeviceToHost));
+      for (int32_t i = 0; i < nr && signalling; ++i) {
+        const int32_t c = rid[(size_t)i];
+        if (op->prefix ? c < op->n_owned : (c < (int32_t)op->h_l2o.size() && op->h_l2o[(size_t)c] >= 0)) signalling = false;
+      }
+    }
+    if (const char *e = getenv("RDYHIP_SIGNALLED_SHRINK")) op->signalled_shrink = std::max(0, atoi(e));  // measurement knob
+    if (signalling) {
+      if (!h->signal) {
+        HIP_TRY(hipExtMallocWithFlags((void **)&h->signal, sizeof(uint64_t), hipMallocSignalMemory));
+      }
+      *h->signal = 0;  // signal memory is host-visible; the device is idle (synchronised above)
+      rc = h->d_send_done.zeros(1);
+      if (!rc) rc = h->d_send_epoch.zeros(1);
+      // the launch's tile list: the XCD chunks of the plain order (launch_rhs), inside each the send-flagged tiles first
+      std::vector<int32_t> order;
+      order.reserve((size_t)op->ntiles);
+      const int32_t chunk = op->tiled_xcd_chunks > 0 ? op->tiled_xcd_chunks : op->ntiles;
+      for (int32_t lo = 0; lo < op->ntiles; lo += chunk) {
+        const int32_t hi = std::min(op->ntiles, lo + chunk);
+        for (int32_t t = lo; t < hi; ++t)
+          if (tiles[(size_t)t].cnt & TILE_SEND_FLAG) order.push_back(t);
+        for (int32_t t = lo; t < hi; ++t)
+          if (!(tiles[(size_t)t].cnt & TILE_SEND_FLAG)) order.push_back(t);
+      }
+      op->d_tiles_send_first.release();
+      if (!rc) rc = op->d_tiles_send_first.upload(order);
+      if (rc) return rc;
+    }
   }
   ColdArgs c;
   HIP_TRY(hipMemcpy(&c, op->d_cold.p, sizeof(c), hipMemcpyDeviceToHost));
-  c.send_off = on ? h->d_send_tile_off.p : nullptr;
-  c.send_ent = on ? h->d_send_ent.p : nullptr;
-  c.send_buf = on ? h->d_send.p : nullptr;
+  c.send_off    = on ? h->d_send_tile_off.p : nullptr;
+  c.send_ent    = on ? h->d_send_ent.p : nullptr;
+  c.send_buf    = on ? h->d_send.p : nullptr;
+  c.send_done   = signalling ? h->d_send_done.p : nullptr;
+  c.send_epoch  = signalling ? h->d_send_epoch.p : nullptr;
+  c.send_signal = signalling ? h->signal : nullptr;
+  c.send_waves  = signalling ? (uint32_t)h->n_send_tiles * (uint32_t)(TILE / 64) : 0u;
+  op->send_signalling = signalling;
+  op->send_epoch      = 0;
+  h->packed_epoch     = 0;
   HIP_TRY(hipMemcpy(op->d_cold.p, &c, sizeof(c), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(op->d_tiles.p, tiles.data(), tiles.size() * sizeof(TileDesc), hipMemcpyHostToDevice));
   op->fused_halo = on ? h : nullptr;
@@ -464,6 +568,9 @@ int rdyhip_halo_invalidate(RDyHipHalo halo) {
 
 int32_t rdyhip_halo_direct_receive(RDyHipHalo halo) { return halo && halo->recv_base >= 0 ? 1 : 0; }
 int32_t rdyhip_halo_pack_fused(RDyHipHalo halo) { return halo && halo->fused_pack ? 1 : 0; }
+int32_t rdyhip_halo_signalled(RDyHipHalo halo) {
+  return halo && halo->fused_pack && halo->signal && halo->op->fused_halo == halo && halo->op->send_signalling && !halo->transport ? 1 : 0;
+}
 
 int rdyhip_halo_destroy(RDyHipHalo *halo) {
   if (!halo) return fail(RDYHIP_ERR_USER, "null argument to rdyhip_halo_destroy");

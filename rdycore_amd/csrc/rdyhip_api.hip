@@ -126,6 +126,13 @@ struct RDyHipOperator_s {
   RDyHipConfig config;
   RDyHipHalo_s *fused_halo = nullptr;  // the halo whose send lists are attached to the tile descriptors (rdyhip_halo_fuse_pack)
   std::vector<int32_t> h_l2o;          // local -> owned cell id, kept only when the owned cells are not a prefix
+  // the signalled form of the multi-rank Euler step (halo_exchange.h): launches that store all send rows count themselves
+  // on the device (wave_signal_send_rows); this is the host's copy of that count, and the tile list that puts the
+  // send-flagged tiles of every XCD chunk first
+  uint64_t        send_epoch = 0;
+  bool            send_signalling = false;
+  int             signalled_shrink = 64;   // a signalled launch leaves 1/signalled_shrink of the workgroup slots to the transfer's kernel (0: none)
+  DevBuf<int32_t> d_tiles_send_first;
   int          device = 0;
   int32_t      n_cells = 0, n_owned = 0, S = 3, K = 0, n_internal = 0;
   int64_t      stride = 0;
@@ -189,7 +196,7 @@ struct RDyHipOperator_s {
     d_mannings.release(); d_extsrc.release(); d_bvalues.release(); d_bflux.release();
     d_baccum.release(); d_bcn.release(); d_bsn.release(); d_pv.release(); d_fdiv.release(); d_blk_max.release();
     d_blk_pos.release(); d_courant.release(); d_cold.release(); d_stage_vals.release(); d_stage_ids.release(); d_scratch_f.release();
-    d_tiles.release(); d_e_lr.release(); d_hcells.release(); d_tile_bk.release(); d_halo_tiles.release();
+    d_tiles.release(); d_e_lr.release(); d_hcells.release(); d_tile_bk.release(); d_halo_tiles.release(); d_tiles_send_first.release();
     d_e_cs.release(); d_slot_ref.release(); d_slot_ref3.release(); d_zc_local.release();
     d_grad.release(); d_e_mid.release(); d_cxy.release(); d_hcells2.release(); d_c_off.release();
     d_bn_idx.release();
@@ -367,7 +374,7 @@ int launch_gradients(RDyHipOperator op, int32_t phase, const double *u, hipStrea
 // ordinary launch); 1 / 2: the first / second half, for the interior and the halo launch of rdyhip_rhs_overlapped, which
 // run side by side on two streams and must not share a bucket
 int launch_rhs(RDyHipOperator op, int32_t phase, int32_t overwrite, int reset_diag, double dt, const double *u, double *f, hipStream_t st,
-               bool gradients_ready = false, double *u_out = nullptr, int bucket_half = 0) {
+               bool gradients_ready = false, double *u_out = nullptr, int bucket_half = 0, bool send_tiles_first = false) {
   if (!op) return fail(RDYHIP_ERR_USER, "null operator");
   // an Euler-step launch rewrites the attached halo's send buffer (tiles flagged TILE_SEND_FLAG): whatever it held is gone
   // (rdyhip_euler_step_overlapped notes the new content itself once its launches are enqueued)
@@ -449,11 +456,14 @@ int launch_rhs(RDyHipOperator op, int32_t phase, int32_t overwrite, int reset_di
       a.phase      = RDYHIP_PHASE_ALL;  // the list already holds exactly the halo tiles
       grid         = std::min(pgrid, op->n_halo_tiles);
     } else {
-      a.list   = nullptr;
+      a.list   = (send_tiles_first && phase == RDYHIP_PHASE_ALL) ? op->d_tiles_send_first.p : nullptr;  // same chunks, another order inside
       a.n_work = op->ntiles;
       // While the interior phase runs, the halo exchange's pack / RCCL / unpack kernels need somewhere
       // to run: the persistent grid would otherwise fill every SIMD's register file for the whole launch.
-      const int pg = (phase == RDYHIP_PHASE_INTERIOR && op->interior_shrink > 0) ? std::max(8, pgrid - pgrid / op->interior_shrink) : pgrid;
+      // (the signalled step's launch likewise: the next step's transfer is meant to run BESIDE it, and a persistent grid that
+      // holds every slot until its last tile lets the RCCL kernel in only at its tail)
+      const int shrink = phase == RDYHIP_PHASE_INTERIOR ? op->interior_shrink : (a.list ? op->signalled_shrink : 0);
+      const int pg     = shrink > 0 ? std::max(8, pgrid - std::max(8, pgrid / shrink)) : pgrid;
       if (op->tiled_xcd_chunks > 0) {
         a.xcd_chunks = op->tiled_xcd_chunks;
         int per_xcd  = std::max(1, std::min(pg >> 3, op->tiled_xcd_chunks));
@@ -475,6 +485,9 @@ int launch_rhs(RDyHipOperator op, int32_t phase, int32_t overwrite, int reset_di
       hipLaunchKernelGGL(HIP_KERNEL_NAME(kfn), dim3(grid), dim3(TILE), op->lds_muscl, st, a, muscl_args(op), dt, u, f);
     } else if (euler_fused) {
       hipLaunchKernelGGL(HIP_KERNEL_NAME(tiled_euler_fn(op->S, xq ? 1 : 0, op->hr, op->lds_fixed)), dim3(grid), dim3(TILE), op->lds_bytes, st, a, dt, u, f);
+      // this launch runs every send-flagged tile (they all have ghost neighbours: no INTERIOR launch touches one) and its
+      // last send wave will advance the device's count: the host's copy follows
+      if (op->send_signalling && phase != RDYHIP_PHASE_INTERIOR) ++op->send_epoch;
     } else {
       const size_t lds = op->lds_bytes;
       const bool cached_f = (op->config.flags & RDYHIP_CONFIG_CACHED_F_STORES) != 0;

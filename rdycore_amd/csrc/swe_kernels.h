@@ -85,6 +85,11 @@ struct ColdArgs {
   const int32_t  *send_off;  // [ntiles + 1] first send entry of each tile
   const uint32_t *send_ent;  // cell-in-tile (bits 0-7) | row of the send buffer (bits 8-31), sorted by tile
   double         *send_buf;  // [send cells][3]
+  // ... and the word that tells the exchange stream they are all there (wave_signal_send_rows): nullptr = no signalling
+  uint32_t *send_done;    // waves of flagged tiles that have stored their rows in the running launch
+  uint64_t *send_epoch;   // launches that have stored ALL their send rows so far
+  uint64_t *send_signal;  // the same number in signal memory: hipStreamWaitValue64 on the exchange stream waits for it
+  uint32_t  send_waves;   // waves of flagged tiles per launch (TILE / 64 per tile)
 };
 
 struct KernelArgs {
@@ -321,10 +326,36 @@ __device__ __forceinline__ void wave_store_send_rows(const KernelArgs &a, int ti
     const int      j   = (int)(ent & 0xFFu);
     const double   v0 = __shfl(n0, j & 63, 64), v1 = __shfl(n1, j & 63, 64), v2 = __shfl(n2, j & 63, 64);
     if (i < s1 && (j >> 6) == wave) {
+      // agent-scope stores: written through this XCD's L2, so that a kernel that starts while this launch is still running
+      // (the signalled transfer, below) finds the rows in memory -- a plain store would sit in the L2 until the launch ends
       const int64_t row = (int64_t)(ent >> 8);
-      sbuf[3 * row + 0] = v0;
-      sbuf[3 * row + 1] = v1;
-      sbuf[3 * row + 2] = v2;
+      __hip_atomic_store(&sbuf[3 * row + 0], v0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&sbuf[3 * row + 1], v1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&sbuf[3 * row + 2], v2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+// The last wave of a launch to have stored its send rows says so to the exchange stream: the ghost transfer of the NEXT step
+// starts while this launch is still at work on the tiles nobody else needs (the host puts the flagged tiles first in the
+// launch's tile list).  A wave is counted once its rows have reached memory: they are agent-scope (write-through) stores and
+// the wave waits for their acknowledgement (vmcnt) -- NOT a release fence, which on this device writes the whole L2 of the XCD
+// back (buffer_wbl2) once per wave.  The counter and the signal are relaxed atomics at agent / system scope (performed at
+// memory); the count is reset by the wave that completes it, so a launch finds it at zero.
+__device__ __forceinline__ void wave_signal_send_rows(const KernelArgs &a, int tid) {
+  uint64_t *sig = RDY_COLD(a, send_signal);
+  if (!sig) return;  // uniform
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if ((tid & 63) == 0) {
+    uint32_t      *done  = RDY_COLD(a, send_done);
+    const uint32_t total = RDY_COLD(a, send_waves);
+    const uint32_t old   = __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (old + 1u == total) {
+      __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      uint64_t      *ep = RDY_COLD(a, send_epoch);
+      const uint64_t e  = __hip_atomic_load(ep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+      __hip_atomic_store(ep, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(sig, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
 }
@@ -762,7 +793,10 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
             RDY_ST(&a.u_out[3 * c + 1], n1);
             RDY_ST(&a.u_out[3 * c + 2], n2);
           }
-          if (send_tile) wave_store_send_rows(a, tile_cur, tid, n0, n1, n2);
+          if (send_tile) {
+            wave_store_send_rows(a, tile_cur, tid, n0, n1, n2);
+            wave_signal_send_rows(a, tid);
+          }
         }
       }
       if (last) break;

@@ -156,6 +156,13 @@ class HaloExchange:
             _lib.check(lib.rdyhip_halo_fuse_pack(self._halo, 0))
         return bool(lib.rdyhip_halo_pack_fused(self._halo))
 
+    @property
+    def signalled(self) -> bool:
+        """fused-pack Euler steps use the signalled form (the next step's transfer starts when the running launch has stored its
+        last send row: rdyhip_halo_signalled)"""
+        from . import _lib
+        return self._halo is not None and bool(_lib.load().rdyhip_halo_signalled(self._halo))
+
     def invalidate(self):
         """the state array was written by somebody else since the last step: the next step packs again"""
         from . import _lib

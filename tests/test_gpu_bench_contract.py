@@ -43,7 +43,7 @@ def test_bench_line_has_the_contract_keys(extra, rdyhip_kernel):
     assert "traffic" in r and r["achieved"] > 0 and r["steady_state_period_median_ms"] > 0
     assert r["algorithmic_bytes_per_cell"] == (192.0 if "dambreak_quads" in extra else 176.0)
     if not extra:
-        assert r["traffic_source"]["kernel_sha"] and set(d["cell_order_study"]) >= {"tiled", "rowmajor", "hilbert"}
+        assert r["traffic_source"]["kernel_source_sha"] and set(d["cell_order_study"]) >= {"tiled", "rowmajor", "hilbert"}
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and c["unit"] == "M cell-updates/s" and "sample" in c
     assert d["value"] > 0 and abs(d["value"] - d["config"]["cells_per_gpu"] / d["ms_per_step"] / 1e3) <= 1e-3 * d["value"] + 0.11

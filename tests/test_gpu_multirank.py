@@ -133,6 +133,7 @@ def _worker(rank, world, port, kernel, q, second_order=False, transport="torch",
                 dts = 0.1 * case.dt
                 EulerStepper(op, halo=halo).advance(ua, dts, 5 * dts)
                 assert lib.rdyhip_halo_pack_fused(halo._halo) == 1
+                assert not halo.signalled                       # a transport callback carries the bytes here: the signalled form is RCCL's
                 stepper = EulerStepper(op, halo=halo)
                 assert halo.fuse_pack(False) is False
                 stepper.advance(uc, dts, 5 * dts)
@@ -332,6 +333,9 @@ def test_rccl_self_exchange_one_rank(rdyhip_kernel):
     for fuse in (1, 0):
         _lib.check(lib.rdyhip_halo_fuse_pack(h, fuse))
         assert lib.rdyhip_halo_pack_fused(h) == fuse
+        # rows 2000.. are OWNED cells here, which the step's launch stores: the signalled form (whose transfer runs beside that
+        # launch) refuses such a pattern and the other forms stay in charge (test_signalled_form_self_exchange has real ghosts)
+        assert lib.rdyhip_halo_signalled(h) == 0
         a, b = expect.clone(), torch.empty_like(expect)
         for _ in range(4):
             _lib.check(lib.rdyhip_euler_step_overlapped(op._h, h, 0.1 * case.dt, int(a.data_ptr()), int(b.data_ptr()), None, st))
@@ -350,6 +354,92 @@ def test_rccl_self_exchange_one_rank(rdyhip_kernel):
     torch.cuda.synchronize()
     assert torch.equal(b[2000:2000 + n], b[0:n])              # the exchange of the second step carried the edited rows
     _lib.check(lib.rdyhip_halo_destroy(C.byref(h)))
+    _lib.check(lib.rdyhip_comm_destroy(comm))
+    op.destroy()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("kind", ["strips", "rcb_houston"])
+def test_signalled_form_self_exchange(rdyhip_kernel, kind):
+    """The signalled form of the fused-pack Euler step (include/rdyhip.h): the launch of step n says when its last send row is in
+    memory and the transfer of step n + 1 runs beside the rest of that launch.  One rank's part of a partitioned mesh (real ghost
+    rows), the exchange looped back through a one-rank RCCL communicator (its boundary cells travel to its own ghost rows): the
+    same twelve steps -- with an RHS evaluation and a host edit of the state in between -- give the same bits (a) signalled,
+    (b) fused pack without the signal, in order and in the two-stream form, (c) with a pack launch per step."""
+    if rdyhip_kernel == "cell":
+        pytest.skip("the fused pack rides on the tiled kernels")
+    import ctypes as C
+    from rdycore_amd import _lib
+    from rdycore_amd import cases as CS
+    from rdycore_amd import mesh as M
+    lib = _lib.load()
+    torch.cuda.set_device(0)
+    if kind == "strips":
+        nxp, ny, world = 160, 96, 3                         # 30 720 owned cells = 120 tiles: eight XCD chunks
+        K = 2 * np.pi / 37
+        mesh = M.strip_partition_tri_mesh(nxp, ny, 1, world, 1.0, zfunc=CS.mms_bathymetry(K=K), order="tiled", tile=8)
+        case = CS.friction_slope_case(mesh, nxp * world, ny, dt=1e-2, K=K)
+    else:
+        case = CS.houston_refined_case(os.path.join(ROOT, "tests", "golden", "houston"), 3, "hilbert", rank=2, world=5)
+        mesh = case.mesh
+    op = CS.create_operator(case)
+    uid = C.create_string_buffer(128)
+    _lib.check(lib.rdyhip_comm_unique_id(uid))
+    comm = C.c_void_p()
+    _lib.check(lib.rdyhip_comm_init_rank(1, 0, uid.raw, C.byref(comm)))
+    i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+    p = lambda a: a.ctypes.data_as(_lib.c_int32_p)
+    ghost = np.nonzero(mesh.cell_is_owned == 0)[0].astype(np.int32)
+    gset = np.zeros(mesh.num_cells, dtype=bool)
+    gset[ghost] = True
+    cl, cr = mesh.edge_cell_ids[0::2], mesh.edge_cell_ids[1::2]
+    cut = (cr >= 0) & (gset[cl] != gset[np.maximum(cr, 0)])
+    sendc = np.unique(np.where(gset[cl[cut]], cr[cut], cl[cut])).astype(np.int32)
+    n = min(sendc.size, ghost.size)
+    assert n > 50
+    sendc, ghost = i32(sendc[:n]), i32(ghost[:n])
+    st = int(torch.cuda.current_stream().cuda_stream)
+    dts = 0.1 * case.dt
+    f = torch.empty((mesh.num_owned_cells, 3), dtype=torch.float64, device="cuda:0")
+
+    def run(fuse, signalled, overlap):
+        os.environ["RDYHIP_OVERLAP"] = overlap
+        os.environ["RDYHIP_SIGNALLED"] = signalled
+        try:
+            h = C.c_void_p()
+            _lib.check(lib.rdyhip_halo_create(op._h, comm, 1, p(i32([0])), p(i32([n])), p(sendc), p(i32([n])), p(ghost), C.byref(h)))
+            _lib.check(lib.rdyhip_halo_fuse_pack(h, fuse))
+        finally:
+            os.environ.pop("RDYHIP_OVERLAP")
+            os.environ.pop("RDYHIP_SIGNALLED")
+        assert lib.rdyhip_halo_signalled(h) == (1 if fuse and signalled == "1" else 0)
+        a = torch.tensor(case.u_local, dtype=torch.float64, device="cuda:0")
+        b = a.clone()
+        step = lambda x, y: _lib.check(lib.rdyhip_euler_step_overlapped(op._h, h, dts, int(x.data_ptr()), int(y.data_ptr()), None, st))
+        for _ in range(5):
+            step(a, b)
+            a, b = b, a
+        _lib.check(lib.rdyhip_rhs_overlapped(op._h, h, dts, int(a.data_ptr()), int(f.data_ptr()), st))     # an RHS in between: packs again
+        fa = f.clone()
+        for _ in range(3):
+            step(a, b)
+            a, b = b, a
+        torch.cuda.synchronize()
+        a[torch.as_tensor(sendc[:7].astype(np.int64), device="cuda:0")] *= 1.01    # the host edits cells that are sent ...
+        _lib.check(lib.rdyhip_halo_invalidate(h))                                  # ... and says so
+        for _ in range(4):
+            step(a, b)
+            a, b = b, a
+        torch.cuda.synchronize()
+        _lib.check(lib.rdyhip_halo_destroy(C.byref(h)))
+        return a.clone(), fa
+
+    ref, fref = run(0, "1", "0")
+    own = torch.as_tensor(mesh.cell_owned_to_local.astype(np.int64), device="cuda:0")
+    assert bool(torch.isfinite(ref[own]).all()) and bool(torch.isfinite(fref).all())
+    for fuse, signalled, overlap in ((1, "1", "0"), (1, "0", "0"), (1, "0", "1"), (0, "1", "1")):
+        got, fgot = run(fuse, signalled, overlap)
+        assert torch.equal(got, ref) and torch.equal(fgot, fref), (fuse, signalled, overlap)
     _lib.check(lib.rdyhip_comm_destroy(comm))
     op.destroy()
 

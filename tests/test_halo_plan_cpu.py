@@ -216,3 +216,75 @@ def test_a_tile_numbering_from_the_c_routine_is_as_compact_as_the_python_one():
         info = OP.probe_layout(OP.RDyFlowConfig(), m, [M.CONDITION_REFLECTING])
         rec[name] = info["num_edge_records"] / m.num_cells
     assert rec["hilbert_c"] < 1.72 < 1.85 < rec["rowmajor"]
+
+
+@pytest.mark.parametrize("world", [5, 8])
+def test_two_pass_numbering_of_a_petscsf_host(world):
+    """what adapter/rdyhip_petsc.c:RDyHipPermuteLocalCells does, without PETSc: pass 1 numbers every rank's owned cells along the
+    curve (ghosts anywhere); the point SF then names each ghost by its owner's NEW local id; pass 2 moves only the ghosts -- by owner
+    rank and that id -- and must leave the owned numbers of pass 1 alone (nobody's remote indices move).  The plan with local-id keys
+    then lists every peer's ghosts as consecutive rows in arrival order: the exchange can receive in place."""
+    import os
+    data = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "houston")
+    meshes = [CS.houston_refined_mesh(data, 1, "natural", rank=r, world=world)[0] for r in range(world)]
+    lib = _lib.load()
+
+    def order(m, owner=None, key=None, start=None):
+        """perm[new] = old for mesh m (optionally on top of an earlier numbering `start`: old ids are positions in start)"""
+        idx = np.arange(m.num_cells) if start is None else start
+        xy = np.ascontiguousarray(m.cell_centroids[idx])
+        owned = _i32(m.cell_is_owned[idx])
+        perm = np.empty(m.num_cells, dtype=np.int32)
+        if owner is None:
+            _lib.check(lib.rdyhip_hilbert_cell_order(m.num_cells, xy.ctypes.data_as(_lib.c_double_p), 3, pi(owned), pi(perm)))
+        else:
+            _lib.check(lib.rdyhip_local_cell_order(m.num_cells, xy.ctypes.data_as(_lib.c_double_p), 3, pi(owned), pi(_i32(owner[idx])), pl(_i64(key[idx])), pi(perm)))
+        return idx[perm]                       # new local id -> original local id
+
+    pass1 = [order(m) for m in meshes]                                     # new -> original
+    new_of = []
+    for m, p1 in zip(meshes, pass1):
+        inv = np.empty(m.num_cells, dtype=np.int64)
+        inv[p1] = np.arange(m.num_cells)
+        new_of.append(inv)                                                 # original -> id after pass 1
+    # the SF after pass 1: a ghost's key is its owner's pass-1 id of that cell (found through the global id)
+    owner_new_id = [dict(zip(m.cell_global_ids[m.cell_owned_to_local].tolist(), new_of[r][m.cell_owned_to_local].tolist())) for r, m in enumerate(meshes)]
+    pass2, keys = [], []
+    for r, m in enumerate(meshes):
+        key = np.full(m.num_cells, -1, dtype=np.int64)
+        ghost = np.nonzero(m.cell_is_owned == 0)[0]
+        key[ghost] = [owner_new_id[o][g] for o, g in zip(m.cell_owner_rank[ghost].tolist(), m.cell_global_ids[ghost].tolist())]
+        keys.append(key)
+        p2 = order(m, owner=m.cell_owner_rank, key=key, start=pass1[r])
+        no = m.num_owned_cells
+        assert np.array_equal(p2[:no], pass1[r][:no])                      # the owned cells keep their pass-1 numbers
+        pass2.append(p2)
+    # the plan on the final numbering, PetscSF-style keys (the owner's local id)
+    plans, counts, kk = [], [], []
+    for r, m in enumerate(meshes):
+        final_of = np.empty(m.num_cells, dtype=np.int64)
+        final_of[pass2[r]] = np.arange(m.num_cells)
+        ghost = np.nonzero(m.cell_is_owned == 0)[0]
+        plan = C.c_void_p()
+        _lib.check(lib.rdyhip_halo_plan_create(world, r, ghost.size, pi(_i32(final_of[ghost])), pi(_i32(m.cell_owner_rank[ghost])), pl(_i64(keys[r][ghost])), C.byref(plan)))
+        cp, kp = _lib.c_int32_p(), _lib.c_int64_p()
+        _lib.check(lib.rdyhip_halo_plan_requests(plan, C.byref(cp), C.byref(kp)))
+        counts.append(np.ctypeslib.as_array(cp, shape=(world,)).copy())
+        kk.append(np.ctypeslib.as_array(kp, shape=(max(ghost.size, 1),))[:ghost.size].copy())
+        plans.append(plan)
+    for r, m in enumerate(meshes):
+        inc_counts = _i32([counts[q][r] for q in range(world)])
+        inc_keys = _i64(np.concatenate([kk[q][int(counts[q][:r].sum()):int(counts[q][:r].sum()) + int(counts[q][r])] for q in range(world)]))
+        owned_final = _i32(m.cell_is_owned[pass2[r]])
+        _lib.check(lib.rdyhip_halo_plan_finish(plans[r], pi(inc_counts), pl(inc_keys), m.num_cells, pi(owned_final), None))
+        n = C.c_int32(0)
+        ptrs = [_lib.c_int32_p() for _ in range(5)]
+        _lib.check(lib.rdyhip_halo_plan_get(plans[r], C.byref(n), *[C.byref(q) for q in ptrs]))
+        nrecv = int(np.ctypeslib.as_array(ptrs[3], shape=(max(n.value, 1),))[:n.value].sum())
+        recv = np.ctypeslib.as_array(ptrs[4], shape=(max(nrecv, 1),))[:nrecv]
+        assert np.array_equal(recv, np.arange(m.num_owned_cells, m.num_cells))          # in place
+        nsend = int(np.ctypeslib.as_array(ptrs[1], shape=(max(n.value, 1),))[:n.value].sum())
+        send = np.ctypeslib.as_array(ptrs[2], shape=(max(nsend, 1),))[:nsend]
+        assert owned_final[send].all()
+    for plan in plans:
+        _lib.check(lib.rdyhip_halo_plan_destroy(C.byref(plan)))

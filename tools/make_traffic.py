@@ -9,8 +9,9 @@ usage: python tools/make_traffic.py gpurun_out/prof_<tag>/summary.json <key> [so
 
 FETCH_SIZE is doubled (gfx950 counts 128-B requests as 64 B, MI355X_MICROARCH.md HBM section) and both counters are
 checked against the calibration kernel of the same session (rdyhip::axpy_owned_kernel on 10 M cells: 480 MB read,
-240 MB written).  The entry carries the hash of the kernel sources it was measured on; bench.py reports the figure
-only while that hash matches (a stale entry is reported as stale, never silently)."""
+240 MB written).  The entry carries the hash of the measured kernel's MACHINE CODE (rdycore_amd/codeobj.py), taken on the GPU box
+from the library the profiled run loaded (gpurun_out/prof_<tag>/kernel_code_hashes.json); bench.py reports the figure only while
+the library it runs has the same bytes for that kernel (a stale entry is reported as stale, never silently)."""
 import json
 import os
 import sys
@@ -58,7 +59,15 @@ def main():
         for ln in open(log):
             if ln.startswith("{"):
                 layout = json.loads(ln)["roofline"]["layout_bytes_per_launch"]
-    ent = {"kernel": kname, "kernel_sha": bench.kernel_sha(second), "layout_bytes_per_launch": layout, "FETCH_SIZE_KB_raw": fetch, "WRITE_SIZE_KB_raw": write,
+    hpath = os.path.join(os.path.dirname(summ), "kernel_code_hashes.json")
+    if not os.path.exists(hpath):
+        raise SystemExit(f"{hpath} is missing: the profiled run did not record the code it measured (tools/profile_gpu.sh)")
+    hashes = json.load(open(hpath))
+    if kname not in hashes or (extra_ent and extra_ent["kernel"] not in hashes):
+        raise SystemExit(f"the measured kernel {kname!r} is not in {hpath}")
+    if extra_ent:
+        extra_ent["code_sha"] = hashes[extra_ent["kernel"]]
+    ent = {"kernel": kname, "code_sha": hashes[kname], "source_sha_at_collection": bench.kernel_sha(second), "layout_bytes_per_launch": layout, "FETCH_SIZE_KB_raw": fetch, "WRITE_SIZE_KB_raw": write,
            "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr,
            "correction": "FETCH_SIZE x2 (gfx950 counts 128-B requests as 64 B, MI355X_MICROARCH.md HBM section); WRITE_SIZE as is",
            "source": note}

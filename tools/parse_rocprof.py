@@ -34,7 +34,7 @@ def mean(x):
 pm = {}
 for sub, ctr in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE"), ("cal_fetch", "FETCH_SIZE"), ("cal_write", "WRITE_SIZE")):
     acc = pmc_per_kernel(sub, ctr)
-    pm[sub] = {k[:80]: {"mean": mean(v), "n": len(v)} for k, v in acc.items() if ("swe_rhs" in k or "axpy_owned" in k or "muscl_gradient" in k)}
+    pm[sub] = {k: {"mean": mean(v), "n": len(v)} for k, v in acc.items() if ("swe_rhs" in k or "axpy_owned" in k or "muscl_gradient" in k)}
 summary["pmc_raw_KB"] = pm
 sq = {}
 for ctr in ("SQ_WAVES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY"):

@@ -42,5 +42,7 @@ for tag in $ORDER; do
   echo "  sq2"; timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_sq2 -o pmc -- python3 $REPO/bench.py $PARGS > $OUT/bench_pmc_sq2.log 2>&1 || echo "  sq2 failed"
   # the calibration passes are shared: parse_rocprof.py looks for cal_fetch / cal_write under the variant's directory
   ln -sfn $CAL/cal_fetch $OUT/cal_fetch; ln -sfn $CAL/cal_write $OUT/cal_write
+  # the machine code that was measured: hash of every kernel of the library these runs loaded (tools/make_traffic.py stamps the entry with it)
+  (cd $REPO && python3 -c "import json; from rdycore_amd import build, codeobj; json.dump(codeobj.kernel_hashes(build.lib_path()), open('$OUT/kernel_code_hashes.json', 'w'), indent=0)")
   (cd $REPO && python3 tools/parse_rocprof.py $OUT ${ROUND}_$tag > $OUT/summary.txt 2>&1; tail -4 $OUT/summary.txt)
 done

@@ -6,8 +6,8 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r03"
-order = ["c3", "c3_200", "hr", "xq", "c2", "quads", "c5", "so", "so_quads", "houston", "houston_natural", "houston_hr", "houston_so", "houston_l7", "delaunay",
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r04"
+order = ["c3", "c3_200", "hr", "xq", "c2", "quads", "c5", "so", "so_quads", "houston", "houston_natural", "houston_hr", "houston_so", "houston_l7", "houston_l7_hr", "houston_l7_so", "delaunay",
          "self_exchange", "self_exchange_so"]
 print("| variant | kernel | ms / step (unprofiled) | M cell-updates/s | frac of 8 TB/s (model B/cell) | PMC traffic vs algorithmic | rocprofv3 kernel avg (launches) |")
 print("|---|---|---|---|---|---|---|")

@@ -8,7 +8,11 @@ xGMI hop).  Per part, microseconds per step (HIP events around 300 back-to-back 
   r03_rhs         rdyhip_rhs_overlapped as round 3 ran it: pack launch, RCCL, unpack launch, kernel   (RDYHIP_DIRECT_RECV=0)
   rhs_direct      rdyhip_rhs_overlapped with the direct receive: pack launch, RCCL into the ghost rows, kernel
   euler_direct    rdyhip_euler_step_overlapped, direct receive, pack launch:        pack, RCCL, kernel
-  euler_fused     the same with rdyhip_halo_fuse_pack: the pack rides on the previous step's kernel:   RCCL, kernel
+  euler_fused     the same with rdyhip_halo_fuse_pack: the pack rides on the previous step's kernel -- RCCL, kernel, in the form the
+                  library chooses (in order at every size since the end of round 4; profiles/r04_small_parts.txt itself was taken
+                  while parts of three rounds and more defaulted to the signalled form: signalled_form says which)
+  euler_fused_in_order / _overlapped   the fused pack without the signal (RDYHIP_SIGNALLED=0): RCCL, kernel in order; or the two-stream form
+  euler_fused_signalled                the signalled form forced (RDYHIP_SIGNALLED=1), whatever the part's size
   exchange        rdyhip_halo_exchange alone (pack, RCCL, direct receive)
 
 usage (GPU box): python tools/small_parts.py > gpurun_out/small_parts.txt"""
@@ -47,7 +51,7 @@ def timed(fn, k=300, lead=100):
     return round(e0.elapsed_time(e1) / k * 1e3, 2), round(host, 2)
 
 
-def self_halo(op, mesh, comm, direct):
+def self_halo(op, mesh, comm, direct, overlap=None):
     """the halo bench.py --self-exchange builds: this rank's ghost-adjacent owned cells are sent to its own ghost rows"""
     ghost = np.nonzero(mesh.cell_is_owned == 0)[0].astype(np.int32)
     gset = np.zeros(mesh.num_cells, dtype=bool)
@@ -58,9 +62,12 @@ def self_halo(op, mesh, comm, direct):
     n = min(sendc.size, ghost.size)
     sendc, ghost = np.ascontiguousarray(sendc[:n]), np.ascontiguousarray(ghost[:n])
     os.environ["RDYHIP_DIRECT_RECV"] = "1" if direct else "0"
+    if overlap is not None:
+        os.environ["RDYHIP_OVERLAP"] = str(int(overlap))
     hh = C.c_void_p()
     _lib.check(lib.rdyhip_halo_create(op._h, comm, 1, pp(i32([0])), pp(i32([n])), pp(sendc), pp(i32([n])), pp(ghost), C.byref(hh)))
     os.environ.pop("RDYHIP_DIRECT_RECV")
+    os.environ.pop("RDYHIP_OVERLAP", None)
     assert lib.rdyhip_halo_direct_receive(hh) == (1 if direct else 0), "the ghosts of this part are not one run of rows"
     return hh, int(n)
 
@@ -104,13 +111,36 @@ def one(tag, argv):
     res["euler_direct"] = timed(pingpong(lambda a, b: _lib.check(lib.rdyhip_euler_step_overlapped(op._h, h1, 0.0, a, b, None, st))))
     res["exchange"] = timed(lambda: _lib.check(lib.rdyhip_halo_exchange(h1, up, 3, st)))
     _lib.check(lib.rdyhip_halo_fuse_pack(h1, 1))
+    res["signalled_form"] = int(lib.rdyhip_halo_signalled(h1))
     res["euler_fused"] = timed(pingpong(lambda a, b: _lib.check(lib.rdyhip_euler_step_overlapped(op._h, h1, 0.0, a, b, None, st))))
     _lib.check(lib.rdyhip_halo_destroy(C.byref(h1)))
+    # the fused-pack Euler step without the signal (RDYHIP_SIGNALLED=0), in its two forms, forced: in order (transfer, one launch)
+    # and overlapped (transfer beside the interior launch, the ghost-adjacent tiles in a second launch on the exchange stream)
+    for name, ov, sg in (("euler_fused_in_order", 0, "0"), ("euler_fused_overlapped", 1, "0"), ("euler_fused_signalled", 0, "1")):
+        hx, _ = self_halo(op, mesh, comm, direct=True, overlap=ov)
+        os.environ["RDYHIP_SIGNALLED"] = sg
+        _lib.check(lib.rdyhip_halo_fuse_pack(hx, 1))
+        os.environ.pop("RDYHIP_SIGNALLED")
+        assert lib.rdyhip_halo_signalled(hx) == int(sg)
+        res[name] = timed(pingpong(lambda a, b: _lib.check(lib.rdyhip_euler_step_overlapped(op._h, hx, 0.0, a, b, None, st))))
+        _lib.check(lib.rdyhip_halo_destroy(C.byref(hx)))
+    # the signalled launch leaves 1 / N of its workgroup slots to the transfer's kernel (RDYHIP_SIGNALLED_SHRINK; 0 = none)
+    if os.environ.get("SMALL_PARTS_SHRINK_STUDY"):
+        res["signalled_shrink_study"] = {}
+        for shrink in ("0", "128", "64", "32", "16"):
+            hx, _ = self_halo(op, mesh, comm, direct=True, overlap=0)
+            os.environ["RDYHIP_SIGNALLED"] = "1"
+            os.environ["RDYHIP_SIGNALLED_SHRINK"] = shrink
+            _lib.check(lib.rdyhip_halo_fuse_pack(hx, 1))
+            os.environ.pop("RDYHIP_SIGNALLED")
+            os.environ.pop("RDYHIP_SIGNALLED_SHRINK")
+            res["signalled_shrink_study"][shrink] = timed(pingpong(lambda a, b: _lib.check(lib.rdyhip_euler_step_overlapped(op._h, hx, 0.0, a, b, None, st))))
+            _lib.check(lib.rdyhip_halo_destroy(C.byref(hx)))
     _lib.check(lib.rdyhip_comm_destroy(comm))
     op.destroy()
     k = res["kernel_rhs"][0]
     res["step_over_kernel"] = {key: round(res[key][0] / (res["kernel_euler"][0] if key.startswith("euler") or key == "r03_euler" else k), 3)
-                               for key in ("r03_rhs", "r03_euler", "rhs_direct", "euler_direct", "euler_fused")}
+                               for key in ("r03_rhs", "r03_euler", "rhs_direct", "euler_direct", "euler_fused", "euler_fused_in_order", "euler_fused_overlapped", "euler_fused_signalled")}
     res["columns"] = "[us per step on the GPU, us per step of host enqueue time]"
     print(json.dumps(res), flush=True)
     del u, u2, f

@@ -4,10 +4,12 @@ import json
 import sys
 
 rows = [json.loads(ln) for ln in open(sys.argv[1]) if ln.startswith("{")]
-print("| part | owned cells (ghosts) | form | kernel (RHS / Euler) | round 3 chain: pack, RCCL, unpack, kernel | direct receive: pack, RCCL, kernel | direct receive + fused pack: RCCL, kernel |")
-print("|---|---|---|---|---|---|---|")
+print("| part | owned cells (ghosts) | form of the RHS step | kernel (RHS / Euler) | round 3 chain: pack, RCCL, unpack, kernel | direct receive: pack, RCCL, kernel | direct receive + fused pack, no signal: RCCL, kernel in order / two-stream form | signalled form (RDYHIP_SIGNALLED=1) |")
+print("|---|---|---|---|---|---|---|---|")
 for d in rows:
     k, ke = d["kernel_rhs"][0], d["kernel_euler"][0]
     f = lambda key, base: f"{d[key][0]:.1f} ({d[key][0] / base:.2f})"
     print(f"| {d['part']} | {d['cells']} ({d['ghosts']}) | {'overlapped' if d['overlapped_form'] else 'in order'} | {k:.1f} / {ke:.1f} | "
-          f"RHS {f('r03_rhs', k)}, Euler {f('r03_euler', ke)} | RHS {f('rhs_direct', k)}, Euler {f('euler_direct', ke)} | Euler {f('euler_fused', ke)} |")
+          f"RHS {f('r03_rhs', k)}, Euler {f('r03_euler', ke)} | RHS {f('rhs_direct', k)}, Euler {f('euler_direct', ke)} | "
+          + (f"Euler {f('euler_fused_in_order', ke)} / {f('euler_fused_overlapped', ke)} | Euler {f('euler_fused_signalled', ke) if 'euler_fused_signalled' in d else 'n/a'} |"
+             if "euler_fused_in_order" in d else f"Euler {f('euler_fused', ke)} | |"))
