@@ -72,10 +72,10 @@ def self_halo(op, mesh, comm, direct, overlap=None):
     return hh, int(n)
 
 
-def one(tag, argv):
+def one(tag, argv, scaling="strong"):
     args = bench.parse(["--no-cpu-baseline"] + argv)
     sav = args.scaling
-    args.scaling = "strong"
+    args.scaling = scaling
     case = bench.build_case(args, args.emulate_rank, args.emulate_world)
     args.scaling = sav
     mesh = case.mesh
@@ -160,8 +160,10 @@ if __name__ == "__main__":
         ("dambreak_5120x2560 rank1/4", ["--workload", "dambreak_quads", "--emulate-world", "4", "--emulate-rank", "1"]),
         ("houston_L6 rank3/8", ["--workload", "houston_refined", "--levels", "6", "--emulate-world", "8", "--emulate-rank", "3"]),
         ("houston_L6 rank1/4", ["--workload", "houston_refined", "--levels", "6", "--emulate-world", "4", "--emulate-rank", "1"]),
+        # the weak-scaling benchmark's rank: an inner strip of 10 M cells with ghost columns on both sides (bench.py --gpus N)
+        ("c3_strip_10M rank1/3", ["--emulate-world", "3", "--emulate-rank", "1"], "weak"),
     ]
     sel = sys.argv[1:]
-    for tag, argv in parts:
-        if not sel or any(s in tag for s in sel):
-            one(tag, argv)
+    for part in parts:
+        if not sel or any(s in part[0] for s in sel):
+            one(*part)
