@@ -825,6 +825,8 @@ def run_rank(args, argv):
         }
         if quads:
             out["roofline"]["frac_176B_model"] = round(n_owned * ALG_BYTES_PER_CELL / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
+        # the whole forward-Euler step by the same byte model (it stores u_out where the RHS stores F; F itself is not written)
+        euler["frac_of_hbm_roofline"] = round(n_owned * alg / (euler["fused_ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
         out["euler_step"] = euler
         if order_study:
             out["cell_order_study"] = order_study
