@@ -210,7 +210,7 @@ int overlapped(RDyHipOperator op, RDyHipHalo h, double dt, double *u, double *f,
     return rc;
   }
   // A fused-pack Euler step over RCCL is the transfer and one launch: in order that is launch + 8-10 us at every size measured
-  // (0.36 - 2.9 M cells per rank), the two-stream form launch + 14 us or more (profiles/r04_small_parts.txt) -- there is no pack
+  // (0.36 - 10 M cells per rank), the two-stream form launch + 14 us or more (profiles/r04_small_parts.txt, _strip_10M) -- there is no pack
   // to hide any more, and the second launch of the ghost-adjacent tiles finds no free workgroup slot until the first one ends.
   // (A transport callback may block the host: it keeps the two-stream form, whose interior launch is enqueued first.)
   const bool fused_euler = h->fused_pack && op->fused_halo == h && u_out && !op->muscl && op->use_tiled && !h->transport;
