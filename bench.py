@@ -304,7 +304,7 @@ def traffic_key(args) -> str:
     return key
 
 
-def load_traffic(workload_key: str, layout_bytes: int, second_order: bool = False):
+def load_traffic(workload_key: str, layout_bytes: int, second_order: bool = False, quiet: bool = False):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic.json), only if they were collected on
     exactly this MACHINE CODE of the measured kernel(s) -- the entry names the kernel and holds the hash of its bytes in the
     library the profiled run loaded; the library this run loads must have the same bytes (rdycore_amd/codeobj.py) -- AND this
@@ -330,13 +330,15 @@ def load_traffic(workload_key: str, layout_bytes: int, second_order: bool = Fals
         now = [codeobj.kernel_sha(_build.lib_path(), k) for k, _ in measured]
     except Exception as exc:
         src["status"] = f"cannot verify the code of the measured kernel: {exc!r}"
-        print(f"bench.py: profiles/traffic.json[{workload_key}]: {src['status']}; roofline.traffic = null", file=sys.stderr)
+        if not quiet:
+            print(f"bench.py: profiles/traffic.json[{workload_key}]: {src['status']}; roofline.traffic = null", file=sys.stderr)
         return None, src
     src["kernel"], src["code_sha"] = measured[0][0], now[0]
     if [m[1] for m in measured] != now or int(ent.get("layout_bytes_per_launch", -1)) != int(layout_bytes):
         src["status"] = (f"STALE: measured on code {[m[1] for m in measured]} / layout {ent.get('layout_bytes_per_launch')} B, "
                          f"current: {now} / {layout_bytes} B -- rerun tools/profile_gpu.sh")
-        print(f"bench.py: profiles/traffic.json[{workload_key}] is stale; roofline.traffic = null", file=sys.stderr)
+        if not quiet:
+            print(f"bench.py: profiles/traffic.json[{workload_key}] is stale; roofline.traffic = null", file=sys.stderr)
         return None, src
     src["status"] = "measured on this machine code of the kernel"
     return ent.get("hbm_bytes_per_launch"), src
@@ -827,6 +829,10 @@ def run_rank(args, argv):
             out["roofline"]["frac_176B_model"] = round(n_owned * ALG_BYTES_PER_CELL / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
         # the whole forward-Euler step by the same byte model (it stores u_out where the RHS stores F; F itself is not written)
         euler["frac_of_hbm_roofline"] = round(n_owned * alg / (euler["fused_ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
+        if world == 1 and halo is None and self_halo is None:
+            # PMC bytes of the Euler-step kernel itself, from the same profiled runs (their Euler launches), same guard
+            et, esrc = load_traffic(traffic_key(args) + "_euler_step", int(info["bytes_per_apply"]), args.second_order, quiet=True)
+            euler["traffic"], euler["traffic_source"] = et, esrc
         out["euler_step"] = euler
         if order_study:
             out["cell_order_study"] = order_study

@@ -44,6 +44,10 @@ def test_bench_line_has_the_contract_keys(extra, rdyhip_kernel):
     assert r["algorithmic_bytes_per_cell"] == (192.0 if "dambreak_quads" in extra else 176.0)
     if not extra:
         assert r["traffic_source"]["kernel_source_sha"] and set(d["cell_order_study"]) >= {"tiled", "rowmajor", "hilbert"}
+    e = d["euler_step"]     # the product's step beside the metric: same byte model, PMC traffic under the same guard (null at these sizes)
+    assert e["fused_ms_per_step"] > 0 and abs(e["frac_of_hbm_roofline"] - r["algorithmic_bytes_per_launch"] / (e["fused_ms_per_step"] * 1e-3) / 8e12) < 1e-3
+    if "--self-exchange" not in extra:
+        assert "traffic" in e and e["traffic_source"]["key"].endswith("_euler_step")
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and c["unit"] == "M cell-updates/s" and "sample" in c
     assert d["value"] > 0 and abs(d["value"] - d["config"]["cells_per_gpu"] / d["ms_per_step"] / 1e3) <= 1e-3 * d["value"] + 0.11

@@ -58,3 +58,8 @@ for tag in tags:
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_traffic.py"), summ, key, f"profiles/{rnd}_{tag}_summary.json", per_step, extra],
                        capture_output=True, text=True)
     print(tag, key, "ok" if r.returncode == 0 else ("FAILED: " + r.stderr[-300:]))
+    if not tag.startswith("self_exchange") and tag != "c5":
+        # the fused Euler step's kernel was launched by the same runs (bench.py's euler_step extra): its entry, same guard
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_traffic.py"), summ, key + "_euler_step", f"profiles/{rnd}_{tag}_summary.json", "1", ""],
+                           capture_output=True, text=True, env=dict(os.environ, MAKE_TRAFFIC_EULER="1"))
+        print(tag, key + "_euler_step", "ok" if r.returncode == 0 else ("FAILED: " + r.stderr[-300:]))

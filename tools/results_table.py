@@ -33,3 +33,26 @@ for tag in order:
         frac += f"; {r['frac_176B_model']:.3f} (176)"
     print(f"| {tag} | `{r['kernel']}` | {d['ms_per_step']:.4f} | {d['value']:.0f} | {frac} | "
           f"{(f'{tr / 1e9:.3f} GB = {tr / alg:.3f} ×') if tr else 'null: ' + str((r.get('traffic_source') or {}).get('status'))} | {kavg} |")
+
+# the whole forward-Euler step (rdyhip_euler_step: the update fused into the kernel's stores, F not written), same byte model
+rows = []
+for tag in order:
+    # (<round>_bench_<tag>_euler.json: lines taken after the Euler-step kernels had been profiled -- another call, another box)
+    p = os.path.join(ROOT, "profiles", f"{rnd}_bench_{tag}_euler.json")
+    if not os.path.exists(p):
+        p = os.path.join(ROOT, "profiles", f"{rnd}_bench_{tag}.json")
+    if not os.path.exists(p):
+        continue
+    d = json.load(open(p))
+    e = d.get("euler_step") or {}
+    if "frac_of_hbm_roofline" not in e:
+        continue
+    alg = d["roofline"]["algorithmic_bytes_per_launch"]
+    tr = e.get("traffic")
+    rows.append(f"| {tag} | {d['ms_per_step']:.4f} | {e['fused_ms_per_step']:.4f} | {e['rhs_plus_axpy_ms_per_step']:.4f} | {e['frac_of_hbm_roofline']:.3f} | "
+                f"{(f'{tr / 1e9:.3f} GB = {tr / alg:.3f} ×') if tr else 'not profiled'} |")
+if rows:
+    print()
+    print("| variant | RHS alone, ms (this box) | fused Euler step, ms | RHS + axpy pair, ms | step: frac of 8 TB/s (RHS byte model) | PMC traffic of the Euler-step kernel vs algorithmic |")
+    print("|---|---|---|---|---|---|")
+    print("\n".join(rows))
