@@ -354,7 +354,7 @@ int rdyhip_unpack_rows(double *dst, int32_t ncomp, const int32_t *row_ids, int32
  *                    by peer, a peer's cells in the agreed order, which is how rdyhip_local_cell_order numbers them -- the
  *                    transfer lands in the caller's array itself (ncclRecv into u_local's ghost rows): no receive buffer, no
  *                    unpack launch.  Detected at rdyhip_halo_create; rdyhip_halo_direct_receive() says whether it applies.
- *   fused pack       rdyhip_halo_fuse_pack(halo, 1): the Euler-step kernels (first order and HR) also store the new state of
+ *   fused pack       rdyhip_halo_fuse_pack(halo, 1): the Euler-step kernels (first order, HR and fused second order) also store the new state of
  *                    the cells other ranks need into the send buffer as they store u_local_out, so that the NEXT
  *                    rdyhip_euler_step_overlapped, called with that array as its u_local, starts with the transfer: no pack
  *                    launch.  The promise the caller makes: between two such steps it does not write the owned rows of that

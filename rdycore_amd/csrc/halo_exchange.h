@@ -152,7 +152,7 @@ int halo_pack_state(RDyHipHalo h, const double *u, hipStream_t s) {
 // first-order operator has just stored them (every send cell is ghost-adjacent, i.e. in a tile of the HALO phase, which
 // runs after this step's transfer has read d_send), nothing the next step could use otherwise
 void halo_note_step(RDyHipOperator op, RDyHipHalo h, const double *u_out) {
-  h->packed_state = (h->fused_pack && op->fused_halo == h && u_out && op->use_tiled && !op->muscl) ? u_out : nullptr;
+  h->packed_state = (h->fused_pack && op->fused_halo == h && u_out && op->use_tiled && (!op->muscl || op->muscl_fused)) ? u_out : nullptr;
   h->packed_epoch = op->send_epoch;  // the launch just enqueued is the one that stores them
 }
 
@@ -285,8 +285,10 @@ int overlapped(RDyHipOperator op, RDyHipHalo h, double dt, double *u, double *f,
     if (!rc && conc) rc = part(RDYHIP_PHASE_HALO, 0, true);
     if (rc) return bail(rc);
     rc = join();
-    if (rc) return rc;
-    return conc ? 0 : part(RDYHIP_PHASE_HALO, 0, true);
+    if (!rc && !conc) rc = part(RDYHIP_PHASE_HALO, 0, true);
+    // (the gradient exchange went through the send buffer; the ghost-adjacent tiles' launch, behind it, has stored the new state's rows)
+    halo_note_step(op, h, rc ? nullptr : u_out);
+    return rc;
   }
   // split kernels: the gradients of the cells without ghost neighbours hide the state exchange, the fluxes of the tiles
   // without ghost-adjacent cells (which read owned gradient rows only) hide the gradient exchange
@@ -484,7 +486,7 @@ static int halo_attach_send_lists(RDyHipHalo h, bool on) {
     // fine (profiles/RESULTS_LOG.md section 11).
     const char *pmc = getenv("ROCPROF_COUNTER_COLLECTION");
     const bool  counters = pmc && atoi(pmc) != 0;
-    signalling = can && h->comm && h->n_send_tiles > 0 && senv && atoi(senv) != 0 && !counters;
+    signalling = can && h->comm && h->n_send_tiles > 0 && senv && atoi(senv) != 0 && !counters && !op->muscl;  // (the first-order / HR kernels signal)
     if (signalling) {
       // the early transfer writes the receive rows of an array the running launch is still storing owned rows of: they must
       // be ghost rows, which no launch writes (always so for a real partition; a synthetic pattern keeps the other forms)
@@ -551,8 +553,8 @@ int rdyhip_halo_fuse_pack(RDyHipHalo halo, int32_t enable) {
     return 0;
   }
   if (halo->fused_pack) return 0;
-  if (!op->use_tiled || op->muscl)
-    return fail(RDYHIP_ERR_USER, "the fused pack rides on the first-order / HR tiled Euler-step kernels (not RDYHIP_KERNEL=cell, not second_order)");
+  if (!op->use_tiled || (op->muscl && !op->muscl_fused))
+    return fail(RDYHIP_ERR_USER, "the fused pack rides on the tiled Euler-step kernels (not RDYHIP_KERNEL=cell, not the split second_order form)");
   if (op->fused_halo && op->fused_halo != halo) return fail(RDYHIP_ERR_USER, "another halo of this operator already has the fused pack");
   const int rc = halo_attach_send_lists(halo, true);
   if (rc) return rc;

@@ -843,6 +843,7 @@ __global__ __launch_bounds__(TILE) RDY_MUSCL_OCC void swe_rhs_muscl_fused_kernel
               RDY_MST(&a.u_out[3 * c + 1], n1);
               RDY_MST(&a.u_out[3 * c + 2], n2);
             }
+            if (td.send()) wave_store_send_rows(a, tile, tid, n0, n1, n2);  // the fused pack of the next state exchange (swe_kernels.h)
           }
         }
         if (idx1 >= hi) break;
@@ -1111,6 +1112,7 @@ __global__ __launch_bounds__(TILE) RDY_MUSCL_OCC void swe_rhs_muscl_fused_kernel
             RDY_MST(&a.u_out[3 * c + 1], n1);
             RDY_MST(&a.u_out[3 * c + 2], n2);
           }
+          if (td.send()) wave_store_send_rows(a, tile, tid, n0, n1, n2);  // the fused pack of the next state exchange (swe_kernels.h)
         }
       }
       idx  = idx1;

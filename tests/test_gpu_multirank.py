@@ -127,13 +127,14 @@ def _worker(rank, world, port, kernel, q, second_order=False, transport="torch",
             from rdycore_amd.timestep import EulerStepper
             lib = _lib.load()
             assert halo.direct_receive
-            if not second_order and kernel != "cell":
+            if kernel != "cell":
                 ua = torch.tensor(case.u_local, dtype=torch.float64, device=dev)
                 uc = ua.clone()
                 dts = 0.1 * case.dt
                 EulerStepper(op, halo=halo).advance(ua, dts, 5 * dts)
                 assert lib.rdyhip_halo_pack_fused(halo._halo) == 1
                 assert not halo.signalled                       # a transport callback carries the bytes here: the signalled form is RCCL's
+                # (second order, fused form: the state pack rides on the kernel, the gradient exchange still packs with a launch)
                 stepper = EulerStepper(op, halo=halo)
                 assert halo.fuse_pack(False) is False
                 stepper.advance(uc, dts, 5 * dts)
@@ -359,8 +360,8 @@ def test_rccl_self_exchange_one_rank(rdyhip_kernel):
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("kind", ["strips", "rcb_houston"])
-def test_signalled_form_self_exchange(rdyhip_kernel, kind):
+@pytest.mark.parametrize("kind,second_order", [("strips", False), ("rcb_houston", False), ("strips", True), ("rcb_houston", True)])
+def test_signalled_form_self_exchange(rdyhip_kernel, kind, second_order):
     """The signalled form of the fused-pack Euler step (include/rdyhip.h): the launch of step n says when its last send row is in
     memory and the transfer of step n + 1 runs beside the rest of that launch.  One rank's part of a partitioned mesh (real ghost
     rows), the exchange looped back through a one-rank RCCL communicator (its boundary cells travel to its own ghost rows): the
@@ -382,6 +383,7 @@ def test_signalled_form_self_exchange(rdyhip_kernel, kind):
     else:
         case = CS.houston_refined_case(os.path.join(ROOT, "tests", "golden", "houston"), 3, "hilbert", rank=2, world=5)
         mesh = case.mesh
+    case.config.second_order = second_order      # fused MUSCL form: the state pack rides on its Euler-step kernel too (no signalled form)
     op = CS.create_operator(case)
     uid = C.create_string_buffer(128)
     _lib.check(lib.rdyhip_comm_unique_id(uid))
@@ -412,7 +414,8 @@ def test_signalled_form_self_exchange(rdyhip_kernel, kind):
         finally:
             os.environ.pop("RDYHIP_OVERLAP")
             os.environ.pop("RDYHIP_SIGNALLED")
-        assert lib.rdyhip_halo_signalled(h) == (1 if fuse and signalled == "1" else 0)
+        assert lib.rdyhip_halo_pack_fused(h) == fuse
+        assert lib.rdyhip_halo_signalled(h) == (1 if fuse and signalled == "1" and not second_order else 0)
         a = torch.tensor(case.u_local, dtype=torch.float64, device="cuda:0")
         b = a.clone()
         step = lambda x, y: _lib.check(lib.rdyhip_euler_step_overlapped(op._h, h, dts, int(x.data_ptr()), int(y.data_ptr()), None, st))
@@ -567,11 +570,20 @@ def test_fused_pack_lifetime_and_argument_errors(rdyhip_kernel):
     _lib.check(lib.rdyhip_halo_destroy(C.byref(h0)))
     op.destroy()                                       # h2 (holding the fused pack on the tiled kernel) outlives its operator
     _lib.check(lib.rdyhip_halo_destroy(C.byref(h2)))
-    # second order keeps its pack launch
+    # second order: the fused form (gradients in LDS) packs in its Euler-step kernel too, the split form keeps its pack launch
     case.config.second_order = True
     if rdyhip_kernel != "cell":
-        op2 = CS.create_operator(case)
-        h = make_halo(op2, 100)
-        assert lib.rdyhip_halo_fuse_pack(h, 1) == 83 and b"second_order" in lib.rdyhip_last_error()
-        _lib.check(lib.rdyhip_halo_destroy(C.byref(h)))
-        op2.destroy()
+        for split in (False, True):
+            if split:
+                os.environ["RDYHIP_MUSCL"] = "split"
+            try:
+                op2 = CS.create_operator(case)
+            finally:
+                os.environ.pop("RDYHIP_MUSCL", None)
+            h = make_halo(op2, 100)
+            if split:
+                assert lib.rdyhip_halo_fuse_pack(h, 1) == 83 and b"second_order" in lib.rdyhip_last_error()
+            else:
+                assert lib.rdyhip_halo_fuse_pack(h, 1) == 0 and lib.rdyhip_halo_pack_fused(h) == 1
+            _lib.check(lib.rdyhip_halo_destroy(C.byref(h)))
+            op2.destroy()

@@ -98,8 +98,10 @@ def one(tag, argv, scaling="strong"):
         return fn
 
     res = {"part": tag, "cells": mesh.num_owned_cells, "ghosts": mesh.num_cells - mesh.num_owned_cells, "tiles": op.layout_info()["num_tiles"]}
-    res["kernel_rhs"] = timed(lambda: op.rhs_function(dt, u, f))
-    res["kernel_euler"] = timed(pingpong(lambda a, b: _lib.check(lib.rdyhip_euler_step(op._h, 0, 2, 0.0, a, b, None, st))))
+    # (second order: the kernel alone takes the ghost cells' gradients as they are -- flag 4 -- since no exchange fills them here)
+    so = 4 if args.second_order else 0
+    res["kernel_rhs"] = timed(lambda: op.apply_phase(0, True, dt, u, f, reset_diagnostics=True, gradients_ready=bool(so)))
+    res["kernel_euler"] = timed(pingpong(lambda a, b: _lib.check(lib.rdyhip_euler_step(op._h, 0, 2 | so, 0.0, a, b, None, st))))
     h0, n = self_halo(op, mesh, comm, direct=False)
     res["halo_cells"] = n
     res["overlapped_form"] = int(lib.rdyhip_halo_overlaps(h0))
@@ -117,6 +119,8 @@ def one(tag, argv, scaling="strong"):
     # the fused-pack Euler step without the signal (RDYHIP_SIGNALLED=0), in its two forms, forced: in order (transfer, one launch)
     # and overlapped (transfer beside the interior launch, the ghost-adjacent tiles in a second launch on the exchange stream)
     for name, ov, sg in (("euler_fused_in_order", 0, "0"), ("euler_fused_overlapped", 1, "0"), ("euler_fused_signalled", 0, "1")):
+        if sg == "1" and args.second_order:
+            continue                       # first order / HR only
         hx, _ = self_halo(op, mesh, comm, direct=True, overlap=ov)
         os.environ["RDYHIP_SIGNALLED"] = sg
         _lib.check(lib.rdyhip_halo_fuse_pack(hx, 1))
@@ -140,7 +144,8 @@ def one(tag, argv, scaling="strong"):
     op.destroy()
     k = res["kernel_rhs"][0]
     res["step_over_kernel"] = {key: round(res[key][0] / (res["kernel_euler"][0] if key.startswith("euler") or key == "r03_euler" else k), 3)
-                               for key in ("r03_rhs", "r03_euler", "rhs_direct", "euler_direct", "euler_fused", "euler_fused_in_order", "euler_fused_overlapped", "euler_fused_signalled")}
+                               for key in ("r03_rhs", "r03_euler", "rhs_direct", "euler_direct", "euler_fused", "euler_fused_in_order", "euler_fused_overlapped", "euler_fused_signalled")
+                               if key in res}
     res["columns"] = "[us per step on the GPU, us per step of host enqueue time]"
     print(json.dumps(res), flush=True)
     del u, u2, f
@@ -160,6 +165,9 @@ if __name__ == "__main__":
         ("dambreak_5120x2560 rank1/4", ["--workload", "dambreak_quads", "--emulate-world", "4", "--emulate-rank", "1"]),
         ("houston_L6 rank3/8", ["--workload", "houston_refined", "--levels", "6", "--emulate-world", "8", "--emulate-rank", "3"]),
         ("houston_L6 rank1/4", ["--workload", "houston_refined", "--levels", "6", "--emulate-world", "4", "--emulate-rank", "1"]),
+        # second order on two of the small parts (the fused pack of the state exchange rides on the MUSCL Euler-step kernel too)
+        ("second_order dambreak_2560x1280 rank0/8", ["--workload", "dambreak_quads", "--nx", "2560", "--ny", "1280", "--emulate-world", "8", "--emulate-rank", "0", "--second-order"]),
+        ("second_order houston_L5 rank3/8", ["--workload", "houston_refined", "--levels", "5", "--emulate-world", "8", "--emulate-rank", "3", "--second-order"]),
         # the weak-scaling benchmark's rank: an inner strip of 10 M cells with ghost columns on both sides (bench.py --gpus N)
         ("c3_strip_10M rank1/3", ["--emulate-world", "3", "--emulate-rank", "1"], "weak"),
     ]
