@@ -732,7 +732,7 @@ static PetscErrorCode TSSetUp_RDyHipEuler(TS ts) {
       HipCall(hipMalloc((void **)&e->d_state[k], bytes));
       HipCall(hipMemset(e->d_state[k], 0, bytes));
     }
-  if (s->halo) RDyHipCall(rdyhip_halo_fuse_pack(s->halo, 1));  // first order / HR: the pack rides on the step kernel (second order keeps its launch)
+  if (s->halo) RDyHipCall(rdyhip_halo_fuse_pack(s->halo, 1));  // the state pack rides on the step kernel (first order, HR, fused second order)
   PetscFunctionReturn(PETSC_SUCCESS);
 }
 
