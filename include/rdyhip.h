@@ -360,6 +360,9 @@ int rdyhip_unpack_rows(double *dst, int32_t ncomp, const int32_t *row_ids, int32
  *                    launch.  The promise the caller makes: between two such steps it does not write the owned rows of that
  *                    array itself -- or calls rdyhip_halo_invalidate() if it did (a host that sets the state, a restart).  A
  *                    step whose u_local is any other array packs as before.  One halo per operator can hold the fused pack.
+ *                    Second order (fused form): the gradient launch over the ghost-adjacent cells then also stores each gradient
+ *                    into the send rows it travels in, so the gradient exchange of rdyhip_rhs_overlapped /
+ *                    rdyhip_euler_step_overlapped needs no pack launch either (RDYHIP_GRAD_PACK_FUSED=0: measurement knob).
  * With both, a step of rdyhip_euler_step_overlapped is the transfer and ONE kernel launch.
  * Such a step runs in order at every size (transfer, launch: there is no pack left to hide, and launch + 8-10 us beats the two-stream
  * form's launch + 14 us up to the largest part measured); RDYHIP_OVERLAP=1 forces the two-stream form, a transport callback keeps it.

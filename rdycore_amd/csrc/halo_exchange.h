@@ -34,6 +34,8 @@ struct RDyHipHalo_s {
   int32_t          n_send_tiles = 0;
   DevBuf<uint32_t> d_send_done;            // [1] the running launch's count of send waves
   DevBuf<uint64_t> d_send_epoch;           // [1] the device's copy of *signal
+  bool             grad_pack_fused = false;  // second order: the gradient launch over the halo cell list stores into d_send too
+  DevBuf<int32_t>  d_gsend_off, d_gsend_rows;
   DevBuf<int32_t>  d_send_tile_off;        // [ntiles + 1]
   DevBuf<uint32_t> d_send_ent;             // cell-in-tile | send row << 8, sorted by tile
   bool            overlap = true;  // exchange hidden behind the interior tiles (large parts) or everything in order (small parts)
@@ -52,7 +54,7 @@ struct RDyHipHalo_s {
   }
   ~RDyHipHalo_s() {
     d_send_ids.release(); d_recv_ids.release(); d_send.release(); d_recv.release(); d_send_tile_off.release(); d_send_ent.release();
-    d_send_done.release(); d_send_epoch.release();
+    d_send_done.release(); d_send_epoch.release(); d_gsend_off.release(); d_gsend_rows.release();
     if (signal) (void)hipFree(signal);
     for (int i = 0; i < NEV; ++i) {
       if (ev_fork_ring[i]) (void)hipEventDestroy(ev_fork_ring[i]);
@@ -67,8 +69,9 @@ namespace {
 void halo_forget_packed_state(RDyHipHalo_s *h) { h->packed_state = nullptr; }
 // the operator is being destroyed before its halo: the send lists die with it
 void halo_operator_gone(RDyHipHalo_s *h) {
-  h->fused_pack   = false;
-  h->packed_state = nullptr;
+  h->fused_pack      = false;
+  h->grad_pack_fused = false;
+  h->packed_state    = nullptr;
 }
 
 #define NCCL_TRY(expr)                                                                                 \
@@ -139,6 +142,17 @@ int halo_exchange_on(RDyHipHalo h, double *rows, int32_t ncomp, hipStream_t s) {
   if (!rc) rc = halo_pack(h, rows, ncomp, s);
   if (!rc) rc = halo_transfer(h, rows, ncomp, s);
   if (!rc) rc = halo_unpack(h, rows, ncomp, s);
+  return rc;
+}
+
+// the exchange of the ghost-adjacent cells' gradients right behind launch_gradients(HALO) on the same stream: that launch has
+// packed them itself where the fused pack is attached (ColdArgs::gsend_*)
+int halo_exchange_gradients(RDyHipOperator op, RDyHipHalo h, hipStream_t s) {
+  if (!(h->grad_pack_fused && op->fused_halo == h && op->muscl_fused)) return halo_exchange_on(h, op->d_grad.p, 6, s);
+  int rc = halo_check(h, op->d_grad.p, 6);
+  h->packed_state = nullptr;  // d_send holds gradient rows now
+  if (!rc) rc = halo_transfer(h, op->d_grad.p, 6, s);
+  if (!rc) rc = halo_unpack(h, op->d_grad.p, 6, s);
   return rc;
 }
 
@@ -225,7 +239,7 @@ int overlapped(RDyHipOperator op, RDyHipHalo h, double dt, double *u, double *f,
     if (!rc && op->muscl) {
       // second order: the ghost-adjacent cells' gradients (fused form) or all of them (split form), then their exchange
       rc = launch_gradients(op, op->muscl_fused ? RDYHIP_PHASE_HALO : RDYHIP_PHASE_ALL, u, st);
-      if (!rc) rc = halo_exchange_on(h, op->d_grad.p, 6, st);
+      if (!rc) rc = halo_exchange_gradients(op, h, st);
     }
     if (!rc) rc = launch_rhs(op, RDYHIP_PHASE_ALL, 1, 1, dt, u, f, st, op->muscl, u_out, 0);
     halo_note_step(op, h, rc ? nullptr : u_out);
@@ -281,7 +295,7 @@ int overlapped(RDyHipOperator op, RDyHipHalo h, double dt, double *u, double *f,
     if (!rc) rc = halo_unpack(h, u, 3, h->cs);
     if (!rc && !h->transport) rc = part(RDYHIP_PHASE_INTERIOR, 1, true);
     if (!rc) rc = launch_gradients(op, RDYHIP_PHASE_HALO, u, h->cs);
-    if (!rc) rc = halo_exchange_on(h, op->d_grad.p, 6, h->cs);
+    if (!rc) rc = halo_exchange_gradients(op, h, h->cs);
     if (!rc && conc) rc = part(RDYHIP_PHASE_HALO, 0, true);
     if (rc) return bail(rc);
     rc = join();
@@ -522,8 +536,44 @@ static int halo_attach_send_lists(RDyHipHalo h, bool on) {
       if (rc) return rc;
     }
   }
+  // second order (fused form): the rows each ghost-adjacent cell's gradient travels in, by position in the halo cell list
+  bool gfused = false;
+  if (on && op->muscl && op->muscl_fused && op->n_halo > 0 && !(getenv("RDYHIP_GRAD_PACK_FUSED") && atoi(getenv("RDYHIP_GRAD_PACK_FUSED")) == 0)) {
+    const int32_t ns = h->send_off.back();
+    std::vector<int32_t> ids((size_t)ns), hl((size_t)op->n_halo), pos((size_t)op->n_owned, -1);
+    if (ns) HIP_TRY(hipMemcpy(ids.data(), h->d_send_ids.p, sizeof(int32_t) * (size_t)ns, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(hl.data(), op->d_halo_list.p, sizeof(int32_t) * (size_t)op->n_halo, hipMemcpyDeviceToHost));
+    for (int32_t i = 0; i < op->n_halo; ++i)
+      if (hl[(size_t)i] >= 0 && hl[(size_t)i] < op->n_owned) pos[(size_t)hl[(size_t)i]] = i;
+    std::vector<int32_t> off((size_t)op->n_halo + 1, 0), rows((size_t)ns);
+    gfused = true;
+    for (int32_t i = 0; i < ns && gfused; ++i) {
+      const int32_t c = ids[(size_t)i];
+      const int32_t o = op->prefix ? c : (c >= 0 && c < (int32_t)op->h_l2o.size() ? op->h_l2o[(size_t)c] : -1);
+      if (o < 0 || o >= op->n_owned || pos[(size_t)o] < 0) gfused = false;  // a send cell the gradient launch does not visit: keep the pack launch
+      else off[(size_t)pos[(size_t)o] + 1]++;
+    }
+    if (gfused) {
+      for (int32_t i = 0; i < op->n_halo; ++i) off[(size_t)i + 1] += off[(size_t)i];
+      std::vector<int32_t> fill(off.begin(), off.end() - 1);
+      for (int32_t i = 0; i < ns; ++i) {
+        const int32_t c = ids[(size_t)i];
+        const int32_t o = op->prefix ? c : op->h_l2o[(size_t)c];
+        rows[(size_t)fill[(size_t)pos[(size_t)o]]++] = i;
+      }
+      h->d_gsend_off.release();
+      h->d_gsend_rows.release();
+      int rc = h->d_gsend_off.upload(off);
+      if (!rc) rc = h->d_gsend_rows.upload(rows);
+      if (rc) return rc;
+    }
+  }
+  h->grad_pack_fused = gfused;
   ColdArgs c;
   HIP_TRY(hipMemcpy(&c, op->d_cold.p, sizeof(c), hipMemcpyDeviceToHost));
+  c.gsend_off   = gfused ? h->d_gsend_off.p : nullptr;
+  c.gsend_rows  = gfused ? h->d_gsend_rows.p : nullptr;
+  c.gsend_buf   = gfused ? h->d_send.p : nullptr;
   c.send_off    = on ? h->d_send_tile_off.p : nullptr;
   c.send_ent    = on ? h->d_send_ent.p : nullptr;
   c.send_buf    = on ? h->d_send.p : nullptr;

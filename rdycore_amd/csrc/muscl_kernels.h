@@ -330,6 +330,19 @@ __global__ __launch_bounds__(BLOCK) void muscl_gradient_kernel(const KernelArgs 
   dst[0]       = make_double2(gr[0], gr[1]);
   dst[1]       = make_double2(gr[2], gr[3]);
   dst[2]       = make_double2(gr[4], gr[5]);
+  // the launch over the halo cell list (a.list) also packs: the rows of the send buffer this cell's gradient travels in
+  // (rdyhip_halo_fuse_pack on a second-order operator; ColdArgs::gsend_*)
+  const int32_t *goff = RDY_COLD(a, gsend_off);
+  if (goff && a.list) {
+    const int32_t *rows = RDY_COLD(a, gsend_rows);
+    double        *sbuf = RDY_COLD(a, gsend_buf);
+    for (int r = goff[i]; r < goff[i + 1]; ++r) {
+      double2 *sd = reinterpret_cast<double2 *>(sbuf + 6 * (int64_t)rows[r]);
+      sd[0]       = make_double2(gr[0], gr[1]);
+      sd[1]       = make_double2(gr[2], gr[3]);
+      sd[2]       = make_double2(gr[4], gr[5]);
+    }
+  }
 }
 
 // split form (RDYHIP_MUSCL=split): the gradients come from memory (muscl_gradient_kernel), kept for A/B

@@ -90,6 +90,11 @@ struct ColdArgs {
   uint64_t *send_epoch;   // launches that have stored ALL their send rows so far
   uint64_t *send_signal;  // the same number in signal memory: hipStreamWaitValue64 on the exchange stream waits for it
   uint32_t  send_waves;   // waves of flagged tiles per launch (TILE / 64 per tile)
+  // second order: the ghost-adjacent cells' gradient launch (muscl_gradient_kernel over the halo cell list) also stores each
+  // gradient into the rows of the send buffer that carry it to other ranks: no pack launch for the gradient exchange
+  const int32_t *gsend_off;   // [n_halo + 1] first send row of the cell at each position of the halo cell list
+  const int32_t *gsend_rows;  // rows of the send buffer ([send cells][6])
+  double        *gsend_buf;
 };
 
 struct KernelArgs {
