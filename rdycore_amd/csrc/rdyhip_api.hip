@@ -154,6 +154,7 @@ struct RDyHipOperator_s {
   bool             use_tiled = true;
   bool             hr = false;   // hydrostatic reconstruction
   bool             lds_fixed = false;  // first-order tiled kernel: compile-time LDS plane lengths (TILED_NS_* / TILED_NE_*)
+  bool             uout_cached = false;  // Euler-step kernels store u_out with the default cache policy: the state fits the Infinity Cache
   DevBuf<double>   d_zc_local;
   int32_t          ntiles = 0, n_halo_tiles = 0, emax = 0;
   int64_t          nrec = 0;
@@ -244,7 +245,14 @@ TiledKernelFn tiled_euler_fn_hr(int S, int src) {
   if (S == 3) return src ? swe_rhs_tiled_kernel<3, 1, true, HR, true, NS3, NE3> : swe_rhs_tiled_kernel<3, 0, true, HR, true, NS3, NE3>;
   return src ? swe_rhs_tiled_kernel<4, 1, true, HR, true, NS4, NE4> : swe_rhs_tiled_kernel<4, 0, true, HR, true, NS4, NE4>;
 }
-TiledKernelFn tiled_euler_fn(int S, int src, bool hr, bool fixed = false) {
+// ... and with plain (cached) stores of u_out, for states that fit the Infinity Cache (fixed LDS layout only, as for cached F)
+template <bool HR>
+TiledKernelFn tiled_euler_fn_cached(int S, int src) {
+  if (S == 3) return src ? swe_rhs_tiled_kernel<3, 1, true, HR, true, TILED_NS_TRI, TILED_NE_TRI, false> : swe_rhs_tiled_kernel<3, 0, true, HR, true, TILED_NS_TRI, TILED_NE_TRI, false>;
+  return src ? swe_rhs_tiled_kernel<4, 1, true, HR, true, TILED_NS_QUAD, TILED_NE_QUAD, false> : swe_rhs_tiled_kernel<4, 0, true, HR, true, TILED_NS_QUAD, TILED_NE_QUAD, false>;
+}
+TiledKernelFn tiled_euler_fn(int S, int src, bool hr, bool fixed = false, bool uout_cached = false) {
+  if (fixed && uout_cached) return hr ? tiled_euler_fn_cached<true>(S, src) : tiled_euler_fn_cached<false>(S, src);
   if (fixed)
     return hr ? tiled_euler_fn_hr<true, TILED_NS_TRI, TILED_NE_TRI, TILED_NS_QUAD, TILED_NE_QUAD>(S, src)
               : tiled_euler_fn_hr<false, TILED_NS_TRI, TILED_NE_TRI, TILED_NS_QUAD, TILED_NE_QUAD>(S, src);
@@ -484,7 +492,7 @@ int launch_rhs(RDyHipOperator op, int32_t phase, int32_t overwrite, int reset_di
                                       : muscl_kernel_fn(op->S, xq ? 1 : 0, overwrite != 0, op->config.limiter, op->muscl_fused, op->muscl_efo, op->muscl_soa);
       hipLaunchKernelGGL(HIP_KERNEL_NAME(kfn), dim3(grid), dim3(TILE), op->lds_muscl, st, a, muscl_args(op), dt, u, f);
     } else if (euler_fused) {
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(tiled_euler_fn(op->S, xq ? 1 : 0, op->hr, op->lds_fixed)), dim3(grid), dim3(TILE), op->lds_bytes, st, a, dt, u, f);
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(tiled_euler_fn(op->S, xq ? 1 : 0, op->hr, op->lds_fixed, op->uout_cached)), dim3(grid), dim3(TILE), op->lds_bytes, st, a, dt, u, f);
       // this launch runs every send-flagged tile (they all have ghost neighbours: no INTERIOR launch touches one) and its
       // last send wave will advance the device's count: the host's copy follows
       if (op->send_signalling && phase != RDYHIP_PHASE_INTERIOR) ++op->send_epoch;
@@ -992,6 +1000,15 @@ int rdyhip_create(const RDyHipConfig *config, const RDyHipMesh *mesh, int32_t nu
   op->hmax         = hmax;
   op->lds_bytes    = lds_bytes;
   op->lds_fixed    = L.lds_fixed;
+  {
+    // The Euler-step kernels' u_out is what the next step reads: stored without the non-temporal hint it is still in the
+    // Infinity Cache (256 MB) then -- when it fits beside what else lives there.  Plain stores while the state array is at
+    // most half the cache (RDYHIP_UOUT_CACHED_MAX_MB, default 128 MB = 5.6 M cells); RDYHIP_UOUT_CACHED=0 / 1 forces.
+    double max_mb = 128.0;
+    if (const char *e = getenv("RDYHIP_UOUT_CACHED_MAX_MB")) max_mb = atof(e);
+    op->uout_cached = L.lds_fixed && 24.0 * (double)op->n_cells <= max_mb * 1048576.0;
+    if (const char *e = getenv("RDYHIP_UOUT_CACHED")) op->uout_cached = L.lds_fixed && atoi(e) != 0;
+  }
   if (lds_bytes > 64 * 1024) {
     // more than the default 64 KB of dynamic LDS (only for numberings with poor locality)
     const int nb = (int)lds_bytes;

@@ -791,12 +791,21 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
         if (EULER) {
           const double n0 = out[3] + dt * out[0], n1 = own_hu + dt * out[1], n2 = own_hv + dt * out[2];
           if (!a.o2l) {
-            wave_store_rows3(a.u_out, base, lane, ncell, n0, n1, n2);
+            // u_out is what the NEXT step reads.  With the hint it is not in the Infinity Cache then; without it, it is -- if it
+            // fits: a 2.8 M-cell part (67 MB of state) steps 8 % faster with plain stores, a 10 M-cell one (240 MB of a 256 MB
+            // cache) 3.5 % slower (profiles/r04_uout_store_policy.txt).  FNT = false is the instantiation for states that fit.
+            wave_store_rows3<FNT>(a.u_out, base, lane, ncell, n0, n1, n2);
           } else if (active) {  // owned cells are not a prefix of the local numbering: scattered rows
             const int64_t c = a.o2l[o];
-            RDY_ST(&a.u_out[3 * c + 0], n0);
-            RDY_ST(&a.u_out[3 * c + 1], n1);
-            RDY_ST(&a.u_out[3 * c + 2], n2);
+            if constexpr (FNT) {
+              RDY_ST(&a.u_out[3 * c + 0], n0);
+              RDY_ST(&a.u_out[3 * c + 1], n1);
+              RDY_ST(&a.u_out[3 * c + 2], n2);
+            } else {
+              a.u_out[3 * c + 0] = n0;
+              a.u_out[3 * c + 1] = n1;
+              a.u_out[3 * c + 2] = n2;
+            }
           }
           if (send_tile) {
             wave_store_send_rows(a, tile_cur, tid, n0, n1, n2);

@@ -309,6 +309,37 @@ def test_cached_f_stores_option_changes_nothing_but_the_cache_policy():
     assert torch.equal(out[0], out[1])
 
 
+def test_uout_store_policy_changes_nothing_but_the_cache_policy():
+    """The Euler-step kernels store u_out with the default cache policy when the state fits the Infinity Cache and with the
+    non-temporal hint when it does not (rdyhip_create decides by size; RDYHIP_UOUT_CACHED forces): the same bits either way,
+    F requested or not, on a part with ghost cells.  (The HR instantiations of both policies are held against the oracle by the
+    trajectory tests: levee, bowl, C5 -- small states, plain stores -- and the 10 M / 45 M-cell cases -- hinted stores.)"""
+    import os
+    torch = _torch()
+    K = 2 * np.pi / 31
+    mesh = M.strip_partition_tri_mesh(40, 30, 1, 3, 1.0, zfunc=CS.mms_bathymetry(K=K), order="tiled", tile=8)   # a part with ghost cells
+    case = CS.friction_slope_case(mesh, 120.0, 30.0, dt=1e-2, K=K)
+    u = torch.tensor(case.u_local, dtype=torch.float64, device="cuda")
+    out = []
+    for policy in ("0", "1"):
+        os.environ["RDYHIP_UOUT_CACHED"] = policy
+        try:
+            op = CS.create_operator(case)
+        finally:
+            os.environ.pop("RDYHIP_UOUT_CACHED")
+        a, b = u.clone(), u.clone()          # (the ghost rows of both arrays hold a valid state: a step writes owned rows only)
+        f = torch.empty((mesh.num_owned_cells, 3), dtype=torch.float64, device="cuda")
+        op.euler_step(case.dt, a, b, f)
+        op.euler_step(case.dt, b, a)
+        torch.cuda.synchronize()
+        out.append((a, b, f))
+        op.destroy()
+    for x, y in zip(*out):
+        assert torch.equal(torch.nan_to_num(x, nan=1e300), torch.nan_to_num(y, nan=1e300))
+    own = torch.as_tensor(mesh.cell_owned_to_local.astype(np.int64), device="cuda")
+    assert not torch.equal(torch.nan_to_num(out[0][0][own], nan=1e300), u[own])      # the steps did move the state
+
+
 def test_error_behaviour():
     from rdycore_amd.operator import Operator, RDyFlowConfig, RDyHipError
     torch = _torch()
