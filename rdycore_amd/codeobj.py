@@ -61,7 +61,6 @@ def kernel_bytes(lib: str) -> dict:
     co = device_code_object(lib)
     secs, cstr = _elf_sections(co)
     _, _, _, symoff, symsize, link, entsize = secs[".symtab"]
-    heads = sorted(secs.values(), key=lambda h: h[3])
     by_index = {}
     shoff, = struct.unpack_from("<Q", co, 0x28)
     shentsize, shnum = struct.unpack_from("<HH", co, 0x3A)
@@ -77,7 +76,6 @@ def kernel_bytes(lib: str) -> dict:
         sec = by_index[shndx]
         start = sec[4] + (value - sec[3])
         out[cstr(strtab, name)] = co[start:start + size]
-    del heads
     return out
 
 

@@ -1,0 +1,15 @@
+"""Documents that name things the code defines: kept in step by the CPU suite."""
+import glob
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_every_environment_variable_the_library_reads_is_documented():
+    src = "".join(open(f).read() for f in glob.glob(os.path.join(ROOT, "rdycore_amd", "csrc", "*.h")) + glob.glob(os.path.join(ROOT, "rdycore_amd", "csrc", "*.hip")))
+    read = set(re.findall(r'getenv\("(RDYHIP_[A-Z0-9_]+|ROCPROF_[A-Z0-9_]+)"\)', src))
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    missing = sorted(v for v in read if v not in doc)
+    assert not missing, f"INTEGRATION.md (environment variables) does not mention {missing}"
+    assert len(read) >= 20
