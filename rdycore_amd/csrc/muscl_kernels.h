@@ -35,14 +35,9 @@
 
 namespace rdyhip {
 
-// non-temporal hints for the fused kernel's streamed-once data (see swe_kernels.h); -DRDYHIP_MUSCL_NO_NT: off
-#ifndef RDYHIP_MUSCL_NO_NT
+// non-temporal hints for the fused kernel's streamed-once data (see swe_kernels.h)
 #define RDY_MLD(ptr) __builtin_nontemporal_load(ptr)
 #define RDY_MST(ptr, val) __builtin_nontemporal_store((val), (ptr))
-#else
-#define RDY_MLD(ptr) (*(ptr))
-#define RDY_MST(ptr, val) (*(ptr) = (val))
-#endif
 
 typedef double   rdy_d2v __attribute__((ext_vector_type(2)));
 typedef uint32_t rdy_u2v __attribute__((ext_vector_type(2)));
@@ -76,13 +71,7 @@ constexpr uint16_t BN_NONE = 0xFFFF, BN_GLOBAL = 0xFFFE;
 // record strides in doubles (gradient: 6 values, edge flux: 4 values).  The gradient records are padded to 7: an odd
 // stride spreads consecutive records over all LDS banks (6 -> 7: -1.6 % on the 10 M-cell RHS; padding the flux records
 // to 5 as well changes nothing more)
-#ifndef RDYHIP_MUSCL_GS
-#define RDYHIP_MUSCL_GS 7
-#endif
-#ifndef RDYHIP_MUSCL_ES
-#define RDYHIP_MUSCL_ES 4
-#endif
-constexpr int MUSCL_GS = RDYHIP_MUSCL_GS, MUSCL_ES = RDYHIP_MUSCL_ES;
+constexpr int MUSCL_GS = 7, MUSCL_ES = 4;
 
 // Where value k of record j lives in LDS.  Two layouts behind the same kernels:
 //   MusclAoS        records of any count (sizes known at run time only): a record's values are consecutive doubles, so one
@@ -139,9 +128,6 @@ __device__ __forceinline__ void ls_add(LsAcc &a, double dx, double dy, double d0
   // agree bit for bit, and the parity bar is 1e-10); coincident centroids give w = 0 as in the reference
   double w = __builtin_amdgcn_rsq(r2);
   w        = w * fma(-0.5 * r2 * w, w, 1.5);
-#ifdef RDYHIP_LS_TWO_NEWTON
-  w        = w * fma(-0.5 * r2 * w, w, 1.5);
-#endif
   if (!(r2 > 0.0)) w = 0.0;
   const double wdx = w * dx, wdy = w * dy;
   a.m00  = fma(wdx, dx, a.m00);
@@ -225,13 +211,8 @@ __device__ __forceinline__ EdgeFlux muscl_edge(const KernelArgs &a, const TileDe
       const double extrap_l = MSG(2 * k, jl) * dl.x + MSG(2 * k + 1, jl) * dl.y;
       const double extrap_r = MSG(2 * k, jr) * dr.x + MSG(2 * k + 1, jr) * dr.y;
       const double dq       = cr_ - cl_;
-#ifndef RDYHIP_EXP_NO_RECON
       ql[k]                 = cl_ + limit_slope<LIM>(extrap_l, 0.5 * dq);
       qr[k]                 = cr_ + limit_slope<LIM>(extrap_r, -0.5 * dq);
-#else
-      ql[k] = cl_ + 1e-300 * (extrap_l + dq);  // timing experiment: operands read, no limiter
-      qr[k] = cr_ + 1e-300 * extrap_r;
-#endif
     }
     ql[0] = fmax(0.0, ql[0]);  // 1201-1203, swe_petsc.c:143-146
     qr[0] = fmax(0.0, qr[0]);
@@ -465,21 +446,12 @@ __global__ __launch_bounds__(TILE) void swe_rhs_muscl_kernel(const KernelArgs a,
 // multiply by a constant) into the block that requests them -- the wave then waits for them before the barriers that were
 // meant to cover their latency -- and, the waits sitting inside `if (active)`, treats the registers as still pending after the
 // merge: a vmcnt(0) between the tile's first store and its second, i.e. a wait for the store itself.
-#ifndef RDYHIP_MUSCL_NO_ARRIVE
 #define RDY_STREAMS_ARRIVE()                                                                                                              \
   do {                                                                                                                                    \
     asm volatile("" ::"v"(dzx), "v"(dzy), "v"(nman), "v"(s0), "v"(s1), "v"(s2), "v"(kf[0]), "v"(kf[1]), "v"(kf[2]), "v"(kf[S - 1]) : "memory"); \
   } while (0)
-#else
-#define RDY_STREAMS_ARRIVE() do { } while (0)
-#endif
-#ifdef RDYHIP_MUSCL_WAVES
-#define RDY_MUSCL_OCC __attribute__((amdgpu_waves_per_eu(RDYHIP_MUSCL_WAVES, RDYHIP_MUSCL_WAVES)))
-#else
-#define RDY_MUSCL_OCC
-#endif
 template <int S, int SRC, bool OVW, int LIM, bool EULER = false, bool EFO = false, class LAY = MusclAoS>
-__global__ __launch_bounds__(TILE) RDY_MUSCL_OCC void swe_rhs_muscl_fused_kernel(const KernelArgs a, const MusclArgs g, const double dt, const double *__restrict__ u,
+__global__ __launch_bounds__(TILE) void swe_rhs_muscl_fused_kernel(const KernelArgs a, const MusclArgs g, const double dt, const double *__restrict__ u,
                                                                     double *__restrict__ f) {
   // LDS: gradients of own + first-ring cells | state of own + first-ring cells | a region that holds the second ring's
   // state (its head, contiguous with the first ring's records) and the tile's edge records (its tail), both read by
@@ -547,11 +519,7 @@ __global__ __launch_bounds__(TILE) RDY_MUSCL_OCC void swe_rhs_muscl_fused_kernel
     for (int s = 0; s < S; ++s) {
       const int n = nb[s];
       if (n < 0) continue;
-#ifndef RDYHIP_EXP_NO_GRAD
       ls_add(acc, MSQ(3, n) - x0, MSQ(4, n) - y0, MSQ(0, n) - q0, MSQ(1, n) - q1, MSQ(2, n) - q2);
-#else
-      acc.b[0] += MSQ(0, n) - q0;  // timing experiment: the LDS traffic without the arithmetic
-#endif
     }
     ls_solve(acc, gr);
   };

@@ -27,28 +27,21 @@ constexpr int32_t NBR_MASK  = (1 << 30) - 1;
 // for normal operands; a zero or non-finite operand yields a non-finite
 // result, as the division would (0 -> the IEEE 1/0 = inf becomes NaN, which
 // only occurs on dry-dry edges whose flux is discarded or reported as NaN by
-// the reference too).  -DRDYHIP_IEEE_DIV restores plain divisions.
+// the reference too).
 __device__ __forceinline__ double rdy_rcp(double x) {
-#ifdef RDYHIP_IEEE_DIV
-  return 1.0 / x;
-#else
   double r = __builtin_amdgcn_rcp(x);
   double e = fma(-x, r, 1.0);
   r        = fma(r, e, r);
   e        = fma(-x, r, 1.0);
   r        = fma(r, e, r);
   return r;
-#endif
 }
 
 // Square root by v_rsq_f64 + one Goldschmidt step + one residual correction
 // (the IEEE expansion minus its denormal-range scaling and its second
 // correction): <= 1 ulp for normal operands, exact for 0 and +inf, NaN for
-// negative operands.  -DRDYHIP_IEEE_SQRT restores plain sqrt().
+// negative operands.
 __device__ __forceinline__ double rdy_sqrt(double x) {
-#ifdef RDYHIP_IEEE_SQRT
-  return sqrt(x);
-#else
   const double y = __builtin_amdgcn_rsq(x);
   double       g = x * y;
   double       h = 0.5 * y;
@@ -58,7 +51,6 @@ __device__ __forceinline__ double rdy_sqrt(double x) {
   const double d = fma(-g, g, x);
   g              = fma(d, h, g);
   return (x == 0.0 || x == __builtin_inf()) ? x : g;
-#endif
 }
 
 // sqrt(x) and 1/sqrt(x) from ONE v_rsq_f64: the Goldschmidt pair (g -> sqrt x, h -> 1/(2 sqrt x)) refined together;
@@ -99,7 +91,6 @@ struct RiemannSide {
 __device__ __forceinline__ RiemannSide riemann_side(double h, double hu, double hv, double tiny_h, double h_anuga_sq) {
   RiemannSide s;
   s.h = h;
-#if !defined(RDYHIP_STUB_FLUX) && !defined(RDYHIP_IEEE_DIV) && !defined(RDYHIP_IEEE_SQRT) && !defined(RDYHIP_NO_SQRT_PAIR)
   if (h_anuga_sq == 0.0) {
     // the default (h_anuga_regular = 0, src/yaml_input.c:855): hu h / (h^2 + 0) = hu / h, and 1/h = (1/sqrt h)^2 comes with
     // the square root the Roe solver needs anyway (wave-uniform branch)
@@ -111,7 +102,6 @@ __device__ __forceinline__ RiemannSide riemann_side(double h, double hu, double 
     s.c                = SQRT_GRAVITY * s.sqh;
     return s;
   }
-#endif
   if (h < tiny_h) {
     s.u = 0.0;
     s.v = 0.0;
@@ -121,16 +111,8 @@ __device__ __forceinline__ RiemannSide riemann_side(double h, double hu, double 
     s.u            = hu * r;
     s.v            = hv * r;
   }
-#ifdef RDYHIP_STUB_FLUX
-  s.sqh = h; s.c = h;
-#else
   s.sqh = rdy_sqrt(h);
-#ifdef RDYHIP_EXP_TWO_SQRT
-  s.c   = rdy_sqrt(GRAVITY * h);
-#else
   s.c   = SQRT_GRAVITY * s.sqh;  // sqrt(g h) = sqrt(g) sqrt(h): one multiply instead of a second square root
-#endif
-#endif
   return s;
 }
 
@@ -138,25 +120,15 @@ __device__ __forceinline__ RiemannSide riemann_side(double h, double hu, double 
 // src/swe/swe_roe_flux_petsc.h:15-81, 103-128.  Same formulas; the divisions
 // by (duml+dumr) and by chat are each done once as a reciprocal.
 __device__ __forceinline__ RoeFlux roe_flux(const RiemannSide &L, const RiemannSide &R, double sn, double cn) {
-#ifdef RDYHIP_STUB_FLUX  // timing experiment only: memory-side floor of the kernel structure
-  RoeFlux o;
-  o.f0 = L.h * cn + R.h * sn; o.f1 = L.u + R.u; o.f2 = L.v + R.v; o.amax = L.c + R.c + L.sqh + R.sqh;
-  return o;
-#endif
   const double hl = L.h, ul = L.u, vl = L.v, hr = R.h, ur = R.u, vr = R.v;
   const double duml = L.sqh, dumr = R.sqh, cl = L.c, cr = R.c;
   const double hhat    = duml * dumr;
   const double inv_sum = rdy_rcp(duml + dumr);
   const double uhat    = (duml * ul + dumr * ur) * inv_sum;
   const double vhat    = (duml * vl + dumr * vr) * inv_sum;
-#if !defined(RDYHIP_IEEE_DIV) && !defined(RDYHIP_IEEE_SQRT) && !defined(RDYHIP_NO_SQRT_PAIR)
   const SqrtPair cp       = rdy_sqrt_rsqrt(0.5 * GRAVITY * (hl + hr));
   const double   chat     = cp.s;
   const double   inv_chat = cp.r;  // 1/chat with the square root, instead of a separate reciprocal
-#else
-  const double chat     = rdy_sqrt(0.5 * GRAVITY * (hl + hr));
-  const double inv_chat = rdy_rcp(chat);
-#endif
   const double uperp   = uhat * cn + vhat * sn;
 
   const double dh     = hr - hl;

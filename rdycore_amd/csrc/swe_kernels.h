@@ -31,28 +31,17 @@
 namespace rdyhip {
 
 constexpr int BLOCK = 256;  // threads per workgroup of the cell-centric kernel
-#ifndef RDYHIP_TILE
-#define RDYHIP_TILE 256
-#endif
-constexpr int TILE = RDYHIP_TILE;  // cells per tile = threads per workgroup of the tiled kernel (a multiple of 64)
+constexpr int TILE = 256;   // cells per tile = threads per workgroup of the tiled kernel (a multiple of 64)
 
 constexpr uint16_t SLOT_EMPTY = 0xFFFF;
-#ifndef RDYHIP_QUAD_ROUNDS
-#define RDYHIP_QUAD_ROUNDS 3  // register-resident edge-record rounds of the S == 4 (quads / mixed) tiled kernel (2 or 3)
-#endif
 
 // Data that is streamed through exactly once per launch -- the per-cell streams (flux coefficients, bed slopes,
 // Manning n, external source), the tile edge records and the outputs F / primitive variables -- is loaded and
 // stored with the non-temporal hint, which leaves the L2 to the state vector (the only data with reuse: halo cells
 // are read by neighbouring tiles).  Measured A/B on one box: 0.342 ms vs 0.359 ms per 10 M-cell RHS; marking the
-// state loads as well costs 5 % (0.375 ms), the stores alone cost 6 %.  -DRDYHIP_NO_NT switches the hints off.
-#ifndef RDYHIP_NO_NT
+// state loads as well costs 5 % (0.375 ms), the stores alone cost 6 %.
 #define RDY_ST(ptr, val) __builtin_nontemporal_store((val), (ptr))
 #define RDY_LD(ptr) __builtin_nontemporal_load(ptr)
-#else
-#define RDY_ST(ptr, val) (*(ptr) = (val))
-#define RDY_LD(ptr) (*(ptr))
-#endif
 
 // persistent Courant diagnostic on the device
 struct DeviceCourant {
@@ -436,12 +425,8 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
   // edge-record rounds held in registers: a 256-cell tile of a well-numbered triangle mesh has <= 2 x 256 edge records
   // (1.6 per cell), a quad tile up to 3 x 256 (a 16 x 16 block: 544).  Records beyond that (poor numberings) are loaded
   // inside the flux phase.
-  constexpr int NR = (S == 3) ? 2 : RDYHIP_QUAD_ROUNDS;
-#ifdef RDYHIP_HR_V1
-  constexpr bool HR_STAGED_VEL = false;
-#else
+  constexpr int  NR            = (S == 3) ? 2 : 3;
   constexpr bool HR_STAGED_VEL = HR;
-#endif
   extern __shared__ double lds[];
   const int nside = NS > 0 ? NS : TILE + a.hmax;
   const int nedge = NE > 0 ? NE : a.emax;
@@ -623,14 +608,6 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
             RiemannSide  Lr, Rr;
             Lr.h   = fmax(0.0, (L.h + zl) - z_max);
             Rr.h   = fmax(0.0, (R.h + zr) - z_max);
-#ifdef RDYHIP_HR_V1
-            Lr.u   = (L.h > a.tiny_h) ? L.u : 0.0;
-            Lr.v   = (L.h > a.tiny_h) ? L.v : 0.0;
-            Rr.u   = (R.h > a.tiny_h) ? R.u : 0.0;
-            Rr.v   = (R.h > a.tiny_h) ? R.v : 0.0;
-            Lr.sqh = rdy_sqrt(Lr.h);
-            Rr.sqh = rdy_sqrt(Rr.h);
-#else
             // the staged velocities already follow the HR operator's rule (hr_velocity_rule, phase 0)
             Lr.u = L.u; Lr.v = L.v; Rr.u = R.u; Rr.v = R.v;
             // Only the side with the LOWER bed changes its depth; the other one keeps (h + z) - z, i.e. its own depth up to one
@@ -641,7 +618,6 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
             const double sx     = rdy_sqrt(l_high ? Rr.h : Lr.h);
             Lr.sqh = l_high ? L.sqh : sx;
             Rr.sqh = l_high ? sx : R.sqh;
-#endif
             Lr.c   = SQRT_GRAVITY * Lr.sqh;
             Rr.c   = SQRT_GRAVITY * Rr.sqh;
             fl     = roe_flux(Lr, Rr, sn, cn);
