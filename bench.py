@@ -43,10 +43,9 @@ HBM_PEAK_GBPS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8 TB/s
 LIMITERS = {"minmod": 0, "none": 1, "van_leer": 2}
 # second order: 176 B + cell centroids (16) + one edge midpoint per edge (1.5 x 16) -- the least-squares coefficients
 # (3 x 16 B per cell in the reference) and the centroid->midpoint displacements (1.5 x 32 B) are formed on the chip from
-# them; the split form (RDYHIP_MUSCL=split) also writes and reads the gradient array (2 x 48) and reads the state and the
-# centroids twice (24 + 16)
+# them
 ALG_BYTES_PER_CELL_SECOND_ORDER = 176.0 + 16.0 + 24.0
-ALG_BYTES_PER_CELL_SECOND_ORDER_SPLIT = ALG_BYTES_PER_CELL_SECOND_ORDER + 96.0 + 24.0 + 16.0
+CPU_FULL_MESH_MAX_CELLS = 12_000_000   # cpu_baseline runs on the benchmark mesh itself up to this size (C3: 10 M cells, ~1 s per RHS on one core)
 KERNEL_SOURCES = ["swe_kernels.h", "swe_device.h", "muscl_kernels.h"]
 HOUSTON_DATA = os.path.join(ROOT, "tests", "golden", "houston")   # the reference's Houston1km fixtures (data files, in the repo)
 
@@ -66,6 +65,7 @@ def parse(argv=None):
                    help="cell numbering of the mesh: generator order, 16x16-square blocks (default of the structured workloads), cells along "
                         "a Hilbert curve (default of the unstructured ones); unstructured only: natural = the order refinement / the "
                         "triangulator leaves, random = a seeded permutation")
+    p.add_argument("--quad-block", default=None, help="dambreak_quads, --order tiled: the block of squares numbered together, e.g. 16x16 (default 16x15 = one tile of the operator)")
     p.add_argument("--source", default="semi_implicit", choices=["semi_implicit", "implicit_xq2018"])
     p.add_argument("--hr", action="store_true", help="hydrostatic-reconstruction variant of the operator (SURVEY 8.f row 2)")
     p.add_argument("--second-order", action="store_true", help="MUSCL second-order variant (SURVEY 8.f row 4)")
@@ -150,7 +150,7 @@ def build_case(args, rank, world, nx=None, ny=None, order=None):
             case = CS.friction_slope_case(mesh, nxg * 1.0, ny * 1.0, dt=1e-3, source_method=src, K=K)
     elif wl == "dambreak_quads":
         nxg = nx if (strong or world == 1) else nx * world
-        mesh = CS.dam_break_quads_mesh(nxg, ny, rank, world, order=order)
+        mesh = CS.dam_break_quads_mesh(nxg, ny, rank, world, order=order, tile=tuple(map(int, args.quad_block.split("x"))) if args.quad_block else None)
         case = CS.dam_break_quads_case(mesh)
         case.config.source_method = src
     elif wl == "houston_refined":
@@ -174,30 +174,37 @@ def build_case(args, rank, world, nx=None, ny=None, order=None):
     return case
 
 
-def cpu_baseline(args):
-    """The CPU oracle (a plain-C restatement of the reference's PETSc path, one
-    core) timed on a bounded sample of the same workload."""
+def _time_oracle(orc, case, min_reps, max_reps, budget_s):
     import numpy as np
-    from oracle import oracle as O  # noqa: F401  test infrastructure; used here only as the timed CPU baseline
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from helpers import oracle_from_case
-    nx, ny = map(int, args.cpu_sample.split("x"))
-    case = build_case(args, 0, 1, nx, ny, "rowmajor")
-    orc = oracle_from_case(case)
     f = np.zeros((case.mesh.num_owned_cells, 3))
     orc.apply(case.dt, case.u_local, f)  # warm
     times = []
-    t_end = time.time() + 12.0
-    while len(times) < 3 or (time.time() < t_end and len(times) < 10):
+    t_end = time.time() + budget_s
+    while len(times) < min_reps or (time.time() < t_end and len(times) < max_reps):
         f[:] = 0.0
         t0 = time.perf_counter()
         orc.apply(case.dt, case.u_local, f)
         times.append(time.perf_counter() - t0)
-    med = float(np.median(times))
+    return float(np.median(times)), len(times)
+
+
+def cpu_baseline(args, case=None):
+    """The CPU oracle (a plain-C restatement of the reference's PETSc path, ApplyOperator of src/operator.c:656-672, one core)
+    timed on `case` -- the benchmark mesh itself -- or, without one, on the bounded sample of the same workload."""
+    from oracle import oracle as O  # noqa: F401  test infrastructure; used here only as the timed CPU baseline
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import oracle_from_case
+    if case is None:
+        nx, ny = map(int, args.cpu_sample.split("x"))
+        case = build_case(args, 0, 1, nx, ny, "rowmajor")
+        what = f"a {nx}x{ny}-square = {case.mesh.num_owned_cells}-cell sample mesh of the same workload"
+        med, reps = _time_oracle(oracle_from_case(case), case, 3, 10, 12.0)
+    else:
+        what = f"the benchmark mesh itself ({case.mesh.num_owned_cells} cells, the numbering the GPU ran)"
+        med, reps = _time_oracle(oracle_from_case(case), case, 3, 5, 8.0)
     nc = case.mesh.num_owned_cells
     return {"value": round(nc / med / 1e6, 3), "unit": "M cell-updates/s", "cores": 1, "kind": "port",
-            "sample": f"{len(times)} RHS evaluations of the same workload on a {nx}x{ny}-square = {nc}-cell mesh, "
-                      f"oracle/swe_oracle.c (gcc -O2, 1 thread), median {med * 1e3:.1f} ms/RHS"}
+            "sample": f"{reps} RHS evaluations on {what}, oracle/swe_oracle.c (gcc -O2, 1 thread), median {med * 1e3:.1f} ms/RHS"}
 
 
 def _cpu_part_worker(a):
@@ -238,17 +245,22 @@ def cpu_baseline_all_cores(args, argv):
                       f"(upper bound on an MPI run), slowest part {tmax * 1e3:.1f} ms/RHS"}
 
 
-def cpu_baseline_openmp(args):
+def cpu_baseline_openmp(args, case=None):
     """SURVEY.md 8.d (ii), second line: ONE process, all host cores through OpenMP -- oracle/libswe_oracle_omp.so, the
     oracle's own source built with -fopenmp (Riemann batch and source terms over all cores, each cell's flux sum by one
-    thread in the serial order: bitwise the serial result, tests/test_oracle_openmp.py)."""
+    thread in the serial order: bitwise the serial result, tests/test_oracle_openmp.py).  On `case` (the benchmark mesh
+    itself) or, without one, on the sample mesh."""
     import numpy as np
     cores = max(1, min(len(os.sched_getaffinity(0)), 32))   # as cpu_baseline_all_cores: the affinity mask of a GPU box lists more
                                                             # cores than its CPU share holds
     from oracle import oracle as O  # noqa: F401  test infrastructure; used here only as the timed CPU baseline
     cores = int(O.lib(openmp=True).oracle_set_num_threads(cores))   # not OMP_NUM_THREADS: torch has initialised libgomp long ago
-    nx, ny = map(int, args.cpu_sample.split("x"))
-    case = build_case(args, 0, 1, nx, ny, "rowmajor")
+    if case is None:
+        nx, ny = map(int, args.cpu_sample.split("x"))
+        case = build_case(args, 0, 1, nx, ny, "rowmajor")
+        what = f"the {nx}x{ny}-square = {case.mesh.num_owned_cells}-cell sample mesh"
+    else:
+        what = f"the benchmark mesh itself ({case.mesh.num_owned_cells} cells)"
     cfg = case.config
     if cfg.second_order or cfg.well_balancing:
         return {"skipped": "the OpenMP build parallelises the first-order path only"}
@@ -269,7 +281,7 @@ def cpu_baseline_openmp(args):
     med = float(np.median(ts))
     nc = case.mesh.num_owned_cells
     return {"value": round(nc / med / 1e6, 2), "unit": "M cell-updates/s", "cores": cores, "kind": "port",
-            "sample": f"10 RHS evaluations on the {nx}x{ny}-square = {nc}-cell sample mesh, oracle/swe_oracle.c built with -fopenmp, "
+            "sample": f"10 RHS evaluations on {what}, oracle/swe_oracle.c built with -fopenmp, "
                       f"{cores} threads in one process, median {med * 1e3:.1f} ms/RHS"}
 
 
@@ -672,10 +684,46 @@ def run_rank(args, argv):
     euler = {"fused_ms_per_step": round(ef, 5), "rhs_plus_axpy_ms_per_step": round(ep, 5), "fused_steps_per_s": round(1e3 / ef, 1)}
     if halo is not None or self_halo is not None:
         euler["pack_fused_into_kernel"] = bool(pack_fused)
-        # the next step's transfer starts when this step's launch has stored its last send row (include/rdyhip.h, "signalled form")
-        euler["signalled_form"] = bool(halo.signalled) if halo is not None else bool(self_halo[0].rdyhip_halo_signalled(self_halo[1]))
         if halo is not None:
             halo.invalidate()
+    # ---- extra (not the metric): the drop-in's real loop, not back-to-back launches.  RDyAdvance (src/rdyadvance.c:261-383) as
+    # the driver's time loop calls it: refresh of the rain source from a host array (RDySetDomainWaterSource -> the
+    # stream-ordered setter), 20 explicit steps, the Courant struct read back (a synchronisation, as with adaptive dt) -- the
+    # device restarts from idle every interval and runs its next few dozen launches 20-35 % slow
+    advance = None
+    if world == 1 and halo is None and self_halo is None:
+        rain = np.full(n_owned, 1e-5)
+        src_before = op.external_sources.clone()
+
+        def one_advance(nsteps=20, sync=True):
+            op.set_domain_external_source(0, rain, ordered=True)
+            cur, nxt = u, u2
+            for _ in range(nsteps):
+                op.euler_step(0.0, cur, nxt)       # dt = 0: every interval does the same work
+                cur, nxt = nxt, cur
+            if sync:
+                op.update_diagnostics()
+
+        u2.copy_(u)
+        rows = {}
+        for name, sync in (("adaptive_dt", True), ("fixed_dt", False)):
+            one_advance(sync=sync)
+            torch.cuda.synchronize()
+            t_a = time.perf_counter()
+            for _ in range(12):
+                one_advance(sync=sync)
+            torch.cuda.synchronize()
+            rows[name] = (time.perf_counter() - t_a) / (12 * 20) * 1e3
+        op.refresh_field(1, src_before)
+        torch.cuda.synchronize()
+        advance = {"steps_per_advance": 20, "advances": 12,
+                   "refresh": "domain-wide rain source from a host array (8 B per cell) through the stream-ordered setter, every advance",
+                   "ms_per_step_adaptive_dt": round(rows["adaptive_dt"], 5), "ms_per_step_fixed_dt": round(rows["fixed_dt"], 5),
+                   "back_to_back_ms_per_step": round(ef, 5),
+                   "vs_back_to_back_adaptive_dt": round(rows["adaptive_dt"] / ef, 4), "vs_back_to_back_fixed_dt": round(rows["fixed_dt"] / ef, 4),
+                   "note": "adaptive_dt: the 16-byte Courant struct is read back after every advance (src/rdyadvance.c:366-372), so the device "
+                           "idles between advances; fixed_dt: nothing synchronises"}
+        del src_before
     del u2, u3, pp
     step()   # leave F and the diagnostics of a plain RHS evaluation behind for the sanity checks below
 
@@ -690,7 +738,21 @@ def run_rank(args, argv):
         finite = bool(fin.item())
 
     # what every rank did (rank 0's line carries all of them): the form of the step, direct receive, cells, ghosts
+    def form_of(kind):
+        """rdyhip_halo_form_info: the form this rank's steps of a kind take (in order / two streams), chosen by the halo's own
+        16-step trial on the communicator of this run, with the two timings"""
+        if halo is not None and halo._halo is not None:
+            return halo.form_info(kind)
+        if self_halo is not None:
+            import ctypes as C
+            fi = _lib.RDyHipHaloFormInfo()
+            _lib.check(self_halo[0].rdyhip_halo_form_info(self_halo[1], 1 if kind == "euler" else 0, C.byref(fi)))
+            return {"form": "two_streams" if fi.form else "in_order", "source": HaloExchange.FORM_SOURCES[fi.source], "trial_steps": int(fi.trial_steps),
+                    "in_order_ms": round(float(fi.in_order_ms), 5), "two_stream_ms": round(float(fi.two_stream_ms), 5)}
+        return None
+
     mine_info = {"rank": rank, "cells": n_owned, "ghost_cells": int(mesh.num_cells - n_owned),
+                 "rhs_step_form": form_of("rhs"), "euler_step_form": form_of("euler"),
                  "halo_overlapped": (int(_lib.load().rdyhip_halo_overlaps(halo._halo)) if halo is not None and halo._halo is not None else None),
                  "direct_receive": (bool(halo.direct_receive) if halo is not None and halo._halo is not None else None),
                  "peers": (len(halo._plan_peers) if halo is not None else 0), "device": dev_index}
@@ -767,8 +829,7 @@ def run_rank(args, argv):
         if world == 1:
             traffic, traffic_src = load_traffic(traffic_key(args), int(info["bytes_per_apply"]), args.second_order)
         if args.second_order:
-            kname = (("swe_rhs_muscl_fused_kernel<%d,%d>" if info["second_order_fused"] else "muscl_gradient_kernel<%d> + swe_rhs_muscl_kernel<.,%d>")
-                     % (info["slots_per_cell"], 0 if args.source == "semi_implicit" else 1))
+            kname = "swe_rhs_muscl_fused_kernel<%d,%d>" % (info["slots_per_cell"], 0 if args.source == "semi_implicit" else 1)
         else:
             kname = "%s<%d,%d%s>" % ("swe_rhs_tiled_kernel" if info["tiled_kernel"] else "swe_rhs_kernel", info["slots_per_cell"],
                                      0 if args.source == "semi_implicit" else 1, ",HR" if args.hr else "")
@@ -823,7 +884,7 @@ def run_rank(args, argv):
                          "algorithmic_bytes_per_launch": int(n_owned * alg),
                          "layout_bytes_per_launch": int(info["bytes_per_apply"]),
                          "persistent_workgroups": int(info["persistent_grid"]), "lds_bytes_per_workgroup": int(info["lds_bytes"]),
-                         "lds_planes": "compile-time lengths" if info.get("lds_fixed_layout") else "lengths from the mesh"},
+                         "cells_per_tile": round(n_owned / max(info["num_tiles"], 1), 1)},
         }
         if quads:
             out["roofline"]["frac_176B_model"] = round(n_owned * ALG_BYTES_PER_CELL / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
@@ -834,27 +895,34 @@ def run_rank(args, argv):
             et, esrc = load_traffic(traffic_key(args) + "_euler_step", int(info["bytes_per_apply"]), args.second_order, quiet=True)
             euler["traffic"], euler["traffic_source"] = et, esrc
         out["euler_step"] = euler
+        if advance is not None:
+            out["advance_pattern"] = advance
         if order_study:
             out["cell_order_study"] = order_study
         if args.second_order:
             # the 176-B figure above keeps variants comparable; the second-order path's own model:
-            b2 = ALG_BYTES_PER_CELL_SECOND_ORDER if info["second_order_fused"] else ALG_BYTES_PER_CELL_SECOND_ORDER_SPLIT
-            if quads:      # two edges per cell instead of 1.5: 192 + centroid 16 + midpoints 2 x 16 (+ the split form's extras)
+            b2 = ALG_BYTES_PER_CELL_SECOND_ORDER
+            if quads:      # two edges per cell instead of 1.5: 192 + centroid 16 + midpoints 2 x 16
                 b2 += ALG_BYTES_PER_CELL_QUADS - ALG_BYTES_PER_CELL + 8.0
             a2 = n_owned * b2 / (kern_ms * 1e-3) / 1e9
             out["roofline"]["second_order_model"] = {"bytes_per_cell_update": b2, "achieved": round(a2, 1),
                                                      "frac": round(a2 / HBM_PEAK_GBPS, 4)}
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(args)
+            # the reference's CPU path beside the GPU figure, ON THE BENCHMARK MESH ITSELF where it fits (C3's
+            # 10 M cells, ~1 s per RHS on one core); the 1 M-cell sample of earlier rounds stays as a second key
+            full = case if (n_owned <= CPU_FULL_MESH_MAX_CELLS and args.emulate_world <= 1) else None
+            out["cpu_baseline"] = cpu_baseline(args, full)
+            if full is not None:
+                out["cpu_baseline_sample"] = cpu_baseline(args)
             if not args.no_cpu_all_cores:
                 try:
-                    out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(args, argv)
+                    out["cpu_baseline_openmp"] = cpu_baseline_openmp(args, full)     # all host cores, one process, the benchmark mesh
                 except Exception as exc:  # a reported extra, never a reason to lose the bench line
-                    out["cpu_baseline_all_cores"] = {"error": repr(exc)}
-                try:
-                    out["cpu_baseline_openmp"] = cpu_baseline_openmp(args)
-                except Exception as exc:
                     out["cpu_baseline_openmp"] = {"error": repr(exc)}
+                try:
+                    out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(args, argv)   # one process per core on the parts of the sample
+                except Exception as exc:
+                    out["cpu_baseline_all_cores"] = {"error": repr(exc)}
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if halo is not None:

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RDYHIP_VERSION 109
+#define RDYHIP_VERSION 110
 
 /* error codes = PETSc's values */
 #define RDYHIP_SUCCESS 0
@@ -343,10 +343,14 @@ int rdyhip_unpack_rows(double *dst, int32_t ncomp, const int32_t *row_ids, int32
  * Second order: the state exchange hides behind the tiles that need no ghost data, then the ghost-adjacent gradients are
  * computed, exchanged (6 values per cell) and the remaining tiles follow.  The exchanges are ordered after everything
  * already enqueued on `stream`; when the call returns all work is enqueued and later work on `stream` is ordered after it.
- * Small parts: when a rank has fewer interior tiles than about twelve rounds of the persistent grid (~2.4 M cells first order,
- * ~3.1 M second order on triangles), nothing is overlapped -- exchange, (gradients, their exchange,) ONE launch over all tiles, in order on `stream` -- because the
- * interior phase is then shorter than the exchange chain and the two cross-stream dependencies cost more than they hide
- * (profiles/r03_step_breakdown_360k.json, profiles/r03_overlap_threshold.txt).  rdyhip_halo_overlaps() says which form a halo uses; RDYHIP_OVERLAP=0 / 1 forces.
+ * The form of a step -- everything in order on `stream`: exchange, (gradients, their exchange,) ONE launch over all tiles; or
+ * on two streams as described above -- is chosen per halo and per kind of step by a TRIAL on the communicator the halo really
+ * has: the first 16 calls alternate between the forms, each timed on the device, and the faster one stays (both forms post
+ * the same send / receive group, so every rank chooses for itself).  A small part wants the first form (its interior tiles
+ * run for less time than the exchange chain, and the two cross-stream dependencies cost more than they hide), a large one
+ * behind a slow link the second.  rdyhip_halo_form_info() reports the choice and the two timings, rdyhip_halo_set_form()
+ * forces a form or restarts the trial; RDYHIP_OVERLAP=0 / 1 and RDYHIP_OVERLAP_MIN_ROUNDS=n (the size rule of earlier
+ * versions), read once at rdyhip_halo_create, force as well.  rdyhip_halo_overlaps() = the RHS step currently runs on two streams.
  *
  * Two ways to shorten the exchange chain of a small part (a 0.36 M-cell rank's kernel runs 17 us; a pack and an unpack launch
  * cost 3.5 us each):
@@ -364,16 +368,9 @@ int rdyhip_unpack_rows(double *dst, int32_t ncomp, const int32_t *row_ids, int32
  *                    into the send rows it travels in, so the gradient exchange of rdyhip_rhs_overlapped /
  *                    rdyhip_euler_step_overlapped needs no pack launch either (RDYHIP_GRAD_PACK_FUSED=0: measurement knob).
  * With both, a step of rdyhip_euler_step_overlapped is the transfer and ONE kernel launch.
- * Such a step runs in order at every size (transfer, launch: there is no pack left to hide, and launch + 8-10 us beats the two-stream
- * form's launch + 14 us up to the largest part measured); RDYHIP_OVERLAP=1 forces the two-stream form, a transport callback keeps it.
- *   signalled form   opt-in, RDYHIP_SIGNALLED=1 at rdyhip_halo_fuse_pack: RCCL halos with the fused pack, on devices whose streams
- *                    can wait for a word in memory (hipDeviceAttributeCanUseStreamWaitValue; rdyhip_halo_signalled() says whether
- *                    it is in use).  The launch of step n runs its send-flagged tiles first and, when the last send row is in
- *                    memory, advances a counter in signal memory; the exchange stream waits for THAT (hipStreamWaitValue64), not
- *                    for the launch, so the transfer of step n + 1 runs beside the rest of step n's launch.  Looped back on one
- *                    device it equals the in-order form to +-3 % from 1.4 M cells per rank on and loses below;
- *                    it is there for transfers that take longer than a loop-back.  Never used under rocprofv3's counter collection
- *                    (ROCPROF_COUNTER_COLLECTION=1 in the environment), whose dispatch serialiser stalls on the wait packet. */
+ * (A fused pack whose send lists hold a cell in a tile no ghost touches -- possible when the DM's overlap is vertex-adjacent,
+ * src/rdydm.c:150 -- is only safe when nothing runs beside the transfer: such a halo keeps its Euler steps in order,
+ * rdyhip_halo_form_info says RDYHIP_HALO_FORM_LOCKED_IN_ORDER.) */
 typedef struct RDyHipHalo_s *RDyHipHalo;
 typedef int (*RDyHipTransportFn)(void *ctx, const double *d_send, double *d_recv, int32_t ncomp, void *stream);
 int rdyhip_halo_create(RDyHipOperator op, void *nccl_comm, int32_t npeers, const int32_t *peers, const int32_t *send_counts,
@@ -383,7 +380,24 @@ int32_t rdyhip_halo_overlaps(RDyHipHalo halo);
 int32_t rdyhip_halo_direct_receive(RDyHipHalo halo);
 int rdyhip_halo_fuse_pack(RDyHipHalo halo, int32_t enable);
 int32_t rdyhip_halo_pack_fused(RDyHipHalo halo);
-int32_t rdyhip_halo_signalled(RDyHipHalo halo);
+/* which form the steps of a halo take and why (see above); kind: RDYHIP_HALO_STEP_RHS = rdyhip_rhs_overlapped,
+ * RDYHIP_HALO_STEP_EULER = rdyhip_euler_step_overlapped */
+#define RDYHIP_HALO_STEP_RHS 0
+#define RDYHIP_HALO_STEP_EULER 1
+#define RDYHIP_HALO_FORM_TRIAL_RUNNING 0   /* the first calls still alternate */
+#define RDYHIP_HALO_FORM_MEASURED 1        /* the faster form of the trial */
+#define RDYHIP_HALO_FORM_FORCED 2          /* environment or rdyhip_halo_set_form */
+#define RDYHIP_HALO_FORM_DEFAULT 3         /* nothing to choose (no peers) or no timing available: in order */
+#define RDYHIP_HALO_FORM_LOCKED_IN_ORDER 4 /* fused pack with a send cell outside the ghost-adjacent tiles */
+typedef struct {
+  int32_t form;           /* 0: in order on the caller's stream, 1: two streams */
+  int32_t source;         /* RDYHIP_HALO_FORM_* */
+  int32_t trial_steps;    /* calls the trial has used so far (16 when done) */
+  double  in_order_ms;    /* mean device time per step of each form in the trial (0 until it is over) */
+  double  two_stream_ms;
+} RDyHipHaloFormInfo;
+int rdyhip_halo_form_info(RDyHipHalo halo, int32_t kind, RDyHipHaloFormInfo *info);
+int rdyhip_halo_set_form(RDyHipHalo halo, int32_t kind, int32_t form /* 0, 1, or < 0: run the trial again */);
 int rdyhip_halo_invalidate(RDyHipHalo halo);
 int rdyhip_halo_set_transport(RDyHipHalo halo, RDyHipTransportFn fn, void *ctx);
 int rdyhip_halo_exchange(RDyHipHalo halo, double *rows, int32_t ncomp, void *stream);

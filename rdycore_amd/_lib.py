@@ -52,6 +52,10 @@ class RDyHipLayoutInfo(C.Structure):
                 ("persistent_grid", C.c_int32), ("lds_bytes", C.c_int32), ("lds_fixed_layout", C.c_int32)]
 
 
+class RDyHipHaloFormInfo(C.Structure):
+    _fields_ = [("form", C.c_int32), ("source", C.c_int32), ("trial_steps", C.c_int32), ("in_order_ms", C.c_double), ("two_stream_ms", C.c_double)]
+
+
 # every symbol include/rdyhip.h declares: name -> (restype, argtypes)
 _H = C.c_void_p  # RDyHipOperator
 SYMBOLS = {
@@ -96,7 +100,8 @@ SYMBOLS = {
     "rdyhip_halo_direct_receive": (C.c_int32, [C.c_void_p]),
     "rdyhip_halo_fuse_pack": (C.c_int, [C.c_void_p, C.c_int32]),
     "rdyhip_halo_pack_fused": (C.c_int32, [C.c_void_p]),
-    "rdyhip_halo_signalled": (C.c_int32, [C.c_void_p]),
+    "rdyhip_halo_form_info": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(RDyHipHaloFormInfo)]),
+    "rdyhip_halo_set_form": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     "rdyhip_halo_invalidate": (C.c_int, [C.c_void_p]),
     "rdyhip_halo_set_transport": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "rdyhip_halo_exchange": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
@@ -125,7 +130,7 @@ SYMBOLS = {
 TRANSPORT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p)
 
 _LIB = None
-ABI_VERSION = 109     # RDYHIP_VERSION of include/rdyhip.h this binding was written against
+ABI_VERSION = 110     # RDYHIP_VERSION of include/rdyhip.h this binding was written against
 
 
 class RDyHipError(RuntimeError):

@@ -217,12 +217,12 @@ def dam_break_keep(nxg: int, nyg: int):
     return keep
 
 
-def dam_break_quads_mesh(nxg: int = 5120, nyg: int = 2560, rank: int = 0, world: int = 1, order: str = "tiled") -> RDyMesh:
+def dam_break_quads_mesh(nxg: int = 5120, nyg: int = 2560, rank: int = 0, world: int = 1, order: str = "tiled", tile=None) -> RDyMesh:
     """The quad mesh of the reference's dam-break benchmark (DamBreak_grid5120x2560: dx = dy = 10 m / 5120), this
     rank's part of an RCB partition; every domain-boundary edge (outer walls and the dam's faces) is one reflecting
     boundary (index.md:11-12)."""
     from . import partition as P
-    return P.partitioned_structured_mesh("quad", nxg, nyg, (10.0 / nxg, 5.0 / nyg), rank, world, order=order,
+    return P.partitioned_structured_mesh("quad", nxg, nyg, (10.0 / nxg, 5.0 / nyg), rank, world, order=order, tile=tile,
                                          keep=dam_break_keep(nxg, nyg))
 
 

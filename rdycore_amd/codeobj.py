@@ -109,3 +109,33 @@ def kernel_sha(lib: str, kernel: str) -> str:
     if len(hits) != 1:
         raise KeyError(f"{len(hits)} different kernels match {kernel!r}")
     return hits.pop()
+
+
+def kernel_resources(lib: str) -> dict:
+    """{demangled kernel name: {vgpr, agpr, sgpr, scratch, lds, vgpr_spills, sgpr_spills}} from the code object's
+    NT_AMDGPU_METADATA note (msgpack): what the compiler allocated per kernel -- registers decide how many workgroups share a
+    CU, scratch must stay zero in every hot kernel (tests/test_isa_cpu.py pins the headline instantiations)."""
+    import msgpack
+    co = device_code_object(lib)
+    secs, _ = _elf_sections(co)
+    out = {}
+    for sname, h in secs.items():
+        if h[1] != 7:      # SHT_NOTE
+            continue
+        off, size = h[3], h[4]
+        p = off
+        while p + 12 <= off + size:
+            namesz, descsz, typ = struct.unpack_from("<III", co, p)
+            p += 12
+            name = co[p:p + namesz].rstrip(b"\0")
+            p += (namesz + 3) & ~3
+            desc = co[p:p + descsz]
+            p += (descsz + 3) & ~3
+            if name == b"AMDGPU" and typ == 32:
+                md = msgpack.unpackb(desc, raw=False, strict_map_key=False)
+                for k in md.get("amdhsa.kernels", []):
+                    out[k[".name"]] = {"vgpr": k.get(".vgpr_count", 0), "agpr": k.get(".agpr_count", 0), "sgpr": k.get(".sgpr_count", 0),
+                                       "scratch": k.get(".private_segment_fixed_size", 0), "lds": k.get(".group_segment_fixed_size", 0),
+                                       "vgpr_spills": k.get(".vgpr_spill_count", 0), "sgpr_spills": k.get(".sgpr_spill_count", 0)}
+    names = _demangle(list(out))
+    return {names[m]: v for m, v in out.items()}

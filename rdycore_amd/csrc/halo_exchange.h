@@ -26,20 +26,31 @@ struct RDyHipHalo_s {
   // u_out (per-tile send lists, swe_kernels.h), so the next step's exchange needs no pack launch either
   bool            fused_pack = false;
   const double   *packed_state = nullptr;  // the state array whose send rows d_send holds ([cells][3]), or nullptr
-  // The signalled form of a fused-pack Euler step (RCCL halos on devices with hipStreamWaitValue64): the launch that stores
-  // the send rows tells the exchange stream when the last of them is in memory (wave_signal_send_rows, swe_kernels.h), so the
-  // NEXT step's transfer runs while that launch is still busy with the tiles no other rank needs
-  uint64_t        *signal = nullptr;       // signal memory (hipMallocSignalMemory): launches that have stored all their send rows
-  uint64_t         packed_epoch = 0;       // the value of *signal that says packed_state's rows are in d_send
-  int32_t          n_send_tiles = 0;
-  DevBuf<uint32_t> d_send_done;            // [1] the running launch's count of send waves
-  DevBuf<uint64_t> d_send_epoch;           // [1] the device's copy of *signal
   bool             grad_pack_fused = false;  // second order: the gradient launch over the halo cell list stores into d_send too
   DevBuf<int32_t>  d_gsend_off, d_gsend_rows;
   DevBuf<int32_t>  d_send_tile_off;        // [ntiles + 1]
   DevBuf<uint32_t> d_send_ent;             // cell-in-tile | send row << 8, sorted by tile
-  bool            overlap = true;  // exchange hidden behind the interior tiles (large parts) or everything in order (small parts)
-  bool            overlap_forced = false;  // RDYHIP_OVERLAP was set at create
+  // every send cell sits in a tile of the HALO phase (true for the edge-adjacent overlap; a vertex-adjacent overlap --
+  // DMPlexDistributeOverlap, src/rdydm.c:150 -- can put one in a tile no ghost touches): only then may a two-stream step
+  // let its launches store send rows while the exchange stream reads the send buffer
+  bool            send_cells_in_halo_tiles = true;
+  // The form of a step, per kind of step (0: rdyhip_rhs_overlapped, 1: rdyhip_euler_step_overlapped): everything in order
+  // on the caller's stream, or the exchange on the library's stream beside the tiles that need no ghost data.  Both forms post
+  // the same send / receive group, so every rank chooses for itself: the first 2 x TRIAL steps of a kind alternate between
+  // the forms, each timed on the device (events on the caller's stream), and the faster one stays -- on the communicator
+  // the run really has, not on a constant tuned elsewhere.  RDYHIP_OVERLAP=0 / 1 or RDYHIP_OVERLAP_MIN_ROUNDS (the size rule
+  // of rounds 3-4), read once at create, force a form.
+  struct FormChoice {
+    static constexpr int TRIAL = 8, SKIP = 2;   // steps per form in the trial; the first SKIP of each are not counted
+    int        form = 0;                         // 0: in order, 1: two streams
+    int        source = RDYHIP_HALO_FORM_TRIAL_RUNNING;
+    int        steps = 0;                        // trial steps taken
+    double     ms[2] = {0.0, 0.0};
+    int        n[2]  = {0, 0};
+    hipEvent_t ev0[2 * TRIAL] = {}, ev1[2 * TRIAL] = {};
+  } choice[2];
+  bool            halo_concurrent = true;   // RDYHIP_HALO_CONCURRENT (measurement knob), read at create
+  bool            grad_pack_allowed = true; // RDYHIP_GRAD_PACK_FUSED (measurement knob), read at create
   hipStream_t     cs = nullptr;  // exchange stream
   // fork / join events: a small ring, one pair per step, so that steps still in flight never share an event (the host
   // runs several steps ahead of the device)
@@ -54,8 +65,12 @@ struct RDyHipHalo_s {
   }
   ~RDyHipHalo_s() {
     d_send_ids.release(); d_recv_ids.release(); d_send.release(); d_recv.release(); d_send_tile_off.release(); d_send_ent.release();
-    d_send_done.release(); d_send_epoch.release(); d_gsend_off.release(); d_gsend_rows.release();
-    if (signal) (void)hipFree(signal);
+    d_gsend_off.release(); d_gsend_rows.release();
+    for (auto &c : choice)
+      for (int i = 0; i < 2 * FormChoice::TRIAL; ++i) {
+        if (c.ev0[i]) (void)hipEventDestroy(c.ev0[i]);
+        if (c.ev1[i]) (void)hipEventDestroy(c.ev1[i]);
+      }
     for (int i = 0; i < NEV; ++i) {
       if (ev_fork_ring[i]) (void)hipEventDestroy(ev_fork_ring[i]);
       if (ev_join_ring[i]) (void)hipEventDestroy(ev_join_ring[i]);
@@ -148,7 +163,7 @@ int halo_exchange_on(RDyHipHalo h, double *rows, int32_t ncomp, hipStream_t s) {
 // the exchange of the ghost-adjacent cells' gradients right behind launch_gradients(HALO) on the same stream: that launch has
 // packed them itself where the fused pack is attached (ColdArgs::gsend_*)
 int halo_exchange_gradients(RDyHipOperator op, RDyHipHalo h, hipStream_t s) {
-  if (!(h->grad_pack_fused && op->fused_halo == h && op->muscl_fused)) return halo_exchange_on(h, op->d_grad.p, 6, s);
+  if (!(h->grad_pack_fused && op->fused_halo == h)) return halo_exchange_on(h, op->d_grad.p, 6, s);
   int rc = halo_check(h, op->d_grad.p, 6);
   h->packed_state = nullptr;  // d_send holds gradient rows now
   if (!rc) rc = halo_transfer(h, op->d_grad.p, 6, s);
@@ -162,33 +177,36 @@ int halo_pack_state(RDyHipHalo h, const double *u, hipStream_t s) {
   if (h->fused_pack && h->packed_state == u && u) return 0;
   return halo_pack(h, u, 3, s);
 }
-// what d_send holds once the launches of a step are enqueued: the send rows of u_out if the fused Euler kernel of a
-// first-order operator has just stored them (every send cell is ghost-adjacent, i.e. in a tile of the HALO phase, which
-// runs after this step's transfer has read d_send), nothing the next step could use otherwise
+// what d_send holds once the launches of a step are enqueued: the send rows of u_out if the fused Euler kernels have just
+// stored them, nothing the next step could use otherwise
 void halo_note_step(RDyHipOperator op, RDyHipHalo h, const double *u_out) {
-  h->packed_state = (h->fused_pack && op->fused_halo == h && u_out && op->use_tiled && (!op->muscl || op->muscl_fused)) ? u_out : nullptr;
-  h->packed_epoch = op->send_epoch;  // the launch just enqueued is the one that stores them
+  h->packed_state = (h->fused_pack && op->fused_halo == h && u_out && op->use_tiled) ? u_out : nullptr;
 }
 
-// OperatorRHSFunction (u_out == nullptr) or one forward-Euler step (u_out != nullptr) with the ghost update of u
-// hidden behind the tiles that need no ghost data
-int overlapped(RDyHipOperator op, RDyHipHalo h, double dt, double *u, double *f, double *u_out, hipStream_t st) {
-  if (!op || !h) return fail(RDYHIP_ERR_USER, "null argument");
-  if (h->op != op) return fail(RDYHIP_ERR_USER, "the halo belongs to another operator");
-  if (op->n_cells > 0 && !u) return fail(RDYHIP_ERR_USER, "null u_local");
-  if (u_out && u_out == u) return fail(RDYHIP_ERR_USER, "rdyhip_euler_step_overlapped needs a second state array (not in place)");
-  {
-    const int rc0 = halo_check(h, u, 3);
-    if (rc0) return rc0;
+// ---- the two forms of a step ----------------------------------------------------------------------------------------------
+// In order: everything on the caller's stream -- exchange, (second order: the ghost-adjacent cells' gradients and their
+// exchange,) ONE launch over all tiles.  What a small part wants: its tiles without ghost data run for less time than the
+// exchange chain takes, and two cross-stream dependencies cost more than they hide (a 360 000-cell rank, one device, the
+// exchange looped back: 30 us against 50, profiles/r03_step_breakdown_360k.json).
+int step_in_order(RDyHipOperator op, RDyHipHalo h, double dt, double *u, double *f, double *u_out, hipStream_t st) {
+  int rc = halo_pack_state(h, u, st);
+  if (!rc) rc = halo_transfer(h, u, 3, st);
+  if (!rc) rc = halo_unpack(h, u, 3, st);
+  if (!rc && op->muscl) {
+    rc = launch_gradients(op, RDYHIP_PHASE_HALO, u, st);
+    if (!rc) rc = halo_exchange_gradients(op, h, st);
   }
-  op->courant = RDyHipCourant{0.0, -1, -1};
-  // The halo tiles go on the exchange stream right behind the unpack, i.e. they run beside the interior tiles' tail
-  // instead of in a launch of their own after the join (-10 us per step): the two launches write disjoint rows, and
-  // each owns one half of the Courant buckets.  Not with the separate Euler update of the cell-centric kernel, which
-  // reads all of F once the halo phase is through, nor with the split second-order form (its own schedule below).
-  // RDYHIP_HALO_CONCURRENT=0: measurement knob
-  const char *cenv = getenv("RDYHIP_HALO_CONCURRENT");
-  const bool  conc = !(cenv && atoi(cenv) == 0) && (!op->muscl || op->muscl_fused) && (!u_out || op->use_tiled);
+  if (!rc) rc = launch_rhs(op, RDYHIP_PHASE_ALL, 1, 1, dt, u, f, st, op->muscl, u_out, 0);
+  halo_note_step(op, h, rc ? nullptr : u_out);
+  return rc;
+}
+
+// Two streams: the exchange on the library's stream, forked from and joined back into the caller's with events, the tiles
+// that need no ghost data on the caller's stream meanwhile; the ghost-adjacent tiles follow the unpack on the library's
+// stream, beside the tail of the others (the two launches write disjoint rows and own one half of the Courant buckets
+// each).  What a large part wants when the transfer is long.
+int step_two_streams(RDyHipOperator op, RDyHipHalo h, double dt, double *u, double *f, double *u_out, hipStream_t st) {
+  const bool conc = h->halo_concurrent && (!u_out || op->use_tiled);  // (the cell kernel's separate Euler update reads all of F)
   auto part = [&](int32_t phase, int reset, bool ready) -> int {
     if (conc && phase == RDYHIP_PHASE_HALO) return launch_rhs(op, phase, 1, 1, dt, u, f, h->cs, ready, u_out, 2);
     if (reset && phase == RDYHIP_PHASE_HALO && (op->use_tiled ? op->n_halo_tiles == 0 : op->n_halo == 0)) {
@@ -197,54 +215,6 @@ int overlapped(RDyHipOperator op, RDyHipHalo h, double dt, double *u, double *f,
     }
     return launch_rhs(op, phase, 1, reset, dt, u, f, st, ready, u_out, conc && phase == RDYHIP_PHASE_INTERIOR ? 1 : 0);
   };
-  int rc;
-  // Fused-pack Euler steps over RCCL, where a stream can wait for a word in memory: the signalled form.
-  //   exchange stream:  [wait until the launch of step n - 1 has stored its last send row]  transfer (, unpack)  -> event
-  //   caller's stream:  [wait for that event]  ONE launch over all tiles, the send-flagged tiles of every XCD chunk first
-  // The transfer of step n thus runs beside the rest of step n - 1's launch and the caller's stream finds its event signalled
-  // (profiles/r04_wait_value_probe.txt: 3 us from the store to the waiting stream's next kernel).  Opt-in: RDYHIP_SIGNALLED=1.
-  // The first step of a run (d_send does not hold u's rows yet) packs with a launch, ordered after the caller's stream.
-  if (h->signal && h->fused_pack && op->fused_halo == h && u_out && !op->muscl && op->use_tiled && !h->transport && op->send_signalling) {
-    h->next_events();
-    if (h->packed_state == u) {
-      HIP_TRY(hipStreamWaitValue64(h->cs, h->signal, h->packed_epoch, hipStreamWaitValueGte, ~0ull));
-    } else {
-      HIP_TRY(hipEventRecord(h->ev_fork, st));
-      HIP_TRY(hipStreamWaitEvent(h->cs, h->ev_fork, 0));
-    }
-    rc = halo_pack_state(h, u, h->cs);  // nothing to do when d_send already holds u's rows
-    if (!rc) rc = halo_transfer(h, u, 3, h->cs);
-    if (!rc) rc = halo_unpack(h, u, 3, h->cs);
-    // (an error leaves the exchange stream joined back all the same: later work on the caller's stream stays ordered behind it)
-    hipError_t e = hipEventRecord(h->ev_join, h->cs);
-    if (e == hipSuccess) e = hipStreamWaitEvent(st, h->ev_join, 0);
-    if (!rc && e != hipSuccess) rc = fail(RDYHIP_ERR_LIB, "joining the exchange stream failed: %s", hipGetErrorString(e));
-    if (!rc) rc = launch_rhs(op, RDYHIP_PHASE_ALL, 1, 1, dt, u, f, st, false, u_out, 0, true);
-    halo_note_step(op, h, rc ? nullptr : u_out);
-    return rc;
-  }
-  // A fused-pack Euler step over RCCL is the transfer and one launch: in order that is launch + 8-10 us at every size measured
-  // (0.36 - 10 M cells per rank), the two-stream form launch + 14 us or more (profiles/r04_small_parts.txt, _strip_10M) -- there is no pack
-  // to hide any more, and the second launch of the ghost-adjacent tiles finds no free workgroup slot until the first one ends.
-  // (A transport callback may block the host: it keeps the two-stream form, whose interior launch is enqueued first.)
-  const bool fused_euler = h->fused_pack && op->fused_halo == h && u_out && !op->muscl && op->use_tiled && !h->transport;
-  if (!h->overlap || (fused_euler && !h->overlap_forced)) {
-    // Small parts: the tiles that need no ghost data run for less time than the exchange chain (pack, transfer, unpack, halo
-    // tiles) takes, and the two cross-stream dependencies of the overlapped form cost more than they hide -- measured on
-    // a 360 000-cell rank (profiles/r03_step_breakdown_360k.json): 51.8 us per overlapped step against 14.0 us for the
-    // exchange plus 18.6 us for ONE launch over all tiles.  So: everything in order on the caller's stream.
-    rc = halo_pack_state(h, u, st);
-    if (!rc) rc = halo_transfer(h, u, 3, st);
-    if (!rc) rc = halo_unpack(h, u, 3, st);
-    if (!rc && op->muscl) {
-      // second order: the ghost-adjacent cells' gradients (fused form) or all of them (split form), then their exchange
-      rc = launch_gradients(op, op->muscl_fused ? RDYHIP_PHASE_HALO : RDYHIP_PHASE_ALL, u, st);
-      if (!rc) rc = halo_exchange_gradients(op, h, st);
-    }
-    if (!rc) rc = launch_rhs(op, RDYHIP_PHASE_ALL, 1, 1, dt, u, f, st, op->muscl, u_out, 0);
-    halo_note_step(op, h, rc ? nullptr : u_out);
-    return rc;
-  }
   h->next_events();
   // fork: the exchange starts once everything already enqueued on the caller's stream (the update that produced u) is done
   HIP_TRY(hipEventRecord(h->ev_fork, st));
@@ -256,78 +226,105 @@ int overlapped(RDyHipOperator op, RDyHipHalo h, double dt, double *u, double *f,
     (void)hipStreamWaitEvent(st, h->ev_join, 0);
     return code;
   };
-  // the join itself; if it fails, bail() tries once more and the error is reported
   auto join = [&]() -> int {
     hipError_t e = hipEventRecord(h->ev_join, h->cs);
     if (e == hipSuccess) e = hipStreamWaitEvent(st, h->ev_join, 0);
     return e == hipSuccess ? 0 : bail(fail(RDYHIP_ERR_LIB, "joining the exchange stream failed: %s", hipGetErrorString(e)));
   };
-  auto fork = [&]() -> int {
-    hipError_t e = hipEventRecord(h->ev_fork, st);
-    if (e == hipSuccess) e = hipStreamWaitEvent(h->cs, h->ev_fork, 0);
-    return e == hipSuccess ? 0 : bail(fail(RDYHIP_ERR_LIB, "forking the exchange stream failed: %s", hipGetErrorString(e)));
-  };
-  if (!op->muscl) {
-    // RCCL (asynchronous): the whole exchange is enqueued first, the interior tiles right behind it on the other stream.
-    // A transport callback may block the host: there the interior tiles are enqueued before it is called, so that it
-    // blocks while the device already works.
-    rc = halo_pack_state(h, u, h->cs);
-    if (!rc && h->transport) rc = part(RDYHIP_PHASE_INTERIOR, 1, false);
-    if (!rc) rc = halo_transfer(h, u, 3, h->cs);
-    if (!rc) rc = halo_unpack(h, u, 3, h->cs);
-    if (!rc && !h->transport) rc = part(RDYHIP_PHASE_INTERIOR, 1, false);
-    if (!rc && conc) rc = part(RDYHIP_PHASE_HALO, 0, false);
-    if (rc) return bail(rc);
-    rc = join();
-    if (!rc && !conc) rc = part(RDYHIP_PHASE_HALO, 0, false);
-    halo_note_step(op, h, rc ? nullptr : u_out);
-    return rc;
-  }
-  // ApplyInteriorFlux2R (src/swe/swe_petsc.c:98-213) needs two exchanges: the state, then the gradients of the ghost
-  // cells (CommunicateCellGradients).  No reverse exchange: every rank evaluates all edges of its owned cells.
-  if (op->muscl_fused) {
-    // tiles whose cells and first ring touch no ghost need nothing from other ranks and hide BOTH exchanges: the state,
-    // then -- still on the exchange stream -- the gradients of the ghost-adjacent owned cells (the only ones that go
-    // through memory; the interior tiles neither read nor write that array) and their exchange
-    rc = halo_pack_state(h, u, h->cs);
-    if (!rc && h->transport) rc = part(RDYHIP_PHASE_INTERIOR, 1, true);
-    if (!rc) rc = halo_transfer(h, u, 3, h->cs);
-    if (!rc) rc = halo_unpack(h, u, 3, h->cs);
-    if (!rc && !h->transport) rc = part(RDYHIP_PHASE_INTERIOR, 1, true);
-    if (!rc) rc = launch_gradients(op, RDYHIP_PHASE_HALO, u, h->cs);
-    if (!rc) rc = halo_exchange_gradients(op, h, h->cs);
-    if (!rc && conc) rc = part(RDYHIP_PHASE_HALO, 0, true);
-    if (rc) return bail(rc);
-    rc = join();
-    if (!rc && !conc) rc = part(RDYHIP_PHASE_HALO, 0, true);
-    // (the gradient exchange went through the send buffer; the ghost-adjacent tiles' launch, behind it, has stored the new state's rows)
-    halo_note_step(op, h, rc ? nullptr : u_out);
-    return rc;
-  }
-  // split kernels: the gradients of the cells without ghost neighbours hide the state exchange, the fluxes of the tiles
-  // without ghost-adjacent cells (which read owned gradient rows only) hide the gradient exchange
-  rc = halo_pack_state(h, u, h->cs);
-  if (!rc && h->transport) rc = launch_gradients(op, RDYHIP_PHASE_INTERIOR, u, st);
+  // A launch of this form that stores send rows (the fused pack) must not run beside the transfer that reads the send
+  // buffer: only the HALO launch, behind the transfer on the same stream, may.  With a send cell in a tile of the INTERIOR
+  // launch (vertex-adjacent overlaps) rdyhip_halo_fuse_pack has locked the Euler step to the in-order form, so this form
+  // only ever sees fused packs whose send cells all sit in HALO tiles.
+  const bool ready = op->muscl;
+  // RCCL (asynchronous): the whole exchange is enqueued first, the interior tiles right behind it on the other stream.
+  // A transport callback may block the host: there the interior tiles are enqueued before it is called, so that it
+  // blocks while the device already works.
+  int rc = halo_pack_state(h, u, h->cs);
+  if (!rc && h->transport) rc = part(RDYHIP_PHASE_INTERIOR, 1, ready);
   if (!rc) rc = halo_transfer(h, u, 3, h->cs);
   if (!rc) rc = halo_unpack(h, u, 3, h->cs);
-  if (!rc && !h->transport) rc = launch_gradients(op, RDYHIP_PHASE_INTERIOR, u, st);
+  if (!rc && !h->transport) rc = part(RDYHIP_PHASE_INTERIOR, 1, ready);
+  if (!rc && op->muscl) {
+    // ApplyInteriorFlux2R (src/swe/swe_petsc.c:98-213) needs two exchanges: the state, then the gradients of the ghost cells
+    // (CommunicateCellGradients).  Tiles whose cells and first ring touch no ghost need nothing from other ranks and hide
+    // BOTH: still on the exchange stream, the gradients of the ghost-adjacent owned cells (the only ones that go through
+    // memory; the interior tiles neither read nor write that array) and their exchange.  No reverse exchange: every rank
+    // evaluates all edges of its owned cells.
+    rc = launch_gradients(op, RDYHIP_PHASE_HALO, u, h->cs);
+    if (!rc) rc = halo_exchange_gradients(op, h, h->cs);
+  }
+  if (!rc && conc) rc = part(RDYHIP_PHASE_HALO, 0, ready);
   if (rc) return bail(rc);
   rc = join();
-  if (rc) return rc;
-  rc = launch_gradients(op, RDYHIP_PHASE_HALO, u, st);
-  if (rc) return bail(rc);
-  h->next_events();
-  rc = fork();
-  if (rc) return rc;
-  rc = halo_pack(h, op->d_grad.p, 6, h->cs);
-  if (!rc && h->transport) rc = part(RDYHIP_PHASE_INTERIOR, 1, true);
-  if (!rc) rc = halo_transfer(h, op->d_grad.p, 6, h->cs);
-  if (!rc) rc = halo_unpack(h, op->d_grad.p, 6, h->cs);
-  if (!rc && !h->transport) rc = part(RDYHIP_PHASE_INTERIOR, 1, true);
-  if (rc) return bail(rc);
-  rc = join();
-  if (rc) return rc;
-  return part(RDYHIP_PHASE_HALO, 0, true);
+  if (!rc && !conc) rc = part(RDYHIP_PHASE_HALO, 0, ready);
+  // (second order: the gradient exchange went through the send buffer; the ghost-adjacent tiles' launch, behind it, has stored
+  // the new state's rows)
+  halo_note_step(op, h, rc ? nullptr : u_out);
+  return rc;
+}
+
+// the trial of the two forms (FormChoice): which form this step takes, and the bookkeeping around it
+int form_begin(RDyHipHalo h, int kind, hipStream_t st, int *slot) {
+  RDyHipHalo_s::FormChoice &c = h->choice[kind];
+  *slot = -1;
+  if (c.source != RDYHIP_HALO_FORM_TRIAL_RUNNING) return c.form;
+  constexpr int T = RDyHipHalo_s::FormChoice::TRIAL;
+  if (c.steps == 2 * T) {
+    // the trial is over: read the timings (one host wait for the last timed step, once in the life of the halo)
+    if (hipEventSynchronize(c.ev1[2 * T - 1]) == hipSuccess) {
+      for (int i = 0; i < 2 * T; ++i) {
+        float ms = 0.0f;
+        if (i / 2 < RDyHipHalo_s::FormChoice::SKIP || hipEventElapsedTime(&ms, c.ev0[i], c.ev1[i]) != hipSuccess) continue;
+        c.ms[i & 1] += ms;
+        c.n[i & 1]++;
+      }
+    }
+    if (c.n[0] > 0 && c.n[1] > 0) {
+      c.ms[0] /= c.n[0];
+      c.ms[1] /= c.n[1];
+      c.form   = c.ms[1] < c.ms[0] ? 1 : 0;
+      c.source = RDYHIP_HALO_FORM_MEASURED;
+    } else {
+      c.form   = 0;
+      c.source = RDYHIP_HALO_FORM_DEFAULT;  // events unavailable: the form without cross-stream dependencies
+    }
+    return c.form;
+  }
+  const int i = c.steps++;
+  if (!c.ev0[i]) {
+    if (hipEventCreate(&c.ev0[i]) != hipSuccess || hipEventCreate(&c.ev1[i]) != hipSuccess) {
+      c.form   = 0;
+      c.source = RDYHIP_HALO_FORM_DEFAULT;
+      return 0;
+    }
+  }
+  (void)hipEventRecord(c.ev0[i], st);
+  *slot = i;
+  return i & 1;
+}
+void form_end(RDyHipHalo h, int kind, hipStream_t st, int slot) {
+  if (slot >= 0) (void)hipEventRecord(h->choice[kind].ev1[slot], st);
+}
+
+// OperatorRHSFunction (u_out == nullptr) or one forward-Euler step (u_out != nullptr) with the ghost update of u
+int overlapped(RDyHipOperator op, RDyHipHalo h, double dt, double *u, double *f, double *u_out, hipStream_t st) {
+  if (!op || !h) return fail(RDYHIP_ERR_USER, "null argument");
+  if (h->op != op) return fail(RDYHIP_ERR_USER, "the halo belongs to another operator");
+  if (op->n_cells > 0 && !u) return fail(RDYHIP_ERR_USER, "null u_local");
+  if (u_out && u_out == u) return fail(RDYHIP_ERR_USER, "rdyhip_euler_step_overlapped needs a second state array (not in place)");
+  {
+    const int rc0 = halo_check(h, u, 3);
+    if (rc0) return rc0;
+  }
+  op->courant = RDyHipCourant{0.0, -1, -1};
+  const int kind = u_out ? 1 : 0;
+  int       slot = -1;
+  int       form = form_begin(h, kind, st, &slot);
+  // a fused pack with a send cell outside the ghost-adjacent tiles is only safe in order (step_two_streams)
+  if (kind == 1 && h->fused_pack && op->fused_halo == h && !h->send_cells_in_halo_tiles) form = 0;
+  const int rc = form ? step_two_streams(op, h, dt, u, f, u_out, st) : step_in_order(op, h, dt, u, f, u_out, st);
+  form_end(h, kind, st, slot);
+  return rc;
 }
 
 }  // namespace
@@ -391,28 +388,37 @@ int rdyhip_halo_create(RDyHipOperator op, void *nccl_comm, int32_t npeers, const
     if (run && !(e && atoi(e) == 0)) h->recv_base = recv_cell_ids[0];
   }
   {
-    // Overlap only where there is something to hide behind: at least RDYHIP_OVERLAP_MIN_ROUNDS rounds of the persistent grid's
-    // worth of interior tiles -- default 12: ~2.4 M cells first order (768 workgroups x 256 cells), ~3.1 M second order on
-    // triangles (1 024 workgroups), ~2.4 M second order on quads (768).  What is known, all of it from ONE device with the
-    // exchange looped back through a one-rank RCCL communicator:
-    //   * the overlapped form costs the kernel + 16-24 us per step at every size measured (two cross-stream event dependencies,
-    //     ~3x the host time): RCB parts of 1.4 M cells 81-88 us for a 59 us kernel, 2.9 M cells 127-130 for 108
-    //     (profiles/r04_small_parts.txt, with RDYHIP_OVERLAP_MIN_ROUNDS=6); strips: 50 vs 17 us at 0.36 M, 83 vs 73 at 2 M,
-    //     113 vs 104 at 3 M, 329 vs 318 at 10 M (profiles/r03_overlap_threshold.txt);
-    //   * the in-order form costs the kernel + the exchange itself: 10-12 us looped back with the direct receive (one pack
-    //     launch + RCCL), ~7.5 us with the fused pack as well.
-    // So the overlapped form pays only where a real xGMI exchange takes longer than ~20 us, and either choice moves a part of
-    // >= 2.4 M cells (kernel >= 90 us) by a few per cent at most.  Round 4 tried the switch at 6 rounds (the advisor's point: a
-    // real exchange is longer than the loop-back's) and measured 1.4 M-cell parts 15 % slower for it; it is back at 12 until a
-    // sweep on two real GPUs exists.  RDYHIP_OVERLAP=0 / 1 forces a form, RDYHIP_OVERLAP_MIN_ROUNDS moves the switch.
-    const int pgrid    = std::max(8, op->muscl ? op->pgrid_muscl : op->pgrid);
-    int       min_rounds = 12;
-    if (const char *e = getenv("RDYHIP_OVERLAP_MIN_ROUNDS")) min_rounds = std::max(0, atoi(e));
-    h->overlap = op->use_tiled ? (int64_t)(op->ntiles - op->n_halo_tiles) >= (int64_t)min_rounds * pgrid : op->n_owned >= 1500000;
-    if (const char *e = getenv("RDYHIP_OVERLAP")) {
-      h->overlap        = atoi(e) != 0;
-      h->overlap_forced = true;
+    // The form of a step is chosen by a trial on the communicator this halo really has (FormChoice), not by a constant
+    // tuned on one device with the exchange looped back (rounds 3-4 switched at twelve rounds of interior tiles).  What
+    // forces it, read once here: RDYHIP_OVERLAP=0 / 1; RDYHIP_OVERLAP_MIN_ROUNDS=n (the old size rule: two streams when the
+    // interior tiles fill at least n rounds of the persistent grid).  A rank without peers has nothing to choose.
+    int forced = -1, source = RDYHIP_HALO_FORM_FORCED;
+    if (const char *e = getenv("RDYHIP_OVERLAP_MIN_ROUNDS")) {
+      const int pgrid = std::max(8, op->muscl ? op->pgrid_muscl : op->pgrid);
+      forced = op->use_tiled ? ((int64_t)(op->ntiles - op->n_halo_tiles) >= (int64_t)std::max(0, atoi(e)) * pgrid ? 1 : 0) : (op->n_owned >= 1500000 ? 1 : 0);
     }
+    if (const char *e = getenv("RDYHIP_OVERLAP")) forced = atoi(e) != 0 ? 1 : 0;
+    if (forced < 0 && ns == 0 && nr == 0) {
+      forced = 0;
+      source = RDYHIP_HALO_FORM_DEFAULT;
+    }
+    // A pattern that receives into OWNED rows (no real partition does: DMPlex's point SF has ghost leaves only; synthetic test
+    // patterns do) cannot run its transfer beside the launch that reads those rows: in order, whatever was asked for
+    for (int32_t i = 0; i < nr; ++i) {
+      const int32_t c = recv_cell_ids[i];
+      if (op->prefix ? c < op->n_owned : (c < (int32_t)op->h_l2o.size() && op->h_l2o[(size_t)c] >= 0 && op->h_l2o[(size_t)c] < op->n_owned)) {
+        forced = 0;
+        source = RDYHIP_HALO_FORM_LOCKED_IN_ORDER;
+        break;
+      }
+    }
+    for (auto &c : h->choice)
+      if (forced >= 0) {
+        c.form   = forced;
+        c.source = source;
+      }
+    if (const char *e = getenv("RDYHIP_HALO_CONCURRENT")) h->halo_concurrent = atoi(e) != 0;   // measurement knob
+    if (const char *e = getenv("RDYHIP_GRAD_PACK_FUSED")) h->grad_pack_allowed = atoi(e) != 0;  // measurement knob
   }
   int rc      = h->d_send_ids.upload(std::vector<int32_t>(send_cell_ids, send_cell_ids + ns));
   if (!rc) rc = h->d_recv_ids.upload(std::vector<int32_t>(recv_cell_ids, recv_cell_ids + nr));
@@ -457,18 +463,20 @@ static int halo_attach_send_lists(RDyHipHalo h, bool on) {
   std::vector<TileDesc> tiles((size_t)op->ntiles + 1);
   HIP_TRY(hipMemcpy(tiles.data(), op->d_tiles.p, tiles.size() * sizeof(TileDesc), hipMemcpyDeviceToHost));
   for (auto &t : tiles) t.cnt &= ~TILE_SEND_FLAG;
-  bool signalling = false;
+  h->send_cells_in_halo_tiles = true;
   if (on) {
     const int32_t ns = h->send_off.back();
     std::vector<int32_t> ids((size_t)ns);
     if (ns) HIP_TRY(hipMemcpy(ids.data(), h->d_send_ids.p, sizeof(int32_t) * (size_t)ns, hipMemcpyDeviceToHost));
     if ((int64_t)ns >= (1 << 24)) return fail(RDYHIP_ERR_ARG_SIZ, "%d send cells do not fit the 24-bit row of a send entry", ns);
     std::vector<std::pair<int32_t, uint32_t>> ent((size_t)ns);  // (tile, cell-in-tile | row << 8)
+    const auto &c0 = op->h_tile_c0;
     for (int32_t i = 0; i < ns; ++i) {
       const int32_t c = ids[i];
       const int32_t o = op->prefix ? c : (c < (int32_t)op->h_l2o.size() ? op->h_l2o[c] : -1);
       if (o < 0 || o >= op->n_owned) return fail(RDYHIP_ERR_USER, "send cell %d is not an owned cell", c);
-      ent[i] = std::make_pair(o / TILE, (uint32_t)(o % TILE) | ((uint32_t)i << 8));
+      const int32_t t = (int32_t)(std::upper_bound(c0.begin(), c0.end(), o) - c0.begin()) - 1;  // the tile that holds owned cell o
+      ent[i] = std::make_pair(t, (uint32_t)(o - c0[(size_t)t]) | ((uint32_t)i << 8));
     }
     std::sort(ent.begin(), ent.end());
     std::vector<int32_t>  off((size_t)op->ntiles + 1, 0);
@@ -477,6 +485,10 @@ static int halo_attach_send_lists(RDyHipHalo h, bool on) {
       off[(size_t)ent[i].first + 1]++;
       packed[i] = ent[i].second;
       tiles[(size_t)ent[i].first].cnt |= TILE_SEND_FLAG;
+      // A send cell in a tile no ghost touches (the DM's overlap is vertex-adjacent, the tiles' halo flag edge-adjacent): the
+      // INTERIOR launch of a two-stream step would store its row while the exchange stream reads the send buffer -- such a
+      // halo keeps its fused-pack Euler steps in order (overlapped())
+      if (!(tiles[(size_t)ent[i].first].cnt & TILE_HALO_FLAG)) h->send_cells_in_halo_tiles = false;
     }
     for (int32_t t = 0; t < op->ntiles; ++t) off[(size_t)t + 1] += off[t];
     h->d_send_tile_off.release();
@@ -484,61 +496,10 @@ static int halo_attach_send_lists(RDyHipHalo h, bool on) {
     int rc = h->d_send_tile_off.upload(off);
     if (!rc) rc = h->d_send_ent.upload(packed);
     if (rc) return rc;
-    // the signalled form (overlapped(), above): RCCL halos on a device whose streams can wait for a word in memory
-    // (RDYHIP_SIGNALLED=0: the forms without it, for A/B timing)
-    h->n_send_tiles = 0;
-    for (int32_t t = 0; t < op->ntiles; ++t) h->n_send_tiles += (tiles[(size_t)t].cnt & TILE_SEND_FLAG) ? 1 : 0;
-    int can = 0;
-    (void)hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, op->device);
-    const char *senv = getenv("RDYHIP_SIGNALLED");
-    // Opt-in (RDYHIP_SIGNALLED=1): on one device, with the transfer looped back, it is within +-3 % of the in-order form at
-    // 1.4 - 2.9 M cells per rank (better on the unstructured part, worse on quads) and loses below ~0.8 M, where the launch is
-    // over before the chain it is meant to hide (profiles/r04_small_parts.txt); what a real xGMI hop -- a longer transfer to
-    // hide -- makes of it cannot be measured on this pool.  Never under rocprofv3's counter collection (it exports
-    // ROCPROF_COUNTER_COLLECTION=1 to the profiled process): its dispatch serialiser does not let the wait packet through --
-    // every PMC pass of the looped-back multi-rank step hung at its first signalled step, while plain kernel tracing runs it
-    // fine (profiles/RESULTS_LOG.md section 11).
-    const char *pmc = getenv("ROCPROF_COUNTER_COLLECTION");
-    const bool  counters = pmc && atoi(pmc) != 0;
-    signalling = can && h->comm && h->n_send_tiles > 0 && senv && atoi(senv) != 0 && !counters && !op->muscl;  // (the first-order / HR kernels signal)
-    if (signalling) {
-      // the early transfer writes the receive rows of an array the running launch is still storing owned rows of: they must
-      // be ghost rows, which no launch writes (always so for a real partition; a synthetic pattern keeps the other forms)
-      const int32_t nr = h->recv_off.back();
-      std::vector<int32_t> rid((size_t)nr);
-      if (nr) HIP_TRY(hipMemcpy(rid.data(), h->d_recv_ids.p, sizeof(int32_t) * (size_t)nr, hipMemcpyDeviceToHost));
-      for (int32_t i = 0; i < nr && signalling; ++i) {
-        const int32_t c = rid[(size_t)i];
-        if (op->prefix ? c < op->n_owned : (c < (int32_t)op->h_l2o.size() && op->h_l2o[(size_t)c] >= 0)) signalling = false;
-      }
-    }
-    if (const char *e = getenv("RDYHIP_SIGNALLED_SHRINK")) op->signalled_shrink = std::max(0, atoi(e));  // measurement knob
-    if (signalling) {
-      if (!h->signal) {
-        HIP_TRY(hipExtMallocWithFlags((void **)&h->signal, sizeof(uint64_t), hipMallocSignalMemory));
-      }
-      *h->signal = 0;  // signal memory is host-visible; the device is idle (synchronised above)
-      rc = h->d_send_done.zeros(1);
-      if (!rc) rc = h->d_send_epoch.zeros(1);
-      // the launch's tile list: the XCD chunks of the plain order (launch_rhs), inside each the send-flagged tiles first
-      std::vector<int32_t> order;
-      order.reserve((size_t)op->ntiles);
-      const int32_t chunk = op->tiled_xcd_chunks > 0 ? op->tiled_xcd_chunks : op->ntiles;
-      for (int32_t lo = 0; lo < op->ntiles; lo += chunk) {
-        const int32_t hi = std::min(op->ntiles, lo + chunk);
-        for (int32_t t = lo; t < hi; ++t)
-          if (tiles[(size_t)t].cnt & TILE_SEND_FLAG) order.push_back(t);
-        for (int32_t t = lo; t < hi; ++t)
-          if (!(tiles[(size_t)t].cnt & TILE_SEND_FLAG)) order.push_back(t);
-      }
-      op->d_tiles_send_first.release();
-      if (!rc) rc = op->d_tiles_send_first.upload(order);
-      if (rc) return rc;
-    }
   }
   // second order (fused form): the rows each ghost-adjacent cell's gradient travels in, by position in the halo cell list
   bool gfused = false;
-  if (on && op->muscl && op->muscl_fused && op->n_halo > 0 && !(getenv("RDYHIP_GRAD_PACK_FUSED") && atoi(getenv("RDYHIP_GRAD_PACK_FUSED")) == 0)) {
+  if (on && op->muscl && op->n_halo > 0 && h->grad_pack_allowed) {
     const int32_t ns = h->send_off.back();
     std::vector<int32_t> ids((size_t)ns), hl((size_t)op->n_halo), pos((size_t)op->n_owned, -1);
     if (ns) HIP_TRY(hipMemcpy(ids.data(), h->d_send_ids.p, sizeof(int32_t) * (size_t)ns, hipMemcpyDeviceToHost));
@@ -577,13 +538,6 @@ static int halo_attach_send_lists(RDyHipHalo h, bool on) {
   c.send_off    = on ? h->d_send_tile_off.p : nullptr;
   c.send_ent    = on ? h->d_send_ent.p : nullptr;
   c.send_buf    = on ? h->d_send.p : nullptr;
-  c.send_done   = signalling ? h->d_send_done.p : nullptr;
-  c.send_epoch  = signalling ? h->d_send_epoch.p : nullptr;
-  c.send_signal = signalling ? h->signal : nullptr;
-  c.send_waves  = signalling ? (uint32_t)h->n_send_tiles * (uint32_t)(TILE / 64) : 0u;
-  op->send_signalling = signalling;
-  op->send_epoch      = 0;
-  h->packed_epoch     = 0;
   HIP_TRY(hipMemcpy(op->d_cold.p, &c, sizeof(c), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(op->d_tiles.p, tiles.data(), tiles.size() * sizeof(TileDesc), hipMemcpyHostToDevice));
   op->fused_halo = on ? h : nullptr;
@@ -603,8 +557,7 @@ int rdyhip_halo_fuse_pack(RDyHipHalo halo, int32_t enable) {
     return 0;
   }
   if (halo->fused_pack) return 0;
-  if (!op->use_tiled || (op->muscl && !op->muscl_fused))
-    return fail(RDYHIP_ERR_USER, "the fused pack rides on the tiled Euler-step kernels (not RDYHIP_KERNEL=cell, not the split second_order form)");
+  if (!op->use_tiled) return fail(RDYHIP_ERR_USER, "the fused pack rides on the tiled Euler-step kernels (not RDYHIP_KERNEL=cell)");
   if (op->fused_halo && op->fused_halo != halo) return fail(RDYHIP_ERR_USER, "another halo of this operator already has the fused pack");
   const int rc = halo_attach_send_lists(halo, true);
   if (rc) return rc;
@@ -620,9 +573,6 @@ int rdyhip_halo_invalidate(RDyHipHalo halo) {
 
 int32_t rdyhip_halo_direct_receive(RDyHipHalo halo) { return halo && halo->recv_base >= 0 ? 1 : 0; }
 int32_t rdyhip_halo_pack_fused(RDyHipHalo halo) { return halo && halo->fused_pack ? 1 : 0; }
-int32_t rdyhip_halo_signalled(RDyHipHalo halo) {
-  return halo && halo->fused_pack && halo->signal && halo->op->fused_halo == halo && halo->op->send_signalling && !halo->transport ? 1 : 0;
-}
 
 int rdyhip_halo_destroy(RDyHipHalo *halo) {
   if (!halo) return fail(RDYHIP_ERR_USER, "null argument to rdyhip_halo_destroy");
@@ -635,7 +585,41 @@ int rdyhip_halo_destroy(RDyHipHalo *halo) {
   return 0;
 }
 
-int32_t rdyhip_halo_overlaps(RDyHipHalo halo) { return halo && halo->overlap ? 1 : 0; }
+int32_t rdyhip_halo_overlaps(RDyHipHalo halo) { return halo && halo->choice[0].form ? 1 : 0; }
+
+int rdyhip_halo_form_info(RDyHipHalo halo, int32_t kind, RDyHipHaloFormInfo *info) {
+  if (!halo || !info) return fail(RDYHIP_ERR_USER, "null argument");
+  if (kind != RDYHIP_HALO_STEP_RHS && kind != RDYHIP_HALO_STEP_EULER) return fail(RDYHIP_ERR_USER, "unknown kind of step %d", kind);
+  const RDyHipHalo_s::FormChoice &c = halo->choice[kind];
+  info->form          = c.form;
+  info->source        = c.source;
+  info->trial_steps   = c.steps;
+  info->in_order_ms   = c.ms[0];
+  info->two_stream_ms = c.ms[1];
+  // the lock of overlapped(): a fused pack with a send cell outside the ghost-adjacent tiles steps in order
+  if (kind == RDYHIP_HALO_STEP_EULER && halo->fused_pack && halo->op->fused_halo == halo && !halo->send_cells_in_halo_tiles) {
+    info->form   = 0;
+    info->source = RDYHIP_HALO_FORM_LOCKED_IN_ORDER;
+  }
+  return 0;
+}
+
+int rdyhip_halo_set_form(RDyHipHalo halo, int32_t kind, int32_t form) {
+  if (!halo) return fail(RDYHIP_ERR_USER, "null halo");
+  if (kind != RDYHIP_HALO_STEP_RHS && kind != RDYHIP_HALO_STEP_EULER) return fail(RDYHIP_ERR_USER, "unknown kind of step %d", kind);
+  RDyHipHalo_s::FormChoice &c = halo->choice[kind];
+  if (form < 0) {  // run the trial (again); the events are kept
+    c.form = 0;
+    c.source = RDYHIP_HALO_FORM_TRIAL_RUNNING;
+    c.steps = 0;
+    c.ms[0] = c.ms[1] = 0.0;
+    c.n[0] = c.n[1] = 0;
+    return 0;
+  }
+  c.form   = form ? 1 : 0;
+  c.source = RDYHIP_HALO_FORM_FORCED;
+  return 0;
+}
 
 int rdyhip_halo_set_transport(RDyHipHalo halo, RDyHipTransportFn fn, void *ctx) {
   if (!halo) return fail(RDYHIP_ERR_USER, "null halo");

@@ -13,14 +13,17 @@
 //    ls_solve below; flops are free on this memory-bound path).  Likewise an edge's
 //    centroid -> midpoint displacements (32 B per edge in ReconstructFaceValues) are
 //    formed from ONE stored midpoint (16 B) and the centroids already on the chip.
-//  * swe_rhs_muscl_kernel: the tiled three-phase structure of swe_kernels.h.
-//    Phase 0 stages the conserved state and the gradient of the tile's own and
-//    halo cells in LDS; phase 1 reconstructs the two limited face states of every
-//    tile edge from LDS, derives the Riemann side data per edge side and evaluates
-//    the Roe flux once per edge; phase 2 is the first-order kernel's (segmented
-//    per-cell sum in the reference's order, source terms, stores).
-//    Boundary edges stay first order (ApplyBoundaryFlux is unchanged by
-//    numerics.second_order).
+//  * swe_rhs_muscl_fused_kernel: the tiled structure of swe_kernels.h with the
+//    gradients formed on the chip.  Phase 0 stages the conserved state and the
+//    centroid of the tile's own cells and of its two rings in LDS; phase G forms
+//    the gradients of own + first-ring cells in LDS; phase 1 reconstructs the two
+//    limited face states of every tile edge from LDS, derives the Riemann side
+//    data per edge side and evaluates the Roe flux once per edge; phase 2 is the
+//    first-order kernel's (segmented per-cell sum in the reference's order, source
+//    terms, stores).  Boundary edges stay first order (ApplyBoundaryFlux is
+//    unchanged by numerics.second_order).  (A split form -- gradients through
+//    memory, a flux kernel that reads them -- was the A/B partner of rounds 1-4:
+//    tools/probes/split_muscl_form.patch.)
 //
 // Across ranks the reference solves each cut edge on the rank that owns it and
 // adds the ghost side back with DMLocalToGlobal(ADD_VALUES).  Here every rank
@@ -30,6 +33,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include <type_traits>
 
 #include "swe_kernels.h"
 
@@ -56,57 +61,39 @@ struct MusclArgs {
   const double *cxy;    // [num_cells][2]: cell centroid (x, y), local cell index
   // fused kernel only: the second ring of each tile and the stencils of its first-ring cells
   const int32_t  *hcells2;  // second-ring cells of each tile (local cell ids): neighbours of first-ring cells outside the tile
-  const int32_t  *c_off;    // [ntiles+1] first hcells2 entry of each tile
+  const int32_t  *r2_off;   // [ntiles+1] first hcells2 entry of each tile
   const uint16_t *bn_idx;   // [halo entries][4] LDS slot of each first-ring cell's s-th neighbour; BN_NONE: no neighbour in that
                             //                   slot; BN_GLOBAL: a ghost cell, its gradient comes from `grad` (exchanged)
-  int32_t         hmax2;    // largest first + second ring of a tile (LDS sizing)
 };
 constexpr uint16_t BN_NONE = 0xFFFF, BN_GLOBAL = 0xFFFE;
 
-// LDS layout of the second-order kernels.  Record layout (MusclAoS): a cell's (h, hu, hv, centroid x, centroid y) are five
-// consecutive doubles, its gradient six (+ one of padding), an edge's (f0, f1, f2, amax) four -- every access to a record
-// is ONE address (slot x record size) plus immediate offsets.  With one plane per component and RUN-TIME plane strides
-// every plane's offset cost an SGPR and the kernel ran out of them (round 2: 161 v_readlane_b32 of spilled plane offsets
-// and 87 address adds in phase 1 alone); compile-time strides (MusclSoA) have neither cost.
-// record strides in doubles (gradient: 6 values, edge flux: 4 values).  The gradient records are padded to 7: an odd
-// stride spreads consecutive records over all LDS banks (6 -> 7: -1.6 % on the 10 M-cell RHS; padding the flux records
-// to 5 as well changes nothing more)
-constexpr int MUSCL_GS = 7, MUSCL_ES = 4;
-
-// Where value k of record j lives in LDS.  Two layouts behind the same kernels:
-//   MusclAoS        records of any count (sizes known at run time only): a record's values are consecutive doubles, so one
-//                   address per record and immediate offsets -- but hipcc fuses the 8-byte reads of a record into
-//                   ds_read2_b64, which the LDS serves at half the rate of ds_read_b64 (MI355X_MICROARCH.md, LDS table);
-//   MusclSoA<..>    one plane per value with COMPILE-TIME plane strides: the plane offsets are immediates as well (no
-//                   register, no address arithmetic) and every read is a full-rate ds_read_b64.  Chosen at create when the
-//                   mesh's tiles fit the fixed capacities (every mesh numbered with some locality does).
-struct MusclAoS {
-  static constexpr bool fixed = false;
-  static constexpr int  n3    = 0;
-  static __device__ __forceinline__ int qidx(int k, int j) { return 5 * j + k; }
-  static __device__ __forceinline__ int gidx(int k, int j) { return MUSCL_GS * j + k; }
-  static __device__ __forceinline__ int eidx(int c, int e_) { return MUSCL_ES * e_ + c; }
-};
+// LDS layout of the second-order kernel: one plane per value with COMPILE-TIME plane strides -- the plane offsets are
+// instruction immediates (no register, no address arithmetic) and every read is a full-rate ds_read_b64.  Every tile is cut
+// at create so that its rings and edge records fit the capacities below (layout_build_tiles).  (Rounds 1-3 also carried a
+// record layout with run-time sizes for meshes numbered without locality: every plane offset cost an SGPR there -- 161
+// v_readlane_b32 of spilled offsets in the edge phase alone -- and ds_read2_b64 pairs served at half rate.)
 template <int NQ, int NG, int NE>
 struct MusclSoA {
-  static constexpr bool fixed = true;
   static constexpr int  nq = NQ, ng = NG, ne = NE;  // capacities: state records (own + both rings), gradient records (own + first ring), edges
   static __device__ __forceinline__ int qidx(int k, int j) { return k * NQ + j; }
   static __device__ __forceinline__ int gidx(int k, int j) { return k * NG + j; }
   static __device__ __forceinline__ int eidx(int c, int e_) { return c * NE + e_; }
-  // edge records beyond the two register rounds (quads: a 16 x 16 block has 544): their normal component and midpoint wait
-  // in LDS instead of being loaded inside the edge phase
-  static constexpr int n3 = NE > 2 * TILE ? NE - 2 * TILE : 0;
-  static constexpr size_t lds_bytes = sizeof(double) * (6 * (size_t)NG + 5 * (size_t)NQ + 3 * (size_t)n3) + sizeof(uint32_t) * (size_t)NE;
+  static constexpr size_t lds_bytes = sizeof(double) * (6 * (size_t)NG + 5 * (size_t)NQ) + sizeof(uint32_t) * (size_t)NE;
 };
 // triangles: 256 own + <= 104 first-ring cells, <= 264 ring cells in all, <= 512 edge records (two register rounds);
-// 40 128 B per workgroup: four workgroups per CU as with the record layout.  The edge fluxes (4 planes) overlay the
-// gradients (6 planes).  The plane strides are deliberately NOT multiples of 64 doubles: hipcc would otherwise fuse the
+// 40 128 B per workgroup: four workgroups per CU.  The edge fluxes (4 planes) overlay the gradients (6 planes): a thread
+// keeps the fluxes of its (at most two) edges in registers across one extra barrier and then writes them over the
+// gradients, dead by then.  The plane strides are deliberately NOT multiples of 64 doubles: hipcc would otherwise fuse the
 // reads of two planes into ds_read2st64_b64, which is served like ds_read2_b64.
-using MusclSoATri = MusclSoA<520, 360, 520>;
-// quads / mixed meshes (three register rounds of edge records, a 16 x 16 block has 544): <= 112 first-ring cells, <= 168 ring
-// cells in all, <= 552 edge records; 37 792 B per workgroup
-using MusclSoAQuad = MusclSoA<424, 368, 552>;
+// (every ring cell is staged by one thread: at most TILE of them; the state planes keep 8 slots of slack so that their stride
+// is no multiple of 64 doubles)
+constexpr int MUSCL_MAX_RING1_TRI = TILE_MAX_HALO_TRI, MUSCL_MAX_RING_TRI = TILE;
+using MusclSoATri = MusclSoA<TILE + MUSCL_MAX_RING_TRI + 8, TILE + MUSCL_MAX_RING1_TRI, TILE_MAX_REC + 8>;
+static_assert(MUSCL_MAX_RING_TRI <= TILE, "one thread stages one ring cell");
+// quads / mixed meshes: <= 112 first-ring cells, <= 168 ring cells in all; 37 664 B per workgroup
+constexpr int MUSCL_MAX_RING1_QUAD = TILE_MAX_HALO_QUAD, MUSCL_MAX_RING_QUAD = 168;
+using MusclSoAQuad = MusclSoA<TILE + MUSCL_MAX_RING_QUAD, TILE + MUSCL_MAX_RING1_QUAD, TILE_MAX_REC + 8>;
+static_assert(MUSCL_MAX_RING_QUAD <= TILE && TILE_MAX_HALO_QUAD <= TILE && TILE_MAX_HALO_TRI <= TILE, "one thread stages one ring / halo cell");
 #define MSQ(k, j) sq[LAY::qidx((k), (j))]
 #define MSG(k, j) sg[LAY::gidx((k), (j))]
 #define MEF(c, e) ef[LAY::eidx((c), (e))]
@@ -190,7 +177,7 @@ __device__ __forceinline__ void store_edge_flux(const KernelArgs &a, double *ef,
   MEF(3, e) = r.am;
 }
 template <int LIM, class LAY>
-__device__ __forceinline__ EdgeFlux muscl_edge(const KernelArgs &a, const TileDesc &td, double dt, uint32_t lr, double cs, double2 mid,
+__device__ __forceinline__ EdgeFlux muscl_edge(const KernelArgs &a, int tile, double dt, uint32_t lr, double cs, double2 mid,
                                                const double *sq, const double *sg) {
   double cn, sn;
   edge_normal(lr, cs, cn, sn);
@@ -222,7 +209,7 @@ __device__ __forceinline__ EdgeFlux muscl_edge(const KernelArgs &a, const TileDe
     wet                 = !(R.h < a.tiny_h && L.h < a.tiny_h);  // swe_petsc.c:184
   } else {
     const RiemannSide L  = riemann_side(MSQ(0, jl), MSQ(1, jl), MSQ(2, jl), a.tiny_h, a.h_anuga_sq);
-    const int         k  = RDY_COLD(a, tile_bk)[td.b_off + ((lr >> EDGE_R_SHIFT) & EDGE_SLOT_MASK)];
+    const int         k  = RDY_COLD(a, tile_bk)[load_uniform(RDY_COLD(a, tile_boff), tile) + ((lr >> EDGE_R_SHIFT) & EDGE_SLOT_MASK)];
     BoundaryFlux      bf = boundary_flux(RDY_COLD(a, btype)[k], true, L, RDY_COLD(a, bvalues) + 3 * (int64_t)k, sn, cn, a.tiny_h, a.h_anuga_sq);
     fl                   = bf.flux;
     wet                  = bf.wet;
@@ -251,9 +238,10 @@ __device__ __forceinline__ int slot_edge(uint32_t r0, uint32_t r1, int s) {
 // Phase 2 of both second-order kernels: a cell's flux sum in the reference's edge order + the Courant number
 // (src/swe/swe_petsc.c:184-201); kf[s] = -+len/area of slot s.
 template <int S, class LAY>
-__device__ __forceinline__ void muscl_cell_sum(const KernelArgs &a, uint32_t r0, uint32_t r1, const double (&kf)[S], const double *ef, double dt, int o,
-                                               double &acc0, double &acc1, double &acc2, double &best,
-                                               int &best_slot, int &best_o) {
+__device__ __forceinline__ void muscl_cell_sum(const KernelArgs &a, uint32_t r0, uint32_t r1, const double (&kf)[S], const double *ef, double dt, int e_off,
+                                               double &acc0, double &acc1, double &acc2, CourantTrack &trk) {
+  bool      tie    = false;  // a slot of this cell met the thread's running Courant maximum to the last bit (CourantTrack, swe_kernels.h)
+  const int rec_in = trk.rec;
 #pragma unroll
   for (int s = 0; s < S; ++s) {
     const int ref = slot_edge<S>(r0, r1, s);
@@ -265,12 +253,24 @@ __device__ __forceinline__ void muscl_cell_sum(const KernelArgs &a, uint32_t r0,
       acc1 += MEF(1, ref) * k;
       acc2 += MEF(2, ref) * k;
       const double cnum = am * fabs(k) * dt;  // len/area_self: the max over the two cells is len / min(area_l, area_r)
-      if (cnum > best) {
-        best      = cnum;
-        best_slot = s;
-        best_o    = o;
+      tie |= cnum == trk.best;
+      if (cnum > trk.best) {
+        trk.best = cnum;
+        trk.rec  = e_off + ref;
       }
     }
+  }
+  if (trk.rec != rec_in) trk.pos = -1;
+  if (tie) {  // cold: which of the equal edges comes first in the reference's loop
+    int first = -1;  // the first slot of this cell at the running maximum: the only one that can come before the incumbent
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      const int ref = slot_edge<S>(r0, r1, s);
+      if (ref < 0) continue;
+      const double am = MEF(3, ref);
+      if (first < 0 && am != -1.0 && am * fabs(kf[s]) * dt == trk.best) first = e_off + ref;
+    }
+    if (first >= 0) courant_resolve_tie(a, trk, first, load_uniform(RDY_COLD(a, e_pos), e_off));
   }
 }
 
@@ -326,114 +326,12 @@ __global__ __launch_bounds__(BLOCK) void muscl_gradient_kernel(const KernelArgs 
   }
 }
 
-// split form (RDYHIP_MUSCL=split): the gradients come from memory (muscl_gradient_kernel), kept for A/B
-template <int S, int SRC, bool OVW, int LIM>
-__global__ __launch_bounds__(TILE) void swe_rhs_muscl_kernel(const KernelArgs a, const MusclArgs g, const double dt, const double *__restrict__ u,
-                                                              double *__restrict__ f) {
-  using LAY = MusclAoS;
-  extern __shared__ double lds[];
-  const int nside = TILE + a.hmax;
-  double   *sq    = lds;              // nside records of 5: h, hu, hv, centroid x, y
-  double   *sg    = lds + 5 * nside;  // nside records of MUSCL_GS: the gradient
-  double   *ef = lds + (5 + MUSCL_GS) * nside;  // emax records of 4: the edge fluxes
-  const int tid = threadIdx.x;
-
-  // the tile sequence of this (persistent) workgroup: as in swe_rhs_tiled_kernel
-  int idx, step, hi;
-  if (a.xcd_chunks > 0) {
-    const int x = blockIdx.x & 7;
-    step        = gridDim.x >> 3;
-    idx         = x * a.xcd_chunks + (blockIdx.x >> 3);
-    hi          = min((x + 1) * a.xcd_chunks, a.n_work);
-  } else {
-    idx  = blockIdx.x;
-    step = gridDim.x;
-    hi   = a.n_work;
-  }
-
-  double best      = 0.0;
-  int    best_slot = -1, best_o = 0;
-
-  for (; idx < hi; idx += step) {
-    const int      tile = __builtin_amdgcn_readfirstlane(a.list ? load_uniform(a.list, idx) : idx);
-    const TileDesc td = a.tiles[tile];
-    if (a.phase == RDYHIP_PHASE_INTERIOR && td.halo()) continue;  // wave-uniform
-    const int  ne = td.ne(), nh = td.nh();
-    const int  o      = tile * TILE + tid;
-    const bool active = o < a.n_owned;
-
-    // ---- phase 0: conserved state, centroid and gradient of the tile's own and halo cells -> LDS
-    {
-      double q[5] = {0.0, 0.0, 0.0, 0.0, 0.0}, gr[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-      if (active) {
-        const int c = a.o2l ? a.o2l[o] : o;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) q[k] = u[3 * (int64_t)c + k];
-        q[3] = g.cxy[2 * (int64_t)c];
-        q[4] = g.cxy[2 * (int64_t)c + 1];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) gr[k] = g.grad[6 * (int64_t)c + k];
-      }
-#pragma unroll
-      for (int k = 0; k < 5; ++k) MSQ(k, tid) = q[k];
-#pragma unroll
-      for (int k = 0; k < 6; ++k) MSG(k, tid) = gr[k];
-      for (int j = tid; j < nh; j += TILE) {
-        const int hc = a.hcells[td.h_off + j];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) MSQ(k, TILE + j) = u[3 * (int64_t)hc + k];
-        MSQ(3, TILE + j) = g.cxy[2 * (int64_t)hc];
-        MSQ(4, TILE + j) = g.cxy[2 * (int64_t)hc + 1];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) MSG(k, TILE + j) = g.grad[6 * (int64_t)hc + k];
-      }
-    }
-    __syncthreads();
-
-    // ---- phase 1: every edge of the tile once
-    for (int e = tid; e < ne; e += TILE) {
-      const double2 mid = *reinterpret_cast<const double2 *>(g.e_mid + 2 * ((int64_t)td.e_off + e));
-      store_edge_flux<LAY>(a, ef, e, muscl_edge<LIM, LAY>(a, td, dt, a.e_lr[td.e_off + e], a.e_cs[td.e_off + e], mid, sq, sg));
-    }
-    __syncthreads();
-
-    // ---- phase 2: per-cell sum in the reference's edge order, source terms, stores
-    if (active) {
-      uint32_t r0, r1 = 0;
-      if (S == 3) {
-        r0 = reinterpret_cast<const uint32_t *>(a.slot_ref)[o];
-      } else {
-        const uint2 w = reinterpret_cast<const uint2 *>(a.slot_ref)[o];
-        r0            = w.x;
-        r1            = w.y;
-      }
-      double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
-      if (!OVW) {
-        acc0 = f[3 * (int64_t)o + 0];
-        acc1 = f[3 * (int64_t)o + 1];
-        acc2 = f[3 * (int64_t)o + 2];
-      }
-      double kf[S];
-#pragma unroll
-      for (int s = 0; s < S; ++s) kf[s] = a.coef[s * a.stride + o];
-      muscl_cell_sum<S, LAY>(a, r0, r1, kf, ef, dt, o, acc0, acc1, acc2, best, best_slot, best_o);
-      const double      h = MSQ(0, tid), hu = MSQ(1, tid), hv = MSQ(2, tid);
-      const RiemannSide self = riemann_side(h, hu, hv, a.tiny_h, a.h_anuga_sq);
-      cell_epilogue<SRC>(a, o, dt, h, hu, hv, self.u, self.v, acc0, acc1, acc2, a.dzdx[o], a.dzdy[o], a.mannings[o], a.extsrc[3 * (int64_t)o + 0],
-                         a.extsrc[3 * (int64_t)o + 1], a.extsrc[3 * (int64_t)o + 2], f);
-    }
-    __syncthreads();  // the LDS planes are rewritten by the next tile
-  }
-  block_courant_reduce<TILE>(a, best, best_slot, best_o);
-}
-
-
 // ---------------------------------------------------------------------------
 // Fused form (default): the gradients never leave the chip.  A tile stages the
 // state and the centroid of its own cells, of its first ring (cells sharing an
 // edge with a tile cell) and of its second ring (the remaining neighbours of
 // first-ring cells), forms the least-squares gradients of own + first-ring
-// cells in LDS, and goes on as above.  Against the split form this saves the
+// cells in LDS, and goes on as above.  Against a form with the gradients in memory this saves the
 // gradient array's write + read, the second read of the state and the streamed
 // least-squares coefficients / displacements.  First-ring cells that are ghosts
 // take their gradient from `grad`, filled by the caller's exchange (their
@@ -442,6 +340,50 @@ __global__ __launch_bounds__(TILE) void swe_rhs_muscl_kernel(const KernelArgs a,
 // mixed meshes three workgroups with the next tile's loads in flight while
 // this one is computed (profiles/r03_ab_muscl_pipeline.txt).
 // ---------------------------------------------------------------------------
+// The extra Courant edges (ColdArgs::x_*, swe_kernels.h) of the second-order path: both cells' states, gradients and centroids
+// from memory (the gradients of ghost cells and of ghost-adjacent owned cells are there: the exchange and the launch over the
+// halo cell list have written them), the reconstruction of muscl_edge, the largest wave speed.
+template <int LIM>
+__device__ __forceinline__ void courant_extra_edges_muscl(const KernelArgs &a, const MusclArgs &g, double dt, const double *__restrict__ u, CourantTrack &t) {
+  const int nx = RDY_COLD(a, n_xedges);
+  if (nx == 0 || a.phase == RDYHIP_PHASE_INTERIOR) return;  // uniform
+  const int32_t  *xlr = RDY_COLD(a, x_lr);
+  const uint32_t *xfl = RDY_COLD(a, x_flags);
+  const double   *xcs = RDY_COLD(a, x_cs), *xcf = RDY_COLD(a, x_cfac), *xmid = RDY_COLD(a, x_mid);
+  const int       rec0 = RDY_COLD(a, x_rec0);
+  for (int i = blockIdx.x * TILE + threadIdx.x; i < nx; i += gridDim.x * TILE) {
+    const int64_t l = xlr[2 * i], r = xlr[2 * i + 1];
+    const double  mx = xmid[2 * i], my = xmid[2 * i + 1];
+    const double  dlx = mx - g.cxy[2 * l], dly = my - g.cxy[2 * l + 1], drx = mx - g.cxy[2 * r], dry = my - g.cxy[2 * r + 1];
+    double        ql[3], qr[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const double cl_ = u[3 * l + k], cr_ = u[3 * r + k];
+      const double extrap_l = g.grad[6 * l + 2 * k] * dlx + g.grad[6 * l + 2 * k + 1] * dly;
+      const double extrap_r = g.grad[6 * r + 2 * k] * drx + g.grad[6 * r + 2 * k + 1] * dry;
+      const double dq       = cr_ - cl_;
+      ql[k]                 = cl_ + limit_slope<LIM>(extrap_l, 0.5 * dq);
+      qr[k]                 = cr_ + limit_slope<LIM>(extrap_r, -0.5 * dq);
+    }
+    ql[0] = fmax(0.0, ql[0]);
+    qr[0] = fmax(0.0, qr[0]);
+    const RiemannSide L = riemann_side(ql[0], ql[1], ql[2], a.tiny_h, a.h_anuga_sq);
+    const RiemannSide R = riemann_side(qr[0], qr[1], qr[2], a.tiny_h, a.h_anuga_sq);
+    double            cn, sn;
+    edge_normal(xfl[i], xcs[i], cn, sn);
+    if (!(R.h < a.tiny_h && L.h < a.tiny_h)) {
+      const double cnum = roe_flux(L, R, sn, cn).amax * xcf[i] * dt;
+      if (cnum > t.best) {
+        t.best = cnum;
+        t.rec  = rec0 + i;
+        t.pos  = -1;
+      } else if (cnum == t.best) {
+        courant_resolve_tie(a, t, rec0 + i, 0);
+      }
+    }
+  }
+}
+
 // The per-cell streams become visible to phase 2 HERE and on every path: without this hipcc hoists their first uses (a
 // multiply by a constant) into the block that requests them -- the wave then waits for them before the barriers that were
 // meant to cover their latency -- and, the waits sitting inside `if (active)`, treats the registers as still pending after the
@@ -450,39 +392,20 @@ __global__ __launch_bounds__(TILE) void swe_rhs_muscl_kernel(const KernelArgs a,
   do {                                                                                                                                    \
     asm volatile("" ::"v"(dzx), "v"(dzy), "v"(nman), "v"(s0), "v"(s1), "v"(s2), "v"(kf[0]), "v"(kf[1]), "v"(kf[2]), "v"(kf[S - 1]) : "memory"); \
   } while (0)
-template <int S, int SRC, bool OVW, int LIM, bool EULER = false, bool EFO = false, class LAY = MusclAoS>
+template <int S, int SRC, bool OVW, int LIM, bool EULER = false>
 __global__ __launch_bounds__(TILE) void swe_rhs_muscl_fused_kernel(const KernelArgs a, const MusclArgs g, const double dt, const double *__restrict__ u,
                                                                     double *__restrict__ f) {
-  // LDS: gradients of own + first-ring cells | state of own + first-ring cells | a region that holds the second ring's
-  // state (its head, contiguous with the first ring's records) and the tile's edge records (its tail), both read by
-  // the gradient phase only (the edge phase has its records in registers).  The edge fluxes take over dead storage:
-  // with EFO (a tile's edges fit the register rounds of the edge phase: 2 TILE for triangles, 3 TILE for quads -- every
-  // mesh numbered with some locality) the gradients' -- 37 KB per workgroup on the 10 M-cell benchmark mesh, so FOUR
-  // workgroups share a CU's 160 KB --, otherwise that third region, grown to 4 emax doubles (45 KB on the same mesh:
-  // three workgroups).
+  // LDS: gradients of own + first-ring cells (6 planes) | state + centroid of own cells and both rings (5 planes) | the
+  // tile's edge records, read by the gradient phase only (the edge phase has its records in registers).  The edge fluxes
+  // take over the gradients' storage once every edge has been evaluated: ~37-40 KB per workgroup, so FOUR workgroups of the
+  // triangle kernel share a CU's 160 KB.
+  using LAY = typename std::conditional<S == 3, MusclSoATri, MusclSoAQuad>::type;
   extern __shared__ double lds[];
-  static_assert(!LAY::fixed || EFO, "the fixed-capacity layout keeps the edge fluxes over the gradients");
-  const int ng = TILE + a.hmax;   // gradient records: own, first ring
-  double   *sg = lds;             // record layout: [ng][MUSCL_GS]; plane layout: 6 planes of LAY::ng
-  double   *sq;                   // state + centroid of own cells, first ring, second ring: h, hu, hv, centroid x, centroid y
-  double   *ef;                   // the edge fluxes: [emax][4] / 4 planes
-  uint32_t *slr;                  // [emax] the tile's edge records (read by the gradient phase only)
-  double   *e3 = nullptr;         // plane layout, third edge round: [3][n3] normal component, midpoint x, midpoint y
-  constexpr bool STAGE3 = LAY::fixed && S == 4 && LAY::n3 > 0;
-  if constexpr (LAY::fixed) {
-    e3  = lds + 6 * LAY::ng + 5 * LAY::nq;
-    sq  = lds + 6 * LAY::ng;
-    ef  = sg;  // 4 x LAY::ne <= 6 x LAY::ng doubles
-    slr = reinterpret_cast<uint32_t *>(sq + 5 * LAY::nq + 3 * LAY::n3);
-    static_assert(4 * LAY::ne <= 6 * LAY::ng, "the flux planes overlay the gradient planes");
-  } else {
-    sq = lds + MUSCL_GS * ng;
-    // EFO: the edge fluxes take the place of the gradients (dead once every edge has been evaluated; the fluxes wait
-    // in registers for a barrier), else they follow the first ring's records, over the second ring and the edge records
-    ef            = EFO ? sg : sq + 5 * ng;
-    const int ovl = EFO ? 5 * (g.hmax2 - a.hmax) + (a.emax + 1) / 2 : max(MUSCL_ES * a.emax, 5 * (g.hmax2 - a.hmax) + (a.emax + 1) / 2);
-    slr           = reinterpret_cast<uint32_t *>(sq + 5 * ng + ovl) - ((a.emax + 1) / 2) * 2;
-  }
+  double   *sg  = lds;                                             // 6 planes of LAY::ng
+  double   *sq  = lds + 6 * LAY::ng;                               // h, hu, hv, centroid x, centroid y: 5 planes of LAY::nq
+  double   *ef  = sg;                                              // the edge fluxes: 4 planes of LAY::ne
+  uint32_t *slr = reinterpret_cast<uint32_t *>(sq + 5 * LAY::nq);  // [LAY::ne] the tile's edge records
+  static_assert(4 * LAY::ne <= 6 * LAY::ng, "the flux planes overlay the gradient planes");
   const int tid = threadIdx.x;
 
   int idx, step, hi;
@@ -501,7 +424,7 @@ __global__ __launch_bounds__(TILE) void swe_rhs_muscl_fused_kernel(const KernelA
     typedef int v4i __attribute__((ext_vector_type(4)));
     const v4i v = load_uniform(reinterpret_cast<const v4i *>(a.tiles), t);
     TileDesc  d;
-    d.e_off = v.x; d.h_off = v.y; d.b_off = v.z; d.cnt = (uint32_t)v.w;
+    d.e_off = v.x; d.h_off = v.y; d.c_off = v.z; d.cnt = (uint32_t)v.w;
     return d;
   };
   // id of the ring cell (first or second ring) this thread stages for a tile
@@ -524,12 +447,11 @@ __global__ __launch_bounds__(TILE) void swe_rhs_muscl_fused_kernel(const KernelA
     ls_solve(acc, gr);
   };
 
-  double best      = 0.0;
-  int    best_slot = -1, best_o = 0;
-  if constexpr (S == 4 && LAY::fixed) {
+  CourantTrack trk;
+  if constexpr (S == 4) {
     // Quads and mixed meshes: cross-tile software pipeline, as in the first-order kernel.  A tile's loads form three groups:
     // CELLS (state + centroid of the own cell and of this thread's ring cell, the slot references), EDGES (the first-ring
-    // stencil, the edge records of the three rounds with their normal component and midpoint) and the per-cell STREAMS of
+    // stencil, the edge records of the two rounds with their normal component and midpoint) and the per-cell STREAMS of
     // phase 2.  Cells and edges of tile T+1 are requested right after phase 0's barrier of tile T (the ids they depend on --
     // ring cell, own cell -- a tile before that) and are first touched before T's stores; the streams of T after its edge
     // phase.  160 - 165 VGPRs, three workgroups per CU: 5.6 % faster than four workgroups without the pipeline on the reference's
@@ -559,31 +481,31 @@ __global__ __launch_bounds__(TILE) void swe_rhs_muscl_fused_kernel(const KernelA
     uint32_t pr0 = ones, pr1 = ones;
     struct EdgeRegs {
       uint2    bw = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
-      uint32_t lr0 = 0, lr1 = 0, lr2 = 0;
-      double   cs0 = 0.0, cs1 = 0.0, cs3 = 0.0;
-      double2  md0 = make_double2(0.0, 0.0), md1 = make_double2(0.0, 0.0), md3 = make_double2(0.0, 0.0);
+      uint32_t lr0 = 0, lr1 = 0;
+      double   cs0 = 0.0, cs1 = 0.0;
+      double2  md0 = make_double2(0.0, 0.0), md1 = make_double2(0.0, 0.0);
     };
     EdgeRegs E;
     // ids of the own cell (local numbering) and of the ring cell this thread stages for the tile at position i
     auto tile_ids = [&](int i, int &c_, int &hid_) {
       const int      t_  = tile_at(i);
       const TileDesc d_  = tile_desc(t_);
-      const int      c0_ = load_uniform(g.c_off, t_);
-      hid_               = ring_id(d_, d_.nh(), c0_, load_uniform(g.c_off, t_ + 1) - c0_);
-      const int o_       = t_ * TILE + tid;
-      c_                 = (a.o2l && o_ < a.n_owned) ? a.o2l[o_] : o_;
+      const int      c0_ = load_uniform(g.r2_off, t_);
+      hid_               = ring_id(d_, d_.nh(), c0_, load_uniform(g.r2_off, t_ + 1) - c0_);
+      const int o_       = d_.c_off + tid;
+      c_                 = (a.o2l && tid < d_.nc()) ? a.o2l[o_] : o_;
     };
-    auto issue_cells = [&](int t_, int c_, int hid_) {
-      const int o_ = t_ * TILE + tid;
+    auto issue_cells = [&](const TileDesc &d_, int c_, int hid_) {
+      const int o_ = d_.c_off + tid;
 #pragma unroll
       for (int k = 0; k < 3; ++k) q[k] = zero;
       cxy = make_double2(zero, zero);
       pr0 = pr1 = ones;
       // the predicates of the loads are opaque to the compiler: where it can prove one equal to the predicate of a later USE
       // it hoists that use's first instructions into the loading block -- and the wave waits for the load right there
-      int nown = a.n_owned;
+      int nown = d_.nc();
       asm volatile("" : "+s"(nown));
-      if (o_ < nown) {
+      if (tid < nown) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) q[k] = u[3 * (int64_t)c_ + k];
         cxy = *reinterpret_cast<const double2 *>(g.cxy + 2 * (int64_t)c_);
@@ -602,11 +524,6 @@ __global__ __launch_bounds__(TILE) void swe_rhs_muscl_fused_kernel(const KernelA
       asm volatile("" : "+s"(ne_), "+s"(nh_));  // opaque predicates, as in issue_cells
       R.bw = make_uint2(ones, ones);
       if (tid < nh_) R.bw = load_u2(g.bn_idx + 4 * ((int64_t)d_.h_off + tid));
-      if (STAGE3 && tid + 2 * TILE < ne_) {  // third round: staged through LDS (no global load inside the edge phase)
-        R.lr2 = RDY_MLD(&a.e_lr[d_.e_off + 2 * TILE + tid]);
-        R.cs3 = RDY_MLD(&a.e_cs[d_.e_off + 2 * TILE + tid]);
-        R.md3 = load_d2(g.e_mid + 2 * ((int64_t)d_.e_off + 2 * TILE + tid));
-      }
       if (tid < ne_) {
         R.lr0 = RDY_MLD(&a.e_lr[d_.e_off + tid]);
         R.cs0 = RDY_MLD(&a.e_cs[d_.e_off + tid]);
@@ -627,7 +544,7 @@ __global__ __launch_bounds__(TILE) void swe_rhs_muscl_fused_kernel(const KernelA
         int c_, hid_;
         tile_ids(idx, c_, hid_);
         const int t_ = tile_at(idx);
-        issue_cells(t_, c_, hid_);
+        issue_cells(tile_desc(t_), c_, hid_);
         issue_edges(tile_desc(t_), E);
         if (idx1 < hi) tile_ids(idx1, c1, hid1);
         asm volatile("" ::"v"(hid1), "v"(c1));
@@ -636,16 +553,16 @@ __global__ __launch_bounds__(TILE) void swe_rhs_muscl_fused_kernel(const KernelA
         const int      tile = tile_at(idx);
         const TileDesc td = tile_desc(tile);
         const int  ne = td.ne(), nh = td.nh();
-        const int  c0 = load_uniform(g.c_off, tile), nc2 = load_uniform(g.c_off, tile + 1) - c0;
-        const int  o      = tile * TILE + tid;
-        const bool active = o < a.n_owned;
+        const int  c0 = load_uniform(g.r2_off, tile), nc2 = load_uniform(g.r2_off, tile + 1) - c0;
+        const int  o      = td.c_off + tid;
+        const bool active = tid < td.nc();
         int idx2 = hi, c2 = 0, hid2 = -1;
         const uint32_t r0 = pr0, r1 = pr1;
         auto pipe_cells = [&]() {  // the cells group of the next tile, the ids of the one after
           if (idx1 < hi) {
             idx2 = next_valid(idx1 + step);
             if (idx2 < hi) tile_ids(idx2, c2, hid2);
-            issue_cells(tile_at(idx1), c1, hid1);
+            issue_cells(tile_desc(tile_at(idx1)), c1, hid1);
           }
         };
         EdgeRegs N;
@@ -664,25 +581,8 @@ __global__ __launch_bounds__(TILE) void swe_rhs_muscl_fused_kernel(const KernelA
           MSQ(3, TILE + tid) = hcxy.x;
           MSQ(4, TILE + tid) = hcxy.y;
         }
-        for (int j = tid + TILE; j < nh + nc2; j += TILE) {  // only numberings with poor locality get here
-          const int hc = (j < nh) ? a.hcells[td.h_off + j] : g.hcells2[c0 + j - nh];
-#pragma unroll
-          for (int k = 0; k < 3; ++k) MSQ(k, TILE + j) = u[3 * (int64_t)hc + k];
-          MSQ(3, TILE + j) = g.cxy[2 * (int64_t)hc];
-          MSQ(4, TILE + j) = g.cxy[2 * (int64_t)hc + 1];
-        }
         if (tid < ne) slr[tid] = E.lr0;
         if (tid + TILE < ne) slr[tid + TILE] = E.lr1;
-        if (STAGE3) {
-          if (tid + 2 * TILE < ne) {
-            slr[tid + 2 * TILE]   = E.lr2;
-            e3[tid]               = E.cs3;
-            e3[LAY::n3 + tid]     = E.md3.x;
-            e3[2 * LAY::n3 + tid] = E.md3.y;
-          }
-        } else {
-          for (int e = tid + 2 * TILE; e < ne; e += TILE) slr[e] = a.e_lr[td.e_off + e];
-        }
         const uint2 bwc = E.bw;
         __syncthreads();
         __builtin_amdgcn_s_setprio(3);
@@ -729,34 +629,17 @@ __global__ __launch_bounds__(TILE) void swe_rhs_muscl_fused_kernel(const KernelA
             for (int k = 0; k < 6; ++k) MSG(k, TILE + j) = hg[k];
           };
           if (tid < nh) ring_gradient(tid, bwc);
-          for (int j = tid + TILE; j < nh; j += TILE)  // poor locality only
-            ring_gradient(j, reinterpret_cast<const uint2 *>(g.bn_idx)[(int64_t)td.h_off + j]);
         }
         __syncthreads();
 
         // ---- phase 1: every edge of the tile once
         auto do_edge = [&](uint32_t lr, double cs, double2 mid) -> EdgeFlux {
-          return muscl_edge<LIM, LAY>(a, td, dt, lr, cs, mid, sq, sg);
+          return muscl_edge<LIM, LAY>(a, tile, dt, lr, cs, mid, sq, sg);
         };
         EdgeFlux x0 = {0.0, 0.0, 0.0, -1.0}, x1 = x0;
         if (tid < ne) x0 = do_edge(E.lr0, E.cs0, E.md0);
-        if (!EFO && tid < ne) store_edge_flux<LAY>(a, ef, tid, x0);
         __builtin_amdgcn_sched_barrier(0);
         if (tid + TILE < ne) x1 = do_edge(E.lr1, E.cs1, E.md1);
-        if (!EFO && tid + TILE < ne) store_edge_flux<LAY>(a, ef, tid + TILE, x1);
-        EdgeFlux x2 = {0.0, 0.0, 0.0, -1.0};
-        if (!EFO) {
-          for (int e = tid + 2 * TILE; e < ne; e += TILE)  // not slr: the fluxes overwrite it
-            store_edge_flux<LAY>(a, ef, e, do_edge(a.e_lr[td.e_off + e], a.e_cs[td.e_off + e], *reinterpret_cast<const double2 *>(g.e_mid + 2 * ((int64_t)td.e_off + e))));
-        } else if (S == 4) {
-          __builtin_amdgcn_sched_barrier(0);
-          const int e = tid + 2 * TILE;
-          if (STAGE3) {
-            if (e < ne) x2 = do_edge(slr[e], e3[tid], make_double2(e3[LAY::n3 + tid], e3[2 * LAY::n3 + tid]));
-          } else {
-            if (e < ne) x2 = do_edge(a.e_lr[td.e_off + e], a.e_cs[td.e_off + e], *reinterpret_cast<const double2 *>(g.e_mid + 2 * ((int64_t)td.e_off + e)));
-          }
-        }
         // the per-cell streams of phase 2 (requested only here: 18 registers less through the edge phase), then the next
         // tile's groups: phase 2 waits for the streams alone
         double kf[S];
@@ -765,7 +648,7 @@ __global__ __launch_bounds__(TILE) void swe_rhs_muscl_fused_kernel(const KernelA
         for (int s = 0; s < S; ++s) kf[s] = 0.0;
         __builtin_amdgcn_s_setprio(3);
         {
-          const int oc = active ? o : a.n_owned - 1;
+          const int oc = active ? o : td.c_off;
 #pragma unroll
           for (int s = 0; s < S; ++s) kf[s] = RDY_MLD(&a.coef[s * a.stride + oc]);
           dzx  = RDY_MLD(&a.dzdx[oc]);
@@ -776,12 +659,9 @@ __global__ __launch_bounds__(TILE) void swe_rhs_muscl_fused_kernel(const KernelA
           s2   = RDY_MLD(&a.extsrc[3 * (int64_t)oc + 2]);
         }
         __builtin_amdgcn_s_setprio(0);
-        if (EFO) {
-          __syncthreads();  // every edge has read its gradients: the fluxes may overwrite them
-          if (tid < ne) store_edge_flux<LAY>(a, ef, tid, x0);
-          if (tid + TILE < ne) store_edge_flux<LAY>(a, ef, tid + TILE, x1);
-          if (S == 4 && tid + 2 * TILE < ne) store_edge_flux<LAY>(a, ef, tid + 2 * TILE, x2);
-        }
+        __syncthreads();  // every edge has read its gradients: the fluxes may overwrite them
+        if (tid < ne) store_edge_flux<LAY>(a, ef, tid, x0);
+        if (tid + TILE < ne) store_edge_flux<LAY>(a, ef, tid + TILE, x1);
         __syncthreads();
 
         // ---- phase 2: per-cell sum in the reference's edge order, source terms, stores
@@ -794,7 +674,7 @@ __global__ __launch_bounds__(TILE) void swe_rhs_muscl_fused_kernel(const KernelA
             acc1 = f[3 * (int64_t)o + 1];
             acc2 = f[3 * (int64_t)o + 2];
           }
-          muscl_cell_sum<S, LAY>(a, r0, r1, kf, ef, dt, o, acc0, acc1, acc2, best, best_slot, best_o);
+          muscl_cell_sum<S, LAY>(a, r0, r1, kf, ef, dt, td.e_off, acc0, acc1, acc2, trk);
           const RiemannSide self = riemann_side(h, hu, hv, a.tiny_h, a.h_anuga_sq);
           pu                     = self.u;
           pv_                    = self.v;
@@ -804,13 +684,12 @@ __global__ __launch_bounds__(TILE) void swe_rhs_muscl_fused_kernel(const KernelA
         // the tile's wait on the next tile's groups comes BEFORE its own stores are issued (vmcnt counts stores too)
         asm volatile("" ::"v"(q[0]), "v"(q[1]), "v"(q[2]), "v"(cxy.x), "v"(cxy.y), "v"(hq[0]), "v"(hq[1]), "v"(hq[2]), "v"(hcxy.x), "v"(hcxy.y), "v"(pr0), "v"(pr1));
         asm volatile("" ::"v"(N.bw.x), "v"(N.bw.y), "v"(N.lr0), "v"(N.lr1), "v"(N.cs0), "v"(N.cs1), "v"(N.md0.x), "v"(N.md0.y), "v"(N.md1.x), "v"(N.md1.y));
-        if (STAGE3) asm volatile("" ::"v"(N.lr2), "v"(N.cs3), "v"(N.md3.x), "v"(N.md3.y));
         E = N;
         __builtin_amdgcn_sched_barrier(0);
         {  // whole-line stores of the [cell][3] rows (wave_store_rows3, swe_kernels.h); all 64 lanes take part
           const int     lane  = tid & 63;
           const int64_t base  = 3 * ((int64_t)o - lane);
-          const int     ncell = a.n_owned - (o - lane);
+          const int     ncell = td.nc() - (tid - lane);  // the wave's cells of this tile
           if (a.fdiv) wave_store_rows3(a.fdiv, base, lane, ncell, acc0, acc1, acc2);
           if (!EULER || f) wave_store_rows3(f, base, lane, ncell, res[0], res[1], res[2]);
           wave_store_rows3(a.pv, base, lane, ncell, h, pu, pv_);
@@ -837,14 +716,14 @@ __global__ __launch_bounds__(TILE) void swe_rhs_muscl_fused_kernel(const KernelA
     }
 
   } else {
-    // Triangles (and quads in the record layout): four workgroups per CU.  A tile's loads are ONE batch at its top -- except the CELLS group (state + centroid
+    // Triangles: four workgroups per CU.  A tile's loads are ONE batch at its top -- except the CELLS group (state + centroid
     // of the own cell and of this thread's ring cell), which for tile T+1 is requested right after phase 0's barrier of tile T,
     // into the registers phase 0 has just emptied: 127 VGPRs instead of 107, still four waves, and every workgroup has
     // requests in flight while it computes (-1.2 % on C3, -2.6 % on the refined Houston mesh: profiles/
     // r03_ab_muscl_tri_prefetch.txt).  The XQ2018 source variant needs four registers more (131: it would lose the fourth
     // workgroup) and requests its cells group with the rest of the batch.  The ids the group depends on (ring cell, own
     // cell) run one tile further ahead.  Every rule of the quads' pipeline above applies to the loads in flight across phases.
-    constexpr bool PF = (SRC == 0) && LAY::fixed;  // the record layout (meshes without locality) would lose the fourth wave too: 130 - 137 VGPRs
+    constexpr bool PF = (SRC == 0);
     auto next_valid = [&](int i) -> int {
       if (a.phase == RDYHIP_PHASE_INTERIOR) {
         while (i < hi && tile_desc(tile_at(i)).halo()) i += step;
@@ -856,19 +735,18 @@ __global__ __launch_bounds__(TILE) void swe_rhs_muscl_fused_kernel(const KernelA
     auto tile_ids = [&](int i, int &c_, int &hid_) {
       const int      t_  = tile_at(i);
       const TileDesc d_  = tile_desc(t_);
-      const int      c0_ = load_uniform(g.c_off, t_);
-      hid_               = ring_id(d_, d_.nh(), c0_, load_uniform(g.c_off, t_ + 1) - c0_);
-      const int o_       = t_ * TILE + tid;
-      c_                 = (a.o2l && o_ < a.n_owned) ? a.o2l[o_] : o_;
+      const int      c0_ = load_uniform(g.r2_off, t_);
+      hid_               = ring_id(d_, d_.nh(), c0_, load_uniform(g.r2_off, t_ + 1) - c0_);
+      const int o_       = d_.c_off + tid;
+      c_                 = (a.o2l && tid < d_.nc()) ? a.o2l[o_] : o_;
     };
-    auto issue_cells = [&](int t_, int c_, int hid_) {
-      const int o_ = t_ * TILE + tid;
+    auto issue_cells = [&](const TileDesc &d_, int c_, int hid_) {
 #pragma unroll
       for (int k = 0; k < 3; ++k) q[k] = 0.0;
       cxy = make_double2(0.0, 0.0);
-      int nown = a.n_owned;
+      int nown = d_.nc();
       asm volatile("" : "+s"(nown));
-      if (o_ < nown) {
+      if (tid < nown) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) q[k] = u[3 * (int64_t)c_ + k];
         cxy = *reinterpret_cast<const double2 *>(g.cxy + 2 * (int64_t)c_);
@@ -886,7 +764,7 @@ __global__ __launch_bounds__(TILE) void swe_rhs_muscl_fused_kernel(const KernelA
       asm volatile("" ::"v"(hid1), "v"(c1));
       idx1 = next_valid(idx + step);
       if (PF) {
-        issue_cells(tile_at(idx), c1, hid1);
+        issue_cells(tile_desc(tile_at(idx)), c1, hid1);
         c1   = 0;
         hid1 = -1;
         if (idx1 < hi) tile_ids(idx1, c1, hid1);
@@ -897,15 +775,15 @@ __global__ __launch_bounds__(TILE) void swe_rhs_muscl_fused_kernel(const KernelA
       const int      tile = tile_at(idx);
       const TileDesc td = tile_desc(tile);
       const int  ne = td.ne(), nh = td.nh();
-      const int  c0 = load_uniform(g.c_off, tile), nc2 = load_uniform(g.c_off, tile + 1) - c0;
-      const int  o      = tile * TILE + tid;
-      const bool active = o < a.n_owned;
+      const int  c0 = load_uniform(g.r2_off, tile), nc2 = load_uniform(g.r2_off, tile + 1) - c0;
+      const int  o      = td.c_off + tid;
+      const bool active = tid < td.nc();
       const int  hid    = (tid < nh + nc2) ? 0 : -1;  // does this thread stage a ring cell
       int idx2 = hi, c2 = 0, hid2 = -1;
 
       __builtin_amdgcn_s_setprio(3);
       if (!PF) {
-        issue_cells(tile, c1, hid1);
+        issue_cells(td, c1, hid1);
         if (idx1 < hi) {
           tile_ids(idx1, c2, hid2);
           idx2 = next_valid(idx1 + step);
@@ -919,9 +797,9 @@ __global__ __launch_bounds__(TILE) void swe_rhs_muscl_fused_kernel(const KernelA
       // unconditional loads with clamped indices (a tile has edges; lanes past the end read the last record, unused): a
       // lane-conditional load costs register copies of the loaded value at its merge -- and a wait in the middle of the batch
       if (S == 3) {
-        r0 = RDY_MLD(&reinterpret_cast<const uint32_t *>(a.slot_ref)[active ? o : a.n_owned - 1]);
+        r0 = RDY_MLD(&reinterpret_cast<const uint32_t *>(a.slot_ref)[active ? o : td.c_off]);
       } else {
-        const uint2 w = load_u2(reinterpret_cast<const uint2 *>(a.slot_ref) + (active ? o : a.n_owned - 1));
+        const uint2 w = load_u2(reinterpret_cast<const uint2 *>(a.slot_ref) + (active ? o : td.c_off));
         r0            = w.x;
         r1            = w.y;
       }
@@ -948,16 +826,8 @@ __global__ __launch_bounds__(TILE) void swe_rhs_muscl_fused_kernel(const KernelA
         MSQ(3, TILE + tid) = hcxy.x;
         MSQ(4, TILE + tid) = hcxy.y;
       }
-      for (int j = tid + TILE; j < nh + nc2; j += TILE) {  // only numberings with poor locality get here
-        const int hc = (j < nh) ? a.hcells[td.h_off + j] : g.hcells2[c0 + j - nh];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) MSQ(k, TILE + j) = u[3 * (int64_t)hc + k];
-        MSQ(3, TILE + j) = g.cxy[2 * (int64_t)hc];
-        MSQ(4, TILE + j) = g.cxy[2 * (int64_t)hc + 1];
-      }
       if (tid < ne) slr[tid] = lr0;
       if (tid + TILE < ne) slr[tid + TILE] = lr1;
-      for (int e = tid + 2 * TILE; e < ne; e += TILE) slr[e] = a.e_lr[td.e_off + e];
       // the top batch has arrived on EVERY path before the next tile's cells are requested (the waits above sit inside
       // lane-conditional branches; a register still "pending" on a skipped path costs a vmcnt(0) at its next use)
       asm volatile("" ::"v"(r0), "v"(bw.x), "v"(bw.y), "v"(lr0), "v"(lr1), "v"(cs0), "v"(cs1), "v"(md0.x), "v"(md0.y), "v"(md1.x), "v"(md1.y));
@@ -966,7 +836,7 @@ __global__ __launch_bounds__(TILE) void swe_rhs_muscl_fused_kernel(const KernelA
         __builtin_amdgcn_s_setprio(3);
         idx2 = next_valid(idx1 + step);
         if (idx2 < hi) tile_ids(idx2, c2, hid2);
-        issue_cells(tile_at(idx1), c1, hid1);
+        issue_cells(tile_desc(tile_at(idx1)), c1, hid1);
         __builtin_amdgcn_s_setprio(0);
       }
 
@@ -1007,21 +877,19 @@ __global__ __launch_bounds__(TILE) void swe_rhs_muscl_fused_kernel(const KernelA
           for (int k = 0; k < 6; ++k) MSG(k, TILE + j) = hg[k];
         };
         if (tid < nh) ring_gradient(tid, bw);
-        for (int j = tid + TILE; j < nh; j += TILE)  // poor locality only
-          ring_gradient(j, reinterpret_cast<const uint2 *>(g.bn_idx)[(int64_t)td.h_off + j]);
       }
       __syncthreads();
 
       // ---- phase 1: every edge of the tile once
       auto do_edge = [&](uint32_t lr, double cs, double2 mid) -> EdgeFlux {
-        return muscl_edge<LIM, LAY>(a, td, dt, lr, cs, mid, sq, sg);
+        return muscl_edge<LIM, LAY>(a, tile, dt, lr, cs, mid, sq, sg);
       };
       // the two register-resident rounds one after the other (no per-value selects between the rounds' registers); the
       // scheduling barrier keeps the compiler from interleaving them, which would double the live registers
       auto request_streams = [&]() {
         // unconditional (cells past the end read the last owned cell's, unused): a branch here costs register copies of
         // loaded values at its merge, and with them a wait for the streams right where they are requested
-        const int oc = active ? o : a.n_owned - 1;
+        const int oc = active ? o : td.c_off;
 #pragma unroll
         for (int s = 0; s < S; ++s) kf[s] = RDY_MLD(&a.coef[s * a.stride + oc]);
         dzx  = RDY_MLD(&a.dzdx[oc]);
@@ -1033,30 +901,16 @@ __global__ __launch_bounds__(TILE) void swe_rhs_muscl_fused_kernel(const KernelA
       };
       EdgeFlux x0 = {0.0, 0.0, 0.0, -1.0}, x1 = x0;
       if (tid < ne) x0 = do_edge(lr0, cs0, md0);
-      if (!EFO && tid < ne) store_edge_flux<LAY>(a, ef, tid, x0);
       __builtin_amdgcn_sched_barrier(0);
       if (tid + TILE < ne) x1 = do_edge(lr1, cs1, md1);
-      if (!EFO && tid + TILE < ne) store_edge_flux<LAY>(a, ef, tid + TILE, x1);
-      EdgeFlux x2 = {0.0, 0.0, 0.0, -1.0};
-      if (!EFO) {
-        for (int e = tid + 2 * TILE; e < ne; e += TILE)  // not slr: the fluxes overwrite it
-          store_edge_flux<LAY>(a, ef, e, do_edge(a.e_lr[td.e_off + e], a.e_cs[td.e_off + e], *reinterpret_cast<const double2 *>(g.e_mid + 2 * ((int64_t)td.e_off + e))));
-      } else if (S == 4) {  // quads in the record layout: the third round (EFO: emax <= 3 TILE) loads its records here
-        __builtin_amdgcn_sched_barrier(0);
-        const int e = tid + 2 * TILE;
-        if (e < ne) x2 = do_edge(a.e_lr[td.e_off + e], a.e_cs[td.e_off + e], *reinterpret_cast<const double2 *>(g.e_mid + 2 * ((int64_t)td.e_off + e)));
-      }
       // the per-cell streams of phase 2 are requested only here: held from the tile's top they would cost 18 registers
       // through the edge phase; the barriers and the flux stores below cover part of their latency, the other resident
       // workgroups the rest (requested between the two edge rounds instead: 123 VGPRs, no gain --
       // profiles/r03_ab_muscl_mid_streams.txt)
       request_streams();
-      if (EFO) {
-        __syncthreads();  // every edge has read its gradients: the fluxes may overwrite them
-        if (tid < ne) store_edge_flux<LAY>(a, ef, tid, x0);
-        if (tid + TILE < ne) store_edge_flux<LAY>(a, ef, tid + TILE, x1);
-        if (S == 4 && tid + 2 * TILE < ne) store_edge_flux<LAY>(a, ef, tid + 2 * TILE, x2);
-      }
+      __syncthreads();  // every edge has read its gradients: the fluxes may overwrite them
+      if (tid < ne) store_edge_flux<LAY>(a, ef, tid, x0);
+      if (tid + TILE < ne) store_edge_flux<LAY>(a, ef, tid + TILE, x1);
       __syncthreads();
 
       // ---- phase 2: per-cell sum in the reference's edge order, source terms, stores
@@ -1070,7 +924,7 @@ __global__ __launch_bounds__(TILE) void swe_rhs_muscl_fused_kernel(const KernelA
           acc1 = f[3 * (int64_t)o + 1];
           acc2 = f[3 * (int64_t)o + 2];
         }
-        muscl_cell_sum<S, LAY>(a, r0, r1, kf, ef, dt, o, acc0, acc1, acc2, best, best_slot, best_o);
+        muscl_cell_sum<S, LAY>(a, r0, r1, kf, ef, dt, td.e_off, acc0, acc1, acc2, trk);
         const RiemannSide self = riemann_side(h, hu, hv, a.tiny_h, a.h_anuga_sq);
         pu                     = self.u;
         pv_                    = self.v;
@@ -1079,7 +933,7 @@ __global__ __launch_bounds__(TILE) void swe_rhs_muscl_fused_kernel(const KernelA
       {  // whole-line stores of the [cell][3] rows (wave_store_rows3, swe_kernels.h); all 64 lanes take part
         const int     lane  = tid & 63;
         const int64_t base  = 3 * ((int64_t)o - lane);
-        const int     ncell = a.n_owned - (o - lane);
+        const int     ncell = td.nc() - (tid - lane);  // the wave's cells of this tile
         if (a.fdiv) wave_store_rows3(a.fdiv, base, lane, ncell, acc0, acc1, acc2);
         if (!EULER || f) wave_store_rows3(f, base, lane, ncell, res[0], res[1], res[2]);
         wave_store_rows3(a.pv, base, lane, ncell, h, pu, pv_);
@@ -1104,7 +958,8 @@ __global__ __launch_bounds__(TILE) void swe_rhs_muscl_fused_kernel(const KernelA
     }
 
   }
-  block_courant_reduce<TILE>(a, best, best_slot, best_o);
+  courant_extra_edges_muscl<LIM>(a, g, dt, u, trk);
+  block_courant_reduce<TILE>(a, trk.best, RDY_COLD(a, e_pos), trk.rec);
 }
 
 }  // namespace rdyhip

@@ -126,13 +126,6 @@ struct RDyHipOperator_s {
   RDyHipConfig config;
   RDyHipHalo_s *fused_halo = nullptr;  // the halo whose send lists are attached to the tile descriptors (rdyhip_halo_fuse_pack)
   std::vector<int32_t> h_l2o;          // local -> owned cell id, kept only when the owned cells are not a prefix
-  // the signalled form of the multi-rank Euler step (halo_exchange.h): launches that store all send rows count themselves
-  // on the device (wave_signal_send_rows); this is the host's copy of that count, and the tile list that puts the
-  // send-flagged tiles of every XCD chunk first
-  uint64_t        send_epoch = 0;
-  bool            send_signalling = false;
-  int             signalled_shrink = 64;   // a signalled launch leaves 1/signalled_shrink of the workgroup slots to the transfer's kernel (0: none)
-  DevBuf<int32_t> d_tiles_send_first;
   int          device = 0;
   int32_t      n_cells = 0, n_owned = 0, S = 3, K = 0, n_internal = 0;
   int64_t      stride = 0;
@@ -153,7 +146,6 @@ struct RDyHipOperator_s {
   // tiled kernel (swe_kernels.h)
   bool             use_tiled = true;
   bool             hr = false;   // hydrostatic reconstruction
-  bool             lds_fixed = false;  // first-order tiled kernel: compile-time LDS plane lengths (TILED_NS_* / TILED_NE_*)
   bool             uout_cached = false;  // Euler-step kernels store u_out with the default cache policy: the state fits the Infinity Cache
   DevBuf<double>   d_zc_local;
   int32_t          ntiles = 0, n_halo_tiles = 0, emax = 0;
@@ -163,15 +155,16 @@ struct RDyHipOperator_s {
   size_t           lds_bytes = 0;
   DevBuf<TileDesc> d_tiles;
   DevBuf<uint32_t> d_e_lr;
-  DevBuf<int32_t>  d_hcells, d_tile_bk, d_halo_tiles;
+  DevBuf<int32_t>  d_hcells, d_tile_bk, d_tile_boff, d_halo_tiles, d_e_pos, d_x_lr;
+  DevBuf<uint32_t> d_x_flags;
+  DevBuf<double>   d_x_cs, d_x_cfac, d_x_mid;
+  int32_t          n_xedges = 0;
+  std::vector<int32_t> h_tile_c0;  // [ntiles + 1] first owned cell of each tile (the fused pack's send lists are built per tile)
   DevBuf<double>   d_e_cs;
   DevBuf<uint16_t> d_slot_ref;   // S == 4
   DevBuf<uint32_t> d_slot_ref3;  // S == 3
   // second order (muscl_kernels.h)
   bool             muscl = false;
-  bool             muscl_fused = true;  // gradients formed in LDS by the flux kernel (RDYHIP_MUSCL=split: separate gradient launch)
-  bool             muscl_efo   = false; // fused form: edge fluxes stored over the gradients (layout_build)
-  bool             muscl_soa   = false; // fused form: fixed-capacity plane layout in LDS (MusclSoATri)
   DevBuf<double>   d_grad, d_e_mid, d_cxy;
   DevBuf<int32_t>  d_hcells2, d_c_off;
   DevBuf<uint16_t> d_bn_idx;
@@ -197,7 +190,8 @@ struct RDyHipOperator_s {
     d_mannings.release(); d_extsrc.release(); d_bvalues.release(); d_bflux.release();
     d_baccum.release(); d_bcn.release(); d_bsn.release(); d_pv.release(); d_fdiv.release(); d_blk_max.release();
     d_blk_pos.release(); d_courant.release(); d_cold.release(); d_stage_vals.release(); d_stage_ids.release(); d_scratch_f.release();
-    d_tiles.release(); d_e_lr.release(); d_hcells.release(); d_tile_bk.release(); d_halo_tiles.release(); d_tiles_send_first.release();
+    d_tiles.release(); d_e_lr.release(); d_e_pos.release(); d_x_lr.release(); d_x_flags.release(); d_x_cs.release(); d_x_cfac.release(); d_x_mid.release();
+    d_hcells.release(); d_tile_bk.release(); d_tile_boff.release(); d_halo_tiles.release();
     d_e_cs.release(); d_slot_ref.release(); d_slot_ref3.release(); d_zc_local.release();
     d_grad.release(); d_e_mid.release(); d_cxy.release(); d_hcells2.release(); d_c_off.release();
     d_bn_idx.release();
@@ -212,124 +206,50 @@ using TiledKernelFn = void (*)(const KernelArgs, const double, const double *, d
 void halo_forget_packed_state(RDyHipHalo_s *h);   // halo_exchange.h
 void halo_operator_gone(RDyHipHalo_s *h);
 
-// the instantiation of the tiled kernel for (slots per cell, source method, overwrite, HR, fixed LDS plane lengths)
-template <bool HR, int NS3, int NE3, int NS4, int NE4>
+// the instantiation of the tiled kernel for (slots per cell, source method, overwrite, HR, F stored with / without the hint)
+template <bool HR, bool FNT>
 TiledKernelFn tiled_kernel_fn_hr(int S, int src, bool ovw) {
   if (S == 3) {
-    if (src) return ovw ? swe_rhs_tiled_kernel<3, 1, true, HR, false, NS3, NE3> : swe_rhs_tiled_kernel<3, 1, false, HR, false, NS3, NE3>;
-    return ovw ? swe_rhs_tiled_kernel<3, 0, true, HR, false, NS3, NE3> : swe_rhs_tiled_kernel<3, 0, false, HR, false, NS3, NE3>;
+    if (src) return ovw ? swe_rhs_tiled_kernel<3, 1, true, HR, false, FNT> : swe_rhs_tiled_kernel<3, 1, false, HR, false, FNT>;
+    return ovw ? swe_rhs_tiled_kernel<3, 0, true, HR, false, FNT> : swe_rhs_tiled_kernel<3, 0, false, HR, false, FNT>;
   }
-  if (src) return ovw ? swe_rhs_tiled_kernel<4, 1, true, HR, false, NS4, NE4> : swe_rhs_tiled_kernel<4, 1, false, HR, false, NS4, NE4>;
-  return ovw ? swe_rhs_tiled_kernel<4, 0, true, HR, false, NS4, NE4> : swe_rhs_tiled_kernel<4, 0, false, HR, false, NS4, NE4>;
+  if (src) return ovw ? swe_rhs_tiled_kernel<4, 1, true, HR, false, FNT> : swe_rhs_tiled_kernel<4, 1, false, HR, false, FNT>;
+  return ovw ? swe_rhs_tiled_kernel<4, 0, true, HR, false, FNT> : swe_rhs_tiled_kernel<4, 0, false, HR, false, FNT>;
 }
-// F stored without the non-temporal hint (RDYHIP_CONFIG_CACHED_F_STORES): the fixed LDS layout's instantiations only
-template <bool HR>
-TiledKernelFn tiled_kernel_fn_cached(int S, int src, bool ovw) {
-  if (S == 3) {
-    if (src) return ovw ? swe_rhs_tiled_kernel<3, 1, true, HR, false, TILED_NS_TRI, TILED_NE_TRI, false> : swe_rhs_tiled_kernel<3, 1, false, HR, false, TILED_NS_TRI, TILED_NE_TRI, false>;
-    return ovw ? swe_rhs_tiled_kernel<3, 0, true, HR, false, TILED_NS_TRI, TILED_NE_TRI, false> : swe_rhs_tiled_kernel<3, 0, false, HR, false, TILED_NS_TRI, TILED_NE_TRI, false>;
-  }
-  if (src) return ovw ? swe_rhs_tiled_kernel<4, 1, true, HR, false, TILED_NS_QUAD, TILED_NE_QUAD, false> : swe_rhs_tiled_kernel<4, 1, false, HR, false, TILED_NS_QUAD, TILED_NE_QUAD, false>;
-  return ovw ? swe_rhs_tiled_kernel<4, 0, true, HR, false, TILED_NS_QUAD, TILED_NE_QUAD, false> : swe_rhs_tiled_kernel<4, 0, false, HR, false, TILED_NS_QUAD, TILED_NE_QUAD, false>;
+TiledKernelFn tiled_kernel_fn(int S, int src, bool ovw, bool hr, bool cached_f = false) {
+  if (cached_f) return hr ? tiled_kernel_fn_hr<true, false>(S, src, ovw) : tiled_kernel_fn_hr<false, false>(S, src, ovw);
+  return hr ? tiled_kernel_fn_hr<true, true>(S, src, ovw) : tiled_kernel_fn_hr<false, true>(S, src, ovw);
 }
-TiledKernelFn tiled_kernel_fn(int S, int src, bool ovw, bool hr, bool fixed = false, bool cached_f = false) {
-  if (fixed && cached_f) return hr ? tiled_kernel_fn_cached<true>(S, src, ovw) : tiled_kernel_fn_cached<false>(S, src, ovw);
-  if (fixed)
-    return hr ? tiled_kernel_fn_hr<true, TILED_NS_TRI, TILED_NE_TRI, TILED_NS_QUAD, TILED_NE_QUAD>(S, src, ovw)
-              : tiled_kernel_fn_hr<false, TILED_NS_TRI, TILED_NE_TRI, TILED_NS_QUAD, TILED_NE_QUAD>(S, src, ovw);
-  return hr ? tiled_kernel_fn_hr<true, 0, 0, 0, 0>(S, src, ovw) : tiled_kernel_fn_hr<false, 0, 0, 0, 0>(S, src, ovw);
-}
-// the instantiation with the forward-Euler update fused into the stores (rdyhip_euler_step)
-template <bool HR, int NS3, int NE3, int NS4, int NE4>
+// the instantiation with the forward-Euler update fused into the stores (rdyhip_euler_step); FNT = false: plain (cached)
+// stores of u_out, for states that fit the Infinity Cache
+template <bool HR, bool FNT>
 TiledKernelFn tiled_euler_fn_hr(int S, int src) {
-  if (S == 3) return src ? swe_rhs_tiled_kernel<3, 1, true, HR, true, NS3, NE3> : swe_rhs_tiled_kernel<3, 0, true, HR, true, NS3, NE3>;
-  return src ? swe_rhs_tiled_kernel<4, 1, true, HR, true, NS4, NE4> : swe_rhs_tiled_kernel<4, 0, true, HR, true, NS4, NE4>;
+  if (S == 3) return src ? swe_rhs_tiled_kernel<3, 1, true, HR, true, FNT> : swe_rhs_tiled_kernel<3, 0, true, HR, true, FNT>;
+  return src ? swe_rhs_tiled_kernel<4, 1, true, HR, true, FNT> : swe_rhs_tiled_kernel<4, 0, true, HR, true, FNT>;
 }
-// ... and with plain (cached) stores of u_out, for states that fit the Infinity Cache (fixed LDS layout only, as for cached F)
-template <bool HR>
-TiledKernelFn tiled_euler_fn_cached(int S, int src) {
-  if (S == 3) return src ? swe_rhs_tiled_kernel<3, 1, true, HR, true, TILED_NS_TRI, TILED_NE_TRI, false> : swe_rhs_tiled_kernel<3, 0, true, HR, true, TILED_NS_TRI, TILED_NE_TRI, false>;
-  return src ? swe_rhs_tiled_kernel<4, 1, true, HR, true, TILED_NS_QUAD, TILED_NE_QUAD, false> : swe_rhs_tiled_kernel<4, 0, true, HR, true, TILED_NS_QUAD, TILED_NE_QUAD, false>;
-}
-TiledKernelFn tiled_euler_fn(int S, int src, bool hr, bool fixed = false, bool uout_cached = false) {
-  if (fixed && uout_cached) return hr ? tiled_euler_fn_cached<true>(S, src) : tiled_euler_fn_cached<false>(S, src);
-  if (fixed)
-    return hr ? tiled_euler_fn_hr<true, TILED_NS_TRI, TILED_NE_TRI, TILED_NS_QUAD, TILED_NE_QUAD>(S, src)
-              : tiled_euler_fn_hr<false, TILED_NS_TRI, TILED_NE_TRI, TILED_NS_QUAD, TILED_NE_QUAD>(S, src);
-  return hr ? tiled_euler_fn_hr<true, 0, 0, 0, 0>(S, src) : tiled_euler_fn_hr<false, 0, 0, 0, 0>(S, src);
+TiledKernelFn tiled_euler_fn(int S, int src, bool hr, bool uout_cached = false) {
+  if (uout_cached) return hr ? tiled_euler_fn_hr<true, false>(S, src) : tiled_euler_fn_hr<false, false>(S, src);
+  return hr ? tiled_euler_fn_hr<true, true>(S, src) : tiled_euler_fn_hr<false, true>(S, src);
 }
 
 using MusclKernelFn = void (*)(const KernelArgs, const MusclArgs, const double, const double *, double *);
 
-template <int LIM>
-MusclKernelFn muscl_kernel_fn_lim(int S, int src, bool ovw) {
-  if (S == 3) {
-    if (src) return ovw ? swe_rhs_muscl_kernel<3, 1, true, LIM> : swe_rhs_muscl_kernel<3, 1, false, LIM>;
-    return ovw ? swe_rhs_muscl_kernel<3, 0, true, LIM> : swe_rhs_muscl_kernel<3, 0, false, LIM>;
-  }
-  if (src) return ovw ? swe_rhs_muscl_kernel<4, 1, true, LIM> : swe_rhs_muscl_kernel<4, 1, false, LIM>;
-  return ovw ? swe_rhs_muscl_kernel<4, 0, true, LIM> : swe_rhs_muscl_kernel<4, 0, false, LIM>;
+template <int S, int LIM>
+MusclKernelFn muscl_fn_lim(int src, bool ovw, bool euler) {
+  if (euler) return src ? swe_rhs_muscl_fused_kernel<S, 1, true, LIM, true> : swe_rhs_muscl_fused_kernel<S, 0, true, LIM, true>;
+  if (src) return ovw ? swe_rhs_muscl_fused_kernel<S, 1, true, LIM, false> : swe_rhs_muscl_fused_kernel<S, 1, false, LIM, false>;
+  return ovw ? swe_rhs_muscl_fused_kernel<S, 0, true, LIM, false> : swe_rhs_muscl_fused_kernel<S, 0, false, LIM, false>;
 }
-template <int LIM, bool EFO>
-MusclKernelFn muscl_fused_fn_lim(int S, int src, bool ovw) {
-  if (S == 3) {
-    if (src) return ovw ? swe_rhs_muscl_fused_kernel<3, 1, true, LIM, false, EFO> : swe_rhs_muscl_fused_kernel<3, 1, false, LIM, false, EFO>;
-    return ovw ? swe_rhs_muscl_fused_kernel<3, 0, true, LIM, false, EFO> : swe_rhs_muscl_fused_kernel<3, 0, false, LIM, false, EFO>;
-  }
-  if (src) return ovw ? swe_rhs_muscl_fused_kernel<4, 1, true, LIM, false, EFO> : swe_rhs_muscl_fused_kernel<4, 1, false, LIM, false, EFO>;
-  return ovw ? swe_rhs_muscl_fused_kernel<4, 0, true, LIM, false, EFO> : swe_rhs_muscl_fused_kernel<4, 0, false, LIM, false, EFO>;
-}
-template <int LIM, bool EFO>
-MusclKernelFn muscl_fused_euler_fn_lim(int S, int src) {
-  if (S == 3) return src ? swe_rhs_muscl_fused_kernel<3, 1, true, LIM, true, EFO> : swe_rhs_muscl_fused_kernel<3, 0, true, LIM, true, EFO>;
-  return src ? swe_rhs_muscl_fused_kernel<4, 1, true, LIM, true, EFO> : swe_rhs_muscl_fused_kernel<4, 0, true, LIM, true, EFO>;
-}
-template <bool EFO>
-MusclKernelFn muscl_fused_euler_fn_e(int S, int src, int limiter) {
+template <int S>
+MusclKernelFn muscl_fn_s(int src, bool ovw, bool euler, int limiter) {
   switch (limiter) {
-    case RDYHIP_LIMITER_NONE: return muscl_fused_euler_fn_lim<LIMITER_NONE, EFO>(S, src);
-    case RDYHIP_LIMITER_VANLEER: return muscl_fused_euler_fn_lim<LIMITER_VANLEER, EFO>(S, src);
-    default: return muscl_fused_euler_fn_lim<LIMITER_MINMOD, EFO>(S, src);
+    case RDYHIP_LIMITER_NONE: return muscl_fn_lim<S, LIMITER_NONE>(src, ovw, euler);
+    case RDYHIP_LIMITER_VANLEER: return muscl_fn_lim<S, LIMITER_VANLEER>(src, ovw, euler);
+    default: return muscl_fn_lim<S, LIMITER_MINMOD>(src, ovw, euler);
   }
 }
-// the fixed-capacity plane layouts (MusclSoATri / MusclSoAQuad, muscl_kernels.h): edge fluxes over the gradients
-template <int S, class LAY, int LIM>
-MusclKernelFn muscl_soa_fn_lim(int src, bool ovw, bool euler) {
-  if (euler) return src ? swe_rhs_muscl_fused_kernel<S, 1, true, LIM, true, true, LAY> : swe_rhs_muscl_fused_kernel<S, 0, true, LIM, true, true, LAY>;
-  if (src) return ovw ? swe_rhs_muscl_fused_kernel<S, 1, true, LIM, false, true, LAY> : swe_rhs_muscl_fused_kernel<S, 1, false, LIM, false, true, LAY>;
-  return ovw ? swe_rhs_muscl_fused_kernel<S, 0, true, LIM, false, true, LAY> : swe_rhs_muscl_fused_kernel<S, 0, false, LIM, false, true, LAY>;
-}
-template <int S, class LAY>
-MusclKernelFn muscl_soa_fn_s(int src, bool ovw, bool euler, int limiter) {
-  switch (limiter) {
-    case RDYHIP_LIMITER_NONE: return muscl_soa_fn_lim<S, LAY, LIMITER_NONE>(src, ovw, euler);
-    case RDYHIP_LIMITER_VANLEER: return muscl_soa_fn_lim<S, LAY, LIMITER_VANLEER>(src, ovw, euler);
-    default: return muscl_soa_fn_lim<S, LAY, LIMITER_MINMOD>(src, ovw, euler);
-  }
-}
-MusclKernelFn muscl_soa_fn(int S, int src, bool ovw, bool euler, int limiter) {
-  return S == 3 ? muscl_soa_fn_s<3, MusclSoATri>(src, ovw, euler, limiter) : muscl_soa_fn_s<4, MusclSoAQuad>(src, ovw, euler, limiter);
-}
-MusclKernelFn muscl_fused_euler_fn(int S, int src, int limiter, bool efo, bool soa = false) {
-  if (soa) return muscl_soa_fn(S, src, true, true, limiter);
-  return efo ? muscl_fused_euler_fn_e<true>(S, src, limiter) : muscl_fused_euler_fn_e<false>(S, src, limiter);
-}
-template <bool EFO>
-MusclKernelFn muscl_fused_fn_e(int S, int src, bool ovw, int limiter) {
-  switch (limiter) {
-    case RDYHIP_LIMITER_NONE: return muscl_fused_fn_lim<LIMITER_NONE, EFO>(S, src, ovw);
-    case RDYHIP_LIMITER_VANLEER: return muscl_fused_fn_lim<LIMITER_VANLEER, EFO>(S, src, ovw);
-    default: return muscl_fused_fn_lim<LIMITER_MINMOD, EFO>(S, src, ovw);
-  }
-}
-MusclKernelFn muscl_kernel_fn(int S, int src, bool ovw, int limiter, bool fused, bool efo, bool soa = false) {
-  if (fused && soa) return muscl_soa_fn(S, src, ovw, false, limiter);
-  if (fused) return efo ? muscl_fused_fn_e<true>(S, src, ovw, limiter) : muscl_fused_fn_e<false>(S, src, ovw, limiter);
-  switch (limiter) {
-    case RDYHIP_LIMITER_NONE: return muscl_kernel_fn_lim<LIMITER_NONE>(S, src, ovw);
-    case RDYHIP_LIMITER_VANLEER: return muscl_kernel_fn_lim<LIMITER_VANLEER>(S, src, ovw);
-    default: return muscl_kernel_fn_lim<LIMITER_MINMOD>(S, src, ovw);
-  }
+MusclKernelFn muscl_kernel_fn(int S, int src, bool ovw, bool euler, int limiter) {
+  return S == 3 ? muscl_fn_s<3>(src, ovw, euler, limiter) : muscl_fn_s<4>(src, ovw, euler, limiter);
 }
 
 MusclArgs muscl_args(RDyHipOperator op) {
@@ -338,9 +258,8 @@ MusclArgs muscl_args(RDyHipOperator op) {
   g.e_mid = op->d_e_mid.p;
   g.cxy   = op->d_cxy.p;
   g.hcells2 = op->d_hcells2.p;
-  g.c_off   = op->d_c_off.p;
+  g.r2_off  = op->d_c_off.p;
   g.bn_idx  = op->d_bn_idx.p;
-  g.hmax2   = op->hmax2;
   return g;
 }
 
@@ -360,6 +279,9 @@ int launch_gradients(RDyHipOperator op, int32_t phase, const double *u, hipStrea
   int grid;
   if (phase == RDYHIP_PHASE_HALO) {
     if (op->n_halo == 0) return 0;
+    // with a fused pack attached this launch stores gradient rows into the halo's send buffer (ColdArgs::gsend_*):
+    // whatever state rows it mirrored are gone
+    if (op->fused_halo) halo_forget_packed_state(op->fused_halo);
     a.list       = op->d_halo_list.p;
     a.n_work     = op->n_halo;
     a.xcd_chunks = 0;
@@ -382,14 +304,14 @@ int launch_gradients(RDyHipOperator op, int32_t phase, const double *u, hipStrea
 // ordinary launch); 1 / 2: the first / second half, for the interior and the halo launch of rdyhip_rhs_overlapped, which
 // run side by side on two streams and must not share a bucket
 int launch_rhs(RDyHipOperator op, int32_t phase, int32_t overwrite, int reset_diag, double dt, const double *u, double *f, hipStream_t st,
-               bool gradients_ready = false, double *u_out = nullptr, int bucket_half = 0, bool send_tiles_first = false) {
+               bool gradients_ready = false, double *u_out = nullptr, int bucket_half = 0) {
   if (!op) return fail(RDYHIP_ERR_USER, "null operator");
   // an Euler-step launch rewrites the attached halo's send buffer (tiles flagged TILE_SEND_FLAG): whatever it held is gone
   // (rdyhip_euler_step_overlapped notes the new content itself once its launches are enqueued)
   if (u_out && op->fused_halo) halo_forget_packed_state(op->fused_halo);
-  // rdyhip_euler_step: the first-order / HR tiled kernel has the update fused into its stores (F optional); the
-  // other kernels evaluate F (into a scratch vector if the caller wants none) and a separate update follows
-  const bool euler_fused = u_out && op->use_tiled && (!op->muscl || op->muscl_fused);
+  // rdyhip_euler_step: the tiled kernels have the update fused into their stores (F optional); the cell-centric
+  // kernel evaluates F (into a scratch vector if the caller wants none) and a separate update follows
+  const bool euler_fused = u_out && op->use_tiled;
   if (u_out && !euler_fused && !f && op->n_owned > 0) {
     if (!op->d_scratch_f.p) {
       int rc = op->d_scratch_f.alloc((size_t)3 * op->n_owned);
@@ -397,18 +319,11 @@ int launch_rhs(RDyHipOperator op, int32_t phase, int32_t overwrite, int reset_di
     }
     f = op->d_scratch_f.p;
   }
-  if (op->muscl && !gradients_ready && op->n_owned > 0 && op->muscl_fused) {
-    // fused kernel: only ghost cells' gradients are read from memory, and they have to come from the exchange
+  if (op->muscl && !gradients_ready && op->n_owned > 0) {
+    // only ghost cells' gradients are read from memory, and they have to come from the exchange (CommunicateCellGradients):
+    // rdyhip_compute_gradients(RDYHIP_PHASE_HALO), exchange of the ghost rows, then RDYHIP_PHASE_GRADIENTS_READY
     if (op->n_cells > op->n_owned || phase != RDYHIP_PHASE_ALL)
       return fail(RDYHIP_ERR_USER, "second_order with ghost cells or a phased apply needs RDYHIP_PHASE_GRADIENTS_READY (see rdyhip_compute_gradients)");
-  } else if (op->muscl && !gradients_ready && op->n_owned > 0) {
-    // the ghost cells' gradients come from their owners (CommunicateCellGradients): the caller has to run
-    // rdyhip_compute_gradients, exchange the ghost rows and pass RDYHIP_PHASE_GRADIENTS_READY
-    if (op->n_cells > op->n_owned || phase != RDYHIP_PHASE_ALL)
-      return fail(RDYHIP_ERR_USER, "second_order with ghost cells or a phased apply needs RDYHIP_PHASE_GRADIENTS_READY (see rdyhip_compute_gradients)");
-    if (!u) return fail(RDYHIP_ERR_USER, "null u_local / f_global");
-    int rc = launch_gradients(op, phase, u, st);
-    if (rc) return rc;
   }
   if (op->n_owned == 0) return reset_diag ? rdyhip_reset_diagnostics(op, (void *)st) : 0;  // a rank may own nothing (f_global is then empty)
   if (!u || (!f && !euler_fused)) return fail(RDYHIP_ERR_USER, "null u_local / f_global");
@@ -445,8 +360,6 @@ int launch_rhs(RDyHipOperator op, int32_t phase, int32_t overwrite, int reset_di
   a.hcells   = op->d_hcells.p;
   a.slot_ref = op->S == 3 ? (const void *)op->d_slot_ref3.p : (const void *)op->d_slot_ref.p;
   a.zc_local = op->d_zc_local.p;
-  a.emax     = op->emax;
-  a.hmax     = op->hmax;
 
   int        grid = 0;
   const bool xq = op->config.source_method == RDYHIP_SOURCE_IMPLICIT_XQ2018;
@@ -464,13 +377,11 @@ int launch_rhs(RDyHipOperator op, int32_t phase, int32_t overwrite, int reset_di
       a.phase      = RDYHIP_PHASE_ALL;  // the list already holds exactly the halo tiles
       grid         = std::min(pgrid, op->n_halo_tiles);
     } else {
-      a.list   = (send_tiles_first && phase == RDYHIP_PHASE_ALL) ? op->d_tiles_send_first.p : nullptr;  // same chunks, another order inside
+      a.list   = nullptr;
       a.n_work = op->ntiles;
       // While the interior phase runs, the halo exchange's pack / RCCL / unpack kernels need somewhere
       // to run: the persistent grid would otherwise fill every SIMD's register file for the whole launch.
-      // (the signalled step's launch likewise: the next step's transfer is meant to run BESIDE it, and a persistent grid that
-      // holds every slot until its last tile lets the RCCL kernel in only at its tail)
-      const int shrink = phase == RDYHIP_PHASE_INTERIOR ? op->interior_shrink : (a.list ? op->signalled_shrink : 0);
+      const int shrink = phase == RDYHIP_PHASE_INTERIOR ? op->interior_shrink : 0;
       const int pg     = shrink > 0 ? std::max(8, pgrid - std::max(8, pgrid / shrink)) : pgrid;
       if (op->tiled_xcd_chunks > 0) {
         a.xcd_chunks = op->tiled_xcd_chunks;
@@ -488,18 +399,14 @@ int launch_rhs(RDyHipOperator op, int32_t phase, int32_t overwrite, int reset_di
       }
     }
     if (op->muscl) {
-      MusclKernelFn kfn = euler_fused ? muscl_fused_euler_fn(op->S, xq ? 1 : 0, op->config.limiter, op->muscl_efo, op->muscl_soa)
-                                      : muscl_kernel_fn(op->S, xq ? 1 : 0, overwrite != 0, op->config.limiter, op->muscl_fused, op->muscl_efo, op->muscl_soa);
+      MusclKernelFn kfn = muscl_kernel_fn(op->S, xq ? 1 : 0, overwrite != 0, euler_fused, op->config.limiter);
       hipLaunchKernelGGL(HIP_KERNEL_NAME(kfn), dim3(grid), dim3(TILE), op->lds_muscl, st, a, muscl_args(op), dt, u, f);
     } else if (euler_fused) {
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(tiled_euler_fn(op->S, xq ? 1 : 0, op->hr, op->lds_fixed, op->uout_cached)), dim3(grid), dim3(TILE), op->lds_bytes, st, a, dt, u, f);
-      // this launch runs every send-flagged tile (they all have ghost neighbours: no INTERIOR launch touches one) and its
-      // last send wave will advance the device's count: the host's copy follows
-      if (op->send_signalling && phase != RDYHIP_PHASE_INTERIOR) ++op->send_epoch;
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(tiled_euler_fn(op->S, xq ? 1 : 0, op->hr, op->uout_cached)), dim3(grid), dim3(TILE), op->lds_bytes, st, a, dt, u, f);
     } else {
       const size_t lds = op->lds_bytes;
       const bool cached_f = (op->config.flags & RDYHIP_CONFIG_CACHED_F_STORES) != 0;
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(tiled_kernel_fn(op->S, xq ? 1 : 0, overwrite != 0, op->hr, op->lds_fixed, cached_f)), dim3(grid), dim3(TILE), lds, st, a, dt, u, f);
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(tiled_kernel_fn(op->S, xq ? 1 : 0, overwrite != 0, op->hr, cached_f)), dim3(grid), dim3(TILE), lds, st, a, dt, u, f);
     }
   } else {
     if (phase == RDYHIP_PHASE_HALO) {
@@ -545,12 +452,16 @@ int launch_rhs(RDyHipOperator op, int32_t phase, int32_t overwrite, int reset_di
 struct HostLayout {
   int32_t nc = 0, no = 0, ne = 0, ni = 0, K = 0, S = 3, ntiles = 0, emax = 0, hmax = 0, hmax2 = 0;
   int64_t stride = 0;
-  bool    prefix = true, hr_on = false, muscl_on = false, muscl_fused = true, muscl_efo = false, muscl_soa = false, lds_fixed = false;
+  bool    prefix = true, hr_on = false, muscl_on = false;
   size_t  lds_bytes = 0, lds_muscl = 0;
-  std::vector<int32_t>  o2l, boff, nbr, pos, btype, bleft, bedge, bghost, halo, hcells, tile_bk, halo_tiles, hcells2, c_off;
+  std::vector<int32_t>  o2l, boff, nbr, pos, btype, bleft, bedge, bghost, halo, hcells, tile_bk, tile_boff, tile_c0, halo_tiles, hcells2, c_off, e_pos;
   std::vector<double>   cn, sn, coef, bcn, bsn, e_cs, e_mid, dzdx, dzdy;
   std::vector<TileDesc> tiles;
   std::vector<uint32_t> e_lr;
+  // the extra Courant edges (ColdArgs::x_*): internal edges the owned cells' slots do not cover as the reference's loop does
+  std::vector<int32_t>  x_lr, x_pos;
+  std::vector<uint32_t> x_flags;
+  std::vector<double>   x_cs, x_cfac, x_mid;
   std::vector<uint16_t> slot_ref, bn_idx;
 };
 
@@ -703,28 +614,151 @@ static int layout_build_slots(const RDyHipConfig *config, const RDyHipMesh *mesh
   return 0;
 }
 
-// the tiles of 256 consecutive owned cells: edge records, halo-cell lists, boundary lists, slot references, and for the
-// second-order kernel the first-ring stencils and the second ring
-static int layout_build_tiles(const RDyHipMesh *mesh, HostLayout &L) {
+// Where the tiles end.  A tile is a run of consecutive owned cells, at most `max_cells` (<= TILE) of them, grown 16 cells
+// at a time (whole 128-byte lines of the [cell][3] outputs) while it fits the kernels' fixed capacities: TILE_MAX_REC edge
+// records (two register rounds of the edge phase), the halo-cell planes in LDS and, for second order, the two rings.  A run
+// also ends where the numbering jumps: when a tile of 64 cells or more meets 16 cells none of which shares an edge with it
+// (the next block of a block-wise numbering, the next row of a row-major one).  Any numbering is accepted; one without
+// locality gets small tiles (a random one: ~30 cells) and runs slowly, correctly.
+// Returns the first owned cell of every tile, [ntiles + 1].
+static std::vector<int32_t> layout_cut_tiles(const RDyHipMesh *mesh, const HostLayout &L, int32_t max_cells) {
+  const int32_t nc = L.nc, no = L.no, S = L.S, npos = L.ni + L.K;
+  const int64_t stride = L.stride;
+  const auto   &nbr = L.nbr;
+  const auto   &pos = L.pos;
+  const int32_t max_rec = TILE_MAX_REC, max_h1 = S == 3 ? TILE_MAX_HALO_TRI : TILE_MAX_HALO_QUAD;
+  const int32_t max_ring = S == 3 ? MUSCL_MAX_RING_TRI : MUSCL_MAX_RING_QUAD;
+  std::vector<int32_t> c0;
+  c0.reserve((size_t)no / 200 + 2);
+  // stamps: edge positions in the tile / in the candidate granule; cells in the first ring / candidates / second ring
+  std::vector<int32_t> emark((size_t)npos, -1), etry((size_t)npos, -1), r1mark((size_t)nc, -1), r1try((size_t)nc, -1), r2try((size_t)nc, -1);
+  std::vector<int32_t> r1, r1new;
+  int32_t stamp = 0, attempt = 0;
+  int32_t base = 0;
+  while (base < no) {
+    c0.push_back(base);
+    ++stamp;
+    r1.clear();
+    int32_t cells = 0, rec = 0;
+    int32_t gran = 16;
+    while (cells < max_cells && base + cells < no) {
+      const int32_t g = std::min(std::min(gran, max_cells - cells), no - (base + cells));
+      const int32_t lo = base, hi = base + cells + g;  // the tile with the granule: owned cells [lo, hi)
+      ++attempt;
+      int32_t newrec = 0, shared = 0;
+      r1new.clear();
+      for (int32_t o = base + cells; o < hi; ++o) {
+        for (int32_t sl = 0; sl < S; ++sl) {
+          const int64_t idx = (int64_t)sl * stride + o;
+          const int32_t id  = nbr[idx];
+          if (id == NBR_EMPTY) continue;
+          const int32_t p = pos[idx];
+          if (emark[p] == stamp) ++shared;
+          else if (etry[p] != attempt) {
+            etry[p] = attempt;
+            ++newrec;
+          }
+          if (id < 0) continue;  // boundary edge: no cell beyond it
+          const int32_t n  = id & NBR_MASK;
+          const int32_t on = mesh->cell_is_owned[n] ? mesh->cell_local_to_owned[n] : -1;
+          if (on >= lo && on < hi) continue;  // inside the tile
+          if (r1mark[n] != stamp && r1try[n] != attempt) {
+            r1try[n] = attempt;
+            r1new.push_back(n);
+          }
+        }
+      }
+      // first-ring cells the granule swallows
+      int32_t left = 0;
+      for (int32_t o = base + cells; o < hi; ++o)
+        if (r1mark[L.o2l[o]] == stamp) ++left;
+      const int32_t nh = (int32_t)r1.size() - left + (int32_t)r1new.size();
+      bool bad = rec + newrec > max_rec || nh > max_h1;
+      if (!bad && cells >= 64 && shared == 0 && g == 16) bad = true;  // the numbering jumps: end the tile here
+      if (!bad && L.muscl_on) {
+        // second ring: the other neighbours of the (owned) first-ring cells
+        int32_t n2 = 0;
+        auto ring2_of = [&](int32_t cell) {
+          if (!mesh->cell_is_owned[cell]) return;  // a ghost's stencil is on another rank
+          const int32_t ob = mesh->cell_local_to_owned[cell];
+          if (ob >= lo && ob < hi) return;          // swallowed by the granule
+          for (int32_t sl = 0; sl < S; ++sl) {
+            const int32_t id = nbr[(int64_t)sl * stride + ob];
+            if (id < 0) continue;
+            const int32_t n  = id & NBR_MASK;
+            const int32_t on = mesh->cell_is_owned[n] ? mesh->cell_local_to_owned[n] : -1;
+            if (on >= lo && on < hi) continue;
+            if ((r1mark[n] == stamp) || r1try[n] == attempt || r2try[n] == attempt) continue;
+            r2try[n] = attempt;
+            ++n2;
+          }
+        };
+        for (int32_t cell : r1) ring2_of(cell);
+        for (int32_t cell : r1new) ring2_of(cell);
+        // (a first-ring cell the granule swallows may still be counted as somebody's second-ring neighbour: it is inside
+        // the tile then, and the test above skips it)
+        bad = nh + n2 > max_ring;
+      }
+      if (bad) {
+        if (cells > 0) break;        // the granule starts the next tile
+        if (gran > 1) {              // not even one granule fits: cell by cell
+          gran = 1;
+          continue;
+        }
+        // a single cell always fits (S records, S halo cells, 3 S ring cells)
+      }
+      // accept
+      for (int32_t o = base + cells; o < hi; ++o)
+        for (int32_t sl = 0; sl < S; ++sl) {
+          const int64_t idx = (int64_t)sl * stride + o;
+          if (nbr[idx] != NBR_EMPTY) emark[pos[idx]] = stamp;
+        }
+      if (left > 0) {
+        size_t w = 0;
+        for (size_t i = 0; i < r1.size(); ++i) {
+          const int32_t cell = r1[i];
+          const int32_t on   = mesh->cell_is_owned[cell] ? mesh->cell_local_to_owned[cell] : -1;
+          if (on >= lo && on < hi) r1mark[cell] = -1;
+          else r1[w++] = cell;
+        }
+        r1.resize(w);
+      }
+      for (int32_t cell : r1new) {
+        r1mark[cell] = stamp;
+        r1.push_back(cell);
+      }
+      cells += g;
+      rec += newrec;
+    }
+    base += cells;
+  }
+  c0.push_back(no);
+  return c0;
+}
+
+// the tiles: edge records, halo-cell lists, boundary lists, slot references, and for the second-order kernel the
+// first-ring stencils and the second ring
+static int layout_build_tiles(const RDyHipConfig *config, const RDyHipMesh *mesh, HostLayout &L) {
   const int32_t nc = L.nc, no = L.no, ni = L.ni, S = L.S;
   const int64_t stride   = L.stride;
   const bool    muscl_on = L.muscl_on;
   const auto &nbr = L.nbr; const auto &pos = L.pos; const auto &bedge = L.bedge; const auto &bleft = L.bleft;
-  // ---- tiles of 256 consecutive owned cells: edge list, halo cells, boundary edges (tiled kernel) ----
-  const int32_t         ntiles = (no + TILE - 1) / TILE;
+  (void)config;
+  int32_t max_cells = TILE;
+  if (const char *e = getenv("RDYHIP_TILE_CELLS")) {  // measurement knob: the largest tile
+    if (atoi(e) > 0) max_cells = std::min<int32_t>(atoi(e), TILE);
+  }
+  std::vector<int32_t>  tile_c0 = layout_cut_tiles(mesh, L, max_cells);
+  const int32_t         ntiles = (int32_t)tile_c0.size() - 1;
   std::vector<TileDesc> tiles((size_t)ntiles + 1);
   std::vector<uint32_t> e_lr;
-  std::vector<int32_t>  hcells, tile_bk, halo_tiles;
+  std::vector<int32_t>  hcells, tile_bk, tile_boff((size_t)ntiles + 1, 0), halo_tiles, e_pos;
   std::vector<double>   e_cs, e_mid;
   std::vector<int32_t>  hslot2, touched2, hcells2, c_off;
   std::vector<uint16_t> bn_idx;
   int32_t               hmax2 = 0;
   std::vector<uint16_t> slot_ref((size_t)no * 4, SLOT_EMPTY);
   int32_t               emax = 0, hmax = 0;
-  // RDYHIP_EDGE_SORT: order of a tile's edge records -- 0: the reference's loop position (the edge numbering); 1: by the LDS
-  // slot of the left cell, then of the right one; 2: by the smaller of the two slots, then the larger
-  int edge_sort = 0;
-  if (const char *es = getenv("RDYHIP_EDGE_SORT")) edge_sort = atoi(es);
   {
     e_lr.reserve((size_t)no * 2);
     e_cs.reserve((size_t)no * 2);
@@ -737,7 +771,7 @@ static int layout_build_tiles(const RDyHipMesh *mesh, HostLayout &L) {
       c_off.assign((size_t)ntiles + 1, 0);
     }
     for (int32_t t = 0; t < ntiles; ++t) {
-      const int32_t base = t * TILE, cntc = std::min<int32_t>(TILE, no - base);
+      const int32_t base = tile_c0[t], cntc = tile_c0[t + 1] - base;
       items.clear();
       bool halo_tile = false;
       for (int32_t j = 0; j < cntc; ++j) {
@@ -751,7 +785,8 @@ static int layout_build_tiles(const RDyHipMesh *mesh, HostLayout &L) {
       std::sort(items.begin(), items.end());
       tiles[t].e_off = (int32_t)e_lr.size();
       tiles[t].h_off = (int32_t)hcells.size();
-      tiles[t].b_off = (int32_t)tile_bk.size();
+      tiles[t].c_off = base;
+      tile_boff[t]   = (int32_t)tile_bk.size();
       tiles[t].cnt   = halo_tile ? TILE_HALO_FLAG : 0u;   // the counts are filled in below
       if (halo_tile) halo_tiles.push_back(t);
       touched.clear();
@@ -806,48 +841,15 @@ static int layout_build_tiles(const RDyHipMesh *mesh, HostLayout &L) {
             e_cs.push_back(esn);
           }
           e_lr.push_back(lr);
+          e_pos.push_back(last);  // records of a tile are in loop order; across tiles only this table orders them
         }
         slot_ref[(size_t)(it.second >> 2) * 4 + (it.second & 3)] = (uint16_t)local;
       }
-      if (edge_sort && local + 1 > 1) {
-        // The order of a tile's records is free (a cell finds its edges through slot_ref, and sums them in slot = loop order):
-        // sorted by the LDS slot of the left cell, the 32 lanes of a ds_read_b64 group read ~20 consecutive slots of every
-        // left-side plane (duplicates broadcast) -- conflict-free -- instead of slots scattered like the edge numbering.
-        const int32_t n_rec = local + 1;
-        const size_t  r0    = (size_t)tiles[t].e_off;
-        std::vector<int32_t> order((size_t)n_rec), inv((size_t)n_rec);
-        for (int32_t i = 0; i < n_rec; ++i) order[i] = i;
-        auto key = [&](int32_t i) -> uint32_t {
-          const uint32_t lr = e_lr[r0 + i];
-          const uint32_t jl = lr & EDGE_SLOT_MASK, jr = (lr & EDGE_BOUNDARY) ? 0x7FFu : ((lr >> EDGE_R_SHIFT) & EDGE_SLOT_MASK);
-          return edge_sort == 2 ? ((std::min(jl, jr) << 11) | std::max(jl, jr)) : ((jl << 11) | jr);
-        };
-        std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return key(x) < key(y); });
-        std::vector<uint32_t> lr2((size_t)n_rec);
-        std::vector<double>   cs2((size_t)n_rec), mid2(muscl_on ? 2 * (size_t)n_rec : 0);
-        for (int32_t i = 0; i < n_rec; ++i) {
-          inv[order[i]] = i;
-          lr2[i]        = e_lr[r0 + order[i]];
-          cs2[i]        = e_cs[r0 + order[i]];
-          if (muscl_on) {
-            mid2[2 * (size_t)i]     = e_mid[2 * (r0 + order[i])];
-            mid2[2 * (size_t)i + 1] = e_mid[2 * (r0 + order[i]) + 1];
-          }
-        }
-        std::copy(lr2.begin(), lr2.end(), e_lr.begin() + r0);
-        std::copy(cs2.begin(), cs2.end(), e_cs.begin() + r0);
-        if (muscl_on) std::copy(mid2.begin(), mid2.end(), e_mid.begin() + 2 * r0);
-        for (int32_t j = 0; j < cntc; ++j)
-          for (int32_t sl = 0; sl < 4; ++sl) {
-            uint16_t &ref = slot_ref[(size_t)(base + j) * 4 + sl];
-            if (ref != SLOT_EMPTY) ref = (uint16_t)inv[ref];
-          }
-      }
+      int32_t nc2 = 0;
       if (muscl_on) {
         // fused second-order kernel: the stencil of every first-ring cell (LDS slots of its neighbours) and the tile's
         // second ring (neighbours of first-ring cells outside tile + ring 1)
         c_off[t]    = (int32_t)hcells2.size();
-        int32_t nc2 = 0;
         touched2.clear();
         for (int32_t b = 0; b < nh; ++b) {
           const int32_t cell  = hcells[(size_t)tiles[t].h_off + b];
@@ -881,28 +883,62 @@ static int layout_build_tiles(const RDyHipMesh *mesh, HostLayout &L) {
         }
         for (int32_t cell : touched2) hslot2[cell] = -1;
         hmax2 = std::max(hmax2, nh + nc2);
-        if (TILE + nh + nc2 >= (int32_t)BN_GLOBAL) return fail(RDYHIP_ERR_USER, "tile working set too large: the cell numbering has no locality");
         tiles[t].cnt = halo_tile ? TILE_HALO_FLAG : 0u;
         if (halo_tile && (halo_tiles.empty() || halo_tiles.back() != t)) halo_tiles.push_back(t);
       }
       for (int32_t cell : touched) hslot[cell] = -1;
-      // a tile has at most 4 x 256 edge records and as many halo cells: 11 bits each
-      if (local + 1 > 0x7FF || nh > 0x7FF) return fail(RDYHIP_ERR_ARG_SIZ, "tile %d: %d edge records / %d halo cells do not fit the tile descriptor", t, local + 1, nh);
-      tiles[t].cnt |= (uint32_t)(local + 1) | ((uint32_t)nh << 11);
+      // what layout_cut_tiles promised (the kernels' LDS planes and register rounds have exactly this room)
+      const int32_t cap_h1 = S == 3 ? TILE_MAX_HALO_TRI : TILE_MAX_HALO_QUAD, cap_ring = S == 3 ? MUSCL_MAX_RING_TRI : MUSCL_MAX_RING_QUAD;
+      if (cntc < 1 || cntc > TILE || local + 1 > TILE_MAX_REC || nh > cap_h1 || (muscl_on && nh + nc2 > cap_ring))
+        return fail(RDYHIP_ERR_LIB, "internal error: tile %d (%d cells, %d edge records, %d + %d ring cells) exceeds the kernels' capacities", t, cntc, local + 1, nh, nc2);
+      tiles[t].cnt |= (uint32_t)(local + 1) | ((uint32_t)nh << 11) | ((uint32_t)(cntc - 1) << 22);
       emax = std::max(emax, local + 1);
       hmax = std::max(hmax, nh);
       if ((int64_t)e_lr.size() > (int64_t)INT32_MAX - 4 * TILE) return fail(RDYHIP_ERR_ARG_SIZ, "too many tile edge records");
     }
     tiles[ntiles].e_off = (int32_t)e_lr.size();
     tiles[ntiles].h_off = (int32_t)hcells.size();
-    tiles[ntiles].b_off = (int32_t)tile_bk.size();
+    tiles[ntiles].c_off = no;
+    tile_boff[ntiles]   = (int32_t)tile_bk.size();
     tiles[ntiles].cnt   = 0;
     if (muscl_on) c_off[ntiles] = (int32_t)hcells2.size();
-    // a tile has at most 4*256 edges, so 256 + hmax <= 1280 slots < 2^11 and <= 1024 boundary edges
   }
   L.ntiles = ntiles; L.emax = emax; L.hmax = hmax; L.hmax2 = hmax2;
-  L.hcells = std::move(hcells); L.tile_bk = std::move(tile_bk); L.halo_tiles = std::move(halo_tiles); L.hcells2 = std::move(hcells2);
+  L.hcells = std::move(hcells); L.tile_bk = std::move(tile_bk); L.tile_boff = std::move(tile_boff); L.halo_tiles = std::move(halo_tiles);
+  L.hcells2 = std::move(hcells2); L.tile_c0 = std::move(tile_c0);
   L.c_off = std::move(c_off); L.e_cs = std::move(e_cs); L.e_mid = std::move(e_mid); L.tiles = std::move(tiles);
+  // ---- extra Courant edges: the reference's interior loop covers every local internal edge with len / min(area_l, area_r)
+  // (swe_petsc.c:275-296); the slots of the owned cells cover an edge from the owned side(s) only
+  for (int32_t p = 0; p < ni; ++p) {
+    const int32_t e = mesh->edge_internal_ids[p];
+    const int32_t l = mesh->edge_cell_ids[2 * e], r = mesh->edge_cell_ids[2 * e + 1];
+    if (r == -1) continue;
+    const bool   lo = mesh->cell_is_owned[l] != 0, ro = mesh->cell_is_owned[r] != 0;
+    const double al = mesh->cell_areas[l], ar = mesh->cell_areas[r];
+    if (lo && ro) continue;
+    if (lo != ro && !((lo ? ar : al) < (lo ? al : ar))) continue;  // the owned cell is the smaller one (or equal): its slot has len / min already
+    L.x_lr.push_back(l);
+    L.x_lr.push_back(r);
+    L.x_pos.push_back(p);
+    const double ecn = mesh->edge_cn[e], esn = mesh->edge_sn[e];
+    if (std::fabs(ecn) <= std::fabs(esn)) {
+      L.x_flags.push_back(EDGE_CS_IS_CN | (std::signbit(esn) ? EDGE_OTHER_NEG : 0u));
+      L.x_cs.push_back(ecn);
+    } else {
+      L.x_flags.push_back(std::signbit(ecn) ? EDGE_OTHER_NEG : 0u);
+      L.x_cs.push_back(esn);
+    }
+    L.x_cfac.push_back(mesh->edge_lengths[e] / std::min(al, ar));
+    if (muscl_on) {
+      const int32_t v0 = mesh->edge_vertex_ids[2 * e], v1 = mesh->edge_vertex_ids[2 * e + 1];
+      if (v0 < 0 || v1 < 0 || v0 >= mesh->num_vertices || v1 >= mesh->num_vertices)
+        return fail(RDYHIP_ERR_ARG_OUTOFRANGE, "edge %d has vertex ids (%d,%d) out of range", e, v0, v1);
+      L.x_mid.push_back(0.5 * (mesh->vertex_points[3 * (size_t)v0 + 0] + mesh->vertex_points[3 * (size_t)v1 + 0]));
+      L.x_mid.push_back(0.5 * (mesh->vertex_points[3 * (size_t)v0 + 1] + mesh->vertex_points[3 * (size_t)v1 + 1]));
+    }
+  }
+  L.e_pos = std::move(e_pos);
+  L.e_pos.insert(L.e_pos.end(), L.x_pos.begin(), L.x_pos.end());  // extra edge i is "record" nrec + i
   L.e_lr = std::move(e_lr); L.slot_ref = std::move(slot_ref); L.bn_idx = std::move(bn_idx);
   return 0;
 }
@@ -911,38 +947,15 @@ static int build_host_layout(const RDyHipConfig *config, const RDyHipMesh *mesh,
                              HostLayout &L) {
   int rc = layout_check_arguments(config, mesh, num_boundaries, boundaries);
   if (!rc) rc = layout_build_slots(config, mesh, num_boundaries, boundaries, L);
-  if (!rc) rc = layout_build_tiles(mesh, L);
+  if (!rc) rc = layout_build_tiles(config, mesh, L);
   if (rc) return rc;
-  const int32_t no = L.no, emax = L.emax, hmax = L.hmax, hmax2 = L.hmax2;
-  const bool    muscl_on = L.muscl_on;
+  const int32_t no = L.no;
   const auto   &o2l      = L.o2l;
   const bool   hr_on     = config->well_balancing == RDYHIP_WELL_BALANCING_HR;
-  // first-order tiled kernel: compile-time plane lengths where the tiles fit them (RDYHIP_LDS_FIXED=0: measurement knob)
-  const char  *fenv      = getenv("RDYHIP_LDS_FIXED");
-  const int    ns_fix = L.S == 3 ? TILED_NS_TRI : TILED_NS_QUAD, ne_fix = L.S == 3 ? TILED_NE_TRI : TILED_NE_QUAD;
-  const bool   lds_fixed = TILE + hmax <= ns_fix && emax <= ne_fix && !(fenv && atoi(fenv) == 0);
-  const size_t ns_lds = lds_fixed ? (size_t)ns_fix : (size_t)TILE + hmax, ne_lds = lds_fixed ? (size_t)ne_fix : (size_t)emax;
-  const size_t lds_bytes = sizeof(double) * ((hr_on ? 6 : 5) * ns_lds + 2 * (size_t)TILE + (hr_on ? 6 : 4) * ne_lds);
-  const char  *menv        = getenv("RDYHIP_MUSCL");
-  const bool   muscl_fused = !(menv && strcmp(menv, "split") == 0);
-  // second order, fused form: where the edge fluxes live (muscl_kernels.h) -- over the gradients when a tile's edges fit
-  // the kernel's register rounds (two for triangles, three for quads) and the gradients' storage (every mesh numbered
-  // with some locality), else behind the first ring's records.  RDYHIP_MUSCL_EF_OVERLAY=0: measurement knob
-  const char  *eenv      = getenv("RDYHIP_MUSCL_EF_OVERLAY");
-  const bool   muscl_efo = muscl_on && muscl_fused && emax <= (L.S == 3 ? 2 : 3) * TILE && MUSCL_ES * (size_t)emax <= MUSCL_GS * ((size_t)TILE + hmax) &&
-                         !(eenv && atoi(eenv) == 0);
-  const size_t ring2     = 5 * (size_t)(hmax2 - hmax) + ((size_t)emax + 1) / 2;
-  // plane layout with compile-time strides where the tiles fit its capacities (triangles).  RDYHIP_MUSCL_SOA=0: measurement knob
-  const char  *senv      = getenv("RDYHIP_MUSCL_SOA");
-  const bool   soa_fits  = L.S == 3 ? (TILE + hmax <= MusclSoATri::ng && TILE + hmax2 <= MusclSoATri::nq && emax <= MusclSoATri::ne)
-                                      : (TILE + hmax <= MusclSoAQuad::ng && TILE + hmax2 <= MusclSoAQuad::nq && emax <= MusclSoAQuad::ne);
-  const bool   muscl_soa = muscl_efo && soa_fits && !(senv && atoi(senv) == 0);
-  const size_t lds_muscl = !muscl_on ? 0
-                           : muscl_soa ? (L.S == 3 ? MusclSoATri::lds_bytes : MusclSoAQuad::lds_bytes)
-                           : sizeof(double) * ((5 + MUSCL_GS) * ((size_t)TILE + hmax) +
-                                               (!muscl_fused ? MUSCL_ES * (size_t)emax : muscl_efo ? ring2 : std::max<size_t>(MUSCL_ES * (size_t)emax, ring2)));
-  if (std::max(lds_bytes, lds_muscl) > 160 * 1024)
-    return fail(RDYHIP_ERR_USER, "tile working set (%zu B of LDS) too large: the cell numbering has no locality", std::max(lds_bytes, lds_muscl));
+  const size_t lds_bytes = tiled_lds_bytes(L.S, hr_on);
+  const size_t lds_muscl = !L.muscl_on ? 0 : (L.S == 3 ? MusclSoATri::lds_bytes : MusclSoAQuad::lds_bytes);
+  static_assert(tiled_lds_bytes(4, true) <= 64 * 1024 && MusclSoATri::lds_bytes <= 64 * 1024 && MusclSoAQuad::lds_bytes <= 64 * 1024,
+                "the kernels' LDS fits the default dynamic allocation");
 
   // ---- per-owned-cell geometry --------------------------------------------
   std::vector<double> dzdx((size_t)no), dzdy((size_t)no);
@@ -951,7 +964,7 @@ static int build_host_layout(const RDyHipConfig *config, const RDyHipMesh *mesh,
     dzdy[o] = mesh->cell_dz_dy[o2l[o]];
   }
 
-  L.hr_on = hr_on; L.muscl_fused = muscl_fused; L.muscl_efo = muscl_efo; L.muscl_soa = muscl_soa; L.lds_fixed = lds_fixed; L.lds_bytes = lds_bytes; L.lds_muscl = lds_muscl;
+  L.hr_on = hr_on; L.lds_bytes = lds_bytes; L.lds_muscl = lds_muscl;
   L.dzdx = std::move(dzdx); L.dzdy = std::move(dzdy);
   return 0;
 }
@@ -972,7 +985,7 @@ int rdyhip_create(const RDyHipConfig *config, const RDyHipMesh *mesh, int32_t nu
   }
   const int32_t nc = L.nc, no = L.no, ne = L.ne, ni = L.ni, K = L.K, S = L.S, ntiles = L.ntiles, emax = L.emax, hmax = L.hmax, hmax2 = L.hmax2;
   const int64_t stride = L.stride;
-  const bool    prefix = L.prefix, hr_on = L.hr_on, muscl_on = L.muscl_on, muscl_fused = L.muscl_fused;
+  const bool    prefix = L.prefix, hr_on = L.hr_on, muscl_on = L.muscl_on;
   const size_t  lds_bytes = L.lds_bytes, lds_muscl = L.lds_muscl;
   auto &o2l = L.o2l; auto &boff = L.boff; auto &nbr = L.nbr; auto &pos = L.pos; auto &btype = L.btype; auto &bleft = L.bleft; auto &bedge = L.bedge;
   auto &bghost = L.bghost; auto &halo = L.halo; auto &hcells = L.hcells; auto &tile_bk = L.tile_bk; auto &halo_tiles = L.halo_tiles;
@@ -999,50 +1012,18 @@ int rdyhip_create(const RDyHipConfig *config, const RDyHipMesh *mesh, int32_t nu
   op->emax         = emax;
   op->hmax         = hmax;
   op->lds_bytes    = lds_bytes;
-  op->lds_fixed    = L.lds_fixed;
   {
     // The Euler-step kernels' u_out is what the next step reads: stored without the non-temporal hint it is still in the
     // Infinity Cache (256 MB) then -- when it fits beside what else lives there.  Plain stores while the state array is at
     // most half the cache (RDYHIP_UOUT_CACHED_MAX_MB, default 128 MB = 5.6 M cells); RDYHIP_UOUT_CACHED=0 / 1 forces.
     double max_mb = 128.0;
     if (const char *e = getenv("RDYHIP_UOUT_CACHED_MAX_MB")) max_mb = atof(e);
-    op->uout_cached = L.lds_fixed && 24.0 * (double)op->n_cells <= max_mb * 1048576.0;
-    if (const char *e = getenv("RDYHIP_UOUT_CACHED")) op->uout_cached = L.lds_fixed && atoi(e) != 0;
-  }
-  if (lds_bytes > 64 * 1024) {
-    // more than the default 64 KB of dynamic LDS (only for numberings with poor locality)
-    const int nb = (int)lds_bytes;
-    bool ok = true;
-    for (int ovw = 0; ovw < 2; ++ovw)
-      for (int src = 0; src < 2; ++src)
-        for (int sl = 3; sl <= 4; ++sl)
-          ok = ok && hipFuncSetAttribute((const void *)tiled_kernel_fn(sl, src, ovw != 0, hr_on, L.lds_fixed), hipFuncAttributeMaxDynamicSharedMemorySize, nb) == hipSuccess &&
-               hipFuncSetAttribute((const void *)tiled_euler_fn(sl, src, hr_on, L.lds_fixed), hipFuncAttributeMaxDynamicSharedMemorySize, nb) == hipSuccess;
-    if (!ok) {
-      delete op;
-      return fail(RDYHIP_ERR_LIB, "cannot reserve %d bytes of LDS per workgroup", nb);
-    }
+    op->uout_cached = 24.0 * (double)op->n_cells <= max_mb * 1048576.0;
+    if (const char *e = getenv("RDYHIP_UOUT_CACHED")) op->uout_cached = atoi(e) != 0;
   }
   op->muscl       = muscl_on;
-  op->muscl_fused = muscl_fused;
-  op->muscl_efo   = L.muscl_efo;
-  op->muscl_soa   = L.muscl_soa;
   op->hmax2       = hmax2;
   op->lds_muscl   = lds_muscl;
-  if (lds_muscl > 64 * 1024) {
-    const int nb = (int)lds_muscl;
-    bool      ok = true;
-    for (int ovw = 0; ovw < 2; ++ovw)
-      for (int src = 0; src < 2; ++src)
-        ok = ok && hipFuncSetAttribute((const void *)muscl_kernel_fn(S, src, ovw != 0, config->limiter, muscl_fused, L.muscl_efo, L.muscl_soa),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, nb) == hipSuccess &&
-             (!muscl_fused || hipFuncSetAttribute((const void *)muscl_fused_euler_fn(S, src, config->limiter, L.muscl_efo, L.muscl_soa),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, nb) == hipSuccess);
-    if (!ok) {
-      delete op;
-      return fail(RDYHIP_ERR_LIB, "cannot reserve %d bytes of LDS per workgroup", nb);
-    }
-  }
   op->nrec         = (int64_t)e_lr.size();
   op->nhalo_entries = (int64_t)hcells.size();
   {
@@ -1071,7 +1052,7 @@ int rdyhip_create(const RDyHipConfig *config, const RDyHipMesh *mesh, int32_t nu
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, op->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
     int q = 0;
-    const void *kfn = (const void *)tiled_kernel_fn(S, config->source_method == RDYHIP_SOURCE_IMPLICIT_XQ2018 ? 1 : 0, true, hr_on, L.lds_fixed);
+    const void *kfn = (const void *)tiled_kernel_fn(S, config->source_method == RDYHIP_SOURCE_IMPLICIT_XQ2018 ? 1 : 0, true, hr_on);
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, kfn, TILE, lds_bytes) == hipSuccess && q > 0) per_cu = q;
     if (const char *e2 = getenv("RDYHIP_BLOCKS_PER_CU")) {
       if (atoi(e2) > 0) per_cu = atoi(e2);
@@ -1079,8 +1060,7 @@ int rdyhip_create(const RDyHipConfig *config, const RDyHipMesh *mesh, int32_t nu
     op->pgrid            = std::max(8, cus * per_cu);
     if (muscl_on) {
       int qm = 0, per_cu_m = 2;
-      const void *mfn =
-          (const void *)muscl_kernel_fn(S, config->source_method == RDYHIP_SOURCE_IMPLICIT_XQ2018 ? 1 : 0, true, config->limiter, muscl_fused, L.muscl_efo, L.muscl_soa);
+      const void *mfn = (const void *)muscl_kernel_fn(S, config->source_method == RDYHIP_SOURCE_IMPLICIT_XQ2018 ? 1 : 0, true, false, config->limiter);
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&qm, mfn, TILE, lds_muscl) == hipSuccess && qm > 0) per_cu_m = qm;
       if (const char *e2 = getenv("RDYHIP_BLOCKS_PER_CU")) {
         if (atoi(e2) > 0) per_cu_m = atoi(e2);
@@ -1125,8 +1105,17 @@ int rdyhip_create(const RDyHipConfig *config, const RDyHipMesh *mesh, int32_t nu
   TRY_RC(op->d_tiles.upload(tiles));
   TRY_RC(op->d_halo_tiles.upload(halo_tiles));
   TRY_RC(op->d_e_lr.upload(e_lr));
+  TRY_RC(op->d_e_pos.upload(L.e_pos));
+  op->n_xedges = (int32_t)L.x_pos.size();
+  TRY_RC(op->d_x_lr.upload(L.x_lr));
+  TRY_RC(op->d_x_flags.upload(L.x_flags));
+  TRY_RC(op->d_x_cs.upload(L.x_cs));
+  TRY_RC(op->d_x_cfac.upload(L.x_cfac));
+  TRY_RC(op->d_x_mid.upload(L.x_mid));
   TRY_RC(op->d_hcells.upload(hcells));
   TRY_RC(op->d_tile_bk.upload(tile_bk));
+  TRY_RC(op->d_tile_boff.upload(L.tile_boff));
+  op->h_tile_c0 = L.tile_c0;
   TRY_RC(op->d_e_cs.upload(e_cs));
   if (S == 3) {
     std::vector<uint32_t> ref3((size_t)no);
@@ -1172,9 +1161,12 @@ int rdyhip_create(const RDyHipConfig *config, const RDyHipMesh *mesh, int32_t nu
   TRY_RC(op->d_courant.zeros(1));
   {
     ColdArgs c{};
-    c.nbr = op->d_nbr.p; c.cn = op->d_cn.p; c.sn = op->d_sn.p; c.pos = op->d_pos.p;
+    c.nbr = op->d_nbr.p; c.cn = op->d_cn.p; c.sn = op->d_sn.p; c.pos = op->d_pos.p; c.e_pos = op->d_e_pos.p;
     c.btype = op->d_btype.p; c.bvalues = op->d_bvalues.p; c.bflux = op->d_bflux.p; c.baccum = op->d_baccum.p;
-    c.tile_bk = op->d_tile_bk.p; c.blk_max = op->d_blk_max.p; c.blk_pos = op->d_blk_pos.p;
+    c.tile_bk = op->d_tile_bk.p; c.tile_boff = op->d_tile_boff.p;
+    c.n_xedges = op->n_xedges; c.x_rec0 = (int32_t)e_lr.size(); c.x_lr = op->d_x_lr.p; c.x_flags = op->d_x_flags.p; c.x_cs = op->d_x_cs.p;
+    c.x_cfac = op->d_x_cfac.p; c.x_mid = op->d_x_mid.p;
+    c.blk_max = op->d_blk_max.p; c.blk_pos = op->d_blk_pos.p;
     TRY_RC(op->d_cold.upload(std::vector<ColdArgs>(1, c)));
   }
 #undef TRY_RC
@@ -1195,7 +1187,7 @@ int rdyhip_create(const RDyHipConfig *config, const RDyHipMesh *mesh, int32_t nu
   op->device_bytes = op->d_o2l.bytes() + op->d_nbr.bytes() + op->d_pos.bytes() + op->d_cn.bytes() + op->d_sn.bytes() + op->d_coef.bytes() +
                      op->d_dzdx.bytes() + op->d_dzdy.bytes() + op->d_mannings.bytes() + op->d_extsrc.bytes() +
                      op->d_pv.bytes() + op->d_bvalues.bytes() + op->d_bflux.bytes() + op->d_baccum.bytes() + op->d_blk_max.bytes() +
-                     op->d_blk_pos.bytes() + op->d_tiles.bytes() + op->d_e_lr.bytes() + op->d_hcells.bytes() + op->d_tile_bk.bytes() +
+                     op->d_blk_pos.bytes() + op->d_tiles.bytes() + op->d_e_lr.bytes() + op->d_e_pos.bytes() + op->d_hcells.bytes() + op->d_tile_bk.bytes() + op->d_tile_boff.bytes() +
                      op->d_e_cs.bytes() + op->d_slot_ref.bytes() + op->d_slot_ref3.bytes() + op->d_grad.bytes() + op->d_e_mid.bytes() +
                      op->d_cxy.bytes() + op->d_hcells2.bytes() + op->d_c_off.bytes() + op->d_bn_idx.bytes();
   *op_out = op;
@@ -1704,7 +1696,7 @@ int rdyhip_probe_layout(const RDyHipConfig *config, const RDyHipMesh *mesh, int3
   tmp.n_cells = L.nc; tmp.n_owned = L.no; tmp.S = L.S; tmp.K = L.K; tmp.n_halo = (int32_t)L.halo.size(); tmp.use_tiled = true;
   tmp.ntiles = L.ntiles; tmp.n_halo_tiles = (int32_t)L.halo_tiles.size(); tmp.emax = L.emax; tmp.hmax = L.hmax;
   tmp.nhalo_entries = (int64_t)L.hcells.size(); tmp.nrec = (int64_t)L.e_lr.size(); tmp.prefix = L.prefix; tmp.muscl = L.muscl_on;
-  tmp.muscl_fused = L.muscl_fused; tmp.muscl_efo = L.muscl_efo; tmp.muscl_soa = L.muscl_soa; tmp.hmax2 = L.hmax2; tmp.d_hcells2.n = L.hcells2.size(); tmp.lds_bytes = L.lds_bytes; tmp.lds_muscl = L.lds_muscl; tmp.lds_fixed = L.lds_fixed;
+  tmp.hmax2 = L.hmax2; tmp.d_hcells2.n = L.hcells2.size(); tmp.lds_bytes = L.lds_bytes; tmp.lds_muscl = L.lds_muscl;
   const int rc2 = rdyhip_layout_info(&tmp, info);
   tmp.d_hcells2.n = 0;
   return rc2;
@@ -1726,11 +1718,11 @@ int rdyhip_layout_info(RDyHipOperator op, RDyHipLayoutInfo *info) {
   info->num_edge_records   = op->nrec;
   info->owned_is_prefix    = op->prefix ? 1 : 0;
   info->device_bytes       = op->device_bytes;
-  info->second_order_fused   = (op->muscl && op->muscl_fused) ? 1 : 0;
+  info->second_order_fused   = op->muscl ? 1 : 0;
   info->max_tile_ring2_cells = op->hmax2;
   info->persistent_grid      = op->muscl ? op->pgrid_muscl : op->pgrid;
   info->lds_bytes            = (int32_t)(op->muscl ? op->lds_muscl : op->lds_bytes);
-  info->lds_fixed_layout     = (op->muscl ? (op->muscl_fused && op->muscl_soa) : (op->use_tiled && op->lds_fixed)) ? 1 : 0;
+  info->lds_fixed_layout     = op->use_tiled ? 1 : 0;  // every tile is cut to the kernels' fixed LDS capacities
   // u (own cell) 24 + slots S*(4+8+8+8) + dz 16 + n 8 + ext src 24 + F 24 + pv 24 (+4 for o2l)
   if (op->use_tiled) {
     // u 24 + slot refs 4 (8 for quads) + coef S*8 + dz 16 + n 8 + ext src 24 + F 24 + pv 24 (+4 for o2l) per cell;
@@ -1745,8 +1737,7 @@ int rdyhip_layout_info(RDyHipOperator op, RDyHipLayoutInfo *info) {
     // first-ring stencils (8 B per halo entry); split: the gradient array written and read (96) + the state, the centroid and
     // the neighbour ids read a second time (24 + 16 + S*4)
     info->bytes_per_apply += (int64_t)op->n_owned * 16 + op->nrec * 16;
-    if (op->muscl_fused) info->bytes_per_apply += (int64_t)op->d_hcells2.n * 4 + op->nhalo_entries * 8;
-    else info->bytes_per_apply += (int64_t)op->n_owned * (96 + 24 + 16 + op->S * 4);
+    info->bytes_per_apply += (int64_t)op->d_hcells2.n * 4 + op->nhalo_entries * 8;
   }
   return 0;
 }

@@ -78,6 +78,16 @@ struct RoeFlux {
   double f0, f1, f2, amax;
 };
 
+// a b + c d with each product rounded on its own: the expression is then symmetric under (a, b) <-> (c, d), as it is
+// in the reference's arithmetic (no contraction there) -- fma(a, b, c d) is not.  The largest wave speed of an edge
+// must not depend on which of its cells is called left, or on a mirror image of the state: edges that tie in the
+// reference (uniform or symmetric states) have to tie here as well, or the Courant diagnostic names another edge.
+__device__ __forceinline__ double sum_of_products(double a, double b, double c, double d) {
+#pragma clang fp contract(off)
+  const double p = a * b, q = c * d;
+  return p + q;
+}
+
 // One side of a Riemann problem with everything that depends on that side
 // alone: velocities (ComputeRiemannVelocities, src/swe/swe_petsc.c:57-73) and
 // the two square roots of swe_roe_flux_petsc.h:21-24.  A cell's own state is
@@ -124,12 +134,12 @@ __device__ __forceinline__ RoeFlux roe_flux(const RiemannSide &L, const RiemannS
   const double duml = L.sqh, dumr = R.sqh, cl = L.c, cr = R.c;
   const double hhat    = duml * dumr;
   const double inv_sum = rdy_rcp(duml + dumr);
-  const double uhat    = (duml * ul + dumr * ur) * inv_sum;
-  const double vhat    = (duml * vl + dumr * vr) * inv_sum;
+  const double uhat    = sum_of_products(duml, ul, dumr, ur) * inv_sum;  // (these three feed amax: see sum_of_products)
+  const double vhat    = sum_of_products(duml, vl, dumr, vr) * inv_sum;
   const SqrtPair cp       = rdy_sqrt_rsqrt(0.5 * GRAVITY * (hl + hr));
   const double   chat     = cp.s;
   const double   inv_chat = cp.r;  // 1/chat with the square root, instead of a separate reciprocal
-  const double uperp   = uhat * cn + vhat * sn;
+  const double uperp   = sum_of_products(uhat, cn, vhat, sn);
 
   const double dh     = hr - hl;
   const double du     = ur - ul;

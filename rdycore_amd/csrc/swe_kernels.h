@@ -3,8 +3,9 @@
 // Two implementations of the same operator share the epilogue and the
 // Courant reduction:
 //
-//  * swe_rhs_tiled_kernel (default): one workgroup = one tile of 256
-//    consecutive owned cells.
+//  * swe_rhs_tiled_kernel (default): one workgroup = one tile of up to 256
+//    consecutive owned cells (cut at create so that a tile's edge records and
+//    halo cells fit fixed capacities: rdyhip_api.hip, layout_build_tiles).
 //      phase 0  every thread loads its cell's state, derives the Riemann side
 //               data (velocities, sqrt(h), sqrt(g h)) once and stages it in LDS;
 //      phase 1  threads sweep the tile's edge list (every edge that touches a
@@ -31,7 +32,12 @@
 namespace rdyhip {
 
 constexpr int BLOCK = 256;  // threads per workgroup of the cell-centric kernel
-constexpr int TILE = 256;   // cells per tile = threads per workgroup of the tiled kernel (a multiple of 64)
+constexpr int TILE = 256;   // threads per workgroup of the tiled kernels = the largest number of cells in a tile (a multiple of 64)
+// Capacities every tile is cut to at create (layout_build_tiles): edge records = two register-resident rounds of the edge
+// phase; halo cells (cells outside the tile that share an edge with it) per slots-per-cell flavour.  The LDS planes have
+// these compile-time lengths, so every plane offset is an instruction immediate.
+constexpr int TILE_MAX_REC = 2 * TILE;
+constexpr int TILE_MAX_HALO_TRI = 104, TILE_MAX_HALO_QUAD = 112;
 
 constexpr uint16_t SLOT_EMPTY = 0xFFFF;
 
@@ -61,12 +67,27 @@ struct TileDesc;
 struct ColdArgs {
   const int32_t *nbr;        // [S][stride] neighbour ids (cell kernel, gradient kernel)
   const double  *cn, *sn;    // [S][stride] (cell kernel)
-  const int32_t *pos;        // [S][stride] loop position of each slot's edge (Courant tie-break only)
+  const int32_t *pos;        // [S][stride] loop position of each slot's edge (Courant tie-break of the cell kernel)
+  const int32_t *e_pos;      // [nrec + n_xedges] loop position of each tile edge record (Courant tie-break of the tiled kernels),
+                             //                   then of each extra Courant edge
+  // Internal edges of the local mesh that no owned cell's slot covers the way the reference's loop does (swe_petsc.c:275-296
+  // runs over ALL local internal edges and divides by min(area_l, area_r) whoever owns the cells): edges between two ghost
+  // cells, and owned / ghost edges whose ghost cell is the smaller one.  O(cut edges); evaluated -- the largest wave speed only --
+  // by the threads of a launch that has ghost data (courant_extra_edges), so that a rank's Courant diagnostic BEFORE the
+  // cross-rank reduction is the reference's, ties and all.
+  int32_t        n_xedges;
+  int32_t        x_rec0;     // = nrec: extra edge i is "record" x_rec0 + i of e_pos
+  const int32_t *x_lr;       // [n_xedges][2] local ids of the left / right cell
+  const uint32_t *x_flags;   // [n_xedges] EDGE_CS_IS_CN | EDGE_OTHER_NEG of the packed normal
+  const double  *x_cs;       // [n_xedges] its stored component
+  const double  *x_cfac;     // [n_xedges] len / min(area_l, area_r)
+  const double  *x_mid;      // [n_xedges][2] edge midpoint (second order)
   const int32_t *btype;      // [K] condition type of boundary edge k
   const double  *bvalues;    // [K][3]
   double        *bflux;      // [K][3]
   double        *baccum;     // [K][3]
   const int32_t *tile_bk;    // boundary-edge ids k of each tile's boundary edges
+  const int32_t *tile_boff;  // [ntiles + 1] first tile_bk entry of each tile
   double        *blk_max;    // [2 * maxgrid] the Courant diagnostic, one running (max, first position) bucket per workgroup slot;
   int32_t       *blk_pos;    //               merged by courant_finalize_kernel only when the host asks (rdyhip_update_diagnostics)
   // the pack of the next ghost update fused into the Euler-step kernels' stores (rdyhip_halo_fuse_pack): tiles flagged
@@ -74,11 +95,6 @@ struct ColdArgs {
   const int32_t  *send_off;  // [ntiles + 1] first send entry of each tile
   const uint32_t *send_ent;  // cell-in-tile (bits 0-7) | row of the send buffer (bits 8-31), sorted by tile
   double         *send_buf;  // [send cells][3]
-  // ... and the word that tells the exchange stream they are all there (wave_signal_send_rows): nullptr = no signalling
-  uint32_t *send_done;    // waves of flagged tiles that have stored their rows in the running launch
-  uint64_t *send_epoch;   // launches that have stored ALL their send rows so far
-  uint64_t *send_signal;  // the same number in signal memory: hipStreamWaitValue64 on the exchange stream waits for it
-  uint32_t  send_waves;   // waves of flagged tiles per launch (TILE / 64 per tile)
   // second order: the ghost-adjacent cells' gradient launch (muscl_gradient_kernel over the halo cell list) also stores each
   // gradient into the rows of the send buffer that carry it to other ranks: no pack launch for the gradient exchange
   const int32_t *gsend_off;   // [n_halo + 1] first send row of the cell at each position of the halo cell list
@@ -115,8 +131,6 @@ struct KernelArgs {
   const void     *slot_ref;  // index of each slot's edge in the tile's edge list: S == 3: uint32[n_owned] (3 x 10 bits),
                              // S == 4: uint16[n_owned][4]
   const double   *zc_local;  // [num_cells] vertex-averaged bed elevation (hydrostatic reconstruction only)
-  int32_t         emax;      // largest edge count of a tile (LDS sizing)
-  int32_t         hmax;      // largest halo-cell count of a tile (LDS sizing)
 };
 
 // Wave-uniform loads of read-only index data through the constant address space,
@@ -207,11 +221,46 @@ __device__ __forceinline__ void wave_store_rows3(double *__restrict__ arr, int64
   }
 }
 
-// Block reduction of the Courant number: max value, then the smallest loop
-// position among the lanes that hold it (the reference keeps the first edge
-// that reaches the max, swe_petsc.c:291).  Writes the block's partial.
+// A thread's running Courant maximum over the tiles it walks (swe_petsc.c:289-296: the reference keeps the FIRST edge in
+// loop order that reaches the maximum).  Inside one cell the slots are in loop order, so "strictly greater" keeps the
+// first; across the cells a thread visits nothing orders the loop positions (DMPlex numbers edges on its own,
+// src/rdymesh.c:693-710).  The hot path only NOTES that a slot met the running maximum to the last bit (one compare per
+// slot, the flag lives in a scalar mask); a cell that did goes through courant_resolve_tie -- cold code, taken by states
+// that are uniform over what a thread has seen so far (a lake at rest, the flat pools of the reference's dam-break
+// benchmark at t = 0) -- which compares loop positions.  That path must be cheap too (the dam break's first steps run
+// through it in every tile): the incumbent's position is looked up once and kept; a tile all of whose records come later
+// in the loop than the incumbent (the first record of a tile has its smallest position: ONE scalar load) is dismissed
+// without touching memory -- every tile after the first, where the edge numbering follows the cells; otherwise one 4-byte
+// load per tying cell, waited for inside the branch.
+struct CourantTrack {
+  double best = 0.0;  // largest Courant number seen by this thread (> 0 only)
+  int    rec  = 0;    // its tile edge record (index into e_lr / e_cs / e_pos)
+  int    pos  = -1;   // the loop position of `rec` once a tie has made the thread look it up
+};
+// rec_new: the record of the FIRST slot of the current cell that equals t.best; tile_pos_lo: the smallest loop position among the
+// current tile's records
+__device__ __forceinline__ void courant_resolve_tie(const KernelArgs &a, CourantTrack &t, int rec_new, int tile_pos_lo) {
+  if (rec_new == t.rec) return;  // the incumbent is that very slot
+  const int32_t *e_pos = RDY_COLD(a, e_pos);
+  if (t.pos < 0) {
+    int po = e_pos[t.rec];
+    // waited for HERE: a load whose result is first used after the merge costs every wave an s_waitcnt vmcnt(0) at the
+    // merge, and with it a wait for the next tile's prefetch batch
+    asm volatile("" : "+v"(po));
+    t.pos = po;
+  }
+  if (t.pos < tile_pos_lo) return;
+  int pn = e_pos[rec_new];
+  asm volatile("" : "+v"(pn));
+  if (pn < t.pos) {
+    t.rec = rec_new;
+    t.pos = pn;
+  }
+}
+
+// `table[index]`: the loop position of the thread's candidate (read only by the lanes that hold the block's maximum)
 template <int NT>
-__device__ __forceinline__ void block_courant_reduce(const KernelArgs &a, double best, int best_slot, int o) {
+__device__ __forceinline__ void block_courant_reduce(const KernelArgs &a, double best, const int32_t *table, int64_t index) {
   __shared__ double s_max[NT / 64];
   __shared__ int    s_pos[NT / 64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -222,7 +271,7 @@ __device__ __forceinline__ void block_courant_reduce(const KernelArgs &a, double
 #pragma unroll
   for (int w = 1; w < NT / 64; ++w) bmax = fmax(bmax, s_max[w]);
   int p = INT32_MAX;
-  if (best_slot >= 0 && best == bmax) p = RDY_COLD(a, pos)[best_slot * a.stride + o];
+  if (best > 0.0 && best == bmax) p = table[index];
   p = wave_min(p);
   if (lane == 0) s_pos[wave] = p;
   __syncthreads();
@@ -294,11 +343,12 @@ __device__ __forceinline__ void edge_normal(uint32_t lr, double cs, double &cn, 
 struct TileDesc {  // 16 B, one per tile (+1 sentinel): everything about a tile in ONE scalar load of four registers
   int32_t  e_off;  // first edge record
   int32_t  h_off;  // first halo-cell entry
-  int32_t  b_off;  // first boundary-edge entry
-  uint32_t cnt;    // edge records (bits 0-10) | halo cells (bits 11-21) | bit 30: a tile cell is sent to another rank (set while a
-                   // halo with the fused pack is attached) | bit 31: a tile cell has a ghost neighbour
+  int32_t  c_off;  // first owned cell (the tile's cells are c_off .. c_off + nc() - 1; a multiple of 16 wherever the numbering allows)
+  uint32_t cnt;    // edge records (bits 0-10) | halo cells (bits 11-21) | cells - 1 (bits 22-29) | bit 30: a tile cell is sent to
+                   // another rank (set while a halo with the fused pack is attached) | bit 31: a tile cell has a ghost neighbour
   __host__ __device__ int  ne() const { return (int)(cnt & 0x7FFu); }
   __host__ __device__ int  nh() const { return (int)((cnt >> 11) & 0x7FFu); }
+  __host__ __device__ int  nc() const { return (int)((cnt >> 22) & 0xFFu) + 1; }
   __host__ __device__ bool halo() const { return (cnt >> 31) != 0; }
   __host__ __device__ bool send() const { return ((cnt >> 30) & 1u) != 0; }
 };
@@ -320,36 +370,10 @@ __device__ __forceinline__ void wave_store_send_rows(const KernelArgs &a, int ti
     const int      j   = (int)(ent & 0xFFu);
     const double   v0 = __shfl(n0, j & 63, 64), v1 = __shfl(n1, j & 63, 64), v2 = __shfl(n2, j & 63, 64);
     if (i < s1 && (j >> 6) == wave) {
-      // agent-scope stores: written through this XCD's L2, so that a kernel that starts while this launch is still running
-      // (the signalled transfer, below) finds the rows in memory -- a plain store would sit in the L2 until the launch ends
       const int64_t row = (int64_t)(ent >> 8);
-      __hip_atomic_store(&sbuf[3 * row + 0], v0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(&sbuf[3 * row + 1], v1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(&sbuf[3 * row + 2], v2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
-}
-
-// The last wave of a launch to have stored its send rows says so to the exchange stream: the ghost transfer of the NEXT step
-// starts while this launch is still at work on the tiles nobody else needs (the host puts the flagged tiles first in the
-// launch's tile list).  A wave is counted once its rows have reached memory: they are agent-scope (write-through) stores and
-// the wave waits for their acknowledgement (vmcnt) -- NOT a release fence, which on this device writes the whole L2 of the XCD
-// back (buffer_wbl2) once per wave.  The counter and the signal are relaxed atomics at agent / system scope (performed at
-// memory); the count is reset by the wave that completes it, so a launch finds it at zero.
-__device__ __forceinline__ void wave_signal_send_rows(const KernelArgs &a, int tid) {
-  uint64_t *sig = RDY_COLD(a, send_signal);
-  if (!sig) return;  // uniform
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if ((tid & 63) == 0) {
-    uint32_t      *done  = RDY_COLD(a, send_done);
-    const uint32_t total = RDY_COLD(a, send_waves);
-    const uint32_t old   = __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (old + 1u == total) {
-      __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      uint64_t      *ep = RDY_COLD(a, send_epoch);
-      const uint64_t e  = __hip_atomic_load(ep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
-      __hip_atomic_store(ep, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(sig, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      sbuf[3 * row + 0] = v0;
+      sbuf[3 * row + 1] = v1;
+      sbuf[3 * row + 2] = v2;
     }
   }
 }
@@ -405,9 +429,9 @@ __device__ __forceinline__ void load_streams(const KernelArgs &a, int o, bool ac
 //
 // EULER = the forward-Euler update fused into the store phase (what TSEULER's VecAXPY does after the RHS,
 // rdyhip_euler_step): the owned rows of a second state array receive u + dt F, F itself is stored only if f != nullptr.
-// NS / NE > 0: the LDS planes have COMPILE-TIME lengths (NS side-data slots, NE edge slots: capacities the mesh's tiles were
-// checked against at create) -- every plane offset is then an instruction immediate instead of a register and an add.
-// 0: lengths from the mesh (a.hmax, a.emax), any numbering.  The lengths are not multiples of 64 doubles on purpose: hipcc
+// The LDS planes have COMPILE-TIME lengths (side-data slots: TILE own + the tile's halo cells; edge slots) -- every tile is
+// cut to those capacities at create -- so every plane offset is an instruction immediate instead of a register and an add.
+// The lengths are not multiples of 64 doubles on purpose: hipcc
 // would fuse the reads of two planes into ds_read2st64_b64, which the LDS serves at half the rate of two ds_read_b64.
 // HR kernels stage the velocities with the HR operator's wet test, "h > tiny_h" (swe_petsc.c:1061-1064), instead of
 // ComputeRiemannVelocities' "h < tiny_h => 0" (62): the edge phase then needs no per-edge selects.  The two rules differ only
@@ -417,19 +441,85 @@ __device__ __forceinline__ void hr_velocity_rule(RiemannSide &s, double tiny_h) 
   s.u            = wet ? s.u : 0.0;
   s.v            = wet ? s.v : 0.0;
 }
-constexpr int TILED_NS_TRI = 360, TILED_NE_TRI = 520, TILED_NS_QUAD = 368, TILED_NE_QUAD = 552;
-// FNT = false: F is stored without the non-temporal hint (RDYHIP_CONFIG_CACHED_F_STORES; instantiated for the fixed LDS layout only)
-template <int S, int SRC, bool OVW, bool HR, bool EULER = false, int NS = 0, int NE = 0, bool FNT = true>
+// The two reconstructed Riemann sides of an interior edge (swe_petsc.c:1046-1071) from the staged ones (velocities already
+// under the HR operator's rule, hr_velocity_rule) and the two bed elevations.
+__device__ __forceinline__ void hr_reconstruct(const RiemannSide &L, const RiemannSide &R, double zl, double zr, RiemannSide &Lr, RiemannSide &Rr) {
+  const double z_max = fmax(zl, zr);
+  Lr.h = fmax(0.0, (L.h + zl) - z_max);
+  Rr.h = fmax(0.0, (R.h + zr) - z_max);
+  Lr.u = L.u; Lr.v = L.v; Rr.u = R.u; Rr.v = R.v;
+  // Only the side with the LOWER bed changes its depth; the other one keeps (h + z) - z, i.e. its own depth up to one
+  // rounding of the sum, and its staged square root stands in for the root of that value (relative difference
+  // <= ulp(h + z) / (4 h): ~1e-13 for 1 cm of water over a bed at 50 m).  One square root
+  // per edge instead of two.  Where the reconstructed depth of that side is clamped to zero -- a negative depth
+  // (a drying overshoot: its staged root is NaN) or a film thinner than ulp(z) -- the root is the reference's
+  // sqrt(0) = 0, not the staged one (swe_petsc.c:1051-1053).
+  // (equal beds: both sides keep their depth, both take their staged root -- the rule must not depend on which cell
+  // is called left, or two edges that tie in the reference would not tie here)
+  const bool   l_high = zl >= zr, r_high = zr >= zl;
+  const double sx     = rdy_sqrt(l_high ? Rr.h : Lr.h);
+  Lr.sqh = l_high ? (Lr.h > 0.0 ? L.sqh : 0.0) : sx;
+  Rr.sqh = r_high ? (Rr.h > 0.0 ? R.sqh : 0.0) : sx;
+  Lr.c   = SQRT_GRAVITY * Lr.sqh;
+  Rr.c   = SQRT_GRAVITY * Rr.sqh;
+}
+// The extra Courant edges (ColdArgs::x_*), first order / HR: the largest wave speed of each, from global memory, through the
+// SAME device functions as the edge phase (riemann_side, hr_reconstruct, roe_flux: every operation that feeds amax is an
+// explicit fma / uncontracted product, so the value has the bits the edge phase would give it -- a tie stays a tie).  Spread
+// over the threads of the launch, after its tile loop; a launch of the INTERIOR phase (no ghost data yet) skips it.
+template <bool HR>
+__device__ __forceinline__ void courant_extra_edges(const KernelArgs &a, double dt, const double *__restrict__ u, CourantTrack &t) {
+  const int nx = RDY_COLD(a, n_xedges);
+  if (nx == 0 || a.phase == RDYHIP_PHASE_INTERIOR) return;  // uniform
+  const int32_t  *xlr = RDY_COLD(a, x_lr);
+  const uint32_t *xfl = RDY_COLD(a, x_flags);
+  const double   *xcs = RDY_COLD(a, x_cs), *xcf = RDY_COLD(a, x_cfac);
+  const int       rec0 = RDY_COLD(a, x_rec0);
+  for (int i = blockIdx.x * TILE + threadIdx.x; i < nx; i += gridDim.x * TILE) {
+    const int64_t l = xlr[2 * i], r = xlr[2 * i + 1];
+    RiemannSide   L = riemann_side(u[3 * l + 0], u[3 * l + 1], u[3 * l + 2], a.tiny_h, a.h_anuga_sq);
+    RiemannSide   R = riemann_side(u[3 * r + 0], u[3 * r + 1], u[3 * r + 2], a.tiny_h, a.h_anuga_sq);
+    double        cn, sn;
+    edge_normal(xfl[i], xcs[i], cn, sn);
+    double am;
+    bool   wet = !(R.h < a.tiny_h && L.h < a.tiny_h);
+    if (!HR) {
+      am = roe_flux(L, R, sn, cn).amax;
+    } else {
+      hr_velocity_rule(L, a.tiny_h);
+      hr_velocity_rule(R, a.tiny_h);
+      RiemannSide Lr, Rr;
+      hr_reconstruct(L, R, a.zc_local[l], a.zc_local[r], Lr, Rr);
+      am  = roe_flux(Lr, Rr, sn, cn).amax;
+      wet = wet && (Lr.h > a.tiny_h || Rr.h > a.tiny_h);
+    }
+    if (wet) {
+      const double cnum = am * xcf[i] * dt;
+      if (cnum > t.best) {
+        t.best = cnum;
+        t.rec  = rec0 + i;
+        t.pos  = -1;
+      } else if (cnum == t.best) {
+        courant_resolve_tie(a, t, rec0 + i, 0);
+      }
+    }
+  }
+}
+
+constexpr int TILED_NS_TRI = TILE + TILE_MAX_HALO_TRI, TILED_NS_QUAD = TILE + TILE_MAX_HALO_QUAD, TILED_NE = TILE_MAX_REC + 8;
+constexpr size_t tiled_lds_bytes(int S, bool hr) {
+  return sizeof(double) * ((hr ? 6 : 5) * (size_t)(S == 3 ? TILED_NS_TRI : TILED_NS_QUAD) + 2 * (size_t)TILE + (hr ? 6 : 4) * (size_t)TILED_NE);
+}
+// FNT = false: F (EULER: u_out) is stored without the non-temporal hint (RDYHIP_CONFIG_CACHED_F_STORES / states that fit the Infinity Cache)
+template <int S, int SRC, bool OVW, bool HR, bool EULER = false, bool FNT = true>
 __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(3, 3))) void swe_rhs_tiled_kernel(const KernelArgs a, const double dt, const double *__restrict__ u,
                                                               double *__restrict__ f) {
-  // edge-record rounds held in registers: a 256-cell tile of a well-numbered triangle mesh has <= 2 x 256 edge records
-  // (1.6 per cell), a quad tile up to 3 x 256 (a 16 x 16 block: 544).  Records beyond that (poor numberings) are loaded
-  // inside the flux phase.
-  constexpr int  NR            = (S == 3) ? 2 : 3;
+  // edge-record rounds held in registers: every tile has <= TILE_MAX_REC = 2 x 256 edge records (a 256-cell tile of a
+  // well-numbered triangle mesh 1.6 per cell; a quad tile is cut at 240 cells, a 16 x 15 block = 511 records; round 4 ran
+  // 256-cell quad tiles, 544 records, with a third round in which 32 of 256 lanes had work)
   constexpr bool HR_STAGED_VEL = HR;
   extern __shared__ double lds[];
-  const int nside = NS > 0 ? NS : TILE + a.hmax;
-  const int nedge = NE > 0 ? NE : a.emax;
+  constexpr int nside = S == 3 ? TILED_NS_TRI : TILED_NS_QUAD, nedge = TILED_NE;
   double   *sd_h = lds, *sd_u = lds + nside, *sd_v = lds + 2 * nside, *sd_sq = lds + 3 * nside, *sd_c = lds + 4 * nside;
   double   *sd_hu = lds + 5 * nside, *sd_hv = sd_hu + TILE;
   double   *ef0 = sd_hv + TILE, *ef1 = ef0 + nedge, *ef2 = ef1 + nedge, *eam = ef2 + nedge;
@@ -458,7 +548,7 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
     typedef int v4i __attribute__((ext_vector_type(4)));
     const v4i v = load_uniform(reinterpret_cast<const v4i *>(a.tiles), t);
     TileDesc  d;
-    d.e_off = v.x; d.h_off = v.y; d.b_off = v.z; d.cnt = (uint32_t)v.w;
+    d.e_off = v.x; d.h_off = v.y; d.c_off = v.z; d.cnt = (uint32_t)v.w;
     return d;
   };
   auto next_valid = [&](int i) -> int {  // INTERIOR phase skips tiles with ghost-adjacent cells (wave-uniform)
@@ -468,8 +558,7 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
     return i;
   };
 
-  double best      = 0.0;  // largest Courant number seen by this thread (> 0 only)
-  int    best_slot = -1, best_o = 0;
+  CourantTrack trk;
 
   idx = next_valid(idx);
   if (idx < hi) {
@@ -479,12 +568,12 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
     double   pu0 = 0.0, pu1 = 0.0, pu2 = 0.0;  // own cell state of the tile being started
     double   ph0 = 0.0, ph1 = 0.0, ph2 = 0.0;  // state of this thread's halo cell
     double   pz = 0.0, phz = 0.0;              // HR: bed elevation of the own / halo cell
-    uint32_t lr0 = 0, lr1 = 0, lr2 = 0;        // first NR rounds of edge records
-    double   cs0 = 0.0, cs1 = 0.0, cs2 = 0.0;
+    uint32_t lr0 = 0, lr1 = 0;                 // the two rounds of edge records
+    double   cs0 = 0.0, cs1 = 0.0;
     CellStreams<S> cur;
     {
-      const int o = tile * TILE + tid;
-      if (o < a.n_owned) {
+      const int o = td.c_off + tid;
+      if (tid < td.nc()) {
         const int c = a.o2l ? a.o2l[o] : o;
         pu0 = u[3 * (int64_t)c + 0]; pu1 = u[3 * (int64_t)c + 1]; pu2 = u[3 * (int64_t)c + 2];
         if (HR) pz = a.zc_local[c];
@@ -497,8 +586,7 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
       const int ne = td.ne();
       if (tid < ne) { lr0 = RDY_LD(&a.e_lr[td.e_off + tid]); cs0 = RDY_LD(&a.e_cs[td.e_off + tid]); }
       if (tid + TILE < ne) { lr1 = RDY_LD(&a.e_lr[td.e_off + TILE + tid]); cs1 = RDY_LD(&a.e_cs[td.e_off + TILE + tid]); }
-      if (NR > 2 && tid + 2 * TILE < ne) { lr2 = RDY_LD(&a.e_lr[td.e_off + 2 * TILE + tid]); cs2 = RDY_LD(&a.e_cs[td.e_off + 2 * TILE + tid]); }
-      load_streams<S, HR>(a, o, o < a.n_owned, cur);
+      load_streams<S, HR>(a, o, tid < td.nc(), cur);
     }
     int      idx1 = next_valid(idx + step);
     int      tile1 = 0, hid1 = 0, c1 = 0;  // next tile: this thread's halo cell and own cell (local ids)
@@ -507,14 +595,14 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
       tile1 = tile_at(idx1);
       td1   = tile_desc(tile1);
       if (tid < td1.nh()) hid1 = a.hcells[td1.h_off + tid];
-      const int o1 = tile1 * TILE + tid;
-      c1           = (a.o2l && o1 < a.n_owned) ? a.o2l[o1] : o1;
+      const int o1 = td1.c_off + tid;
+      c1           = (a.o2l && tid < td1.nc()) ? a.o2l[o1] : o1;
     }
 
     while (true) {
       const int  ne = td.ne(), nh = td.nh();
-      const int  o      = tile * TILE + tid;
-      const bool active = o < a.n_owned;
+      const int  o      = td.c_off + tid;
+      const bool active = tid < td.nc();
 
       // ---- phase 0: Riemann side data of the tile's own and halo cells -> LDS
       {
@@ -531,13 +619,6 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
           if (HR_STAGED_VEL) hr_velocity_rule(hs, a.tiny_h);
           sd_h[TILE + tid] = hs.h; sd_u[TILE + tid] = hs.u; sd_v[TILE + tid] = hs.v; sd_sq[TILE + tid] = hs.sqh; sd_c[TILE + tid] = hs.c;
           if (HR) sd_zc[TILE + tid] = phz;
-        }
-        for (int j = tid + TILE; j < nh; j += TILE) {  // only numberings with poor locality get here
-          const int         hc = a.hcells[td.h_off + j];
-          RiemannSide hs = riemann_side(u[3 * (int64_t)hc + 0], u[3 * (int64_t)hc + 1], u[3 * (int64_t)hc + 2], a.tiny_h, a.h_anuga_sq);
-          if (HR_STAGED_VEL) hr_velocity_rule(hs, a.tiny_h);
-          sd_h[TILE + j] = hs.h; sd_u[TILE + j] = hs.u; sd_v[TILE + j] = hs.v; sd_sq[TILE + j] = hs.sqh; sd_c[TILE + j] = hs.c;
-          if (HR) sd_zc[TILE + j] = a.zc_local[hc];
         }
       }
       __syncthreads();
@@ -558,16 +639,16 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
           tile2 = tile_at(idx2);
           td2   = tile_desc(tile2);
           if (tid < td2.nh()) hid2 = a.hcells[td2.h_off + tid];
-          const int o2 = tile2 * TILE + tid;
-          c2           = (a.o2l && o2 < a.n_owned) ? a.o2l[o2] : o2;
+          const int o2 = td2.c_off + tid;
+          c2           = (a.o2l && tid < td2.nc()) ? a.o2l[o2] : o2;
         }
       }
       // (b) the next tile's cell states, edge records and per-cell streams
-      uint32_t nlr0 = 0, nlr1 = 0, nlr2 = 0;
-      double   ncs0 = 0.0, ncs1 = 0.0, ncs2 = 0.0;
+      uint32_t nlr0 = 0, nlr1 = 0;
+      double   ncs0 = 0.0, ncs1 = 0.0;
       CellStreams<S> nxt;
       if (idx1 < hi) {
-        if (tile1 * TILE + tid < a.n_owned) {
+        if (tid < td1.nc()) {
           pu0 = u[3 * (int64_t)c1 + 0]; pu1 = u[3 * (int64_t)c1 + 1]; pu2 = u[3 * (int64_t)c1 + 2];
           if (HR) pz = a.zc_local[c1];
         }
@@ -578,9 +659,8 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
         const int ne1 = td1.ne();
         if (tid < ne1) { nlr0 = RDY_LD(&a.e_lr[td1.e_off + tid]); ncs0 = RDY_LD(&a.e_cs[td1.e_off + tid]); }
         if (tid + TILE < ne1) { nlr1 = RDY_LD(&a.e_lr[td1.e_off + TILE + tid]); ncs1 = RDY_LD(&a.e_cs[td1.e_off + TILE + tid]); }
-        if (NR > 2 && tid + 2 * TILE < ne1) { nlr2 = RDY_LD(&a.e_lr[td1.e_off + 2 * TILE + tid]); ncs2 = RDY_LD(&a.e_cs[td1.e_off + 2 * TILE + tid]); }
       }
-      load_streams<S, HR>(a, tile1 * TILE + tid, idx1 < hi && tile1 * TILE + tid < a.n_owned, nxt);
+      load_streams<S, HR>(a, td1.c_off + tid, idx1 < hi && tid < td1.nc(), nxt);
       __builtin_amdgcn_s_setprio(0);
 
       // ---- phase 1: every edge of the tile once, operands from LDS only
@@ -604,22 +684,8 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
             // hydrostatic reconstruction (swe_petsc.c:1046-1071); velocities are kept, with the strict
             // "h > tiny_h" wet test of the HR operator (1061-1064)
             const double zl = sd_zc[jl], zr = sd_zc[jr];
-            const double z_max = fmax(zl, zr);
             RiemannSide  Lr, Rr;
-            Lr.h   = fmax(0.0, (L.h + zl) - z_max);
-            Rr.h   = fmax(0.0, (R.h + zr) - z_max);
-            // the staged velocities already follow the HR operator's rule (hr_velocity_rule, phase 0)
-            Lr.u = L.u; Lr.v = L.v; Rr.u = R.u; Rr.v = R.v;
-            // Only the side with the LOWER bed changes its depth; the other one keeps (h + z) - z, i.e. its own depth up to one
-            // rounding of the sum, and its staged square root stands in for the root of that value (relative difference
-            // <= ulp(h + z) / (4 h): ~1e-13 for 1 cm of water over a bed at 50 m).  One square root
-            // per edge instead of two.
-            const bool   l_high = zl >= zr;
-            const double sx     = rdy_sqrt(l_high ? Rr.h : Lr.h);
-            Lr.sqh = l_high ? L.sqh : sx;
-            Rr.sqh = l_high ? sx : R.sqh;
-            Lr.c   = SQRT_GRAVITY * Lr.sqh;
-            Rr.c   = SQRT_GRAVITY * Rr.sqh;
+            hr_reconstruct(L, R, zl, zr, Lr, Rr);
             fl     = roe_flux(Lr, Rr, sn, cn);
             const bool outer = !(R.h < a.tiny_h && L.h < a.tiny_h);       // 1094
             wet              = outer && (Lr.h > a.tiny_h || Rr.h > a.tiny_h);  // inner guard, 1112
@@ -636,7 +702,7 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
           }
         } else {
           // boundary edges: HR is a no-op (operator_fluxes_petsc.c:57-58); their cell is the left one
-          const int    k  = RDY_COLD(a, tile_bk)[td.b_off + ((lr >> EDGE_R_SHIFT) & EDGE_SLOT_MASK)];
+          const int    k  = RDY_COLD(a, tile_bk)[load_uniform(RDY_COLD(a, tile_boff), tile) + ((lr >> EDGE_R_SHIFT) & EDGE_SLOT_MASK)];
           if (HR_STAGED_VEL && L.h == a.tiny_h) {
             // the staged velocities carry the HR operator's "h > tiny_h" rule, ApplyBoundaryFlux wants ComputeRiemannVelocities'
             // "h < tiny_h => 0" (swe_petsc.c:62): they differ at equality only (the left cell of a boundary edge is a tile cell)
@@ -661,16 +727,14 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
         ef2[e] = fl.f2;
         eam[e] = wet ? fl.amax : -1.0;  // -1 marks a dry-dry edge (skipped, swe_petsc.c:285)
       };
-      // The first NR rounds take their records from registers.  This loop must contain no global load on any
+      // Both rounds take their records from registers.  This loop must contain no global load on any
       // path: hipcc would put an s_waitcnt vmcnt(0) at the merge, and every round would then wait for
       // the whole prefetch batch issued above.
 #pragma unroll 1
-      for (int r = 0; r < NR; ++r) {
+      for (int r = 0; r < 2; ++r) {
         const int e = tid + r * TILE;
-        if (e < ne) do_edge(e, r == 0 ? lr0 : (r == 1 || NR == 2 ? lr1 : lr2), r == 0 ? cs0 : (r == 1 || NR == 2 ? cs1 : cs2));
+        if (e < ne) do_edge(e, r == 0 ? lr0 : lr1, r == 0 ? cs0 : cs1);
       }
-      // further rounds (numberings with poor locality) load their records here
-      for (int e = tid + NR * TILE; e < ne; e += TILE) do_edge(e, a.e_lr[td.e_off + e], a.e_cs[td.e_off + e]);
       __syncthreads();
 
       // ---- phase 2: per-cell sum in the reference's edge order, source terms; the stores come last
@@ -684,6 +748,8 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
           acc1 = f[3 * (int64_t)o + 1];
           acc2 = f[3 * (int64_t)o + 2];
         }
+        bool      tie      = false;  // a slot of this cell met the thread's running Courant maximum to the last bit
+        const int rec_in   = trk.rec;
 #pragma unroll
         for (int s = 0; s < S; ++s) {
           uint32_t ref;
@@ -711,12 +777,31 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
           if (am != -1.0) {
             // len/area_self: the max over an edge's two cells is len / min(area_l, area_r) (swe_petsc.c:289)
             const double cnum = am * fabs(k) * dt;
-            if (cnum > best) {
-              best      = cnum;
-              best_slot = s;
-              best_o    = o;
+            tie |= cnum == trk.best;
+            if (cnum > trk.best) {
+              trk.best = cnum;
+              trk.rec  = td.e_off + (int)ref;
             }
           }
+        }
+        if (trk.rec != rec_in) trk.pos = -1;
+        if (tie) {  // cold: which of the equal edges comes first in the reference's loop (CourantTrack)
+          int first = -1;  // the first slot of this cell at the running maximum: the only one that can come before the incumbent
+#pragma unroll
+          for (int s = 0; s < S; ++s) {
+            uint32_t ref;
+            if (S == 3) {
+              ref = (cur.r0 >> (10 * s)) & 0x3FF;
+              if (ref == REF3_EMPTY) continue;
+            } else {
+              const uint32_t w = (s < 2) ? cur.r0 : cur.r1;
+              ref              = (s & 1) ? (w >> 16) : (w & 0xFFFFu);
+              if (ref == SLOT_EMPTY) continue;
+            }
+            const double am = eam[ref];
+            if (first < 0 && am != -1.0 && am * fabs(cur.coef[s]) * dt == trk.best) first = td.e_off + (int)ref;
+          }
+          if (first >= 0) courant_resolve_tie(a, trk, first, load_uniform(RDY_COLD(a, e_pos), td.e_off));
         }
         acc_fdiv[0] = acc0;
         acc_fdiv[1] = acc1;
@@ -741,16 +826,14 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
       // materialised at the very end of the loop body).
       asm volatile("" ::"v"(pu0), "v"(pu1), "v"(pu2), "v"(ph0), "v"(ph1), "v"(ph2), "v"(pz), "v"(phz), "v"(nlr0), "v"(nlr1), "v"(ncs0), "v"(ncs1),
                    "v"(hid2), "v"(c2));
-      if (NR > 2) asm volatile("" ::"v"(nlr2), "v"(ncs2));
       asm volatile("" ::"v"(nxt.r0), "v"(nxt.r1), "v"(nxt.coef[0]), "v"(nxt.coef[1]), "v"(nxt.coef[2]), "v"(nxt.coef[S - 1]), "v"(nxt.dzdx),
                    "v"(nxt.dzdy), "v"(nxt.nman), "v"(nxt.s0), "v"(nxt.s1), "v"(nxt.s2));
       // rotate the pipeline registers, store
       const bool send_tile = EULER && td.send();  // wave-uniform
-      const int  tile_cur  = tile;
+      const int  tile_cur  = tile, nc_cur = td.nc();
       idx = idx1; tile = tile1; td = td1;
       idx1 = idx2; tile1 = tile2; td1 = td2; hid1 = hid2; c1 = c2;
       lr0 = nlr0; lr1 = nlr1; cs0 = ncs0; cs1 = ncs1;
-      if (NR > 2) { lr2 = nlr2; cs2 = ncs2; }
       cur = nxt;
       __builtin_amdgcn_sched_barrier(0);
       // F, pv (and fdiv, u_out) are [cell][3]: a wave's 64 cells own 192 consecutive doubles of each.  The rows are
@@ -760,7 +843,7 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
       {
         const int     lane  = tid & 63;
         const int64_t base  = 3 * ((int64_t)o - lane);
-        const int     ncell = a.n_owned - (o - lane);
+        const int     ncell = nc_cur - (tid - lane);  // the wave's cells of this tile
         if (!EULER || f) wave_store_rows3<FNT>(f, base, lane, ncell, out[0], out[1], out[2]);
         wave_store_rows3(a.pv, base, lane, ncell, out[3], out[4], out[5]);
         if (a.fdiv) wave_store_rows3(a.fdiv, base, lane, ncell, acc_fdiv[0], acc_fdiv[1], acc_fdiv[2]);
@@ -783,16 +866,14 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
               a.u_out[3 * c + 2] = n2;
             }
           }
-          if (send_tile) {
-            wave_store_send_rows(a, tile_cur, tid, n0, n1, n2);
-            wave_signal_send_rows(a, tid);
-          }
+          if (send_tile) wave_store_send_rows(a, tile_cur, tid, n0, n1, n2);
         }
       }
       if (last) break;
     }
   }
-  block_courant_reduce<TILE>(a, best, best_slot, best_o);
+  courant_extra_edges<HR>(a, dt, u, trk);
+  block_courant_reduce<TILE>(a, trk.best, RDY_COLD(a, e_pos), trk.rec);
 }
 
 // ---------------------------------------------------------------------------
@@ -882,7 +963,7 @@ __global__ __launch_bounds__(BLOCK) void swe_rhs_kernel(const KernelArgs a, cons
     cell_epilogue<SRC>(a, o, dt, h, hu, hv, self.u, self.v, acc0, acc1, acc2, a.dzdx[o], a.dzdy[o], a.mannings[o], a.extsrc[3 * (int64_t)o + 0],
                        a.extsrc[3 * (int64_t)o + 1], a.extsrc[3 * (int64_t)o + 2], f);
   }
-  block_courant_reduce<BLOCK>(a, best, best_slot, o);
+  block_courant_reduce<BLOCK>(a, best, RDY_COLD(a, pos), (best_slot < 0 ? 0 : best_slot) * a.stride + o);
 }
 
 // merges the per-workgroup buckets into the 16-byte diagnostic the host reads (rdyhip_update_diagnostics)

@@ -156,12 +156,27 @@ class HaloExchange:
             _lib.check(lib.rdyhip_halo_fuse_pack(self._halo, 0))
         return bool(lib.rdyhip_halo_pack_fused(self._halo))
 
-    @property
-    def signalled(self) -> bool:
-        """fused-pack Euler steps use the signalled form (the next step's transfer starts when the running launch has stored its
-        last send row: rdyhip_halo_signalled)"""
+    FORM_SOURCES = ("trial_running", "measured", "forced", "default", "locked_in_order")
+
+    def form_info(self, kind: str = "rhs") -> dict:
+        """rdyhip_halo_form_info: which form the steps of this halo take (in order on the caller's stream / two streams) and why:
+        the library times both forms over the first 16 calls of a kind ("rhs": rhs_overlapped, "euler": step_overlapped) on the
+        communicator it really has and keeps the faster one"""
+        import ctypes as C
         from . import _lib
-        return self._halo is not None and bool(_lib.load().rdyhip_halo_signalled(self._halo))
+        if self._halo is None:
+            return {"form": "none", "source": "no_halo"}
+        info = _lib.RDyHipHaloFormInfo()
+        _lib.check(_lib.load().rdyhip_halo_form_info(self._halo, 1 if kind == "euler" else 0, C.byref(info)))
+        return {"form": "two_streams" if info.form else "in_order", "source": self.FORM_SOURCES[info.source], "trial_steps": int(info.trial_steps),
+                "in_order_ms": float(info.in_order_ms), "two_stream_ms": float(info.two_stream_ms)}
+
+    def set_form(self, kind: str, form) -> None:
+        """rdyhip_halo_set_form: force a form ("in_order" / "two_streams") or run the trial again (None)"""
+        from . import _lib
+        if self._halo is not None:
+            f = -1 if form is None else (1 if form in (1, True, "two_streams") else 0)
+            _lib.check(_lib.load().rdyhip_halo_set_form(self._halo, 1 if kind == "euler" else 0, f))
 
     def invalidate(self):
         """the state array was written by somebody else since the last step: the next step packs again"""

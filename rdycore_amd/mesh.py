@@ -492,6 +492,84 @@ def hilbert_cell_order(centroids: np.ndarray) -> np.ndarray:
     return np.argsort(d, kind="stable")
 
 
+def renumber_edges(mesh: "RDyMesh", new_of_old: np.ndarray, flip: Optional[np.ndarray] = None) -> "RDyMesh":
+    """The same mesh with its edges renumbered (`new_of_old[e]` = new id of edge e) and, where `flip` is set, an internal
+    edge's left and right cells swapped (normal negated, vertices exchanged) -- cells untouched.
+
+    build_mesh numbers edges in order of first appearance while walking the cells and puts the lower-numbered cell on the
+    left; DMPlex does neither: edges are points of their own stratum, numbered independently of the cells
+    (src/rdymesh.c:693-710 builds internal_edge_ids by walking that numbering), and left / right follow the support
+    order and the orientation flip of src/rdymesh.c:607-673.  This is what a drop-in sees.  internal / boundary edge
+    lists and every boundary's edge list come out ascending in the NEW numbering, as a DMPlex stratum walk gives them."""
+    new_of_old = np.asarray(new_of_old, dtype=np.int64)
+    ne = mesh.num_edges
+    assert new_of_old.shape == (ne,) and np.array_equal(np.sort(new_of_old), np.arange(ne))
+    old_of_new = np.empty(ne, dtype=np.int64)
+    old_of_new[new_of_old] = np.arange(ne)
+    left = mesh.edge_cell_ids[0::2][old_of_new].copy()
+    right = mesh.edge_cell_ids[1::2][old_of_new].copy()
+    cn = mesh.edge_cn[old_of_new].copy()
+    sn = mesh.edge_sn[old_of_new].copy()
+    ev = mesh.edge_vertex_ids[old_of_new].copy()
+    if flip is not None:
+        f = np.asarray(flip, dtype=bool)[old_of_new] & (right >= 0)
+        left[f], right[f] = right[f], left[f].copy()
+        cn[f] = -cn[f]
+        sn[f] = -sn[f]
+        ev[f] = ev[f][:, ::-1]
+    cell_ids = np.empty(2 * ne, dtype=np.int32)
+    cell_ids[0::2] = left
+    cell_ids[1::2] = right
+    out = dataclasses.replace(
+        mesh, edge_cell_ids=cell_ids, edge_vertex_ids=np.ascontiguousarray(ev, dtype=np.int32),
+        edge_internal_ids=np.nonzero(right >= 0)[0].astype(np.int32), edge_boundary_ids=np.nonzero(right < 0)[0].astype(np.int32),
+        edge_global_ids=np.ascontiguousarray(mesh.edge_global_ids[old_of_new]), edge_lengths=np.ascontiguousarray(mesh.edge_lengths[old_of_new]),
+        edge_cn=cn, edge_sn=sn, edge_centroids=np.ascontiguousarray(mesh.edge_centroids[old_of_new]),
+        boundaries=[RDyBoundary(b.id, b.name, np.sort(new_of_old[b.edge_ids]).astype(np.int32)) for b in mesh.boundaries])
+    return out
+
+
+def renumber_cells(mesh: "RDyMesh", order: np.ndarray) -> "RDyMesh":
+    """The same mesh with its LOCAL cells renumbered (`order[n]` = old id of new cell n) and nothing else: the edges keep
+    their numbers, their left / right cells and their loop order -- what DMPlexPermute over the cell stratum does
+    (RDyHipPermuteLocalCells in adapter/rdyhip_petsc.c: "the other points keep their numbers").  Owned cells keep their
+    relative order in the owned numbering (local_to_owned follows the new local order), global ids travel with the cells."""
+    order = np.asarray(order, dtype=np.int64)
+    nc = mesh.num_cells
+    assert order.shape == (nc,) and np.array_equal(np.sort(order), np.arange(nc))
+    new_of_old = np.empty(nc, dtype=np.int64)
+    new_of_old[order] = np.arange(nc)
+    is_owned = np.ascontiguousarray(mesh.cell_is_owned[order])
+    owned = np.nonzero(is_owned)[0].astype(np.int32)
+    ghost = np.nonzero(is_owned == 0)[0].astype(np.int32)
+    l2o = np.empty(nc, dtype=np.int32)
+    l2o[owned] = np.arange(owned.size, dtype=np.int32)
+    l2o[ghost] = owned.size + np.arange(ghost.size, dtype=np.int32)
+    ec = mesh.edge_cell_ids
+    out = dataclasses.replace(
+        mesh, cell_conn=np.ascontiguousarray(mesh.cell_conn[order]), cell_nverts=np.ascontiguousarray(mesh.cell_nverts[order]),
+        cell_is_owned=is_owned, cell_local_to_owned=l2o, cell_owned_to_local=owned,
+        cell_global_ids=np.ascontiguousarray(mesh.cell_global_ids[order]), cell_centroids=np.ascontiguousarray(mesh.cell_centroids[order]),
+        cell_areas=np.ascontiguousarray(mesh.cell_areas[order]), cell_dz_dx=np.ascontiguousarray(mesh.cell_dz_dx[order]),
+        cell_dz_dy=np.ascontiguousarray(mesh.cell_dz_dy[order]), cell_zc=np.ascontiguousarray(mesh.cell_zc[order]),
+        edge_cell_ids=np.where(ec >= 0, new_of_old[np.maximum(ec, 0)], -1).astype(np.int32),
+        cell_owner_rank=None if mesh.cell_owner_rank is None else np.ascontiguousarray(mesh.cell_owner_rank[order]))
+    return out
+
+
+def dmplex_like_numbering(mesh: "RDyMesh", seed: int = 0, flip_fraction: float = 0.5, hilbert: bool = True) -> "RDyMesh":
+    """`mesh` as the drop-in hands it over: cells permuted along a Hilbert curve (owned first, then the ghosts: what
+    RDyHipPermuteLocalCells does), edges in an order that owes nothing to the cells, left / right not tied to the cell
+    numbers."""
+    rng = np.random.default_rng(seed)
+    m = mesh
+    if hilbert:
+        h = hilbert_cell_order(m.cell_centroids)
+        h = np.concatenate([h[m.cell_is_owned[h] != 0], h[m.cell_is_owned[h] == 0]])
+        m = renumber_cells(m, h)
+    return renumber_edges(m, rng.permutation(m.num_edges), flip=rng.random(m.num_edges) < flip_fraction)
+
+
 def refine_triangles(xyz: np.ndarray, conn: np.ndarray, tagged_edges: Optional[np.ndarray] = None):
     """Regular refinement: every triangle -> 4 by edge midpoints (what
     `-dm_refine` does to a simplex DMPlex, used by src/rdymms.c:945-948 and by

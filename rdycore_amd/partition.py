@@ -119,7 +119,7 @@ def owned_cell_boundaries(namer: Optional[Callable[[np.ndarray, np.ndarray], np.
     return f
 
 
-def _block_connectivity(kind: str, i0: int, i1: int, j0: int, j1: int, d: Tuple[float, float], order: str, tile: int):
+def _block_connectivity(kind: str, i0: int, i1: int, j0: int, j1: int, d: Tuple[float, float], order: str, tile):
     """Squares [i0,i1) x [j0,j1) of a global structured grid: vertices, cells (2 triangles per square with the global
     diagonal parity, or 1 quad), and each cell's global square index (qi, qj)."""
     nx, ny = i1 - i0, j1 - j0
@@ -130,10 +130,11 @@ def _block_connectivity(kind: str, i0: int, i1: int, j0: int, j1: int, d: Tuple[
     qi, qj = np.meshgrid(np.arange(nx, dtype=np.int64), np.arange(ny, dtype=np.int64), indexing="xy")
     qi, qj = qi.ravel(), qj.ravel()
     if order == "tiled":
-        # tile x tile blocks aligned to the GLOBAL grid, so that the numbering of a cell's block does not depend on the cut
+        # tx x ty blocks of squares aligned to the GLOBAL grid, so that the numbering of a cell's block does not depend on the cut
+        tx, ty = (tile, tile) if np.isscalar(tile) else tile
         gi, gj = qi + i0, qj + j0
-        nbx = (i1 + tile - 1) // tile + 1
-        key = ((gj // tile) * nbx + (gi // tile)) * (tile * tile) + (gj % tile) * tile + (gi % tile)
+        nbx = (i1 + tx - 1) // tx + 1
+        key = ((gj // ty) * nbx + (gi // tx)) * (tx * ty) + (gj % ty) * tx + (gi % tx)
         perm = np.argsort(key, kind="stable")
         qi, qj = qi[perm], qj[perm]
     elif order == "hilbert":
@@ -161,13 +162,18 @@ def _block_connectivity(kind: str, i0: int, i1: int, j0: int, j1: int, d: Tuple[
 
 
 def partitioned_structured_mesh(kind: str, nxg: int, nyg: int, d, rank: int, world: int,
-                                zfunc: Optional[Callable] = None, order: str = "tiled", tile: int = 16,
+                                zfunc: Optional[Callable] = None, order: str = "tiled", tile=None,
                                 keep: Optional[Callable[[np.ndarray, np.ndarray], np.ndarray]] = None,
                                 boundary_classifier=None, project_2d: bool = False) -> M.RDyMesh:
     """Rank `rank`'s local mesh of the nxg x nyg structured mesh (`kind` = "tri": two triangles per square, alternating
     diagonals; "quad") cut into `world` parts by RCB of the square centres.  `keep(qi, qj)` (bool per square) removes
     squares from the domain (their edges become domain boundaries).  Global cell id = cells_per_square * (qj*nxg + qi) + t.
-    With world == 1 this is the whole mesh (every kept square owned)."""
+    With world == 1 this is the whole mesh (every kept square owned).
+    `tile` (order "tiled"): the block of squares numbered together, default 16 x 16 squares for triangles (two 256-cell tiles
+    of the operator) and 16 x 15 for quads -- 240 cells with 511 edges, what one tile of the operator holds (its edge phase
+    keeps 512 edge records in registers; a 16 x 16 block of quads has 544)."""
+    if tile is None:
+        tile = 16 if kind == "tri" else (16, 15)
     d = (float(d), float(d)) if np.isscalar(d) else (float(d[0]), float(d[1]))
     per = 2 if kind == "tri" else 1
     if world == 1:

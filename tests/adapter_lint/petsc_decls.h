@@ -38,6 +38,9 @@ typedef int MPI_Op;
 #define MPI_INT64_T 2
 #define MPI_BYTE 3
 #define MPI_DOUBLE 4
+#define MPIU_INT MPI_INT
+#define MPI_SUM 1
+#define MPI_IN_PLACE ((void *)1)
 extern MPI_Comm PETSC_COMM_WORLD, PETSC_COMM_SELF;
 int MPI_Comm_size(MPI_Comm, int *);
 int MPI_Comm_rank(MPI_Comm, int *);

@@ -70,3 +70,40 @@ def oracle_rk4(orc, u, dt, nsteps):
         k4 = orc.apply(dt, u + dt * k3)
         u = u + dt * (k1 / 6.0 + k2 / 3.0 + k3 / 3.0 + k4 / 6.0)
     return u
+
+
+def interior_courant_numbers(case):
+    """Per internal edge (position in edges.internal_edge_ids): the Courant number the reference's interior-flux loop forms
+    (src/swe/swe_petsc.c:289; with hydrostatic reconstruction 1046-1071, 1117), restated in numpy for first order and HR --
+    only the largest wave speed, chat + |uperp|, of the Roe solver is needed.  NaN where the edge is skipped (both sides dry).
+    Used to tell a genuine disagreement about the edge of the maximal Courant number from two edges whose numbers agree to
+    rounding (symmetric states: which of them a run reports then hangs on its last bits)."""
+    m, cfg = case.mesh, case.config
+    g = 9.806
+    e = m.edge_internal_ids
+    l, r = m.edge_cell_ids[2 * e], m.edge_cell_ids[2 * e + 1]
+    u = case.u_local
+    hl, hr = u[l, 0].copy(), u[r, 0].copy()
+
+    def vel(h, hu, hv, strict):
+        wet = (h > cfg.tiny_h) if strict else ~(h < cfg.tiny_h)
+        den = h * h + cfg.h_anuga_regular ** 2
+        with np.errstate(all="ignore"):
+            return np.where(wet, hu * h / den, 0.0), np.where(wet, hv * h / den, 0.0)
+    hr_on = cfg.well_balancing != 0
+    ul, vl = vel(u[l, 0], u[l, 1], u[l, 2], hr_on)
+    ur, vr = vel(u[r, 0], u[r, 1], u[r, 2], hr_on)
+    skip = (u[l, 0] < cfg.tiny_h) & (u[r, 0] < cfg.tiny_h)
+    if hr_on:
+        zl, zr = m.cell_zc[l], m.cell_zc[r]
+        zm = np.maximum(zl, zr)
+        hl = np.maximum(0.0, (u[l, 0] + zl) - zm)
+        hr = np.maximum(0.0, (u[r, 0] + zr) - zm)
+        skip |= ~((hl > cfg.tiny_h) | (hr > cfg.tiny_h))
+    with np.errstate(all="ignore"):
+        dl, dr = np.sqrt(hl), np.sqrt(hr)
+        uhat = (dl * ul + dr * ur) / (dl + dr)
+        vhat = (dl * vl + dr * vr) / (dl + dr)
+        amax = np.sqrt(0.5 * g * (hl + hr)) + np.abs(uhat * m.edge_cn[e] + vhat * m.edge_sn[e])
+        c = amax * m.edge_lengths[e] / np.minimum(m.cell_areas[l], m.cell_areas[r]) * case.dt
+    return np.where(skip, np.nan, c)

@@ -23,7 +23,7 @@ def test_library_builds_for_gfx950_and_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"librdyhip.so does not export {n}"
     assert sorted(_lib.SYMBOLS) == names, "ctypes table and header disagree"
-    assert lib.rdyhip_version() == 109
+    assert lib.rdyhip_version() == 110
 
 
 def test_code_object_targets_gfx950_only():

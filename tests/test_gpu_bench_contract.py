@@ -50,4 +50,20 @@ def test_bench_line_has_the_contract_keys(extra, rdyhip_kernel):
         assert "traffic" in e and e["traffic_source"]["key"].endswith("_euler_step")
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and c["unit"] == "M cell-updates/s" and "sample" in c
+    # the CPU figure is taken on the benchmark mesh itself (the sample of earlier rounds is the second key); a rank's part of an
+    # emulated partition keeps the sample only
+    if "--emulate-world" in extra:
+        assert "sample mesh" in c["sample"] and "cpu_baseline_sample" not in d
+    else:
+        assert "the benchmark mesh itself" in c["sample"] and str(d["config"]["cells_per_gpu"]) in c["sample"]
+        assert d["cpu_baseline_sample"]["cores"] == 1 and "sample mesh" in d["cpu_baseline_sample"]["sample"]
+    # the drop-in's real loop beside the back-to-back rate: 20 steps per RDyAdvance, rain refreshed from a host array, the Courant
+    # struct read back (or not: fixed dt)
+    if "--self-exchange" not in extra:
+        a = d["advance_pattern"]
+        assert a["steps_per_advance"] == 20 and a["ms_per_step_adaptive_dt"] > 0 and a["ms_per_step_fixed_dt"] > 0
+        assert abs(a["vs_back_to_back_adaptive_dt"] - a["ms_per_step_adaptive_dt"] / a["back_to_back_ms_per_step"]) < 1e-2
+    else:
+        f1 = d["config"]["per_rank"][0]["rhs_step_form"]
+        assert f1["form"] in ("in_order", "two_streams") and f1["source"] in ("measured", "trial_running", "forced")
     assert d["value"] > 0 and abs(d["value"] - d["config"]["cells_per_gpu"] / d["ms_per_step"] / 1e3) <= 1e-3 * d["value"] + 0.11

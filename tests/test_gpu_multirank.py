@@ -133,7 +133,7 @@ def _worker(rank, world, port, kernel, q, second_order=False, transport="torch",
                 dts = 0.1 * case.dt
                 EulerStepper(op, halo=halo).advance(ua, dts, 5 * dts)
                 assert lib.rdyhip_halo_pack_fused(halo._halo) == 1
-                assert not halo.signalled                       # a transport callback carries the bytes here: the signalled form is RCCL's
+                assert halo.form_info("euler")["source"] == "forced"   # RDYHIP_OVERLAP above
                 # (second order, fused form: the state pack rides on the kernel, the gradient exchange still packs with a launch)
                 stepper = EulerStepper(op, halo=halo)
                 assert halo.fuse_pack(False) is False
@@ -334,9 +334,6 @@ def test_rccl_self_exchange_one_rank(rdyhip_kernel):
     for fuse in (1, 0):
         _lib.check(lib.rdyhip_halo_fuse_pack(h, fuse))
         assert lib.rdyhip_halo_pack_fused(h) == fuse
-        # rows 2000.. are OWNED cells here, which the step's launch stores: the signalled form (whose transfer runs beside that
-        # launch) refuses such a pattern and the other forms stay in charge (test_signalled_form_self_exchange has real ghosts)
-        assert lib.rdyhip_halo_signalled(h) == 0
         a, b = expect.clone(), torch.empty_like(expect)
         for _ in range(4):
             _lib.check(lib.rdyhip_euler_step_overlapped(op._h, h, 0.1 * case.dt, int(a.data_ptr()), int(b.data_ptr()), None, st))
@@ -361,12 +358,13 @@ def test_rccl_self_exchange_one_rank(rdyhip_kernel):
 
 @pytest.mark.timeout(300)
 @pytest.mark.parametrize("kind,second_order", [("strips", False), ("rcb_houston", False), ("strips", True), ("rcb_houston", True)])
-def test_signalled_form_self_exchange(rdyhip_kernel, kind, second_order):
-    """The signalled form of the fused-pack Euler step (include/rdyhip.h): the launch of step n says when its last send row is in
-    memory and the transfer of step n + 1 runs beside the rest of that launch.  One rank's part of a partitioned mesh (real ghost
-    rows), the exchange looped back through a one-rank RCCL communicator (its boundary cells travel to its own ghost rows): the
-    same twelve steps -- with an RHS evaluation and a host edit of the state in between -- give the same bits (a) signalled,
-    (b) fused pack without the signal, in order and in the two-stream form, (c) with a pack launch per step."""
+def test_step_forms_self_exchange(rdyhip_kernel, kind, second_order):
+    """The forms of the multi-rank step (include/rdyhip.h) give the same bits.  One rank's part of a partitioned mesh (real ghost
+    rows), the exchange looped back through a one-rank RCCL communicator (its boundary cells travel to its own ghost rows):
+    twelve Euler steps -- with an RHS evaluation and a host edit of the state in between -- (a) with a pack launch per step, in
+    order; (b) fused pack, in order and on two streams; (c) no pack fused, two streams; (d) the halo left to itself: its first
+    sixteen steps of a kind alternate between the forms (the trial), then the faster one stays -- and rdyhip_halo_form_info
+    says which, with both timings."""
     if rdyhip_kernel == "cell":
         pytest.skip("the fused pack rides on the tiled kernels")
     import ctypes as C
@@ -383,7 +381,7 @@ def test_signalled_form_self_exchange(rdyhip_kernel, kind, second_order):
     else:
         case = CS.houston_refined_case(os.path.join(ROOT, "tests", "golden", "houston"), 3, "hilbert", rank=2, world=5)
         mesh = case.mesh
-    case.config.second_order = second_order      # fused MUSCL form: the state pack rides on its Euler-step kernel too (no signalled form)
+    case.config.second_order = second_order
     op = CS.create_operator(case)
     uid = C.create_string_buffer(128)
     _lib.check(lib.rdyhip_comm_unique_id(uid))
@@ -404,18 +402,23 @@ def test_signalled_form_self_exchange(rdyhip_kernel, kind, second_order):
     dts = 0.1 * case.dt
     f = torch.empty((mesh.num_owned_cells, 3), dtype=torch.float64, device="cuda:0")
 
-    def run(fuse, signalled, overlap):
-        os.environ["RDYHIP_OVERLAP"] = overlap
-        os.environ["RDYHIP_SIGNALLED"] = signalled
+    def form_info(h, kind_):
+        info = _lib.RDyHipHaloFormInfo()
+        _lib.check(lib.rdyhip_halo_form_info(h, kind_, C.byref(info)))
+        return info
+
+    def run(fuse, overlap, steps_after=4):
+        if overlap is not None:
+            os.environ["RDYHIP_OVERLAP"] = overlap
         try:
             h = C.c_void_p()
             _lib.check(lib.rdyhip_halo_create(op._h, comm, 1, p(i32([0])), p(i32([n])), p(sendc), p(i32([n])), p(ghost), C.byref(h)))
             _lib.check(lib.rdyhip_halo_fuse_pack(h, fuse))
         finally:
-            os.environ.pop("RDYHIP_OVERLAP")
-            os.environ.pop("RDYHIP_SIGNALLED")
+            os.environ.pop("RDYHIP_OVERLAP", None)
         assert lib.rdyhip_halo_pack_fused(h) == fuse
-        assert lib.rdyhip_halo_signalled(h) == (1 if fuse and signalled == "1" and not second_order else 0)
+        if overlap is not None:
+            assert form_info(h, 1).source == 2 and form_info(h, 1).form == int(overlap) == lib.rdyhip_halo_overlaps(h)
         a = torch.tensor(case.u_local, dtype=torch.float64, device="cuda:0")
         b = a.clone()
         step = lambda x, y: _lib.check(lib.rdyhip_euler_step_overlapped(op._h, h, dts, int(x.data_ptr()), int(y.data_ptr()), None, st))
@@ -430,19 +433,102 @@ def test_signalled_form_self_exchange(rdyhip_kernel, kind, second_order):
         torch.cuda.synchronize()
         a[torch.as_tensor(sendc[:7].astype(np.int64), device="cuda:0")] *= 1.01    # the host edits cells that are sent ...
         _lib.check(lib.rdyhip_halo_invalidate(h))                                  # ... and says so
-        for _ in range(4):
+        for _ in range(steps_after):
             step(a, b)
             a, b = b, a
         torch.cuda.synchronize()
+        info = form_info(h, 1)
         _lib.check(lib.rdyhip_halo_destroy(C.byref(h)))
-        return a.clone(), fa
+        return a.clone(), fa, info
 
-    ref, fref = run(0, "1", "0")
+    ref, fref, _ = run(0, "0")
     own = torch.as_tensor(mesh.cell_owned_to_local.astype(np.int64), device="cuda:0")
     assert bool(torch.isfinite(ref[own]).all()) and bool(torch.isfinite(fref).all())
-    for fuse, signalled, overlap in ((1, "1", "0"), (1, "0", "0"), (1, "0", "1"), (0, "1", "1")):
-        got, fgot = run(fuse, signalled, overlap)
-        assert torch.equal(got, ref) and torch.equal(fgot, fref), (fuse, signalled, overlap)
+    for fuse, overlap in ((1, "0"), (1, "1"), (0, "1"), (1, None), (0, None)):
+        got, fgot, info = run(fuse, overlap)
+        assert torch.equal(got, ref) and torch.equal(fgot, fref), (fuse, overlap)
+        if overlap is None:
+            assert info.source == 0 and info.trial_steps == 12           # twelve Euler steps so far: the trial is still running
+    # ... and through to its end: 16 steps alternate, the 17th reads the timings and settles
+    ref2, _, _ = run(0, "0", steps_after=12)
+    got2, _, info = run(1, None, steps_after=12)
+    assert torch.equal(got2, ref2)
+    assert info.source == 1 and info.trial_steps == 16 and info.in_order_ms > 0.0 and info.two_stream_ms > 0.0, (info.source, info.trial_steps)
+    assert info.form == (1 if info.two_stream_ms < info.in_order_ms else 0)
+    _lib.check(lib.rdyhip_comm_destroy(comm))
+    op.destroy()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("second_order", [False, True])
+def test_send_cells_outside_the_ghost_adjacent_tiles(rdyhip_kernel, second_order):
+    """the DM's overlap is vertex-adjacent (DMPlexDistributeOverlap, src/rdydm.c:150), so a cell that touches
+    another rank through a vertex only is a send cell -- and can sit in a tile no ghost touches, which the INTERIOR launch of a
+    two-stream step runs beside the transfer that reads the send buffer.  A halo whose send list holds such cells keeps its
+    fused-pack Euler steps in order (rdyhip_halo_form_info: locked), whatever RDYHIP_OVERLAP says, and gives the bits of the
+    steps with a pack launch each."""
+    if rdyhip_kernel == "cell":
+        pytest.skip("the fused pack rides on the tiled kernels")
+    import ctypes as C
+    from rdycore_amd import _lib
+    from rdycore_amd import cases as CS
+    from rdycore_amd import mesh as M
+    lib = _lib.load()
+    torch.cuda.set_device(0)
+    nxp, ny, world = 160, 96, 3
+    K = 2 * np.pi / 37
+    mesh = M.strip_partition_tri_mesh(nxp, ny, 1, world, 1.0, zfunc=CS.mms_bathymetry(K=K), order="tiled", tile=8)
+    case = CS.friction_slope_case(mesh, nxp * world, ny, dt=1e-2, K=K)
+    case.config.second_order = second_order
+    op = CS.create_operator(case)
+    info = op.layout_info()
+    assert 0 < info["num_halo_tiles"] < info["num_tiles"] // 4
+    uid = C.create_string_buffer(128)
+    _lib.check(lib.rdyhip_comm_unique_id(uid))
+    comm = C.c_void_p()
+    _lib.check(lib.rdyhip_comm_init_rank(1, 0, uid.raw, C.byref(comm)))
+    i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+    p = lambda a: a.ctypes.data_as(_lib.c_int32_p)
+    ghost = np.nonzero(mesh.cell_is_owned == 0)[0].astype(np.int32)
+    # send cells: the edge-adjacent ones AND owned cells from the middle of the strip (what a vertex-adjacent overlap may add)
+    gset = np.zeros(mesh.num_cells, dtype=bool)
+    gset[ghost] = True
+    cl, cr = mesh.edge_cell_ids[0::2], mesh.edge_cell_ids[1::2]
+    cut = (cr >= 0) & (gset[cl] != gset[np.maximum(cr, 0)])
+    edge_adj = np.unique(np.where(gset[cl[cut]], cr[cut], cl[cut]))
+    xc = mesh.cell_centroids[:, 0]
+    mid = np.nonzero((mesh.cell_is_owned != 0) & (np.abs(xc - xc[mesh.cell_is_owned != 0].mean()) < 2.0))[0][:40]
+    sendc = np.concatenate([edge_adj, mid]).astype(np.int32)
+    n = min(sendc.size, ghost.size)
+    sendc, ghostr = i32(np.concatenate([mid, edge_adj])[:n]), i32(ghost[:n])
+    st = int(torch.cuda.current_stream().cuda_stream)
+    dts = 0.1 * case.dt
+
+    def run(fuse, overlap):
+        os.environ["RDYHIP_OVERLAP"] = overlap
+        try:
+            h = C.c_void_p()
+            _lib.check(lib.rdyhip_halo_create(op._h, comm, 1, p(i32([0])), p(i32([n])), p(sendc), p(i32([n])), p(ghostr), C.byref(h)))
+            _lib.check(lib.rdyhip_halo_fuse_pack(h, fuse))
+        finally:
+            os.environ.pop("RDYHIP_OVERLAP")
+        fi = _lib.RDyHipHaloFormInfo()
+        _lib.check(lib.rdyhip_halo_form_info(h, 1, C.byref(fi)))
+        a = torch.tensor(case.u_local, dtype=torch.float64, device="cuda:0")
+        b = a.clone()
+        for _ in range(6):
+            _lib.check(lib.rdyhip_euler_step_overlapped(op._h, h, dts, int(a.data_ptr()), int(b.data_ptr()), None, st))
+            a, b = b, a
+        torch.cuda.synchronize()
+        _lib.check(lib.rdyhip_halo_destroy(C.byref(h)))
+        return a.clone(), (fi.form, fi.source)
+
+    ref, _ = run(0, "0")
+    got, form = run(1, "1")                       # two streams asked for: refused for this pattern
+    assert form == (0, 4), form                   # in order, RDYHIP_HALO_FORM_LOCKED_IN_ORDER
+    assert torch.equal(got, ref)
+    got, form = run(0, "1")                       # without the fused pack the two-stream form is fine (the pack launch runs first)
+    assert form == (1, 2) and torch.equal(got, ref)
     _lib.check(lib.rdyhip_comm_destroy(comm))
     op.destroy()
 
@@ -570,20 +656,11 @@ def test_fused_pack_lifetime_and_argument_errors(rdyhip_kernel):
     _lib.check(lib.rdyhip_halo_destroy(C.byref(h0)))
     op.destroy()                                       # h2 (holding the fused pack on the tiled kernel) outlives its operator
     _lib.check(lib.rdyhip_halo_destroy(C.byref(h2)))
-    # second order: the fused form (gradients in LDS) packs in its Euler-step kernel too, the split form keeps its pack launch
+    # second order packs in its Euler-step kernel too
     case.config.second_order = True
     if rdyhip_kernel != "cell":
-        for split in (False, True):
-            if split:
-                os.environ["RDYHIP_MUSCL"] = "split"
-            try:
-                op2 = CS.create_operator(case)
-            finally:
-                os.environ.pop("RDYHIP_MUSCL", None)
-            h = make_halo(op2, 100)
-            if split:
-                assert lib.rdyhip_halo_fuse_pack(h, 1) == 83 and b"second_order" in lib.rdyhip_last_error()
-            else:
-                assert lib.rdyhip_halo_fuse_pack(h, 1) == 0 and lib.rdyhip_halo_pack_fused(h) == 1
-            _lib.check(lib.rdyhip_halo_destroy(C.byref(h)))
-            op2.destroy()
+        op2 = CS.create_operator(case)
+        h = make_halo(op2, 100)
+        assert lib.rdyhip_halo_fuse_pack(h, 1) == 0 and lib.rdyhip_halo_pack_fused(h) == 1
+        _lib.check(lib.rdyhip_halo_destroy(C.byref(h)))
+        op2.destroy()

@@ -42,7 +42,7 @@ def run_both(case, accumulate_from=None, check_diag=True):
     return f.cpu().numpy(), f_ref, op, orc
 
 
-def check_all(case, f_gpu, f_ref, op, orc):
+def check_all(case, f_gpu, f_ref, op, orc, near_tie_ok=False):
     err = rel_linf(f_gpu, f_ref)
     assert np.isfinite(f_ref).all()
     assert err <= TOL, f"{case.name}: RHS L-inf {err:.3e}"
@@ -57,8 +57,20 @@ def check_all(case, f_gpu, f_ref, op, orc):
     # which unlimited extrapolation on jittered meshes passes on to the wave speeds; the bar there is the RHS's 1e-10
     ctol = 1e-10 if case.config.second_order else 1e-12
     assert abs(d.max_courant_num - cmax) <= ctol * max(1.0, cmax)
-    if case.mesh.num_owned_cells == case.mesh.num_cells:
-        assert (d.global_edge_id, d.global_cell_id) == (ce, cc)
+    if case.mesh.num_owned_cells == case.mesh.num_cells and (d.global_edge_id, d.global_cell_id) != (ce, cc):
+        # Another edge than the oracle's: only legitimate if the reference's own Courant numbers of the two edges agree to
+        # rounding (mirror-image edges of a symmetric state: which of them comes out on top hangs on the last bits of sin()
+        # at the two centroids, and the device's last bits -- FMA contraction, its own square roots -- are not the oracle's).
+        # Edges that tie EXACTLY in the reference (uniform states) must give the reference's edge: near_tie_ok is off there.
+        assert near_tie_ok and not case.config.second_order, ((d.global_edge_id, d.global_cell_id), (ce, cc))
+        from helpers import interior_courant_numbers
+        m = case.mesh
+        c = interior_courant_numbers(case)
+        pos = np.nonzero(m.edge_global_ids[m.edge_internal_ids] == d.global_edge_id)[0]
+        assert pos.size == 1 and abs(c[pos[0]] - cmax) <= 1e-13 * cmax, ((d.global_edge_id, d.global_cell_id), (ce, cc))
+        e = int(m.edge_internal_ids[pos[0]])
+        l, r = int(m.edge_cell_ids[2 * e]), int(m.edge_cell_ids[2 * e + 1])
+        assert d.global_cell_id == int(m.cell_global_ids[l if m.cell_areas[l] < m.cell_areas[r] else r])
     # boundary fluxes and their dt-weighted accumulation
     for b, bnd in enumerate(case.mesh.boundaries):
         bf = op.boundary_fluxes(b)
@@ -363,7 +375,7 @@ def test_error_behaviour():
 @pytest.mark.parametrize("kind", ["tri", "quad"])
 def test_random_cell_numbering(kind):
     # a numbering with no locality: every tile's neighbours are almost all outside the tile
-    # (exercises the halo-cell staging of the tiled kernel and its > 64 KB LDS request)
+    # (the tiles are then cut small enough for the kernel's fixed halo capacity: rdyhip_api.hip, layout_cut_tiles)
     rng = np.random.default_rng(3)
     K = 2 * np.pi / 31
     if kind == "tri":
@@ -379,8 +391,9 @@ def test_random_cell_numbering(kind):
     f, fr, op, orc = run_both(case)
     check_all(case, f, fr, op, orc)
     info = op.layout_info()
-    if info["tiled_kernel"]:
-        assert info["max_tile_halo_cells"] > 256
+    if info["tiled_kernel"]:      # tiles of ~30 cells: three edge records and three halo cells per cell, cut at the halo capacity
+        assert info["num_edge_records"] > 2.9 * mesh.num_cells and 90 <= info["max_tile_halo_cells"] <= 112
+        assert info["num_tiles"] > mesh.num_cells // 48
 
 
 # ---------------------------------------------------------------------------

@@ -18,20 +18,13 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-10
 
 
-@pytest.fixture(autouse=True, params=["fused", "split"])
-def muscl_mode(request, rdyhip_kernel):
-    """both forms of the second-order path behind the C ABI: gradients formed in LDS by the flux kernel
-    (default) and the separate gradient launch (RDYHIP_MUSCL=split)"""
-    import os
+@pytest.fixture(autouse=True)
+def muscl_mode(rdyhip_kernel):
+    """second order lives in the tiled kernel alone (the gradients formed in LDS by the flux kernel; the split form of rounds
+    1-4 -- a gradient launch, a flux kernel reading the gradients -- is tools/probes/split_muscl_form.patch)"""
     if rdyhip_kernel == "cell":
         pytest.skip("second order is implemented by the tiled kernels")
-    old = os.environ.get("RDYHIP_MUSCL")
-    os.environ["RDYHIP_MUSCL"] = request.param
-    yield request.param
-    if old is None:
-        os.environ.pop("RDYHIP_MUSCL", None)
-    else:
-        os.environ["RDYHIP_MUSCL"] = old
+    yield "fused"
 
 
 def _torch():
@@ -56,7 +49,7 @@ def test_tri_all_bcs_sources_limiters(limiter, source_method, muscl_mode):
     op.compute_gradients(torch.tensor(case.u_local, dtype=torch.float64, device="cuda"))
     g = op.gradients.cpu().numpy()
     assert rel_linf(g, orc.gradients6()) <= TOL
-    assert op.layout_info()["second_order_fused"] == (1 if muscl_mode == "fused" else 0)
+    assert op.layout_info()["second_order_fused"] == 1
     # and the scheme differs from first order on this state
     case.config.second_order = False
     assert np.abs(oracle_from_case(case).apply(case.dt, case.u_local) - fr).max() > 1e-8
@@ -215,8 +208,6 @@ def test_resident_workgroups_of_the_fused_kernels(muscl_mode):
     """A register-count regression guard for the two tile loops of the fused kernel (csrc/muscl_kernels.h): triangles in the
     plane layout must keep FOUR workgroups per CU (<= 128 VGPRs: the next tile's cells group in flight costs twenty), quads
     run the cross-tile pipeline at THREE (<= 168)."""
-    if muscl_mode != "fused":
-        pytest.skip("the fused kernel's occupancy")
     torch = _torch()
     cus = torch.cuda.get_device_properties(0).multi_processor_count
     tri = second_order(CS.dam_break_case(M.structured_tri_mesh(64, 32, order="tiled"), 24.0))
@@ -290,12 +281,9 @@ def test_mixed_tri_quad_mesh_second_order():
 
 @pytest.mark.parametrize("kind", ["tri", "quad"])
 @pytest.mark.parametrize("limiter", [LIMITER_MINMOD, LIMITER_VANLEER])
-def test_both_flux_storage_layouts_give_the_same_bits(limiter, kind, muscl_mode, monkeypatch):
-    """fused kernel: edge fluxes stored over the gradients (tiles whose edges fit the register rounds -- 2 x 256 for
-    triangles, 3 x 256 for quads --, four workgroups per CU) or behind the first ring's records
-    (RDYHIP_MUSCL_EF_OVERLAY=0, the layout of every other mesh) -- storage only, same arithmetic"""
-    if muscl_mode != "fused":
-        pytest.skip("layouts of the fused kernel")
+def test_tile_size_changes_nothing_but_the_tiling(limiter, kind, monkeypatch):
+    """the tiles a mesh is cut into (RDYHIP_TILE_CELLS: 256 / 128 / 64 cells at most) decide which edges are evaluated twice and
+    which gradients three times -- all copies from the same code path, so F, the Courant number and its ids have the same bits"""
     torch = _torch()
     if kind == "tri":
         case = second_order(tri_mms_case(64, 48, SOURCE_SEMI_IMPLICIT, order="tiled"), limiter)
@@ -304,17 +292,17 @@ def test_both_flux_storage_layouts_give_the_same_bits(limiter, kind, muscl_mode,
         mesh = M.structured_quad_mesh(80, 64, 1.0, 1.0, zfunc=CS.mms_bathymetry(K=K))
         case = second_order(CS.friction_slope_case(mesh, 80, 64, dt=1e-2, K=K), limiter)
     u = torch.tensor(case.u_local, dtype=torch.float64, device="cuda")
-    out, lds = [], []
-    for overlay in ("1", "0"):
-        monkeypatch.setenv("RDYHIP_MUSCL_EF_OVERLAY", overlay)
+    out, ntiles = [], []
+    for cells in ("256", "128", "64"):
+        monkeypatch.setenv("RDYHIP_TILE_CELLS", cells)
         op = CS.create_operator(case)
         f = torch.empty((case.mesh.num_owned_cells, 3), dtype=torch.float64, device="cuda")
         op.rhs_function(case.dt, u, f)
         torch.cuda.synchronize()
         op.update_diagnostics()
         out.append((f.cpu().numpy(), op.get_diagnostics()))
-        lds.append(op.layout_info()["lds_bytes"])
+        ntiles.append(op.layout_info()["num_tiles"])
         op.destroy()
-    assert lds[0] < lds[1]
-    assert np.array_equal(out[0][0], out[1][0])
-    assert out[0][1] == out[1][1]
+    assert ntiles[0] < ntiles[1] < ntiles[2]
+    for o in out[1:]:
+        assert np.array_equal(out[0][0], o[0]) and out[0][1] == o[1]

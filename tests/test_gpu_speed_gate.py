@@ -1,0 +1,86 @@
+"""A speed gate that does not depend on the box: in one process, the RHS kernel of each headline variant
+is timed against `axpy_owned_kernel` on the same number of cells -- 72 B per cell of pure streaming, the PMC calibration
+kernel of tools/calib_traffic.py -- and the RATIO of the two must stay within 4 % of the one recorded when the kernels were
+last profiled (tests/golden/speed_gate.json).  Boxes of the pool differ by up to 10 % in absolute time; the ratio moves with
+neither the HBM clock nor the launch overhead.  Round 4 lost the non-temporal hints of every store to an optimiser merge for
+most of the round (-5.6 %): bits unchanged, every parity test green -- this gate would have tripped on any box.
+
+RDYHIP_RECORD_SPEED_GATE=<file>: write the measured ratios there instead of asserting (how the golden file is made:
+tools/record_speed_gate.sh on the GPU box, after a change that is MEANT to move a kernel)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from rdycore_amd import cases as CS
+from rdycore_amd import mesh as M
+from rdycore_amd import partition as P
+from rdycore_amd.operator import WELL_BALANCING_HR
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden", "speed_gate.json")
+TOLERANCE = 0.04
+
+
+def _time_ms(torch, fn, n=80, lead=60):
+    """ms per call of n back-to-back calls, `lead` untimed ones right in front (the post-idle dip)"""
+    best = None
+    for _ in range(3):
+        for _ in range(lead):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        t = e0.elapsed_time(e1) / n
+        best = t if best is None else min(best, t)
+    return best
+
+
+def test_rhs_kernels_against_the_streaming_kernel(rdyhip_kernel):
+    if rdyhip_kernel == "cell":
+        pytest.skip("the gate is on the tiled kernels")
+    import torch
+    assert torch.cuda.is_available()
+    measured = {}
+    K = 2 * np.pi / 200.0
+    # C3 (BASELINE configs[2]): 2500 x 2000 squares = 10 M triangles, x-y projected lengths so that HR runs on the same mesh
+    tri = M.structured_tri_mesh(2500, 2000, 1.0, zfunc=CS.mms_bathymetry(K=K), order="tiled", project_2d=True)
+    base = CS.friction_slope_case(tri, 2500.0, 2000.0, dt=1e-3, K=K)
+    quad = CS.dam_break_quads_case(P.partitioned_structured_mesh("quad", 1920, 960, (10.0 / 1920, 5.0 / 960), 0, 1, keep=CS.dam_break_keep(1920, 960)))
+    for name, case, tweak in (("first", base, {}), ("hr", base, {"well_balancing": WELL_BALANCING_HR}), ("second_order", base, {"second_order": True}),
+                              ("quads", quad, {}), ("quads_second_order", quad, {"second_order": True})):
+        import copy
+        c = copy.copy(case)
+        c.config = copy.copy(case.config)
+        for k, v in tweak.items():
+            setattr(c.config, k, v)
+        op = CS.create_operator(c)
+        u = torch.tensor(c.u_local, dtype=torch.float64, device="cuda")
+        u2 = u.clone()
+        f = torch.empty((c.mesh.num_owned_cells, 3), dtype=torch.float64, device="cuda")
+        rhs = _time_ms(torch, lambda: op.rhs_function(c.dt, u, f))
+        axpy = _time_ms(torch, lambda: op.axpy_owned(0.0, f, u2))
+        euler = _time_ms(torch, lambda: op.euler_step(0.0, u, u2))
+        measured[name] = {"cells": int(c.mesh.num_owned_cells), "rhs_ms": round(rhs, 5), "axpy_ms": round(axpy, 5), "euler_step_ms": round(euler, 5),
+                          "rhs_over_axpy": round(rhs / axpy, 4), "euler_step_over_axpy": round(euler / axpy, 4)}
+        op.destroy()
+        del u, u2, f
+    rec = os.environ.get("RDYHIP_RECORD_SPEED_GATE")
+    if rec:
+        with open(rec, "w") as fh:
+            json.dump(measured, fh, indent=1)
+        return
+    gold = json.load(open(GOLDEN))
+    slow = {}
+    for name, m in measured.items():
+        g = gold[name]
+        assert g["cells"] == m["cells"]
+        for key in ("rhs_over_axpy", "euler_step_over_axpy"):
+            if m[key] > g[key] * (1.0 + TOLERANCE):
+                slow[f"{name}.{key}"] = (m[key], g[key])
+    assert not slow, f"kernels slower than recorded against the streaming kernel of the same box (measured, recorded): {slow}; all: {measured}"

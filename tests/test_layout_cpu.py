@@ -11,27 +11,62 @@ from rdycore_amd import mesh as M
 from rdycore_amd.operator import RDyFlowConfig, RDyHipError, probe_layout
 
 
-def test_tile_numbers_follow_the_cell_numbering():
+# the capacities every tile is cut to (csrc/swe_kernels.h: TILE_MAX_REC, TILE_MAX_HALO_*; muscl_kernels.h: MUSCL_MAX_RING_*)
+CAP = {3: dict(rec=512, halo=104, ring=256), 4: dict(rec=512, halo=112, ring=168)}
+
+
+def _fits(i, second_order=False):
+    c = CAP[i["slots_per_cell"]]
+    ok = i["max_tile_edges"] <= c["rec"] and i["max_tile_halo_cells"] <= c["halo"] and i["lds_fixed_layout"] == 1 and i["lds_bytes"] <= 64 * 1024
+    return ok and (not second_order or i["max_tile_ring2_cells"] <= c["ring"])
+
+
+def test_tiles_are_cut_to_the_kernels_capacities_whatever_the_numbering():
     info = {o: probe_layout(RDyFlowConfig(), M.structured_tri_mesh(160, 128, order=o)) for o in ("rowmajor", "tiled", "hilbert")}
     n = 2 * 160 * 128
     for i in info.values():
         assert i["num_owned_cells"] == i["num_cells"] == n and i["slots_per_cell"] == 3 and i["tiled_kernel"] == 1
-        assert i["num_tiles"] == n // 256 and i["num_halo_tiles"] == 0 and i["num_halo_cells"] == 0 and i["owned_is_prefix"] == 1
+        assert i["num_halo_tiles"] == 0 and i["num_halo_cells"] == 0 and i["owned_is_prefix"] == 1
         assert i["num_boundary_edges"] == 2 * (160 + 128)
         # every internal edge appears once if both cells share a tile, twice if not; boundary edges once
         assert 1.5 * n - (160 + 128) + i["num_boundary_edges"] <= i["num_edge_records"] <= 3 * n
+        assert _fits(i)
+    # a block numbering: every tile is one 16 x 8 block of squares = 256 triangles; along a Hilbert curve nearly so; row by
+    # row a tile is a strip whose halo cells (the rows above and below) fill the LDS planes long before 256 cells
+    assert info["tiled"]["num_tiles"] == n // 256 and info["hilbert"]["num_tiles"] <= 1.03 * n / 256
+    assert 2 * n // 256 < info["rowmajor"]["num_tiles"]
     rec = {o: i["num_edge_records"] / n for o, i in info.items()}
     assert rec["rowmajor"] > 1.95 and rec["tiled"] < 1.65 and rec["hilbert"] < 1.68
     assert info["rowmajor"]["num_halo_entries"] > 4 * info["tiled"]["num_halo_entries"]
-    assert info["tiled"]["lds_bytes"] < info["rowmajor"]["lds_bytes"] < 64 * 1024
-    # a numbering with locality fits the kernels' fixed LDS capacities (plane offsets become immediates), row-major does not
-    assert info["tiled"]["lds_fixed_layout"] == 1 and info["hilbert"]["lds_fixed_layout"] == 1 and info["rowmajor"]["lds_fixed_layout"] == 0
-    # a random numbering: three records per cell (every edge cut), halo lists of hundreds of cells, > 64 KB of LDS
+    # a random numbering: three records per cell (every edge cut), three halo cells per cell -- tiles of ~32 cells, and
+    # still the same kernels (rounds 1-4 ran such meshes with 256-cell tiles in > 64 KB of run-time-sized LDS)
     rng = np.random.default_rng(0)
     xyz, conn, _, _ = M.structured_tri_connectivity(64, 48)
     mesh = M.build_mesh(xyz, conn[rng.permutation(conn.shape[0])], boundary_classifier=M.single_boundary())
-    i = probe_layout(RDyFlowConfig(), mesh)
-    assert i["num_edge_records"] / mesh.num_cells > 2.9 and i["max_tile_halo_cells"] > 256 and i["lds_bytes"] > 64 * 1024
+    for so in (False, True):
+        i = probe_layout(RDyFlowConfig(second_order=so), mesh)
+        assert i["num_edge_records"] / mesh.num_cells > 2.9 and i["num_tiles"] > mesh.num_cells // 48 and _fits(i, so)
+
+
+def test_quad_tiles_hold_two_rounds_of_edge_records():
+    """a 16 x 16 block of quads has 544 edges: 32 more than the edge phase keeps in registers (two rounds of 256).  Tiles are
+    cut where the 513th record would come: a 16 x 15 block (511) -- which is how partition.partitioned_structured_mesh numbers
+    quads -- or 220-odd cells of a Hilbert curve."""
+    for order, lo in (("tiled", 236.0), ("hilbert", 215.0)):
+        q = CS.dam_break_quads_mesh(640, 320, 0, 1, order=order)
+        for so in (False, True):
+            i = probe_layout(RDyFlowConfig(second_order=so), q)
+            assert i["slots_per_cell"] == 4 and _fits(i, so) and i["num_owned_cells"] / i["num_tiles"] >= lo - (3.0 if so else 0.0), (order, so, i)
+    # (a row-major quad mesh: strips again)
+    assert _fits(probe_layout(RDyFlowConfig(), M.structured_quad_mesh(200, 150)))
+    # the measurement knob that makes all tiles smaller (small parts: more independent tiles per CU)
+    import os
+    os.environ["RDYHIP_TILE_CELLS"] = "128"
+    try:
+        i = probe_layout(RDyFlowConfig(), M.structured_tri_mesh(160, 128, order="tiled"))
+    finally:
+        os.environ.pop("RDYHIP_TILE_CELLS")
+    assert i["num_tiles"] == 2 * 160 * 128 // 128 and _fits(i)
 
 
 def test_quads_ghosts_and_second_order_tables():
@@ -45,20 +80,11 @@ def test_quads_ghosts_and_second_order_tables():
     interleaved = M.extract_local_mesh(*M.structured_tri_connectivity(24, 10)[:2], M.structured_tri_connectivity(24, 10)[2] < 12,
                                        ghosts="interleaved")
     assert probe_layout(RDyFlowConfig(), interleaved)["owned_is_prefix"] == 0
-    # second order: the fused kernel also stages a second ring; its halo tiles include tiles whose FIRST RING touches a ghost
+    # second order: the kernel also stages a second ring; its halo tiles include tiles whose FIRST RING touches a ghost
     s = probe_layout(RDyFlowConfig(second_order=True), m)
     assert s["second_order_fused"] == 1 and s["max_tile_ring2_cells"] > s["max_tile_halo_cells"] and s["lds_bytes"] > i["lds_bytes"]
-    assert s["lds_fixed_layout"] == 1 and s["lds_bytes"] == 8 * (6 * 360 + 5 * 520 + 3 * 8) + 4 * 520       # MusclSoATri
+    assert _fits(s, True) and s["lds_bytes"] == 8 * (6 * 360 + 5 * 520) + 4 * 520 <= 40 * 1024       # MusclSoATri: four workgroups per CU
     assert s["num_halo_tiles"] >= i["num_halo_tiles"]
-    old = os.environ.get("RDYHIP_MUSCL")
-    os.environ["RDYHIP_MUSCL"] = "split"
-    try:
-        assert probe_layout(RDyFlowConfig(second_order=True), m)["second_order_fused"] == 0
-    finally:
-        if old is None:
-            os.environ.pop("RDYHIP_MUSCL")
-        else:
-            os.environ["RDYHIP_MUSCL"] = old
 
 
 def _code(fn):
@@ -105,29 +131,3 @@ def test_argument_errors_of_create_without_a_device():
     assert _code(lambda: probe_layout(RDyFlowConfig(well_balancing=1), base)) == 83                        # BS2002: CEED only
     assert _code(lambda: probe_layout(RDyFlowConfig(source_method=5), base)) == 83
     assert _code(lambda: probe_layout(RDyFlowConfig(second_order=True, limiter=9), base)) == 83
-
-
-def test_second_order_flux_storage_is_chosen_from_the_tiles(monkeypatch):
-    """fused second-order kernel: the edge fluxes take the gradients' LDS storage when every tile's edges fit the kernel's
-    register rounds (2 x 256 for triangles, 3 x 256 for quads) -- a smaller workgroup footprint, four per CU on the
-    benchmark meshes -- and the separate region otherwise (rdyhip_api.hip: layout_build; RDYHIP_MUSCL_EF_OVERLAY=0 forces it)"""
-    def lds(mesh, case, overlay):
-        monkeypatch.setenv("RDYHIP_MUSCL_EF_OVERLAY", overlay)
-        case.config.second_order = True
-        return probe_layout(case.config, mesh, case.condition_types)
-
-    tri = M.structured_tri_mesh(96, 64, order="tiled")
-    ctri = CS.friction_slope_case(tri, 96.0, 64.0, dt=1e-3)
-    a, b = lds(tri, ctri, "1"), lds(tri, ctri, "0")
-    assert a["max_tile_edges"] <= 512 and a["lds_bytes"] < b["lds_bytes"] and a["lds_bytes"] <= 40 * 1024
-    quad = CS.dam_break_quads_mesh(640, 320, 0, 1, order="tiled")
-    cq = CS.dam_break_quads_case(quad)
-    a, b = lds(quad, cq, "1"), lds(quad, cq, "0")
-    assert 512 < a["max_tile_edges"] <= 768 and a["lds_bytes"] < b["lds_bytes"] and a["lds_bytes"] <= 40 * 1024
-    # a numbering without locality: more edges per tile than the register rounds hold -> the separate region either way
-    rng = np.random.default_rng(0)
-    xyz, conn, _, _ = M.structured_tri_connectivity(96, 64)
-    rnd = M.build_mesh(xyz, conn[rng.permutation(conn.shape[0])], boundary_classifier=M.box_side_boundaries(0.0, 96.0, 0.0, 64.0))
-    cr = CS.friction_slope_case(rnd, 96.0, 64.0, dt=1e-3)
-    a, b = lds(rnd, cr, "1"), lds(rnd, cr, "0")
-    assert a["max_tile_edges"] > 512 and a["lds_bytes"] == b["lds_bytes"]

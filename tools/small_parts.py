@@ -9,10 +9,9 @@ xGMI hop).  Per part, microseconds per step (HIP events around 300 back-to-back 
   rhs_direct      rdyhip_rhs_overlapped with the direct receive: pack launch, RCCL into the ghost rows, kernel
   euler_direct    rdyhip_euler_step_overlapped, direct receive, pack launch:        pack, RCCL, kernel
   euler_fused     the same with rdyhip_halo_fuse_pack: the pack rides on the previous step's kernel -- RCCL, kernel, in the form the
-                  library chooses (in order at every size since the end of round 4; profiles/r04_small_parts.txt itself was taken
-                  while parts of three rounds and more defaulted to the signalled form: signalled_form says which)
-  euler_fused_in_order / _overlapped   the fused pack without the signal (RDYHIP_SIGNALLED=0): RCCL, kernel in order; or the two-stream form
-  euler_fused_signalled                the signalled form forced (RDYHIP_SIGNALLED=1), whatever the part's size
+                  halo's own trial chooses (round 5: rdyhip_halo_form_info; `forms` holds what it chose and the two timings)
+  euler_fused_in_order / _overlapped   the two forms forced (RDYHIP_OVERLAP=0 / 1): RCCL, kernel in order; or the two-stream form
+                  (round 4's third form, signalled, is tools/probes/round4_forms.patch)
   exchange        rdyhip_halo_exchange alone (pack, RCCL, direct receive)
 
 usage (GPU box): python tools/small_parts.py > gpurun_out/small_parts.txt"""
@@ -113,38 +112,26 @@ def one(tag, argv, scaling="strong"):
     res["euler_direct"] = timed(pingpong(lambda a, b: _lib.check(lib.rdyhip_euler_step_overlapped(op._h, h1, 0.0, a, b, None, st))))
     res["exchange"] = timed(lambda: _lib.check(lib.rdyhip_halo_exchange(h1, up, 3, st)))
     _lib.check(lib.rdyhip_halo_fuse_pack(h1, 1))
-    res["signalled_form"] = int(lib.rdyhip_halo_signalled(h1))
     res["euler_fused"] = timed(pingpong(lambda a, b: _lib.check(lib.rdyhip_euler_step_overlapped(op._h, h1, 0.0, a, b, None, st))))
+    res["forms"] = {}
+    for kind, name in ((0, "rhs"), (1, "euler")):
+        fi = _lib.RDyHipHaloFormInfo()
+        _lib.check(lib.rdyhip_halo_form_info(h1, kind, C.byref(fi)))
+        res["forms"][name] = {"form": "two_streams" if fi.form else "in_order", "source": int(fi.source), "in_order_us": round(1e3 * fi.in_order_ms, 2),
+                              "two_stream_us": round(1e3 * fi.two_stream_ms, 2)}
     _lib.check(lib.rdyhip_halo_destroy(C.byref(h1)))
-    # the fused-pack Euler step without the signal (RDYHIP_SIGNALLED=0), in its two forms, forced: in order (transfer, one launch)
-    # and overlapped (transfer beside the interior launch, the ghost-adjacent tiles in a second launch on the exchange stream)
-    for name, ov, sg in (("euler_fused_in_order", 0, "0"), ("euler_fused_overlapped", 1, "0"), ("euler_fused_signalled", 0, "1")):
-        if sg == "1" and args.second_order:
-            continue                       # first order / HR only
+    # the fused-pack Euler step in its two forms, forced: in order (transfer, one launch) and two streams (transfer beside the
+    # interior launch, the ghost-adjacent tiles in a second launch on the exchange stream)
+    for name, ov in (("euler_fused_in_order", 0), ("euler_fused_overlapped", 1)):
         hx, _ = self_halo(op, mesh, comm, direct=True, overlap=ov)
-        os.environ["RDYHIP_SIGNALLED"] = sg
         _lib.check(lib.rdyhip_halo_fuse_pack(hx, 1))
-        os.environ.pop("RDYHIP_SIGNALLED")
-        assert lib.rdyhip_halo_signalled(hx) == int(sg)
         res[name] = timed(pingpong(lambda a, b: _lib.check(lib.rdyhip_euler_step_overlapped(op._h, hx, 0.0, a, b, None, st))))
         _lib.check(lib.rdyhip_halo_destroy(C.byref(hx)))
-    # the signalled launch leaves 1 / N of its workgroup slots to the transfer's kernel (RDYHIP_SIGNALLED_SHRINK; 0 = none)
-    if os.environ.get("SMALL_PARTS_SHRINK_STUDY"):
-        res["signalled_shrink_study"] = {}
-        for shrink in ("0", "128", "64", "32", "16"):
-            hx, _ = self_halo(op, mesh, comm, direct=True, overlap=0)
-            os.environ["RDYHIP_SIGNALLED"] = "1"
-            os.environ["RDYHIP_SIGNALLED_SHRINK"] = shrink
-            _lib.check(lib.rdyhip_halo_fuse_pack(hx, 1))
-            os.environ.pop("RDYHIP_SIGNALLED")
-            os.environ.pop("RDYHIP_SIGNALLED_SHRINK")
-            res["signalled_shrink_study"][shrink] = timed(pingpong(lambda a, b: _lib.check(lib.rdyhip_euler_step_overlapped(op._h, hx, 0.0, a, b, None, st))))
-            _lib.check(lib.rdyhip_halo_destroy(C.byref(hx)))
     _lib.check(lib.rdyhip_comm_destroy(comm))
     op.destroy()
     k = res["kernel_rhs"][0]
     res["step_over_kernel"] = {key: round(res[key][0] / (res["kernel_euler"][0] if key.startswith("euler") or key == "r03_euler" else k), 3)
-                               for key in ("r03_rhs", "r03_euler", "rhs_direct", "euler_direct", "euler_fused", "euler_fused_in_order", "euler_fused_overlapped", "euler_fused_signalled")
+                               for key in ("r03_rhs", "r03_euler", "rhs_direct", "euler_direct", "euler_fused", "euler_fused_in_order", "euler_fused_overlapped")
                                if key in res}
     res["columns"] = "[us per step on the GPU, us per step of host enqueue time]"
     print(json.dumps(res), flush=True)
