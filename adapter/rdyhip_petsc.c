@@ -231,6 +231,7 @@ static PetscErrorCode CreateShared(RDyConfig *config, RDyMesh *mesh, PetscInt nu
     hm.cell_centroids  = (const double *)mesh->cells.centroids;  // RDyPoint is PetscReal X[3]
     hm.edge_vertex_ids = evertex;
     hm.vertex_points   = (const double *)mesh->vertices.points;
+    hm.edge_is_owned   = (const int32_t *)mesh->edges.is_owned;  // PetscBool is an enum (int): who reports a cut edge's Courant number
   }
 
   RDyHipBoundary *hb;

@@ -66,6 +66,9 @@ def parse(argv=None):
                         "a Hilbert curve (default of the unstructured ones); unstructured only: natural = the order refinement / the "
                         "triangulator leaves, random = a seeded permutation")
     p.add_argument("--quad-block", default=None, help="dambreak_quads, --order tiled: the block of squares numbered together, e.g. 16x16 (default 16x15 = one tile of the operator)")
+    p.add_argument("--moving-state", action="store_true",
+                   help="dambreak_quads: a smooth velocity field and a tilted surface instead of the benchmark's two flat pools at rest (in "
+                        "which every edge of a kind reaches the same Courant number: the diagnostic's tie path runs in every tile)")
     p.add_argument("--source", default="semi_implicit", choices=["semi_implicit", "implicit_xq2018"])
     p.add_argument("--hr", action="store_true", help="hydrostatic-reconstruction variant of the operator (SURVEY 8.f row 2)")
     p.add_argument("--second-order", action="store_true", help="MUSCL second-order variant (SURVEY 8.f row 4)")
@@ -153,6 +156,11 @@ def build_case(args, rank, world, nx=None, ny=None, order=None):
         mesh = CS.dam_break_quads_mesh(nxg, ny, rank, world, order=order, tile=tuple(map(int, args.quad_block.split("x"))) if args.quad_block else None)
         case = CS.dam_break_quads_case(mesh)
         case.config.source_method = src
+        if args.moving_state:
+            xc, yc = mesh.cell_centroids[:, 0], mesh.cell_centroids[:, 1]
+            case.u_local[:, 0] *= 1.0 + 1e-3 * xc / 10.0 + 2e-3 * yc / 5.0
+            case.u_local[:, 1] = 0.3 * case.u_local[:, 0] * np.sin(1.7 * xc + 0.9 * yc)
+            case.u_local[:, 2] = 0.2 * case.u_local[:, 0] * np.cos(1.1 * xc - 2.3 * yc)
     elif wl == "houston_refined":
         # nx = refinement levels here
         case = CS.houston_refined_case(HOUSTON_DATA, nx, order if order in ("hilbert", "natural", "random") else "hilbert", hr=args.hr,

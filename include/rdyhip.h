@@ -120,6 +120,9 @@ typedef struct {
   const double  *cell_centroids;      /* cells.centroids      [num_cells][3]    (RDyPoint.X) */
   const int32_t *edge_vertex_ids;     /* edges.vertex_ids     [2*num_edges] */
   const double  *vertex_points;       /* vertices.points      [num_vertices][3] (RDyPoint.X) */
+  const int32_t *edge_is_owned;       /* edges.is_owned       [num_edges] (PetscBool; src/rdymesh.c:571-599).  Read by second_order
+                                         only: ApplyInteriorFlux2R evaluates the Courant number of an edge on the rank that owns
+                                         it (src/swe/swe_petsc.c:172-190); NULL: every edge of an owned cell counts (one rank) */
 } RDyHipMesh;
 
 /* RDyBoundary (include/private/rdyboundaryimpl.h:7-14) + the flow condition

@@ -30,6 +30,7 @@ class RDyHipMesh(C.Structure):
         ("edge_cell_ids", c_int32_p), ("edge_internal_ids", c_int32_p), ("edge_global_ids", c_int64_p),
         ("edge_lengths", c_double_p), ("edge_cn", c_double_p), ("edge_sn", c_double_p), ("cell_zc", c_double_p),
         ("num_vertices", C.c_int32), ("cell_centroids", c_double_p), ("edge_vertex_ids", c_int32_p), ("vertex_points", c_double_p),
+        ("edge_is_owned", c_int32_p),
     ]
 
 

@@ -219,7 +219,8 @@ __device__ __forceinline__ EdgeFlux muscl_edge(const KernelArgs &a, int tile, do
   r.f0 = fl.f0;
   r.f1 = fl.f1;
   r.f2 = fl.f2;
-  r.am = wet ? fl.amax : -1.0;
+  // (-2: a wet edge of another rank -- any value other than -1 adds the flux; a negative one never reaches the Courant maximum)
+  r.am = wet ? ((lr & EDGE_NOT_OWNED) ? -2.0 : fl.amax) : -1.0;
   return r;
 }
 
@@ -261,7 +262,10 @@ __device__ __forceinline__ void muscl_cell_sum(const KernelArgs &a, uint32_t r0,
     }
   }
   if (trk.rec != rec_in) trk.pos = -1;
-  if (tie) {  // cold: which of the equal edges comes first in the reference's loop
+  // cold: which of the equal edges comes first in the reference's loop; dismissed at once where the incumbent's position is
+  // known and smaller than every position of this tile
+  const int pos_lo = tie ? load_uniform(RDY_COLD(a, e_pos), e_off) : 0;
+  if (tie && !(trk.pos >= 0 && trk.pos < pos_lo)) {
     int first = -1;  // the first slot of this cell at the running maximum: the only one that can come before the incumbent
 #pragma unroll
     for (int s = 0; s < S; ++s) {
@@ -270,7 +274,7 @@ __device__ __forceinline__ void muscl_cell_sum(const KernelArgs &a, uint32_t r0,
       const double am = MEF(3, ref);
       if (first < 0 && am != -1.0 && am * fabs(kf[s]) * dt == trk.best) first = e_off + ref;
     }
-    if (first >= 0) courant_resolve_tie(a, trk, first, load_uniform(RDY_COLD(a, e_pos), e_off));
+    if (first >= 0) courant_resolve_tie(a, trk, first, pos_lo);
   }
 }
 
@@ -335,10 +339,11 @@ __global__ __launch_bounds__(BLOCK) void muscl_gradient_kernel(const KernelArgs 
 // gradient array's write + read, the second read of the state and the streamed
 // least-squares coefficients / displacements.  First-ring cells that are ghosts
 // take their gradient from `grad`, filled by the caller's exchange (their
-// stencil is not local).  Two tile loops share the phases: triangles run four
-// workgroups per CU with each tile's loads in one batch at its top; quads and
-// mixed meshes three workgroups with the next tile's loads in flight while
-// this one is computed (profiles/r03_ab_muscl_pipeline.txt).
+// stencil is not local).  Four workgroups per CU, each tile's loads in one batch
+// at its top.  (Rounds 3-4 ran quads at three workgroups with a cross-tile
+// software pipeline, worth 5.6 % while a quad tile had a third flux round;
+// with tiles of two rounds the fourth workgroup wins: 2-6 %,
+// profiles/r05_quads_ab.txt.)
 // ---------------------------------------------------------------------------
 // The extra Courant edges (ColdArgs::x_*, swe_kernels.h) of the second-order path: both cells' states, gradients and centroids
 // from memory (the gradients of ghost cells and of ghost-adjacent owned cells are there: the exchange and the launch over the
@@ -448,514 +453,251 @@ __global__ __launch_bounds__(TILE) void swe_rhs_muscl_fused_kernel(const KernelA
   };
 
   CourantTrack trk;
-  if constexpr (S == 4) {
-    // Quads and mixed meshes: cross-tile software pipeline, as in the first-order kernel.  A tile's loads form three groups:
-    // CELLS (state + centroid of the own cell and of this thread's ring cell, the slot references), EDGES (the first-ring
-    // stencil, the edge records of the two rounds with their normal component and midpoint) and the per-cell STREAMS of
-    // phase 2.  Cells and edges of tile T+1 are requested right after phase 0's barrier of tile T (the ids they depend on --
-    // ring cell, own cell -- a tile before that) and are first touched before T's stores; the streams of T after its edge
-    // phase.  160 - 165 VGPRs, three workgroups per CU: 5.6 % faster than four workgroups without the pipeline on the reference's
-    // dam-break quads; on triangles (147 VGPRs against 107) the fourth workgroup is worth more than the pipeline, 2 - 3 %
-    // (profiles/r03_ab_muscl_pipeline.txt), so they keep the loop below -- as do quads in the record layout (meshes numbered
-    // without locality: their third edge round loads its records inside the edge phase, which no pipeline survives, and
-    // one instantiation would need 170 VGPRs).
-    // What makes it a pipeline is what is NOT between the request and the first use: (i) no global load on any path every wave
-    // takes -- hipcc answers a conditional load whose result is used after the merge with s_waitcnt vmcnt(0) AT THE MERGE,
-    // for every wave (the ghost gradients below wait inside their branch for that reason); (ii) no first use hoisted into
-    // the requesting block (opaque predicates and initial values, below); (iii) no register that is "pending" at the loop
-    // header (the ids are waited for explicitly).
-    auto next_valid = [&](int i) -> int {  // INTERIOR phase skips tiles with ghost-adjacent cells (wave-uniform)
-      if (a.phase == RDYHIP_PHASE_INTERIOR) {
-        while (i < hi && tile_desc(tile_at(i)).halo()) i += step;
-      }
-      return i;
-    };
-    // Values a conditional load may leave untouched start from OPAQUE registers, not constants: with a constant on the other
-    // side hipcc folds the first operation on the loaded value into the loading block (phi(load, c) op k -> phi(load op k, c'))
-    // and the wave then waits for the load where it is requested.
-    double   zero = 0.0;
-    uint32_t ones = 0xFFFFFFFFu;
-    asm volatile("" : "+v"(zero), "+v"(ones));
-    double   q[3] = {zero, zero, zero}, hq[3] = {zero, zero, zero};
-    double2  cxy = make_double2(zero, zero), hcxy = make_double2(zero, zero);
-    uint32_t pr0 = ones, pr1 = ones;
-    struct EdgeRegs {
-      uint2    bw = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
-      uint32_t lr0 = 0, lr1 = 0;
-      double   cs0 = 0.0, cs1 = 0.0;
-      double2  md0 = make_double2(0.0, 0.0), md1 = make_double2(0.0, 0.0);
-    };
-    EdgeRegs E;
-    // ids of the own cell (local numbering) and of the ring cell this thread stages for the tile at position i
-    auto tile_ids = [&](int i, int &c_, int &hid_) {
-      const int      t_  = tile_at(i);
-      const TileDesc d_  = tile_desc(t_);
-      const int      c0_ = load_uniform(g.r2_off, t_);
-      hid_               = ring_id(d_, d_.nh(), c0_, load_uniform(g.r2_off, t_ + 1) - c0_);
-      const int o_       = d_.c_off + tid;
-      c_                 = (a.o2l && tid < d_.nc()) ? a.o2l[o_] : o_;
-    };
-    auto issue_cells = [&](const TileDesc &d_, int c_, int hid_) {
-      const int o_ = d_.c_off + tid;
-#pragma unroll
-      for (int k = 0; k < 3; ++k) q[k] = zero;
-      cxy = make_double2(zero, zero);
-      pr0 = pr1 = ones;
-      // the predicates of the loads are opaque to the compiler: where it can prove one equal to the predicate of a later USE
-      // it hoists that use's first instructions into the loading block -- and the wave waits for the load right there
-      int nown = d_.nc();
-      asm volatile("" : "+s"(nown));
-      if (tid < nown) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) q[k] = u[3 * (int64_t)c_ + k];
-        cxy = *reinterpret_cast<const double2 *>(g.cxy + 2 * (int64_t)c_);
-        const uint2 w = reinterpret_cast<const uint2 *>(a.slot_ref)[o_];
-        pr0           = w.x;
-        pr1           = w.y;
-      }
-      if (hid_ >= 0) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) hq[k] = u[3 * (int64_t)hid_ + k];
-        hcxy = *reinterpret_cast<const double2 *>(g.cxy + 2 * (int64_t)hid_);
-      }
-    };
-    auto issue_edges = [&](const TileDesc &d_, EdgeRegs &R) {
-      int ne_ = d_.ne(), nh_ = d_.nh();
-      asm volatile("" : "+s"(ne_), "+s"(nh_));  // opaque predicates, as in issue_cells
-      R.bw = make_uint2(ones, ones);
-      if (tid < nh_) R.bw = load_u2(g.bn_idx + 4 * ((int64_t)d_.h_off + tid));
-      if (tid < ne_) {
-        R.lr0 = RDY_MLD(&a.e_lr[d_.e_off + tid]);
-        R.cs0 = RDY_MLD(&a.e_cs[d_.e_off + tid]);
-        R.md0 = load_d2(g.e_mid + 2 * ((int64_t)d_.e_off + tid));
-      }
-      if (tid + TILE < ne_) {
-        R.lr1 = RDY_MLD(&a.e_lr[d_.e_off + TILE + tid]);
-        R.cs1 = RDY_MLD(&a.e_cs[d_.e_off + TILE + tid]);
-        R.md1 = load_d2(g.e_mid + 2 * ((int64_t)d_.e_off + TILE + tid));
-      }
-    };
-
-    idx = next_valid(idx);
-    if (idx < hi) {
-      int idx1 = next_valid(idx + step);
-      int c1 = 0, hid1 = -1;
-      {  // prologue: both groups of the first tile, the ids of the second
-        int c_, hid_;
-        tile_ids(idx, c_, hid_);
-        const int t_ = tile_at(idx);
-        issue_cells(tile_desc(t_), c_, hid_);
-        issue_edges(tile_desc(t_), E);
-        if (idx1 < hi) tile_ids(idx1, c1, hid1);
-        asm volatile("" ::"v"(hid1), "v"(c1));
-      }
-      while (true) {
-        const int      tile = tile_at(idx);
-        const TileDesc td = tile_desc(tile);
-        const int  ne = td.ne(), nh = td.nh();
-        const int  c0 = load_uniform(g.r2_off, tile), nc2 = load_uniform(g.r2_off, tile + 1) - c0;
-        const int  o      = td.c_off + tid;
-        const bool active = tid < td.nc();
-        int idx2 = hi, c2 = 0, hid2 = -1;
-        const uint32_t r0 = pr0, r1 = pr1;
-        auto pipe_cells = [&]() {  // the cells group of the next tile, the ids of the one after
-          if (idx1 < hi) {
-            idx2 = next_valid(idx1 + step);
-            if (idx2 < hi) tile_ids(idx2, c2, hid2);
-            issue_cells(tile_desc(tile_at(idx1)), c1, hid1);
-          }
-        };
-        EdgeRegs N;
-        auto pipe_edges = [&]() {
-          if (idx1 < hi) issue_edges(tile_desc(tile_at(idx1)), N);
-        };
-
-        // ---- phase 0: state + centroid of own cells, first ring, second ring; the tile's edge records -> LDS
-#pragma unroll
-        for (int k = 0; k < 3; ++k) MSQ(k, tid) = q[k];
-        MSQ(3, tid) = cxy.x;
-        MSQ(4, tid) = cxy.y;
-        if (tid < nh + nc2) {
-#pragma unroll
-          for (int k = 0; k < 3; ++k) MSQ(k, TILE + tid) = hq[k];
-          MSQ(3, TILE + tid) = hcxy.x;
-          MSQ(4, TILE + tid) = hcxy.y;
-        }
-        if (tid < ne) slr[tid] = E.lr0;
-        if (tid + TILE < ne) slr[tid + TILE] = E.lr1;
-        const uint2 bwc = E.bw;
-        __syncthreads();
-        __builtin_amdgcn_s_setprio(3);
-        pipe_cells();
-        pipe_edges();
-        __builtin_amdgcn_s_setprio(0);
-
-        // ---- phase G: least-squares gradients of own and first-ring cells -> LDS
-        {
-          double gr[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-          if (active) {
-            int nb[S];
-#pragma unroll
-            for (int s = 0; s < S; ++s) {
-              nb[s]         = -1;
-              const int ref = slot_edge<S>(r0, r1, s);
-              if (ref < 0) continue;
-              const uint32_t lr = slr[ref];
-              if (lr & EDGE_BOUNDARY) continue;
-              const int jl = lr & EDGE_SLOT_MASK, jr = (lr >> EDGE_R_SHIFT) & EDGE_SLOT_MASK;
-              nb[s]        = (jl == tid) ? jr : jl;
-            }
-            lds_gradient(tid, nb, gr);
-          }
-#pragma unroll
-          for (int k = 0; k < 6; ++k) MSG(k, tid) = gr[k];
-          auto ring_gradient = [&](int j, uint2 w) {
-            const uint32_t ix[4] = {w.x & 0xFFFFu, w.x >> 16, w.y & 0xFFFFu, w.y >> 16};
-            double         hg[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-            if (ix[0] == BN_GLOBAL) {  // a ghost cell: its gradient was computed by its owner
-              const int hc = a.hcells[td.h_off + j];
-#pragma unroll
-              for (int k = 0; k < 6; ++k) hg[k] = g.grad[6 * (int64_t)hc + k];
-              // wait for them HERE: at the merge below hipcc would wait with vmcnt(0) in every wave, ghost or not, and with
-              // that for the next tile's groups
-              asm volatile("" ::"v"(hg[0]), "v"(hg[1]), "v"(hg[2]), "v"(hg[3]), "v"(hg[4]), "v"(hg[5]));
-            } else {
-              int nb[S];
-#pragma unroll
-              for (int s = 0; s < S; ++s) nb[s] = (ix[s] == BN_NONE) ? -1 : (int)ix[s];
-              lds_gradient(TILE + j, nb, hg);
-            }
-#pragma unroll
-            for (int k = 0; k < 6; ++k) MSG(k, TILE + j) = hg[k];
-          };
-          if (tid < nh) ring_gradient(tid, bwc);
-        }
-        __syncthreads();
-
-        // ---- phase 1: every edge of the tile once
-        auto do_edge = [&](uint32_t lr, double cs, double2 mid) -> EdgeFlux {
-          return muscl_edge<LIM, LAY>(a, tile, dt, lr, cs, mid, sq, sg);
-        };
-        EdgeFlux x0 = {0.0, 0.0, 0.0, -1.0}, x1 = x0;
-        if (tid < ne) x0 = do_edge(E.lr0, E.cs0, E.md0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (tid + TILE < ne) x1 = do_edge(E.lr1, E.cs1, E.md1);
-        // the per-cell streams of phase 2 (requested only here: 18 registers less through the edge phase), then the next
-        // tile's groups: phase 2 waits for the streams alone
-        double kf[S];
-        double dzx = 0.0, dzy = 0.0, nman = 0.0, s0 = 0.0, s1 = 0.0, s2 = 0.0;
-#pragma unroll
-        for (int s = 0; s < S; ++s) kf[s] = 0.0;
-        __builtin_amdgcn_s_setprio(3);
-        {
-          const int oc = active ? o : td.c_off;
-#pragma unroll
-          for (int s = 0; s < S; ++s) kf[s] = RDY_MLD(&a.coef[s * a.stride + oc]);
-          dzx  = RDY_MLD(&a.dzdx[oc]);
-          dzy  = RDY_MLD(&a.dzdy[oc]);
-          nman = RDY_MLD(&a.mannings[oc]);
-          s0   = RDY_MLD(&a.extsrc[3 * (int64_t)oc + 0]);
-          s1   = RDY_MLD(&a.extsrc[3 * (int64_t)oc + 1]);
-          s2   = RDY_MLD(&a.extsrc[3 * (int64_t)oc + 2]);
-        }
-        __builtin_amdgcn_s_setprio(0);
-        __syncthreads();  // every edge has read its gradients: the fluxes may overwrite them
-        if (tid < ne) store_edge_flux<LAY>(a, ef, tid, x0);
-        if (tid + TILE < ne) store_edge_flux<LAY>(a, ef, tid + TILE, x1);
-        __syncthreads();
-
-        // ---- phase 2: per-cell sum in the reference's edge order, source terms, stores
-        RDY_STREAMS_ARRIVE();
-        double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, res[3] = {0.0, 0.0, 0.0}, pu = 0.0, pv_ = 0.0;
-        const double h = MSQ(0, tid), hu = MSQ(1, tid), hv = MSQ(2, tid);
-        if (active) {
-          if (!OVW) {
-            acc0 = f[3 * (int64_t)o + 0];
-            acc1 = f[3 * (int64_t)o + 1];
-            acc2 = f[3 * (int64_t)o + 2];
-          }
-          muscl_cell_sum<S, LAY>(a, r0, r1, kf, ef, dt, td.e_off, acc0, acc1, acc2, trk);
-          const RiemannSide self = riemann_side(h, hu, hv, a.tiny_h, a.h_anuga_sq);
-          pu                     = self.u;
-          pv_                    = self.v;
-          cell_results<SRC>(a, dt, h, hu, hv, acc0, acc1, acc2, dzx, dzy, nman, s0, s1, s2, res);
-        }
-        asm volatile("" ::"v"(hid2), "v"(c2));  // the ids are never "pending" at the loop header: hipcc would answer with vmcnt(0) at their use
-        // the tile's wait on the next tile's groups comes BEFORE its own stores are issued (vmcnt counts stores too)
-        asm volatile("" ::"v"(q[0]), "v"(q[1]), "v"(q[2]), "v"(cxy.x), "v"(cxy.y), "v"(hq[0]), "v"(hq[1]), "v"(hq[2]), "v"(hcxy.x), "v"(hcxy.y), "v"(pr0), "v"(pr1));
-        asm volatile("" ::"v"(N.bw.x), "v"(N.bw.y), "v"(N.lr0), "v"(N.lr1), "v"(N.cs0), "v"(N.cs1), "v"(N.md0.x), "v"(N.md0.y), "v"(N.md1.x), "v"(N.md1.y));
-        E = N;
-        __builtin_amdgcn_sched_barrier(0);
-        {  // whole-line stores of the [cell][3] rows (wave_store_rows3, swe_kernels.h); all 64 lanes take part
-          const int     lane  = tid & 63;
-          const int64_t base  = 3 * ((int64_t)o - lane);
-          const int     ncell = td.nc() - (tid - lane);  // the wave's cells of this tile
-          if (a.fdiv) wave_store_rows3(a.fdiv, base, lane, ncell, acc0, acc1, acc2);
-          if (!EULER || f) wave_store_rows3(f, base, lane, ncell, res[0], res[1], res[2]);
-          wave_store_rows3(a.pv, base, lane, ncell, h, pu, pv_);
-          if (EULER) {  // rdyhip_euler_step: the forward-Euler update rides on the stores, F only if asked for
-            const double n0 = h + dt * res[0], n1 = hu + dt * res[1], n2 = hv + dt * res[2];
-            if (!a.o2l) {
-              wave_store_rows3(a.u_out, base, lane, ncell, n0, n1, n2);
-            } else if (active) {
-              const int64_t c = a.o2l[o];
-              RDY_MST(&a.u_out[3 * c + 0], n0);
-              RDY_MST(&a.u_out[3 * c + 1], n1);
-              RDY_MST(&a.u_out[3 * c + 2], n2);
-            }
-            if (td.send()) wave_store_send_rows(a, tile, tid, n0, n1, n2);  // the fused pack of the next state exchange (swe_kernels.h)
-          }
-        }
-        if (idx1 >= hi) break;
-        idx  = idx1;
-        idx1 = idx2;
-        c1   = c2;
-        hid1 = hid2;
-        __syncthreads();  // the LDS records are rewritten by the next tile
-      }
+  {
+  // Triangles: four workgroups per CU.  A tile's loads are ONE batch at its top -- except the CELLS group (state + centroid
+  // of the own cell and of this thread's ring cell), which for tile T+1 is requested right after phase 0's barrier of tile T,
+  // into the registers phase 0 has just emptied: 127 VGPRs instead of 107, still four waves, and every workgroup has
+  // requests in flight while it computes (-1.2 % on C3, -2.6 % on the refined Houston mesh: profiles/
+  // r03_ab_muscl_tri_prefetch.txt).  The XQ2018 source variant needs four registers more (131: it would lose the fourth
+  // workgroup) and requests its cells group with the rest of the batch.  The ids the group depends on (ring cell, own
+  // cell) run one tile further ahead.  What keeps loads in flight across phases is what is NOT between the request and the first
+  // use: (i) no global load on any path every wave takes -- hipcc answers a conditional load whose result is used after the
+  // merge with s_waitcnt vmcnt(0) AT THE MERGE, for every wave (the ghost gradients below wait inside their branch for that
+  // reason); (ii) no first use hoisted into the requesting block (opaque predicates); (iii) no register that is "pending" at
+  // the loop header (the ids are waited for explicitly).
+  constexpr bool PF = (SRC == 0);
+  auto next_valid = [&](int i) -> int {
+    if (a.phase == RDYHIP_PHASE_INTERIOR) {
+      while (i < hi && tile_desc(tile_at(i)).halo()) i += step;
     }
-
-  } else {
-    // Triangles: four workgroups per CU.  A tile's loads are ONE batch at its top -- except the CELLS group (state + centroid
-    // of the own cell and of this thread's ring cell), which for tile T+1 is requested right after phase 0's barrier of tile T,
-    // into the registers phase 0 has just emptied: 127 VGPRs instead of 107, still four waves, and every workgroup has
-    // requests in flight while it computes (-1.2 % on C3, -2.6 % on the refined Houston mesh: profiles/
-    // r03_ab_muscl_tri_prefetch.txt).  The XQ2018 source variant needs four registers more (131: it would lose the fourth
-    // workgroup) and requests its cells group with the rest of the batch.  The ids the group depends on (ring cell, own
-    // cell) run one tile further ahead.  Every rule of the quads' pipeline above applies to the loads in flight across phases.
-    constexpr bool PF = (SRC == 0);
-    auto next_valid = [&](int i) -> int {
-      if (a.phase == RDYHIP_PHASE_INTERIOR) {
-        while (i < hi && tile_desc(tile_at(i)).halo()) i += step;
-      }
-      return i;
-    };
-    double  q[3] = {0.0, 0.0, 0.0}, hq[3] = {0.0, 0.0, 0.0};  // their first use is a plain LDS store: nothing to fold into the loading block
-    double2 cxy = make_double2(0.0, 0.0), hcxy = make_double2(0.0, 0.0);
-    auto tile_ids = [&](int i, int &c_, int &hid_) {
-      const int      t_  = tile_at(i);
-      const TileDesc d_  = tile_desc(t_);
-      const int      c0_ = load_uniform(g.r2_off, t_);
-      hid_               = ring_id(d_, d_.nh(), c0_, load_uniform(g.r2_off, t_ + 1) - c0_);
-      const int o_       = d_.c_off + tid;
-      c_                 = (a.o2l && tid < d_.nc()) ? a.o2l[o_] : o_;
-    };
-    auto issue_cells = [&](const TileDesc &d_, int c_, int hid_) {
+    return i;
+  };
+  double  q[3] = {0.0, 0.0, 0.0}, hq[3] = {0.0, 0.0, 0.0};  // their first use is a plain LDS store: nothing to fold into the loading block
+  double2 cxy = make_double2(0.0, 0.0), hcxy = make_double2(0.0, 0.0);
+  auto tile_ids = [&](int i, int &c_, int &hid_) {
+    const int      t_  = tile_at(i);
+    const TileDesc d_  = tile_desc(t_);
+    const int      c0_ = load_uniform(g.r2_off, t_);
+    hid_               = ring_id(d_, d_.nh(), c0_, load_uniform(g.r2_off, t_ + 1) - c0_);
+    const int o_       = d_.c_off + tid;
+    c_                 = (a.o2l && tid < d_.nc()) ? a.o2l[o_] : o_;
+  };
+  auto issue_cells = [&](const TileDesc &d_, int c_, int hid_) {
 #pragma unroll
-      for (int k = 0; k < 3; ++k) q[k] = 0.0;
-      cxy = make_double2(0.0, 0.0);
-      int nown = d_.nc();
-      asm volatile("" : "+s"(nown));
-      if (tid < nown) {
+    for (int k = 0; k < 3; ++k) q[k] = 0.0;
+    cxy = make_double2(0.0, 0.0);
+    int nown = d_.nc();
+    asm volatile("" : "+s"(nown));
+    if (tid < nown) {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) q[k] = u[3 * (int64_t)c_ + k];
-        cxy = *reinterpret_cast<const double2 *>(g.cxy + 2 * (int64_t)c_);
-      }
-      if (hid_ >= 0) {
+      for (int k = 0; k < 3; ++k) q[k] = u[3 * (int64_t)c_ + k];
+      cxy = *reinterpret_cast<const double2 *>(g.cxy + 2 * (int64_t)c_);
+    }
+    if (hid_ >= 0) {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) hq[k] = u[3 * (int64_t)hid_ + k];
-        hcxy = *reinterpret_cast<const double2 *>(g.cxy + 2 * (int64_t)hid_);
-      }
-    };
-    idx = next_valid(idx);
-    int idx1 = hi, c1 = 0, hid1 = -1;
-    if (idx < hi) {  // c1 / hid1: the ids of the tile whose cells group is requested next (PF: the next tile's, else this one's)
-      tile_ids(idx, c1, hid1);
+      for (int k = 0; k < 3; ++k) hq[k] = u[3 * (int64_t)hid_ + k];
+      hcxy = *reinterpret_cast<const double2 *>(g.cxy + 2 * (int64_t)hid_);
+    }
+  };
+  idx = next_valid(idx);
+  int idx1 = hi, c1 = 0, hid1 = -1;
+  if (idx < hi) {  // c1 / hid1: the ids of the tile whose cells group is requested next (PF: the next tile's, else this one's)
+    tile_ids(idx, c1, hid1);
+    asm volatile("" ::"v"(hid1), "v"(c1));
+    idx1 = next_valid(idx + step);
+    if (PF) {
+      issue_cells(tile_desc(tile_at(idx)), c1, hid1);
+      c1   = 0;
+      hid1 = -1;
+      if (idx1 < hi) tile_ids(idx1, c1, hid1);
       asm volatile("" ::"v"(hid1), "v"(c1));
-      idx1 = next_valid(idx + step);
-      if (PF) {
-        issue_cells(tile_desc(tile_at(idx)), c1, hid1);
-        c1   = 0;
-        hid1 = -1;
-        if (idx1 < hi) tile_ids(idx1, c1, hid1);
-        asm volatile("" ::"v"(hid1), "v"(c1));
+    }
+  }
+  while (idx < hi) {
+    const int      tile = tile_at(idx);
+    const TileDesc td = tile_desc(tile);
+    const int  ne = td.ne(), nh = td.nh();
+    const int  c0 = load_uniform(g.r2_off, tile), nc2 = load_uniform(g.r2_off, tile + 1) - c0;
+    const int  o      = td.c_off + tid;
+    const bool active = tid < td.nc();
+    const int  hid    = (tid < nh + nc2) ? 0 : -1;  // does this thread stage a ring cell
+    int idx2 = hi, c2 = 0, hid2 = -1;
+
+    __builtin_amdgcn_s_setprio(3);
+    if (!PF) {
+      issue_cells(td, c1, hid1);
+      if (idx1 < hi) {
+        tile_ids(idx1, c2, hid2);
+        idx2 = next_valid(idx1 + step);
       }
     }
-    while (idx < hi) {
-      const int      tile = tile_at(idx);
-      const TileDesc td = tile_desc(tile);
-      const int  ne = td.ne(), nh = td.nh();
-      const int  c0 = load_uniform(g.r2_off, tile), nc2 = load_uniform(g.r2_off, tile + 1) - c0;
-      const int  o      = td.c_off + tid;
-      const bool active = tid < td.nc();
-      const int  hid    = (tid < nh + nc2) ? 0 : -1;  // does this thread stage a ring cell
-      int idx2 = hi, c2 = 0, hid2 = -1;
-
+    uint32_t  r0 = 0xFFFFFFFFu, r1 = 0xFFFFFFFFu;  // triangles: three 10-bit slot references in r0; quads: four 16-bit ones in r0, r1
+    double    kf[S];
+    double    dzx = 0.0, dzy = 0.0, nman = 0.0, s0 = 0.0, s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int s = 0; s < S; ++s) kf[s] = 0.0;
+    // unconditional loads with clamped indices (a tile has edges; lanes past the end read the last record, unused): a
+    // lane-conditional load costs register copies of the loaded value at its merge -- and a wait in the middle of the batch
+    if (S == 3) {
+      r0 = RDY_MLD(&reinterpret_cast<const uint32_t *>(a.slot_ref)[active ? o : td.c_off]);
+    } else {
+      const uint2 w = load_u2(reinterpret_cast<const uint2 *>(a.slot_ref) + (active ? o : td.c_off));
+      r0            = w.x;
+      r1            = w.y;
+    }
+    uint32_t ones = 0xFFFFFFFFu;
+    asm volatile("" : "+v"(ones));
+    uint2 bw = make_uint2(ones, ones);
+    if (tid < nh) bw = load_u2(g.bn_idx + 4 * ((int64_t)td.h_off + tid));
+    const int      e0 = td.e_off + min(tid, ne - 1), e1 = td.e_off + min(tid + TILE, ne - 1);
+    const uint32_t lr0 = RDY_MLD(&a.e_lr[e0]);
+    const double   cs0 = RDY_MLD(&a.e_cs[e0]);
+    const double2  md0 = load_d2(g.e_mid + 2 * (int64_t)e0);
+    const uint32_t lr1 = RDY_MLD(&a.e_lr[e1]);
+    const double   cs1 = RDY_MLD(&a.e_cs[e1]);
+    const double2  md1 = load_d2(g.e_mid + 2 * (int64_t)e1);
+    __builtin_amdgcn_s_setprio(0);
+    // ---- phase 0: state + centroid of own cells, first ring, second ring; the tile's edge records -> LDS
+#pragma unroll
+    for (int k = 0; k < 3; ++k) MSQ(k, tid) = q[k];
+    MSQ(3, tid) = cxy.x;
+    MSQ(4, tid) = cxy.y;
+    if (hid >= 0) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) MSQ(k, TILE + tid) = hq[k];
+      MSQ(3, TILE + tid) = hcxy.x;
+      MSQ(4, TILE + tid) = hcxy.y;
+    }
+    if (tid < ne) slr[tid] = lr0;
+    if (tid + TILE < ne) slr[tid + TILE] = lr1;
+    // the top batch has arrived on EVERY path before the next tile's cells are requested (the waits above sit inside
+    // lane-conditional branches; a register still "pending" on a skipped path costs a vmcnt(0) at its next use)
+    asm volatile("" ::"v"(r0), "v"(bw.x), "v"(bw.y), "v"(lr0), "v"(lr1), "v"(cs0), "v"(cs1), "v"(md0.x), "v"(md0.y), "v"(md1.x), "v"(md1.y));
+    __syncthreads();
+    if (PF && idx1 < hi) {
       __builtin_amdgcn_s_setprio(3);
-      if (!PF) {
-        issue_cells(td, c1, hid1);
-        if (idx1 < hi) {
-          tile_ids(idx1, c2, hid2);
-          idx2 = next_valid(idx1 + step);
-        }
-      }
-      uint32_t  r0 = 0xFFFFFFFFu, r1 = 0xFFFFFFFFu;  // triangles: three 10-bit slot references in r0; quads: four 16-bit ones in r0, r1
-      double    kf[S];
-      double    dzx = 0.0, dzy = 0.0, nman = 0.0, s0 = 0.0, s1 = 0.0, s2 = 0.0;
-#pragma unroll
-      for (int s = 0; s < S; ++s) kf[s] = 0.0;
-      // unconditional loads with clamped indices (a tile has edges; lanes past the end read the last record, unused): a
-      // lane-conditional load costs register copies of the loaded value at its merge -- and a wait in the middle of the batch
-      if (S == 3) {
-        r0 = RDY_MLD(&reinterpret_cast<const uint32_t *>(a.slot_ref)[active ? o : td.c_off]);
-      } else {
-        const uint2 w = load_u2(reinterpret_cast<const uint2 *>(a.slot_ref) + (active ? o : td.c_off));
-        r0            = w.x;
-        r1            = w.y;
-      }
-      uint32_t ones = 0xFFFFFFFFu;
-      asm volatile("" : "+v"(ones));
-      uint2 bw = make_uint2(ones, ones);
-      if (tid < nh) bw = load_u2(g.bn_idx + 4 * ((int64_t)td.h_off + tid));
-      const int      e0 = td.e_off + min(tid, ne - 1), e1 = td.e_off + min(tid + TILE, ne - 1);
-      const uint32_t lr0 = RDY_MLD(&a.e_lr[e0]);
-      const double   cs0 = RDY_MLD(&a.e_cs[e0]);
-      const double2  md0 = load_d2(g.e_mid + 2 * (int64_t)e0);
-      const uint32_t lr1 = RDY_MLD(&a.e_lr[e1]);
-      const double   cs1 = RDY_MLD(&a.e_cs[e1]);
-      const double2  md1 = load_d2(g.e_mid + 2 * (int64_t)e1);
+      idx2 = next_valid(idx1 + step);
+      if (idx2 < hi) tile_ids(idx2, c2, hid2);
+      issue_cells(tile_desc(tile_at(idx1)), c1, hid1);
       __builtin_amdgcn_s_setprio(0);
-      // ---- phase 0: state + centroid of own cells, first ring, second ring; the tile's edge records -> LDS
-#pragma unroll
-      for (int k = 0; k < 3; ++k) MSQ(k, tid) = q[k];
-      MSQ(3, tid) = cxy.x;
-      MSQ(4, tid) = cxy.y;
-      if (hid >= 0) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) MSQ(k, TILE + tid) = hq[k];
-        MSQ(3, TILE + tid) = hcxy.x;
-        MSQ(4, TILE + tid) = hcxy.y;
-      }
-      if (tid < ne) slr[tid] = lr0;
-      if (tid + TILE < ne) slr[tid + TILE] = lr1;
-      // the top batch has arrived on EVERY path before the next tile's cells are requested (the waits above sit inside
-      // lane-conditional branches; a register still "pending" on a skipped path costs a vmcnt(0) at its next use)
-      asm volatile("" ::"v"(r0), "v"(bw.x), "v"(bw.y), "v"(lr0), "v"(lr1), "v"(cs0), "v"(cs1), "v"(md0.x), "v"(md0.y), "v"(md1.x), "v"(md1.y));
-      __syncthreads();
-      if (PF && idx1 < hi) {
-        __builtin_amdgcn_s_setprio(3);
-        idx2 = next_valid(idx1 + step);
-        if (idx2 < hi) tile_ids(idx2, c2, hid2);
-        issue_cells(tile_desc(tile_at(idx1)), c1, hid1);
-        __builtin_amdgcn_s_setprio(0);
-      }
+    }
 
-      // ---- phase G: least-squares gradients of own and first-ring cells -> LDS
-      {
-        double gr[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-        if (active) {
+    // ---- phase G: least-squares gradients of own and first-ring cells -> LDS
+    {
+      double gr[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+      if (active) {
+        int nb[S];
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+          nb[s]         = -1;
+          const int ref = slot_edge<S>(r0, r1, s);
+          if (ref < 0) continue;
+          const uint32_t lr = slr[ref];
+          if (lr & EDGE_BOUNDARY) continue;
+          const int jl = lr & EDGE_SLOT_MASK, jr = (lr >> EDGE_R_SHIFT) & EDGE_SLOT_MASK;
+          nb[s]        = (jl == tid) ? jr : jl;
+        }
+        lds_gradient(tid, nb, gr);
+      }
+#pragma unroll
+      for (int k = 0; k < 6; ++k) MSG(k, tid) = gr[k];
+      auto ring_gradient = [&](int j, uint2 w) {
+        const uint32_t ix[4] = {w.x & 0xFFFFu, w.x >> 16, w.y & 0xFFFFu, w.y >> 16};
+        double         hg[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        if (ix[0] == BN_GLOBAL) {  // a ghost cell: its gradient was computed by its owner
+          const int hc = a.hcells[td.h_off + j];
+#pragma unroll
+          for (int k = 0; k < 6; ++k) hg[k] = g.grad[6 * (int64_t)hc + k];
+          asm volatile("" ::"v"(hg[0]), "v"(hg[1]), "v"(hg[2]), "v"(hg[3]), "v"(hg[4]), "v"(hg[5]));  // waited for inside the branch: at the merge hipcc would wait with vmcnt(0) in every wave, ghost or not
+        } else {
           int nb[S];
 #pragma unroll
-          for (int s = 0; s < S; ++s) {
-            nb[s]         = -1;
-            const int ref = slot_edge<S>(r0, r1, s);
-            if (ref < 0) continue;
-            const uint32_t lr = slr[ref];
-            if (lr & EDGE_BOUNDARY) continue;
-            const int jl = lr & EDGE_SLOT_MASK, jr = (lr >> EDGE_R_SHIFT) & EDGE_SLOT_MASK;
-            nb[s]        = (jl == tid) ? jr : jl;
-          }
-          lds_gradient(tid, nb, gr);
+          for (int s = 0; s < S; ++s) nb[s] = (ix[s] == BN_NONE) ? -1 : (int)ix[s];
+          lds_gradient(TILE + j, nb, hg);
         }
 #pragma unroll
-        for (int k = 0; k < 6; ++k) MSG(k, tid) = gr[k];
-        auto ring_gradient = [&](int j, uint2 w) {
-          const uint32_t ix[4] = {w.x & 0xFFFFu, w.x >> 16, w.y & 0xFFFFu, w.y >> 16};
-          double         hg[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-          if (ix[0] == BN_GLOBAL) {  // a ghost cell: its gradient was computed by its owner
-            const int hc = a.hcells[td.h_off + j];
-#pragma unroll
-            for (int k = 0; k < 6; ++k) hg[k] = g.grad[6 * (int64_t)hc + k];
-            asm volatile("" ::"v"(hg[0]), "v"(hg[1]), "v"(hg[2]), "v"(hg[3]), "v"(hg[4]), "v"(hg[5]));  // waited for inside the branch, as in the quads' loop
-          } else {
-            int nb[S];
-#pragma unroll
-            for (int s = 0; s < S; ++s) nb[s] = (ix[s] == BN_NONE) ? -1 : (int)ix[s];
-            lds_gradient(TILE + j, nb, hg);
-          }
-#pragma unroll
-          for (int k = 0; k < 6; ++k) MSG(k, TILE + j) = hg[k];
-        };
-        if (tid < nh) ring_gradient(tid, bw);
-      }
-      __syncthreads();
-
-      // ---- phase 1: every edge of the tile once
-      auto do_edge = [&](uint32_t lr, double cs, double2 mid) -> EdgeFlux {
-        return muscl_edge<LIM, LAY>(a, tile, dt, lr, cs, mid, sq, sg);
+        for (int k = 0; k < 6; ++k) MSG(k, TILE + j) = hg[k];
       };
-      // the two register-resident rounds one after the other (no per-value selects between the rounds' registers); the
-      // scheduling barrier keeps the compiler from interleaving them, which would double the live registers
-      auto request_streams = [&]() {
-        // unconditional (cells past the end read the last owned cell's, unused): a branch here costs register copies of
-        // loaded values at its merge, and with them a wait for the streams right where they are requested
-        const int oc = active ? o : td.c_off;
-#pragma unroll
-        for (int s = 0; s < S; ++s) kf[s] = RDY_MLD(&a.coef[s * a.stride + oc]);
-        dzx  = RDY_MLD(&a.dzdx[oc]);
-        dzy  = RDY_MLD(&a.dzdy[oc]);
-        nman = RDY_MLD(&a.mannings[oc]);
-        s0   = RDY_MLD(&a.extsrc[3 * (int64_t)oc + 0]);
-        s1   = RDY_MLD(&a.extsrc[3 * (int64_t)oc + 1]);
-        s2   = RDY_MLD(&a.extsrc[3 * (int64_t)oc + 2]);
-      };
-      EdgeFlux x0 = {0.0, 0.0, 0.0, -1.0}, x1 = x0;
-      if (tid < ne) x0 = do_edge(lr0, cs0, md0);
-      __builtin_amdgcn_sched_barrier(0);
-      if (tid + TILE < ne) x1 = do_edge(lr1, cs1, md1);
-      // the per-cell streams of phase 2 are requested only here: held from the tile's top they would cost 18 registers
-      // through the edge phase; the barriers and the flux stores below cover part of their latency, the other resident
-      // workgroups the rest (requested between the two edge rounds instead: 123 VGPRs, no gain --
-      // profiles/r03_ab_muscl_mid_streams.txt)
-      request_streams();
-      __syncthreads();  // every edge has read its gradients: the fluxes may overwrite them
-      if (tid < ne) store_edge_flux<LAY>(a, ef, tid, x0);
-      if (tid + TILE < ne) store_edge_flux<LAY>(a, ef, tid + TILE, x1);
-      __syncthreads();
-
-      // ---- phase 2: per-cell sum in the reference's edge order, source terms, stores
-      RDY_STREAMS_ARRIVE();
-      asm volatile("" ::"v"(hid2), "v"(c2));
-      double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, res[3] = {0.0, 0.0, 0.0}, pu = 0.0, pv_ = 0.0;
-      const double h = MSQ(0, tid), hu = MSQ(1, tid), hv = MSQ(2, tid);
-      if (active) {
-        if (!OVW) {
-          acc0 = f[3 * (int64_t)o + 0];
-          acc1 = f[3 * (int64_t)o + 1];
-          acc2 = f[3 * (int64_t)o + 2];
-        }
-        muscl_cell_sum<S, LAY>(a, r0, r1, kf, ef, dt, td.e_off, acc0, acc1, acc2, trk);
-        const RiemannSide self = riemann_side(h, hu, hv, a.tiny_h, a.h_anuga_sq);
-        pu                     = self.u;
-        pv_                    = self.v;
-        cell_results<SRC>(a, dt, h, hu, hv, acc0, acc1, acc2, dzx, dzy, nman, s0, s1, s2, res);
-      }
-      {  // whole-line stores of the [cell][3] rows (wave_store_rows3, swe_kernels.h); all 64 lanes take part
-        const int     lane  = tid & 63;
-        const int64_t base  = 3 * ((int64_t)o - lane);
-        const int     ncell = td.nc() - (tid - lane);  // the wave's cells of this tile
-        if (a.fdiv) wave_store_rows3(a.fdiv, base, lane, ncell, acc0, acc1, acc2);
-        if (!EULER || f) wave_store_rows3(f, base, lane, ncell, res[0], res[1], res[2]);
-        wave_store_rows3(a.pv, base, lane, ncell, h, pu, pv_);
-        if (EULER) {  // rdyhip_euler_step: the forward-Euler update rides on the stores, F only if asked for
-          const double n0 = h + dt * res[0], n1 = hu + dt * res[1], n2 = hv + dt * res[2];
-          if (!a.o2l) {
-            wave_store_rows3(a.u_out, base, lane, ncell, n0, n1, n2);
-          } else if (active) {
-            const int64_t c = a.o2l[o];
-            RDY_MST(&a.u_out[3 * c + 0], n0);
-            RDY_MST(&a.u_out[3 * c + 1], n1);
-            RDY_MST(&a.u_out[3 * c + 2], n2);
-          }
-          if (td.send()) wave_store_send_rows(a, tile, tid, n0, n1, n2);  // the fused pack of the next state exchange (swe_kernels.h)
-        }
-      }
-      idx  = idx1;
-      idx1 = idx2;
-      c1   = c2;
-      hid1 = hid2;
-      __syncthreads();  // the LDS records are rewritten by the next tile (dropping this barrier where the layout allows it gains nothing)
+      if (tid < nh) ring_gradient(tid, bw);
     }
+    __syncthreads();
+
+    // ---- phase 1: every edge of the tile once
+    auto do_edge = [&](uint32_t lr, double cs, double2 mid) -> EdgeFlux {
+      return muscl_edge<LIM, LAY>(a, tile, dt, lr, cs, mid, sq, sg);
+    };
+    // the two register-resident rounds one after the other (no per-value selects between the rounds' registers); the
+    // scheduling barrier keeps the compiler from interleaving them, which would double the live registers
+    auto request_streams = [&]() {
+      // unconditional (cells past the end read the last owned cell's, unused): a branch here costs register copies of
+      // loaded values at its merge, and with them a wait for the streams right where they are requested
+      const int oc = active ? o : td.c_off;
+#pragma unroll
+      for (int s = 0; s < S; ++s) kf[s] = RDY_MLD(&a.coef[s * a.stride + oc]);
+      dzx  = RDY_MLD(&a.dzdx[oc]);
+      dzy  = RDY_MLD(&a.dzdy[oc]);
+      nman = RDY_MLD(&a.mannings[oc]);
+      s0   = RDY_MLD(&a.extsrc[3 * (int64_t)oc + 0]);
+      s1   = RDY_MLD(&a.extsrc[3 * (int64_t)oc + 1]);
+      s2   = RDY_MLD(&a.extsrc[3 * (int64_t)oc + 2]);
+    };
+    EdgeFlux x0 = {0.0, 0.0, 0.0, -1.0}, x1 = x0;
+    if (tid < ne) x0 = do_edge(lr0, cs0, md0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (tid + TILE < ne) x1 = do_edge(lr1, cs1, md1);
+    // the per-cell streams of phase 2 are requested only here: held from the tile's top they would cost 18 registers
+    // through the edge phase; the barriers and the flux stores below cover part of their latency, the other resident
+    // workgroups the rest (requested between the two edge rounds instead: 123 VGPRs, no gain --
+    // profiles/r03_ab_muscl_mid_streams.txt)
+    request_streams();
+    __syncthreads();  // every edge has read its gradients: the fluxes may overwrite them
+    if (tid < ne) store_edge_flux<LAY>(a, ef, tid, x0);
+    if (tid + TILE < ne) store_edge_flux<LAY>(a, ef, tid + TILE, x1);
+    __syncthreads();
+
+    // ---- phase 2: per-cell sum in the reference's edge order, source terms, stores
+    RDY_STREAMS_ARRIVE();
+    asm volatile("" ::"v"(hid2), "v"(c2));
+    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, res[3] = {0.0, 0.0, 0.0}, pu = 0.0, pv_ = 0.0;
+    const double h = MSQ(0, tid), hu = MSQ(1, tid), hv = MSQ(2, tid);
+    if (active) {
+      if (!OVW) {
+        acc0 = f[3 * (int64_t)o + 0];
+        acc1 = f[3 * (int64_t)o + 1];
+        acc2 = f[3 * (int64_t)o + 2];
+      }
+      muscl_cell_sum<S, LAY>(a, r0, r1, kf, ef, dt, td.e_off, acc0, acc1, acc2, trk);
+      const RiemannSide self = riemann_side(h, hu, hv, a.tiny_h, a.h_anuga_sq);
+      pu                     = self.u;
+      pv_                    = self.v;
+      cell_results<SRC>(a, dt, h, hu, hv, acc0, acc1, acc2, dzx, dzy, nman, s0, s1, s2, res);
+    }
+    {  // whole-line stores of the [cell][3] rows (wave_store_rows3, swe_kernels.h); all 64 lanes take part
+      const int     lane  = tid & 63;
+      const int64_t base  = 3 * ((int64_t)o - lane);
+      const int     ncell = td.nc() - (tid - lane);  // the wave's cells of this tile
+      if (a.fdiv) wave_store_rows3(a.fdiv, base, lane, ncell, acc0, acc1, acc2);
+      if (!EULER || f) wave_store_rows3(f, base, lane, ncell, res[0], res[1], res[2]);
+      wave_store_rows3(a.pv, base, lane, ncell, h, pu, pv_);
+      if (EULER) {  // rdyhip_euler_step: the forward-Euler update rides on the stores, F only if asked for
+        const double n0 = h + dt * res[0], n1 = hu + dt * res[1], n2 = hv + dt * res[2];
+        if (!a.o2l) {
+          wave_store_rows3(a.u_out, base, lane, ncell, n0, n1, n2);
+        } else if (active) {
+          const int64_t c = a.o2l[o];
+          RDY_MST(&a.u_out[3 * c + 0], n0);
+          RDY_MST(&a.u_out[3 * c + 1], n1);
+          RDY_MST(&a.u_out[3 * c + 2], n2);
+        }
+        if (td.send()) wave_store_send_rows(a, tile, tid, n0, n1, n2);  // the fused pack of the next state exchange (swe_kernels.h)
+      }
+    }
+    idx  = idx1;
+    idx1 = idx2;
+    c1   = c2;
+    hid1 = hid2;
+    __syncthreads();  // the LDS records are rewritten by the next tile (dropping this barrier where the layout allows it gains nothing)
+  }
 
   }
   courant_extra_edges_muscl<LIM>(a, g, dt, u, trk);

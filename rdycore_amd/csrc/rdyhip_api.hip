@@ -814,6 +814,7 @@ static int layout_build_tiles(const RDyHipConfig *config, const RDyHipMesh *mesh
           if (last < ni) {
             e  = mesh->edge_internal_ids[last];
             lr = slot_of(mesh->edge_cell_ids[2 * e]) | (slot_of(mesh->edge_cell_ids[2 * e + 1]) << EDGE_R_SHIFT);
+            if (muscl_on && mesh->edge_is_owned && !mesh->edge_is_owned[e]) lr |= EDGE_NOT_OWNED;
             if (muscl_on) {
               // the edge midpoint of ReconstructFaceValues (src/operator_fluxes_ceed.c:1169-1172); the kernel subtracts the
               // two cell centroids itself (1175-1178)
@@ -917,6 +918,9 @@ static int layout_build_tiles(const RDyHipConfig *config, const RDyHipMesh *mesh
     const double al = mesh->cell_areas[l], ar = mesh->cell_areas[r];
     if (lo && ro) continue;
     if (lo != ro && !((lo ? ar : al) < (lo ? al : ar))) continue;  // the owned cell is the smaller one (or equal): its slot has len / min already
+    // second order: only the rank that owns an edge reports it (swe_petsc.c:172-190) -- never an edge between two ghosts
+    if (muscl_on && mesh->edge_is_owned && !mesh->edge_is_owned[e]) continue;
+    if (muscl_on && !mesh->edge_is_owned && !lo && !ro) continue;
     L.x_lr.push_back(l);
     L.x_lr.push_back(r);
     L.x_pos.push_back(p);

@@ -329,6 +329,9 @@ constexpr uint32_t EDGE_BOUNDARY  = 1u << 22;
 // magnitude; the other is +-sqrt(1 - cs^2) (well conditioned: cs^2 <= 1/2).
 constexpr uint32_t EDGE_CS_IS_CN     = 1u << 23;  // the stored component is cn (else sn)
 constexpr uint32_t EDGE_OTHER_NEG    = 1u << 24;  // the reconstructed component is negative
+// second order: the edge belongs to another rank (edges.is_owned = false): ApplyInteriorFlux2R evaluates its Courant number
+// there (swe_petsc.c:172-190); here its flux still feeds the owned cell, its wave speed is kept out of the diagnostic
+constexpr uint32_t EDGE_NOT_OWNED    = 1u << 25;
 // slot references of a triangle mesh (S == 3): 3 x 10 bits in one uint32, 0x3FF = unused
 constexpr uint32_t REF3_EMPTY = 0x3FF;
 
@@ -785,7 +788,10 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
           }
         }
         if (trk.rec != rec_in) trk.pos = -1;
-        if (tie) {  // cold: which of the equal edges comes first in the reference's loop (CourantTrack)
+        // cold: which of the equal edges comes first in the reference's loop (CourantTrack).  Dismissed at once where the
+        // incumbent's position is known and smaller than every position of this tile.
+        const int pos_lo = tie ? load_uniform(RDY_COLD(a, e_pos), td.e_off) : 0;
+        if (tie && !(trk.pos >= 0 && trk.pos < pos_lo)) {
           int first = -1;  // the first slot of this cell at the running maximum: the only one that can come before the incumbent
 #pragma unroll
           for (int s = 0; s < S; ++s) {
@@ -801,7 +807,7 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
             const double am = eam[ref];
             if (first < 0 && am != -1.0 && am * fabs(cur.coef[s]) * dt == trk.best) first = td.e_off + (int)ref;
           }
-          if (first >= 0) courant_resolve_tie(a, trk, first, load_uniform(RDY_COLD(a, e_pos), td.e_off));
+          if (first >= 0) courant_resolve_tie(a, trk, first, pos_lo);
         }
         acc_fdiv[0] = acc0;
         acc_fdiv[1] = acc1;

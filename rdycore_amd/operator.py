@@ -104,6 +104,8 @@ def _abi_arguments(config: "RDyFlowConfig", mesh: RDyMesh, condition_types: Opti
         m.cell_centroids = arr(mesh.cell_centroids, np.float64).ctypes.data_as(_lib.c_double_p)
         m.edge_vertex_ids = arr(mesh.edge_vertex_ids, np.int32).ctypes.data_as(_lib.c_int32_p)
         m.vertex_points = arr(mesh.xyz, np.float64).ctypes.data_as(_lib.c_double_p)
+        if mesh.num_cells > mesh.num_owned_cells:      # edges.is_owned: who reports the Courant number of a cut edge (swe_petsc.c:172-190)
+            m.edge_is_owned = arr(mesh.edge_is_owned(), np.int32).ctypes.data_as(_lib.c_int32_p)
     barr = (_lib.RDyHipBoundary * max(nb, 1))()
     for i, b in enumerate(mesh.boundaries):
         barr[i].num_edges = b.num_edges

@@ -85,7 +85,10 @@ def _worker(rank, world, port, kernel, q, second_order=False, transport="torch",
     os.environ["MASTER_PORT"] = str(port)
     # these meshes are small: left to itself the library would run them in its in-order form (rdyhip_halo_overlaps);
     # "1" forces the overlapped two-stream form the big meshes use, "0" the in-order one
-    os.environ["RDYHIP_OVERLAP"] = overlap
+    if overlap == "trial":
+        os.environ.pop("RDYHIP_OVERLAP", None)       # the halo chooses by itself: the first 16 steps of a kind alternate
+    else:
+        os.environ["RDYHIP_OVERLAP"] = overlap
     if kernel:
         os.environ["RDYHIP_KERNEL"] = kernel
     import torch.distributed as dist
@@ -103,7 +106,8 @@ def _worker(rank, world, port, kernel, q, second_order=False, transport="torch",
         halo = HaloExchange(mesh, dev, transport=transport, op=op)
         if transport == "c":
             from rdycore_amd import _lib
-            assert _lib.load().rdyhip_halo_overlaps(halo._halo) == int(overlap)
+            if overlap != "trial":
+                assert _lib.load().rdyhip_halo_overlaps(halo._halo) == int(overlap)
         u_np = case.u_local.copy()
         u_np[mesh.cell_is_owned == 0] = np.nan          # ghosts unknown until exchanged
         u = torch.tensor(u_np, dtype=torch.float64, device=dev)
@@ -133,7 +137,7 @@ def _worker(rank, world, port, kernel, q, second_order=False, transport="torch",
                 dts = 0.1 * case.dt
                 EulerStepper(op, halo=halo).advance(ua, dts, 5 * dts)
                 assert lib.rdyhip_halo_pack_fused(halo._halo) == 1
-                assert halo.form_info("euler")["source"] == "forced"   # RDYHIP_OVERLAP above
+                assert halo.form_info("euler")["source"] == ("forced" if overlap != "trial" else "trial_running")
                 # (second order, fused form: the state pack rides on the kernel, the gradient exchange still packs with a launch)
                 stepper = EulerStepper(op, halo=halo)
                 assert halo.fuse_pack(False) is False
@@ -196,6 +200,15 @@ def _worker(rank, world, port, kernel, q, second_order=False, transport="torch",
         info = op.layout_info()
         if not ids_ok:
             print(f"rank {rank}: Courant struct-max {red} vs the oracle's ({cg}, edge {eg} = key {ekey(eg) if eg >= 0 else -1}, cell {cellg})", file=sys.stderr)
+        if overlap == "trial" and transport == "c":
+            # through the rest of the trial and past it: same bits in whatever form a step runs, and every rank has chosen
+            fa = f.clone()
+            for _ in range(20):
+                halo.rhs_overlapped(op, case.dt, u, f)
+            torch.cuda.synchronize()
+            assert torch.equal(f, fa)
+            fi = halo.form_info("rhs")
+            assert fi["source"] == "measured" and fi["trial_steps"] == 16 and fi["in_order_ms"] > 0 and fi["two_stream_ms"] > 0, fi
         q.put((rank, err, abs(red.max_courant_num - cg), bool(ids_ok), info["num_halo_tiles"], info["num_tiles"]))
         halo.destroy()
         op.destroy()
@@ -279,6 +292,103 @@ def test_five_ranks_one_gpu(rdyhip_kernel, kind, second_order):
         assert err <= 1e-10, (rank, err)
         assert cerr <= 1e-10 and ids_ok
         assert 0 < nhalo_tiles <= ntiles
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("second_order", [False, True])
+def test_five_ranks_choose_the_form_of_their_step(rdyhip_kernel, second_order):
+    """nothing forced: every rank's halo alternates between the two forms of the step over its first 16 calls, times them and
+    keeps the faster one (rdyhip_halo_form_info) -- five gloo ranks on one device, every step of the trial and after it = the
+    single-rank oracle's rows"""
+    if rdyhip_kernel == "cell":
+        pytest.skip("one kernel variant is enough")
+    for rank, err, cerr, ids_ok, nhalo_tiles, ntiles in _run(5, (rdyhip_kernel, second_order, "c", "strips", "trial"), join=420):
+        assert err <= 1e-10, (rank, err)
+        assert cerr <= 1e-10 and ids_ok
+
+
+@pytest.mark.timeout(300)
+def test_a_slow_transfer_flips_the_form(rdyhip_kernel):
+    """The trial decides by what it measures: the same part, the same exchange pattern, a transport callback that copies the send
+    rows to the ghost rows on the device -- once as fast as it can, once behind a device-side delay about as long as the interior
+    tiles' launch.  Fast: the step in order wins (the two cross-stream hops of the other form cost more than the copy they hide).
+    Slow: two streams win (the delay runs beside the interior launch).  Same bits either way."""
+    if rdyhip_kernel == "cell":
+        pytest.skip("one kernel variant is enough")
+    import ctypes as C
+    from rdycore_amd import _lib
+    from rdycore_amd import cases as CS
+    from rdycore_amd import mesh as M
+    from rdycore_amd.operator import _DeviceArray
+    lib = _lib.load()
+    torch.cuda.set_device(0)
+    nxp, ny, world = 1200, 1250, 3                          # 3.0 M owned cells: a launch of ~100 us, long enough to hide something behind
+    K = 2 * np.pi / 97
+    mesh = M.strip_partition_tri_mesh(nxp, ny, 1, world, 1.0, zfunc=CS.mms_bathymetry(K=K), order="tiled")
+    case = CS.friction_slope_case(mesh, nxp * world, ny, dt=1e-3, K=K)
+    op = CS.create_operator(case)
+    i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+    p = lambda a: a.ctypes.data_as(_lib.c_int32_p)
+    ghost = np.nonzero(mesh.cell_is_owned == 0)[0].astype(np.int32)
+    gset = np.zeros(mesh.num_cells, dtype=bool)
+    gset[ghost] = True
+    cl, cr = mesh.edge_cell_ids[0::2], mesh.edge_cell_ids[1::2]
+    cut = (cr >= 0) & (gset[cl] != gset[np.maximum(cr, 0)])
+    sendc = np.unique(np.where(gset[cl[cut]], cr[cut], cl[cut])).astype(np.int32)
+    n = min(sendc.size, ghost.size)
+    sendc, ghost = i32(sendc[:n]), i32(ghost[:n])
+    st = int(torch.cuda.current_stream().cuda_stream)
+    u = torch.tensor(case.u_local, dtype=torch.float64, device="cuda:0")
+    f = torch.empty((mesh.num_owned_cells, 3), dtype=torch.float64, device="cuda:0")
+    owner = object()
+    delay = {"cycles": 0}
+
+    def transport(ctx, d_send, d_recv, ncomp, stream):
+        try:
+            s = torch.cuda.ExternalStream(stream) if stream else torch.cuda.current_stream()
+            with torch.cuda.stream(s):
+                if delay["cycles"]:
+                    torch.cuda._sleep(delay["cycles"])                     # the "link": device time on the stream the bytes travel on
+                src = torch.as_tensor(_DeviceArray(d_send, (n * ncomp,), owner), device="cuda:0")
+                dst = torch.as_tensor(_DeviceArray(d_recv, (n * ncomp,), owner), device="cuda:0")
+                dst.copy_(src)
+            return 0
+        except Exception:                                                  # never let an exception cross the C boundary
+            import traceback
+            traceback.print_exc()
+            return 1
+    cb = _lib.TRANSPORT_FN(transport)
+
+    def run(cycles):
+        delay["cycles"] = cycles
+        h = C.c_void_p()
+        _lib.check(lib.rdyhip_halo_create(op._h, None, 1, p(i32([0])), p(i32([n])), p(sendc), p(i32([n])), p(ghost), C.byref(h)))
+        _lib.check(lib.rdyhip_halo_set_transport(h, C.cast(cb, C.c_void_p), None))
+        for _ in range(24):
+            _lib.check(lib.rdyhip_rhs_overlapped(op._h, h, case.dt, int(u.data_ptr()), int(f.data_ptr()), st))
+        torch.cuda.synchronize()
+        fi = _lib.RDyHipHaloFormInfo()
+        _lib.check(lib.rdyhip_halo_form_info(h, 0, C.byref(fi)))
+        _lib.check(lib.rdyhip_halo_destroy(C.byref(h)))
+        return f.clone(), fi
+
+    # a delay of ~100 us, whatever the counter torch.cuda._sleep spins on ticks at
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda._sleep(1000)
+    e0.record()
+    torch.cuda._sleep(100_000)
+    e1.record()
+    torch.cuda.synchronize()
+    cycles = max(1000, int(100_000 * 0.100 / max(e0.elapsed_time(e1), 1e-4)))
+    f_fast, fast = run(0)
+    f_slow, slow = run(cycles)
+    assert torch.equal(f_fast, f_slow)
+    assert fast.source == 1 and slow.source == 1
+    assert fast.form == 0, (fast.in_order_ms, fast.two_stream_ms)
+    assert slow.form == 1, (slow.in_order_ms, slow.two_stream_ms)
+    assert slow.in_order_ms > fast.in_order_ms + 0.05                      # the delay is on the critical path of the in-order step ...
+    assert slow.two_stream_ms < slow.in_order_ms                           # ... and beside the interior launch in the other form
+    op.destroy()
 
 
 @pytest.mark.timeout(300)

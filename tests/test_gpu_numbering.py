@@ -198,8 +198,12 @@ def test_courant_ids_per_rank_without_tilting(monkeypatch, kind, variant, state,
             m = M.strip_partition_tri_mesh(40, 48, rank, world, 1.0, order="tiled", tile=8)
             lx = 120.0
         else:
-            m = CS.dam_break_quads_mesh(192, 96, rank, world)
-            lx = 8.0
+            # (the dam-break domain on a lattice of exactly representable coordinates: the ties of a uniform state are exact
+            # only where equal edges have bitwise-equal lengths and areas; on the benchmark's own 10 m / 5120 lattice they agree to
+            # rounding, which makes near-ties of them -- DESIGN.md section 2)
+            from rdycore_amd import partition as P
+            m = P.partitioned_structured_mesh("quad", 192, 96, (0.5, 0.5), rank, world, keep=CS.dam_break_keep(192, 96))
+            lx = 96.0
         m = M.dmplex_like_numbering(m, seed=50 + rank)
         assert m.num_cells > m.num_owned_cells and (m.cell_is_owned[: m.num_owned_cells] != 0).all()
         el, er = m.edge_cell_ids[0::2], m.edge_cell_ids[1::2]
@@ -231,7 +235,8 @@ def test_courant_ids_per_rank_without_tilting(monkeypatch, kind, variant, state,
         cmax, ce, cc = orc.diagnostics()
         assert abs(d.max_courant_num - cmax) <= 1e-12 * max(1.0, cmax)
         assert (d.global_edge_id, d.global_cell_id) == (ce, cc), (rank, (d.global_edge_id, d.global_cell_id), (ce, cc))
-        if edge_order == "ghost_edges_first" and kind == "rcb_quads" and state == "lake_at_rest":
+        if edge_order == "ghost_edges_first" and kind == "rcb_quads" and state == "lake_at_rest" and variant == "first":
+            # (second order: only the rank that owns an edge reports it, src/swe/swe_petsc.c:172-190 -- never one between two ghosts)
             e = int(np.nonzero(m.edge_global_ids == ce)[0][0])          # all edges of the uniform quad mesh tie: the first one wins
             assert m.cell_is_owned[m.edge_cell_ids[2 * e]] == 0 and m.cell_is_owned[m.edge_cell_ids[2 * e + 1]] == 0
         got.append(d)

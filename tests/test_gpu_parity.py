@@ -482,6 +482,63 @@ def test_hydrostatic_reconstruction_lake_at_rest(rdyhip_kernel):
     assert float(f.abs().max()) < 1e-12
 
 
+@pytest.mark.parametrize("z0", [500.0, 3000.0])
+def test_hydrostatic_reconstruction_at_mountain_elevations(z0, rdyhip_kernel):
+    """the HR edge phase takes ONE square root per edge -- the side with the higher bed keeps (h + z) - z and its
+    staged sqrt(h) stands in for the root of that value (src/swe/swe_petsc.c:1046-1071 takes the root of the reconstructed depth):
+    a relative difference of at most ulp(h + z) / (4 h), which grows with the bed's elevation and shrinks with the depth.
+    Films of 1e-4 .. 1e-2 m (and deeper water, and dry cells) over a rough bed at 500 m and at 3000 m: still inside 1e-10."""
+    if rdyhip_kernel == "cell":
+        pytest.skip("HR lives in the tiled kernel")
+    from rdycore_amd.operator import WELL_BALANCING_HR
+    rng = np.random.default_rng(int(z0))
+    K = 2 * np.pi / 17
+    mesh = M.structured_tri_mesh(48, 36, 1.0, zfunc=lambda x, y: z0 + 0.8 * np.sin(K * x) * np.cos(K * y) + 0.03 * y, order="tiled", tile=4, project_2d=True)
+    case = CS.dam_break_case(mesh, 1e9, perturb=0.0)
+    nc = mesh.num_cells
+    kind = rng.integers(0, 4, nc)
+    h = np.where(kind == 0, 0.0, np.where(kind == 1, 10.0 ** rng.uniform(-4, -2, nc), np.where(kind == 2, rng.uniform(0.05, 0.5, nc), rng.uniform(0.5, 2.5, nc))))
+    case.u_local[:, 0] = h
+    case.u_local[:, 1] = h * rng.normal(size=nc) * 0.3
+    case.u_local[:, 2] = h * rng.normal(size=nc) * 0.3
+    case.config.well_balancing = WELL_BALANCING_HR
+    f, fr, op, orc = run_both(case)
+    err = check_all(case, f, fr, op, orc)
+    # (measured: ~1e-13 at 500 m and at 3000 m -- the films that see the largest relative difference carry the smallest fluxes)
+    assert err <= 1e-11
+    op.destroy()
+
+
+def test_hydrostatic_reconstruction_with_negative_depths(rdyhip_kernel):
+    """a cell with a slightly negative depth (a drying overshoot) on the higher-bed side of an edge.  The
+    reference clamps the reconstructed depth to 0 and takes sqrt(0) = 0 (src/swe/swe_petsc.c:1051-1053): a finite flux.  The staged
+    square root of a negative depth is NaN; the one-root shortcut must not pass it on."""
+    if rdyhip_kernel == "cell":
+        pytest.skip("HR lives in the tiled kernel")
+    case = hr_case("tri", SOURCE_SEMI_IMPLICIT)
+    m = case.mesh
+    rng = np.random.default_rng(12)
+    # (not on the domain boundary: boundary edges are not reconstructed, src/operator_fluxes_petsc.c:57-58, and pow(h, 0.5) of a
+    # negative depth is NaN there in the reference as well)
+    on_boundary = np.zeros(m.num_cells, dtype=bool)
+    on_boundary[m.edge_cell_ids[2 * m.edge_boundary_ids]] = True
+    wet = np.nonzero((case.u_local[:, 0] > 0.05) & ~on_boundary)[0]
+    neg = rng.choice(wet, 60, replace=False)
+    case.u_local[neg, 0] = -10.0 ** rng.uniform(-9, -5, neg.size)
+    case.u_local[neg, 1:] = 0.0
+    # ... some of them certainly higher than a wet neighbour
+    cl, cr = m.edge_cell_ids[2 * m.edge_internal_ids], m.edge_cell_ids[2 * m.edge_internal_ids + 1]
+    isneg = np.zeros(m.num_cells, dtype=bool)
+    isneg[neg] = True
+    high_neg = (isneg[cl] & ~isneg[cr] & (m.cell_zc[cl] > m.cell_zc[cr]) & (case.u_local[cr, 0] > 0.05)) | \
+               (isneg[cr] & ~isneg[cl] & (m.cell_zc[cr] > m.cell_zc[cl]) & (case.u_local[cl, 0] > 0.05))
+    assert high_neg.sum() > 10
+    f, fr, op, orc = run_both(case)
+    assert np.isfinite(fr).all() and np.isfinite(f).all()
+    assert rel_linf(f, fr) <= TOL
+    op.destroy()
+
+
 def test_unsupported_well_balancing_is_rejected():
     from rdycore_amd.operator import Operator, RDyFlowConfig, RDyHipError
     _torch()

@@ -46,3 +46,65 @@ def test_rhs_kernels_keep_their_nontemporal_stores(tmp_path):
     plain = [k for k, d in euler if re.search(r", false>\(", d)]
     assert hinted and all(rhs[k][1] >= 9 for k in hinted), [(k, rhs[k]) for k in hinted if rhs[k][1] < 9][:3]
     assert len(plain) == 8 and all(6 <= rhs[k][1] < 9 for k in plain), [(k, rhs[k]) for k in plain][:3]
+
+
+# What the compiler allocated for the headline instantiations (code object metadata + disassembly of the built library, no GPU):
+# registers decide how many workgroups share a CU -- the triangle second-order kernel must stay at <= 128 VGPRs (four workgroups
+# per CU: one register more cost the Euler-step instantiation 15 % for an afternoon in round 5), everything else at <= 168 (three)
+# --, scratch must be zero, and the number of waits on vector memory says whether a load crept into a place where every wave waits
+# for the whole prefetch batch (the first-order kernel has ONE wait per tile on its hot path; the rest sit in prologue, tail and
+# cold branches).  Upper bounds with a little slack: a change that moves them is looked at, then the table is updated.
+PINS = {
+    # kernel (demangled prefix):                                  (max VGPRs, max vmcnt waits, min hinted stores, min hinted loads)
+    "swe_rhs_tiled_kernel<3, 0, true, false, false, true>":      (152, 26, 9, 20),
+    "swe_rhs_tiled_kernel<3, 0, true, true, false, true>":       (152, 26, 9, 18),
+    "swe_rhs_tiled_kernel<4, 0, true, false, false, true>":      (160, 27, 9, 20),
+    "swe_rhs_tiled_kernel<3, 0, true, false, true, true>":       (156, 28, 12, 20),
+    "swe_rhs_tiled_kernel<4, 0, true, false, true, true>":       (160, 29, 12, 20),
+    "swe_rhs_muscl_fused_kernel<3, 0, true, 0, false>":          (128, 33, 9, 14),
+    "swe_rhs_muscl_fused_kernel<3, 0, true, 0, true>":           (128, 35, 12, 14),
+    "swe_rhs_muscl_fused_kernel<3, 0, true, 2, true>":           (128, 35, 12, 14),
+    "swe_rhs_muscl_fused_kernel<4, 0, true, 0, false>":          (168, 32, 9, 20),
+    "swe_rhs_muscl_fused_kernel<4, 0, true, 0, true>":           (168, 34, 12, 20),
+}
+
+
+@pytest.mark.skipif(not all(os.path.exists(t) for t in TOOLS) or shutil.which("c++filt") is None, reason="ROCm's llvm binutils are not installed")
+def test_headline_kernels_keep_their_registers_and_waits(tmp_path):
+    from rdycore_amd import codeobj
+    lib = build.lib_path()
+    res = codeobj.kernel_resources(lib)
+    fat, co = str(tmp_path / "fatbin.bin"), str(tmp_path / "dev.co")
+    subprocess.check_call([TOOLS[0], "-O", "binary", "--only-section=.hip_fatbin", lib, fat])
+    subprocess.check_call([TOOLS[1], "--unbundle", "--type=o", f"--input={fat}", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"])
+    asm = subprocess.run([TOOLS[2], "-d", co], capture_output=True, text=True, check=True).stdout
+    bodies, name = {}, None
+    for line in asm.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(\S+)>:$", line)
+        if m:
+            name = m.group(1)
+            bodies[name] = []
+        elif name:
+            bodies[name].append(line.split("//")[0].strip())
+    names = subprocess.run(["c++filt"], input="\n".join(bodies), capture_output=True, text=True, check=True).stdout.splitlines()
+    by_name = dict(zip(names, bodies.values()))
+    # every RHS kernel: no scratch, no VGPR spills
+    rhs = {k: v for k, v in res.items() if "swe_rhs_tiled_kernel<" in k or "swe_rhs_muscl_fused_kernel<" in k}
+    assert len(rhs) == 84
+    assert all(v["scratch"] == 0 and v["vgpr_spills"] == 0 for v in rhs.values()), {k: v for k, v in rhs.items() if v["scratch"] or v["vgpr_spills"]}
+    # the triangle second-order kernels: four workgroups per CU, all 18 instantiations
+    tri_so = {k: v["vgpr"] for k, v in rhs.items() if "swe_rhs_muscl_fused_kernel<3," in k}
+    assert len(tri_so) == 18 and max(tri_so.values()) <= 128, tri_so
+    assert max(v["vgpr"] for v in rhs.values()) <= 168
+    bad = {}
+    for prefix, (max_vgpr, max_waits, min_nt_st, min_nt_ld) in PINS.items():
+        hits = [k for k in by_name if k.startswith("void rdyhip::" + prefix)]
+        assert len(hits) == 1, (prefix, hits)
+        body = by_name[hits[0]]
+        r = res[hits[0]]
+        waits = sum(1 for ln in body if ln.startswith("s_waitcnt") and "vmcnt" in ln)
+        nt_st = sum(1 for ln in body if ln.startswith("global_store") and re.search(r"\bnt\b", ln))
+        nt_ld = sum(1 for ln in body if ln.startswith("global_load") and re.search(r"\bnt\b", ln))
+        if r["vgpr"] > max_vgpr or waits > max_waits or nt_st < min_nt_st or nt_ld < min_nt_ld:
+            bad[prefix] = {"vgpr": r["vgpr"], "vmcnt_waits": waits, "nt_stores": nt_st, "nt_loads": nt_ld}
+    assert not bad, bad
