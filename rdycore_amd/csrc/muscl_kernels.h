@@ -240,7 +240,7 @@ __device__ __forceinline__ int slot_edge(uint32_t r0, uint32_t r1, int s) {
 // (src/swe/swe_petsc.c:184-201); kf[s] = -+len/area of slot s.
 template <int S, class LAY>
 __device__ __forceinline__ void muscl_cell_sum(const KernelArgs &a, uint32_t r0, uint32_t r1, const double (&kf)[S], const double *ef, double dt, int e_off,
-                                               double &acc0, double &acc1, double &acc2, CourantTrack &trk) {
+                                               int pos_lo, int pos_q, double &acc0, double &acc1, double &acc2, CourantTrack &trk) {
   bool      tie    = false;  // a slot of this cell met the thread's running Courant maximum to the last bit (CourantTrack, swe_kernels.h)
   const int rec_in = trk.rec;
 #pragma unroll
@@ -264,7 +264,6 @@ __device__ __forceinline__ void muscl_cell_sum(const KernelArgs &a, uint32_t r0,
   if (trk.rec != rec_in) trk.pos = -1;
   // cold: which of the equal edges comes first in the reference's loop; dismissed at once where the incumbent's position is
   // known and smaller than every position of this tile
-  const int pos_lo = tie ? load_uniform(RDY_COLD(a, e_pos), e_off) : 0;
   if (tie && !(trk.pos >= 0 && trk.pos < pos_lo)) {
     int first = -1;  // the first slot of this cell at the running maximum: the only one that can come before the incumbent
 #pragma unroll
@@ -272,9 +271,9 @@ __device__ __forceinline__ void muscl_cell_sum(const KernelArgs &a, uint32_t r0,
       const int ref = slot_edge<S>(r0, r1, s);
       if (ref < 0) continue;
       const double am = MEF(3, ref);
-      if (first < 0 && am != -1.0 && am * fabs(kf[s]) * dt == trk.best) first = e_off + ref;
+      if (first < 0 && am != -1.0 && am * fabs(kf[s]) * dt == trk.best) first = ref;
     }
-    if (first >= 0) courant_resolve_tie(a, trk, first, pos_lo);
+    if (first >= 0) courant_resolve_tie(a, trk, e_off + first, first >= COURANT_Q ? pos_q : pos_lo);
   }
 }
 
@@ -518,6 +517,8 @@ __global__ __launch_bounds__(TILE) void swe_rhs_muscl_fused_kernel(const KernelA
     const TileDesc td = tile_desc(tile);
     const int  ne = td.ne(), nh = td.nh();
     const int  c0 = load_uniform(g.r2_off, tile), nc2 = load_uniform(g.r2_off, tile + 1) - c0;
+    const int  pos_lo = load_uniform(RDY_COLD(a, e_pos), td.e_off);  // smallest loop position of the tile's records (Courant tie path)
+    const int  pos_q  = load_uniform(RDY_COLD(a, e_pos), td.e_off + min(COURANT_Q, ne - 1));
     const int  o      = td.c_off + tid;
     const bool active = tid < td.nc();
     const int  hid    = (tid < nh + nc2) ? 0 : -1;  // does this thread stage a ring cell
@@ -666,7 +667,7 @@ __global__ __launch_bounds__(TILE) void swe_rhs_muscl_fused_kernel(const KernelA
         acc1 = f[3 * (int64_t)o + 1];
         acc2 = f[3 * (int64_t)o + 2];
       }
-      muscl_cell_sum<S, LAY>(a, r0, r1, kf, ef, dt, td.e_off, acc0, acc1, acc2, trk);
+      muscl_cell_sum<S, LAY>(a, r0, r1, kf, ef, dt, td.e_off, pos_lo, pos_q, acc0, acc1, acc2, trk);
       const RiemannSide self = riemann_side(h, hu, hv, a.tiny_h, a.h_anuga_sq);
       pu                     = self.u;
       pv_                    = self.v;

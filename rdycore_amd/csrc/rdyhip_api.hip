@@ -1018,11 +1018,14 @@ int rdyhip_create(const RDyHipConfig *config, const RDyHipMesh *mesh, int32_t nu
   op->lds_bytes    = lds_bytes;
   {
     // The Euler-step kernels' u_out is what the next step reads: stored without the non-temporal hint it is still in the
-    // Infinity Cache (256 MB) then -- when it fits beside what else lives there.  Plain stores while the state array is at
-    // most half the cache (RDYHIP_UOUT_CACHED_MAX_MB, default 128 MB = 5.6 M cells); RDYHIP_UOUT_CACHED=0 / 1 forces.
-    double max_mb = 128.0;
+    // Infinity Cache (256 MB) then -- when it fits beside what else lives there.  A sweep over 0.36 M .. 10 M cells in a time loop
+    // (profiles/r05_uout_policy_sweep.txt): plain stores win 3-5 % from 1.2 M to 6 M cells (29 .. 150 MB of state), lose 0.3-3 %
+    // below 1 M (the launch is over before a second pass could profit) and 2 % from 8 M cells.  So: plain stores for
+    // 28 MB <= state <= RDYHIP_UOUT_CACHED_MAX_MB (default 144); RDYHIP_UOUT_CACHED=0 / 1 forces.
+    double max_mb = 144.0;
     if (const char *e = getenv("RDYHIP_UOUT_CACHED_MAX_MB")) max_mb = atof(e);
-    op->uout_cached = 24.0 * (double)op->n_cells <= max_mb * 1048576.0;
+    const double state_bytes = 24.0 * (double)op->n_cells;
+    op->uout_cached = state_bytes >= 28.0 * 1048576.0 && state_bytes <= max_mb * 1048576.0;
     if (const char *e = getenv("RDYHIP_UOUT_CACHED")) op->uout_cached = atoi(e) != 0;
   }
   op->muscl       = muscl_on;

@@ -228,10 +228,13 @@ __device__ __forceinline__ void wave_store_rows3(double *__restrict__ arr, int64
 // slot, the flag lives in a scalar mask); a cell that did goes through courant_resolve_tie -- cold code, taken by states
 // that are uniform over what a thread has seen so far (a lake at rest, the flat pools of the reference's dam-break
 // benchmark at t = 0) -- which compares loop positions.  That path must be cheap too (the dam break's first steps run
-// through it in every tile): the incumbent's position is looked up once and kept; a tile all of whose records come later
-// in the loop than the incumbent (the first record of a tile has its smallest position: ONE scalar load) is dismissed
-// without touching memory -- every tile after the first, where the edge numbering follows the cells; otherwise one 4-byte
-// load per tying cell, waited for inside the branch.
+// through it in every tile): the incumbent's position is looked up once and kept; a candidate whose position is known
+// to be larger is dismissed without touching memory -- the records of a tile are sorted by position, so the position of
+// record 0 bounds every candidate of the tile from below and that of record COURANT_Q bounds the candidates from
+// record COURANT_Q on (two scalars per tile, fetched a tile ahead; where the edge numbering follows the cells the first
+// few dozen records of a tile are the edges it shares with earlier tiles, everything behind them is newer than any
+// incumbent); otherwise one 4-byte load per tying cell, waited for inside the branch.
+constexpr int COURANT_Q = 48;
 struct CourantTrack {
   double best = 0.0;  // largest Courant number seen by this thread (> 0 only)
   int    rec  = 0;    // its tile edge record (index into e_lr / e_cs / e_pos)
@@ -591,6 +594,10 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
       if (tid + TILE < ne) { lr1 = RDY_LD(&a.e_lr[td.e_off + TILE + tid]); cs1 = RDY_LD(&a.e_cs[td.e_off + TILE + tid]); }
       load_streams<S, HR>(a, o, tid < td.nc(), cur);
     }
+    // the loop positions of the tile's records 0 and COURANT_Q (sorted by position): what lets the Courant tie path dismiss a
+    // candidate without touching memory (CourantTrack); fetched a tile ahead like everything else
+    int      pos_lo = load_uniform(RDY_COLD(a, e_pos), td.e_off);
+    int      pos_q  = load_uniform(RDY_COLD(a, e_pos), td.e_off + min(COURANT_Q, td.ne() - 1));
     int      idx1 = next_valid(idx + step);
     int      tile1 = 0, hid1 = 0, c1 = 0;  // next tile: this thread's halo cell and own cell (local ids)
     TileDesc td1 = td;
@@ -649,8 +656,11 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
       // (b) the next tile's cell states, edge records and per-cell streams
       uint32_t nlr0 = 0, nlr1 = 0;
       double   ncs0 = 0.0, ncs1 = 0.0;
+      int      npos_lo = 0, npos_q = 0;
       CellStreams<S> nxt;
       if (idx1 < hi) {
+        npos_lo = load_uniform(RDY_COLD(a, e_pos), td1.e_off);
+        npos_q  = load_uniform(RDY_COLD(a, e_pos), td1.e_off + min(COURANT_Q, td1.ne() - 1));
         if (tid < td1.nc()) {
           pu0 = u[3 * (int64_t)c1 + 0]; pu1 = u[3 * (int64_t)c1 + 1]; pu2 = u[3 * (int64_t)c1 + 2];
           if (HR) pz = a.zc_local[c1];
@@ -790,7 +800,6 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
         if (trk.rec != rec_in) trk.pos = -1;
         // cold: which of the equal edges comes first in the reference's loop (CourantTrack).  Dismissed at once where the
         // incumbent's position is known and smaller than every position of this tile.
-        const int pos_lo = tie ? load_uniform(RDY_COLD(a, e_pos), td.e_off) : 0;
         if (tie && !(trk.pos >= 0 && trk.pos < pos_lo)) {
           int first = -1;  // the first slot of this cell at the running maximum: the only one that can come before the incumbent
 #pragma unroll
@@ -805,9 +814,9 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
               if (ref == SLOT_EMPTY) continue;
             }
             const double am = eam[ref];
-            if (first < 0 && am != -1.0 && am * fabs(cur.coef[s]) * dt == trk.best) first = td.e_off + (int)ref;
+            if (first < 0 && am != -1.0 && am * fabs(cur.coef[s]) * dt == trk.best) first = (int)ref;
           }
-          if (first >= 0) courant_resolve_tie(a, trk, first, pos_lo);
+          if (first >= 0) courant_resolve_tie(a, trk, td.e_off + first, first >= COURANT_Q ? pos_q : pos_lo);
         }
         acc_fdiv[0] = acc0;
         acc_fdiv[1] = acc1;
@@ -839,6 +848,8 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
       const int  tile_cur  = tile, nc_cur = td.nc();
       idx = idx1; tile = tile1; td = td1;
       idx1 = idx2; tile1 = tile2; td1 = td2; hid1 = hid2; c1 = c2;
+      pos_lo = npos_lo;
+      pos_q  = npos_q;
       lr0 = nlr0; lr1 = nlr1; cs0 = ncs0; cs1 = ncs1;
       cur = nxt;
       __builtin_amdgcn_sched_barrier(0);

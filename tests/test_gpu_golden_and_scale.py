@@ -524,17 +524,19 @@ def test_c3_strip_rank_with_ghosts_full_size(rdyhip_kernel):
     p = lambda a: a.ctypes.data_as(_lib.c_int32_p)
     h = C.c_void_p()
     _lib.check(lib.rdyhip_halo_create(op._h, comm, 1, p(i32([0])), p(i32([n])), p(i32(sendc[:n])), p(i32([n])), p(i32(ghost[:n])), C.byref(h)))
-    assert lib.rdyhip_halo_overlaps(h) == 1 and lib.rdyhip_halo_direct_receive(h) == 1
+    assert lib.rdyhip_halo_direct_receive(h) == 1
     st = int(torch.cuda.current_stream().cuda_stream)
-    w = u.clone()
-    _lib.check(lib.rdyhip_rhs_overlapped(op._h, h, case.dt, int(w.data_ptr()), int(f.data_ptr()), st))
-    torch.cuda.synchronize()
     expect = u.clone()
     expect[mesh.num_owned_cells:mesh.num_owned_cells + n] = u[torch.as_tensor(sendc[:n].astype(np.int64), device="cuda")]
-    assert torch.equal(w, expect)
     op.rhs_function(case.dt, expect, f2)
-    torch.cuda.synchronize()
-    assert torch.equal(f, f2)
+    for form in (1, 0):                  # two streams (exchange beside the interior tiles), then everything in order
+        _lib.check(lib.rdyhip_halo_set_form(h, 0, form))
+        assert lib.rdyhip_halo_overlaps(h) == form
+        w = u.clone()
+        f.fill_(-3.0)
+        _lib.check(lib.rdyhip_rhs_overlapped(op._h, h, case.dt, int(w.data_ptr()), int(f.data_ptr()), st))
+        torch.cuda.synchronize()
+        assert torch.equal(w, expect) and torch.equal(f, f2), form
     _lib.check(lib.rdyhip_halo_destroy(C.byref(h)))
     _lib.check(lib.rdyhip_comm_destroy(comm))
     op.destroy()

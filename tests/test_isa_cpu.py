@@ -49,23 +49,25 @@ def test_rhs_kernels_keep_their_nontemporal_stores(tmp_path):
 
 
 # What the compiler allocated for the headline instantiations (code object metadata + disassembly of the built library, no GPU):
-# registers decide how many workgroups share a CU -- the triangle second-order kernel must stay at <= 128 VGPRs (four workgroups
-# per CU: one register more cost the Euler-step instantiation 15 % for an afternoon in round 5), everything else at <= 168 (three)
-# --, scratch must be zero, and the number of waits on vector memory says whether a load crept into a place where every wave waits
+# registers decide how many workgroups share a CU -- the second-order kernels must stay at <= 128 VGPRs (four workgroups per CU:
+# one register more cost an Euler-step instantiation 15 % for an afternoon in round 5), the first-order ones at <= 168 (three) --,
+# scratch must be zero, and the number of waits on vector memory says whether a load crept into a place where every wave waits
 # for the whole prefetch batch (the first-order kernel has ONE wait per tile on its hot path; the rest sit in prologue, tail and
 # cold branches).  Upper bounds with a little slack: a change that moves them is looked at, then the table is updated.
 PINS = {
     # kernel (demangled prefix):                                  (max VGPRs, max vmcnt waits, min hinted stores, min hinted loads)
-    "swe_rhs_tiled_kernel<3, 0, true, false, false, true>":      (152, 26, 9, 20),
-    "swe_rhs_tiled_kernel<3, 0, true, true, false, true>":       (152, 26, 9, 18),
-    "swe_rhs_tiled_kernel<4, 0, true, false, false, true>":      (160, 27, 9, 20),
-    "swe_rhs_tiled_kernel<3, 0, true, false, true, true>":       (156, 28, 12, 20),
-    "swe_rhs_tiled_kernel<4, 0, true, false, true, true>":       (160, 29, 12, 20),
-    "swe_rhs_muscl_fused_kernel<3, 0, true, 0, false>":          (128, 33, 9, 14),
-    "swe_rhs_muscl_fused_kernel<3, 0, true, 0, true>":           (128, 35, 12, 14),
-    "swe_rhs_muscl_fused_kernel<3, 0, true, 2, true>":           (128, 35, 12, 14),
-    "swe_rhs_muscl_fused_kernel<4, 0, true, 0, false>":          (168, 32, 9, 20),
-    "swe_rhs_muscl_fused_kernel<4, 0, true, 0, true>":           (168, 34, 12, 20),
+    # measured on the round-5 build: (143, 35, 9, 26), (141, 36, 9, 22), (148, 35, 9, 26), (145, 37, 14, 26), (150, 37, 14, 26),
+    #                                (121, 41, 9, 16), (121, 43, 14, 16), (121, 46, 14, 16), (121, 41, 9, 17), (123, 43, 14, 17)
+    "swe_rhs_tiled_kernel<3, 0, true, false, false, true>":      (150, 38, 9, 26),
+    "swe_rhs_tiled_kernel<3, 0, true, true, false, true>":       (150, 39, 9, 22),
+    "swe_rhs_tiled_kernel<4, 0, true, false, false, true>":      (156, 38, 9, 26),
+    "swe_rhs_tiled_kernel<3, 0, true, false, true, true>":       (152, 40, 14, 26),
+    "swe_rhs_tiled_kernel<4, 0, true, false, true, true>":       (158, 40, 14, 26),
+    "swe_rhs_muscl_fused_kernel<3, 0, true, 0, false>":          (128, 44, 9, 16),
+    "swe_rhs_muscl_fused_kernel<3, 0, true, 0, true>":           (128, 46, 14, 16),
+    "swe_rhs_muscl_fused_kernel<3, 0, true, 2, true>":           (128, 49, 14, 16),
+    "swe_rhs_muscl_fused_kernel<4, 0, true, 0, false>":          (128, 44, 9, 17),
+    "swe_rhs_muscl_fused_kernel<4, 0, true, 0, true>":           (128, 46, 14, 17),
 }
 
 
@@ -92,9 +94,9 @@ def test_headline_kernels_keep_their_registers_and_waits(tmp_path):
     rhs = {k: v for k, v in res.items() if "swe_rhs_tiled_kernel<" in k or "swe_rhs_muscl_fused_kernel<" in k}
     assert len(rhs) == 84
     assert all(v["scratch"] == 0 and v["vgpr_spills"] == 0 for v in rhs.values()), {k: v for k, v in rhs.items() if v["scratch"] or v["vgpr_spills"]}
-    # the triangle second-order kernels: four workgroups per CU, all 18 instantiations
-    tri_so = {k: v["vgpr"] for k, v in rhs.items() if "swe_rhs_muscl_fused_kernel<3," in k}
-    assert len(tri_so) == 18 and max(tri_so.values()) <= 128, tri_so
+    # the second-order kernels: four workgroups per CU, all 36 instantiations
+    so = {k: v["vgpr"] for k, v in rhs.items() if "swe_rhs_muscl_fused_kernel<" in k}
+    assert len(so) == 36 and max(so.values()) <= 128, so
     assert max(v["vgpr"] for v in rhs.values()) <= 168
     bad = {}
     for prefix, (max_vgpr, max_waits, min_nt_st, min_nt_ld) in PINS.items():

@@ -1,11 +1,5 @@
-mkdir -p gpurun_out/g7
-timeout -k 10 600 python -m pytest tests/test_gpu_numbering.py -q -m gpu -k "per_rank" > gpurun_out/g7/tests1.log 2>&1; echo "tests1 rc=$?" | tee -a gpurun_out/g7/rc.txt
-tail -5 gpurun_out/g7/tests1.log
-timeout -k 10 900 python -m pytest tests/test_gpu_multirank.py -q -m gpu -k "flips_the_form or second_order" > gpurun_out/g7/tests2.log 2>&1; echo "tests2 rc=$?" | tee -a gpurun_out/g7/rc.txt
-tail -12 gpurun_out/g7/tests2.log
-timeout -k 10 600 python -m pytest tests/test_gpu_second_order.py -q -m gpu > gpurun_out/g7/tests3.log 2>&1; echo "tests3 rc=$?" | tee -a gpurun_out/g7/rc.txt
-tail -5 gpurun_out/g7/tests3.log
-mkdir -p ab_hold; mv ab_libs/a_r4.so ab_hold/
-(tools/ab_libs_run.sh --steps 100 --warmup 10 --workload dambreak_quads --second-order --moving-state; tools/ab_libs_run.sh --steps 100 --warmup 10 --workload dambreak_quads --second-order;  tools/ab_libs_run.sh --steps 100 --warmup 10 --workload dambreak_quads --second-order --nx 2560 --ny 1280 --moving-state) > gpurun_out/g7/ab.txt 2>&1
-mv ab_hold/a_r4.so ab_libs/
-cat gpurun_out/g7/ab.txt
+mkdir -p gpurun_out/g16
+timeout -k 10 900 python -m pytest tests/test_gpu_numbering.py tests/test_gpu_second_order.py tests/test_gpu_parity.py -q -m gpu -x > gpurun_out/g16/tests1.log 2>&1; echo "tests1 rc=$?" | tee -a gpurun_out/g16/rc.txt
+tail -4 gpurun_out/g16/tests1.log
+(AB_ARGS_a_r4="--quad-block 16x16" tools/ab_libs_run.sh --steps 100 --warmup 10 --workload dambreak_quads; AB_ARGS_a_r4="--quad-block 16x16" tools/ab_libs_run.sh --steps 100 --warmup 10 --workload dambreak_quads --second-order; tools/ab_libs_run.sh --steps 100 --warmup 10; tools/ab_libs_run.sh --steps 100 --warmup 10 --second-order; tools/ab_libs_run.sh --steps 100 --warmup 10 --hr) > gpurun_out/g16/ab.txt 2>&1
+cat gpurun_out/g16/ab.txt

@@ -1,7 +1,7 @@
 #!/bin/bash
 # On the GPU box: the unprofiled bench line of every reported variant -> gpurun_out/<round>_bench_<tag>.json (copied to profiles/).
 # usage: tools/bench_all.sh <round tag> [variant ...]
-ROUND=${1:-r03}; shift || true
+ROUND=${1:-r05}; shift || true
 declare -A V
 V[c3]="--steps 20 --warmup 5"                 # the driver's flags
 V[c3_200]=""

@@ -40,7 +40,7 @@ def main():
     if os.environ.get("MAKE_TRAFFIC_EULER"):
         # the Euler-step instantiation of the tiled kernel (template argument EULER = true), launched by the bench's euler_step extra
         import re
-        rx = re.compile(r"swe_rhs_(tiled_kernel<\d, \d, true, (true|false), true,|muscl_fused_kernel<\d, \d, true, \d, true,)")
+        rx = re.compile(r"swe_rhs_(tiled_kernel<\d, \d, true, (true|false), true, (true|false)>|muscl_fused_kernel<\d, \d, true, \d, true>)")
 
         def pick(sub, needle, _rx=rx):  # noqa: F811
             best = (None, None, -1)

@@ -3,7 +3,7 @@
 # One calibration of FETCH_SIZE / WRITE_SIZE per session (tools/calib_traffic.py), then per variant: a traced run
 # (--kernel-trace --stats), a FETCH_SIZE pass, a WRITE_SIZE pass and two SQ passes -- each pass on its own, never a --pmc
 # pass combined with a trace domain beyond --kernel-trace.  usage: tools/profile_all.sh <round tag> [variant ...]
-ROUND=${1:-r03}; shift || true
+ROUND=${1:-r05}; shift || true
 REPO=$(pwd); export TMPDIR=/tmp
 CAL=$REPO/gpurun_out/prof_${ROUND}_cal; mkdir -p $CAL
 declare -A V
