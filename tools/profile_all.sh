@@ -45,4 +45,6 @@ for tag in $ORDER; do
   # the machine code that was measured: hash of every kernel of the library these runs loaded (tools/make_traffic.py stamps the entry with it)
   (cd $REPO && python3 -c "import json; from rdycore_amd import build, codeobj; json.dump(codeobj.kernel_hashes(build.lib_path()), open('$OUT/kernel_code_hashes.json', 'w'), indent=0)")
   (cd $REPO && python3 tools/parse_rocprof.py $OUT ${ROUND}_$tag > $OUT/summary.txt 2>&1; tail -4 $OUT/summary.txt)
+  # gpurun copies back at most 64 MiB per call: once parsed, the raw per-dispatch counter rows (~8 MB per variant) stay on the box
+  if [ -s $OUT/summary.json ] && [ -z "$KEEP_RAW" ]; then rm -f $OUT/pmc_*/pmc_counter_collection.csv; fi
 done
