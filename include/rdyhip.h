@@ -253,6 +253,8 @@ int rdyhip_set_mannings(RDyHipOperator op, int32_t n, const int32_t *owned_cell_
  * caller's to order).  `values` / `owned_cell_ids` are host arrays and may be reused as soon as the call returns: they are
  * copied into pinned staging memory of the operator, travel to the device on the operator's own copy stream beside whatever
  * `stream` is executing, and only the last step -- a scatter launch or a device-to-device copy -- is ordered on `stream`.
+ * Arrays above 8 MB go in 8-MB chunks, the upload of a chunk beside the host copies of the chunks behind it: with an adaptive
+ * time step the caller has just read the Courant struct back, the device is idle and waits for exactly this.
  * Nothing blocks and nothing drains the device: with a fixed time step RDyAdvance needs no synchronisation at all
  * (src/rdyadvance.c:303-305), and a drained device runs its next ~40 launches 20-30 % slow (profiles/r02_launch_series.json).
  * rdyhip_refresh_field replaces a whole input field (RDYHIP_FIELD_EXTERNAL_SOURCES [owned][3], RDYHIP_FIELD_MANNINGS [owned])

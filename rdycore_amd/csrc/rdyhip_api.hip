@@ -28,6 +28,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <atomic>
 #include <thread>
 #include <vector>
 
@@ -616,10 +617,10 @@ static int layout_build_slots(const RDyHipConfig *config, const RDyHipMesh *mesh
 
 // Where the tiles end.  A tile is a run of consecutive owned cells, at most `max_cells` (<= TILE) of them, grown 16 cells
 // at a time (whole 128-byte lines of the [cell][3] outputs) while it fits the kernels' fixed capacities: TILE_MAX_REC edge
-// records (two register rounds of the edge phase), the halo-cell planes in LDS and, for second order, the two rings.  A run
-// also ends where the numbering jumps: when a tile of 64 cells or more meets 16 cells none of which shares an edge with it
-// (the next block of a block-wise numbering, the next row of a row-major one).  Any numbering is accepted; one without
-// locality gets small tiles (a random one: ~30 cells) and runs slowly, correctly.
+// records (two register rounds of the edge phase), the halo-cell planes in LDS and, for second order, the two rings.  Nothing
+// else ends a tile (round 5 first also ended one where 16 cells shared no edge with it -- "the numbering jumps" -- which cut
+// the nested numbering of a refined mesh into 64-cell tiles: 2.3 x slower, profiles/RESULTS_LOG.md section 12).  Any numbering
+// is accepted; one without locality gets small tiles (a random one: ~30 cells) and runs slowly, correctly.
 // Returns the first owned cell of every tile, [ntiles + 1].
 static std::vector<int32_t> layout_cut_tiles(const RDyHipMesh *mesh, const HostLayout &L, int32_t max_cells) {
   const int32_t nc = L.nc, no = L.no, S = L.S, npos = L.ni + L.K;
@@ -645,7 +646,7 @@ static std::vector<int32_t> layout_cut_tiles(const RDyHipMesh *mesh, const HostL
       const int32_t g = std::min(std::min(gran, max_cells - cells), no - (base + cells));
       const int32_t lo = base, hi = base + cells + g;  // the tile with the granule: owned cells [lo, hi)
       ++attempt;
-      int32_t newrec = 0, shared = 0;
+      int32_t newrec = 0;
       r1new.clear();
       for (int32_t o = base + cells; o < hi; ++o) {
         for (int32_t sl = 0; sl < S; ++sl) {
@@ -653,8 +654,7 @@ static std::vector<int32_t> layout_cut_tiles(const RDyHipMesh *mesh, const HostL
           const int32_t id  = nbr[idx];
           if (id == NBR_EMPTY) continue;
           const int32_t p = pos[idx];
-          if (emark[p] == stamp) ++shared;
-          else if (etry[p] != attempt) {
+          if (emark[p] != stamp && etry[p] != attempt) {
             etry[p] = attempt;
             ++newrec;
           }
@@ -674,7 +674,6 @@ static std::vector<int32_t> layout_cut_tiles(const RDyHipMesh *mesh, const HostL
         if (r1mark[L.o2l[o]] == stamp) ++left;
       const int32_t nh = (int32_t)r1.size() - left + (int32_t)r1new.size();
       bool bad = rec + newrec > max_rec || nh > max_h1;
-      if (!bad && cells >= 64 && shared == 0 && g == 16) bad = true;  // the numbering jumps: end the tile here
       if (!bad && L.muscl_on) {
         // second ring: the other neighbours of the (owned) first-ring cells
         int32_t n2 = 0;
@@ -1358,26 +1357,43 @@ static int stage_acquire(RDyHipOperator op, size_t bytes, StageRing::Slot **out)
   *out = &s;
   return 0;
 }
-// host -> pinned (a few threads for large arrays: one core copies ~10 GB/s, which at 8 B per cell is as long as 25 RHS
-// evaluations of that many cells)
-static void stage_memcpy(void *dst, const void *src, size_t bytes) {
+// host -> pinned -> device, `bytes` from `src` to offset `off` of the slot.  Large arrays go in 8-MB chunks through a few
+// threads (one core copies ~10 GB/s: 8 B per cell take it as long as 25 RHS evaluations of that many cells), and the upload of
+// a chunk starts as soon as it sits in pinned memory, beside the host copies of the chunks behind it: a caller that has just
+// read the Courant struct back (adaptive dt: the device is idle) waits for max(host copy, DMA), not for their sum.
+static int stage_push(RDyHipOperator op, StageRing::Slot *s, size_t off, const void *src, size_t bytes) {
   constexpr size_t CHUNK = 8u << 20;
-  const int nt = (int)std::min<size_t>(4, bytes / CHUNK);
+  char            *h = (char *)s->h + off, *d = (char *)s->d + off;
+  const size_t     nchunks = (bytes + CHUNK - 1) / CHUNK;
+  const int        nt = (int)std::min<size_t>(4, nchunks);
   if (nt <= 1) {
-    memcpy(dst, src, bytes);
-    return;
+    memcpy(h, src, bytes);
+    HIP_TRY(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, op->stage.copy));
+    return 0;
   }
+  std::vector<std::atomic<int>> ready(nchunks);
+  for (auto &r : ready) r.store(0, std::memory_order_relaxed);
   std::vector<std::thread> th;
-  const size_t per = ((bytes / nt) + 63) & ~(size_t)63;
-  for (int t = 0; t < nt; ++t) {
-    const size_t off = (size_t)t * per, len = t == nt - 1 ? bytes - off : per;
-    th.emplace_back([=] { memcpy((char *)dst + off, (const char *)src + off, len); });
+  for (int t = 0; t < nt; ++t)
+    th.emplace_back([=, &ready] {
+      for (size_t c = (size_t)t; c < nchunks; c += (size_t)nt) {
+        const size_t o = c * CHUNK, len = std::min(CHUNK, bytes - o);
+        memcpy(h + o, (const char *)src + o, len);
+        ready[c].store(1, std::memory_order_release);
+      }
+    });
+  hipError_t err = hipSuccess;
+  for (size_t c = 0; c < nchunks; ++c) {
+    while (!ready[c].load(std::memory_order_acquire)) std::this_thread::yield();
+    const size_t o = c * CHUNK, len = std::min(CHUNK, bytes - o);
+    if (err == hipSuccess) err = hipMemcpyAsync(d + o, h + o, len, hipMemcpyHostToDevice, op->stage.copy);
   }
   for (auto &t : th) t.join();
+  HIP_TRY(err);
+  return 0;
 }
-// values (and ids) -> slot: pinned now, device on the copy stream; `st` then waits for that copy
-static int stage_upload(RDyHipOperator op, StageRing::Slot *s, size_t bytes, hipStream_t st) {
-  HIP_TRY(hipMemcpyAsync(s->d, s->h, bytes, hipMemcpyHostToDevice, op->stage.copy));
+// everything pushed into the slot is on its way: `st` waits for the last upload
+static int stage_ready(RDyHipOperator op, StageRing::Slot *s, hipStream_t st) {
   HIP_TRY(hipEventRecord(s->copied, op->stage.copy));
   HIP_TRY(hipStreamWaitEvent(st, s->copied, 0));
   return 0;
@@ -1400,9 +1416,9 @@ static int scatter_component_on(RDyHipOperator op, double *dst, int ncomp, int c
   StageRing::Slot *s;
   int rc = stage_acquire(op, vbytes + ibytes, &s);
   if (rc) return rc;
-  stage_memcpy(s->h, values, vbytes);
-  if (ids) stage_memcpy((char *)s->h + vbytes, ids, ibytes);
-  rc = stage_upload(op, s, vbytes + ibytes, st);
+  rc = stage_push(op, s, 0, values, vbytes);
+  if (!rc && ids) rc = stage_push(op, s, vbytes, ids, ibytes);
+  if (!rc) rc = stage_ready(op, s, st);
   if (rc) return rc;
   const int32_t *dids = ids ? (const int32_t *)((const char *)s->d + vbytes) : nullptr;
   hipLaunchKernelGGL(scatter_component_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, dids, (const double *)s->d, dst, ncomp, comp);
@@ -1435,8 +1451,8 @@ int rdyhip_set_boundary_values_on(RDyHipOperator op, int32_t boundary, int32_t c
   StageRing::Slot *s;
   int rc = stage_acquire(op, bytes, &s);
   if (rc) return rc;
-  stage_memcpy(s->h, values, bytes);
-  rc = stage_upload(op, s, bytes, st);
+  rc = stage_push(op, s, 0, values, bytes);
+  if (!rc) rc = stage_ready(op, s, st);
   if (rc) return rc;
   double *dst = op->d_bvalues.p + 3 * (size_t)op->h_boff[boundary];
   if (comp_offset == 0 && num_comp == 3) {
@@ -1467,8 +1483,8 @@ int rdyhip_refresh_field(RDyHipOperator op, RDyHipField field, const double *val
   StageRing::Slot *s;
   rc = stage_acquire(op, bytes, &s);
   if (rc) return rc;
-  stage_memcpy(s->h, values, bytes);
-  rc = stage_upload(op, s, bytes, st);
+  rc = stage_push(op, s, 0, values, bytes);
+  if (!rc) rc = stage_ready(op, s, st);
   if (rc) return rc;
   HIP_TRY(hipMemcpyAsync(dst, s->d, bytes, hipMemcpyDeviceToDevice, st));
   return stage_release(s, st);

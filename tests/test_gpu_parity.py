@@ -299,6 +299,45 @@ def test_stream_ordered_setters():
     op.destroy(); ref.destroy()
 
 
+def test_stream_ordered_setters_of_large_arrays():
+    """the staged path in chunks (arrays above 8 MB go host -> pinned -> device chunk by chunk, the uploads beside the host
+    copies): 2.6 M cells = 2.6 chunks of values, a regional list with ids behind the values in the same slot, a field refresh of
+    7.8 chunks; several in flight, the host arrays scribbled over right after each call"""
+    torch = _torch()
+    mesh = M.structured_tri_mesh(1300, 1000, 1.0, order="tiled")
+    case = CS.friction_slope_case(mesh, 1300.0, 1000.0, dt=1e-3)
+    op = CS.create_operator(case)
+    no = mesh.num_owned_cells
+    rng = np.random.default_rng(5)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        for rep in range(3):
+            rain = rng.random(no)
+            keep_rain = rain.copy()
+            op.set_domain_external_source(0, rain, ordered=True)
+            rain[:] = np.nan
+            ids = np.sort(rng.choice(no, size=no - 12345, replace=False)).astype(np.int32)
+            vals = rng.random(ids.size)
+            keep_vals = vals.copy()
+            op.set_regional_external_source(ids, 2, vals, ordered=True)
+            vals[:] = np.nan
+            man = 0.02 + 0.01 * rng.random(no)
+            keep_man = man.copy()
+            op.set_domain_mannings_n(man, ordered=True)
+            man[:] = np.nan
+    s.synchronize()
+    ext = op.external_sources.cpu().numpy()
+    assert np.array_equal(ext[:, 0], keep_rain) and np.array_equal(ext[ids, 2], keep_vals) and np.array_equal(op.mannings_n.cpu().numpy(), keep_man)
+    whole = rng.random((no, 3))
+    keep = whole.copy()
+    with torch.cuda.stream(s):
+        op.refresh_field(1, whole)
+        whole[:] = np.nan
+    s.synchronize()
+    assert np.array_equal(op.external_sources.cpu().numpy(), keep)
+    op.destroy()
+
+
 def test_cached_f_stores_option_changes_nothing_but_the_cache_policy():
     """RDYHIP_CONFIG_CACHED_F_STORES (for hosts whose TSEULER reads F straight back): same bits"""
     torch = _torch()

@@ -26,6 +26,6 @@ ORDER="${@:-c3 c3_200 hr xq c2 quads c5 so so_quads houston houston_hr houston_n
 mkdir -p gpurun_out
 for tag in $ORDER; do
   echo "bench $tag: ${V[$tag]}"
-  python3 bench.py ${V[$tag]} > gpurun_out/${ROUND}_bench_$tag.json 2> gpurun_out/${ROUND}_bench_$tag.err || echo "  FAILED"
+  timeout -k 10 420 python3 bench.py ${V[$tag]} > gpurun_out/${ROUND}_bench_$tag.json 2> gpurun_out/${ROUND}_bench_$tag.err || echo "  FAILED"
   python3 -c "import json,sys; d=json.load(open('gpurun_out/${ROUND}_bench_$tag.json')); r=d['roofline']; print('  ', d['value'], 'M cell-updates/s', d['ms_per_step'], 'ms  frac', r['frac'], 'traffic', r['traffic'], r['traffic_source']['status'] if r.get('traffic_source') else None)" 2>/dev/null || tail -3 gpurun_out/${ROUND}_bench_$tag.err
 done

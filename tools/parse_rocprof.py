@@ -36,17 +36,19 @@ for sub, ctr in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE"), ("cal
     acc = pmc_per_kernel(sub, ctr)
     pm[sub] = {k: {"mean": mean(v), "n": len(v)} for k, v in acc.items() if ("swe_rhs" in k or "axpy_owned" in k or "muscl_gradient" in k)}
 summary["pmc_raw_KB"] = pm
-sq = {}
-for ctr in ("SQ_WAVES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY"):
-    acc = pmc_per_kernel("pmc_sq", ctr)
-    for k, v in acc.items():
-        if "swe_rhs" in k:
-            sq[ctr] = mean(v)
-for ctr in ("SQ_INSTS_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_SALU", "SQ_WAIT_INST_LDS", "GRBM_GUI_ACTIVE"):
-    acc = pmc_per_kernel("pmc_sq2", ctr)
-    for k, v in acc.items():
-        if "swe_rhs" in k:
-            sq[ctr] = mean(v)
+# the SQ counters of the timed RHS kernel and of its Euler-step instantiation (template argument EULER = true; launched about as
+# often by the bench's euler_step / advance_pattern extras) are kept apart: "sq" is the RHS kernel
+import re
+EULER_RX = re.compile(r"swe_rhs_(tiled_kernel<\d, \d, true, (true|false), true, (true|false)>|muscl_fused_kernel<\d, \d, true, \d, true>)")
+sq, sq_euler = {}, {}
+for sub, ctrs in (("pmc_sq", ("SQ_WAVES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY")),
+                  ("pmc_sq2", ("SQ_INSTS_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_SALU", "SQ_WAIT_INST_LDS", "GRBM_GUI_ACTIVE"))):
+    for ctr in ctrs:
+        acc = pmc_per_kernel(sub, ctr)
+        for k, v in acc.items():
+            if "swe_rhs" in k:
+                (sq_euler if EULER_RX.search(k) else sq)[ctr] = mean(v)
+summary["sq_euler_step"] = sq_euler
 summary["sq"] = sq
 with open(os.path.join(out, "summary.json"), "w") as fh:
     json.dump(summary, fh, indent=1)
