@@ -89,8 +89,7 @@ typedef struct {
  *   reads F straight back in a separate kernel -- PETSc's TSEULER: VecAXPY(U, dt, F) after every RHS (TSStep_Euler) -- the
  *   hint costs ~6 % of the RHS + axpy pair, because F has then left the Infinity Cache (DESIGN.md section 7 note 6); a host
  *   that takes the step through rdyhip_euler_step (F never stored) or lets F sit (RK stages summed later) leaves it clear.
- *   Honoured by the first-order and HR tiled kernels on meshes whose tiles fit the fixed LDS layout (every numbering with
- *   locality: RDyHipLayoutInfo.lds_fixed_layout); the second-order kernels and the run-time-length layout keep the hint. */
+ *   Honoured by the first-order and HR tiled kernels; the second-order kernels keep the hint. */
 #define RDYHIP_CONFIG_CACHED_F_STORES 1
 
 /* The RDyMesh arrays the SWE operators read (include/private/rdymeshimpl.h:26-202).
@@ -500,8 +499,8 @@ typedef struct {
   int32_t max_tile_ring2_cells; /* second order: largest first + second ring of a tile */
   int32_t persistent_grid;    /* workgroups of a full apply of the tiled kernel (resident workgroups per CU x CUs) */
   int32_t lds_bytes;          /* dynamic LDS per workgroup of that kernel */
-  int32_t lds_fixed_layout;   /* 1: that kernel's LDS planes have compile-time lengths (the mesh's tiles fit the fixed capacities:
-                                 plane offsets are instruction immediates); 0: lengths taken from the mesh (any numbering) */
+  int32_t lds_fixed_layout;   /* 1 for the tiled kernels: every tile is cut to their fixed capacities at create, the LDS planes have
+                                 compile-time lengths (plane offsets are instruction immediates); 0: the cell-centric kernel */
 } RDyHipLayoutInfo;
 int rdyhip_layout_info(RDyHipOperator op, RDyHipLayoutInfo *info);
 /* the same numbers from the host-side layout pass alone (validation of the mesh, slot tables, tiles): no device is
