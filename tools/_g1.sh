@@ -1,5 +1,4 @@
-mkdir -p gpurun_out/g17
-run() { lib=$1; shift; RDYHIP_LIB=$PWD/ab_libs/$lib.so python3 bench.py --no-cpu-baseline --no-order-study "$@" 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('$lib', '$*', d['value'], d['ms_per_step'], d['roofline']['steady_state_period_median_ms'], d['euler_step']['fused_ms_per_step'], d['roofline'].get('cells_per_tile'), d['config']['cells_per_gpu'])"; }
-(for lib in a_r4 b_r5 a_r4 b_r5; do run $lib --steps 50 --warmup 10 --nx 5000 --ny 4000; done
-for lib in a_r4 b_r5; do run $lib --steps 30 --warmup 10 --workload houston_refined --levels 7; done) > gpurun_out/g17/ab.txt 2>&1
-cat gpurun_out/g17/ab.txt
+mkdir -p gpurun_out/g18
+(tools/ab_libs_run.sh --steps 100 --warmup 10 --workload houston_refined; tools/ab_libs_run.sh --steps 100 --warmup 10 --workload houston_refined --order natural; tools/ab_libs_run.sh --steps 100 --warmup 10) > gpurun_out/g18/ab.txt 2>&1
+cat gpurun_out/g18/ab.txt
+bash tools/bench_all.sh r05 houston_l7 houston_l7_so houston_l7_hr 2>&1 | tee gpurun_out/bench_all_r05_l7.log

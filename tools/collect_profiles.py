@@ -52,7 +52,18 @@ for tag in tags:
         if line is None:
             print(tag, ": no bench line under the tracer, cannot tell the form of the step -- skipped")
             continue
-        per_step = "2" if line["config"].get("halo_overlapped") else "1"
+        # ... as the PMC passes ran it, not the traced run: with counters on, kernels are serialised, the two-stream form cannot
+        # overlap anything and the halo's own trial picks the in-order form (one launch per step) whatever the traced run chose
+        forms = set()
+        for name in ("bench_pmc_fetch.log", "bench_pmc_write.log"):
+            lp = os.path.join(d, name)
+            for ln in (open(lp) if os.path.exists(lp) else []):
+                if ln.startswith("{"):
+                    forms.add(bool(json.loads(ln)["config"].get("halo_overlapped")))
+        if len(forms) != 1:
+            print(tag, ": the FETCH_SIZE and WRITE_SIZE passes did not run the same form of the step -- skipped")
+            continue
+        per_step = "2" if forms.pop() else "1"
         if "second" in line["config"].get("spatial_order", ""):
             extra = "muscl_gradient_kernel"
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_traffic.py"), summ, key, f"profiles/{rnd}_{tag}_summary.json", per_step, extra],
