@@ -11,6 +11,7 @@ import hashlib
 import os
 import shutil
 import struct
+import re
 import subprocess
 
 BUNDLE_MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
@@ -139,3 +140,13 @@ def kernel_resources(lib: str) -> dict:
                                        "vgpr_spills": k.get(".vgpr_spill_count", 0), "sgpr_spills": k.get(".sgpr_spill_count", 0)}
     names = _demangle(list(out))
     return {names[m]: v for m, v in out.items()}
+
+
+# swe_rhs_tiled_kernel<S, SRC, OVW, HR, EULER, FNT> / swe_rhs_muscl_fused_kernel<S, SRC, OVW, LIM, EULER>: the fifth template
+# argument says whether a kernel is the RHS or its Euler-step instantiation (rdyhip_euler_step).  A profiled bench run launches
+# both about as often; the profile tools tell them apart by this, never by launch counts.
+_EULER_RX = re.compile(r"swe_rhs_(tiled_kernel<\d, \d, (?:true|false), (?:true|false), true, (?:true|false)>|muscl_fused_kernel<\d, \d, (?:true|false), \d, true>)")
+
+
+def is_euler_step_kernel(name: str) -> bool:
+    return bool(_EULER_RX.search(name))

@@ -51,3 +51,23 @@ def test_traffic_entries_were_measured_on_the_kernels_of_this_build():
         # the figure itself: corrected counters, both directions, per launch (or per step)
         assert ent["hbm_bytes_per_launch"] == ent["hbm_read_bytes_per_launch"] + ent["hbm_write_bytes_per_launch"] > 0
     assert not stale, f"profile these workloads again (tools/profile_all.sh): {stale}"
+
+
+def test_rhs_and_euler_step_kernels_are_told_apart_by_their_template_arguments():
+    """the profile tools (tools/make_traffic.py, parse_rocprof.py) pick the RHS kernel or its Euler-step instantiation by name:
+    codeobj.is_euler_step_kernel must agree with the fifth template argument of EVERY instantiation in the built library (a
+    new template parameter would silently send the traffic of one kernel to the other's entry), and every traffic.json entry
+    must name the kind of kernel its key says"""
+    h = codeobj.kernel_hashes(build.lib_path())
+    rhs = [k for k in h if "swe_rhs_tiled_kernel<" in k or "swe_rhs_muscl_fused_kernel<" in k]
+    n_euler = 0
+    for k in rhs:
+        args = [a.strip() for a in k[k.index("<") + 1:k.index(">")].split(",")]
+        assert len(args) == (6 if "tiled" in k else 5), k
+        assert codeobj.is_euler_step_kernel(k) == (args[4] == "true"), k
+        n_euler += args[4] == "true"
+    assert 0 < n_euler < len(rhs)
+    assert not codeobj.is_euler_step_kernel("rdyhip::axpy_owned_kernel(int, int const*, double, double const*, double*)")
+    t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    for key, ent in t.items():
+        assert codeobj.is_euler_step_kernel(ent["kernel"]) == key.endswith("_euler_step"), key

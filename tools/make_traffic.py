@@ -31,14 +31,13 @@ def main():
 
     # the Euler-step instantiations (template argument EULER = true) are launched by the bench's euler_step and advance_pattern
     # extras, about as often as the timed RHS kernel: told apart by their template arguments, not by their launch counts
-    import re
-    rx = re.compile(r"swe_rhs_(tiled_kernel<\d, \d, true, (true|false), true, (true|false)>|muscl_fused_kernel<\d, \d, true, \d, true>)")
+    from rdycore_amd.codeobj import is_euler_step_kernel
     want_euler = bool(os.environ.get("MAKE_TRAFFIC_EULER"))
 
     def pick(sub, needle):
         best = (None, None, -1)
         for k, v in raw.get(sub, {}).items():
-            ok = (needle in k and bool(rx.search(k)) == want_euler) if needle == "swe_rhs" else needle in k
+            ok = (needle in k and is_euler_step_kernel(k) == want_euler) if needle == "swe_rhs" else needle in k
             if ok and v["mean"] is not None and v.get("n", 0) > best[2]:
                 best = (k, v["mean"], v.get("n", 0))
         return best[0], best[1]

@@ -38,8 +38,8 @@ for sub, ctr in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE"), ("cal
 summary["pmc_raw_KB"] = pm
 # the SQ counters of the timed RHS kernel and of its Euler-step instantiation (template argument EULER = true; launched about as
 # often by the bench's euler_step / advance_pattern extras) are kept apart: "sq" is the RHS kernel
-import re
-EULER_RX = re.compile(r"swe_rhs_(tiled_kernel<\d, \d, true, (true|false), true, (true|false)>|muscl_fused_kernel<\d, \d, true, \d, true>)")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from rdycore_amd.codeobj import is_euler_step_kernel  # noqa: E402
 sq, sq_euler = {}, {}
 for sub, ctrs in (("pmc_sq", ("SQ_WAVES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY")),
                   ("pmc_sq2", ("SQ_INSTS_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_SALU", "SQ_WAIT_INST_LDS", "GRBM_GUI_ACTIVE"))):
@@ -47,7 +47,7 @@ for sub, ctrs in (("pmc_sq", ("SQ_WAVES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "S
         acc = pmc_per_kernel(sub, ctr)
         for k, v in acc.items():
             if "swe_rhs" in k:
-                (sq_euler if EULER_RX.search(k) else sq)[ctr] = mean(v)
+                (sq_euler if is_euler_step_kernel(k) else sq)[ctr] = mean(v)
 summary["sq_euler_step"] = sq_euler
 summary["sq"] = sq
 with open(os.path.join(out, "summary.json"), "w") as fh:
