@@ -493,9 +493,9 @@ typedef struct {
   int32_t owned_is_prefix;    /* 1 if owned cell o is local cell o */
   int64_t device_bytes;       /* bytes of device memory held by the operator */
   int64_t bytes_per_apply;    /* bytes one full apply must move (layout-exact, not the 176 B/cell model) */
-  int32_t second_order_fused; /* second order: 1 = gradients formed in LDS by the flux kernel (default), 0 = separate gradient
-                                 launch (RDYHIP_MUSCL=split); with 1 only rdyhip_compute_gradients(RDYHIP_PHASE_HALO) is needed
-                                 before the gradient exchange */
+  int32_t second_order_fused; /* 1 for a second-order operator: the gradients are formed in LDS by the flux kernel, only
+                                 rdyhip_compute_gradients(RDYHIP_PHASE_HALO) is needed before the gradient exchange (the
+                                 two-launch form of rounds 1-4 is gone); 0: first order */
   int32_t max_tile_ring2_cells; /* second order: largest first + second ring of a tile */
   int32_t persistent_grid;    /* workgroups of a full apply of the tiled kernel (resident workgroups per CU x CUs) */
   int32_t lds_bytes;          /* dynamic LDS per workgroup of that kernel */

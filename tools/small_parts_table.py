@@ -4,7 +4,7 @@ import json
 import sys
 
 rows = [json.loads(ln) for ln in open(sys.argv[1]) if ln.startswith("{")]
-print("| part | owned cells (ghosts) | form of the RHS step | kernel (RHS / Euler) | round 3 chain: pack, RCCL, unpack, kernel | direct receive: pack, RCCL, kernel | direct receive + fused pack, no signal: RCCL, kernel in order / two-stream form | signalled form (RDYHIP_SIGNALLED=1) |")
+print("| part | owned cells (ghosts) | form of the RHS step | kernel (RHS / Euler) | round 3 chain: pack, RCCL, unpack, kernel | direct receive: pack, RCCL, kernel | direct receive + fused pack: RCCL, kernel in order / two-stream form | signalled form (round 4 files only; the form is tools/probes/round4_forms.patch) |")
 print("|---|---|---|---|---|---|---|---|")
 for d in rows:
     k, ke = d["kernel_rhs"][0], d["kernel_euler"][0]
